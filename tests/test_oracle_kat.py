@@ -1,0 +1,285 @@
+"""Pins the CPU oracle against every known-answer test the reference's own test
+suite holds for the hot path.  Each test names the
+reference test it restates (file:line under /root/reference) and uses the
+reference's own tolerance.  CPU only.
+"""
+import math
+import os
+import wave
+
+import numpy as np
+import pytest
+
+
+def _read_wav16(path):
+    """hound: 16-bit PCM / (i32::MAX >> (32 - bits)) = / 32767 (tests/lib.rs:17-19)."""
+    with wave.open(path, "rb") as w:
+        assert w.getsampwidth() == 2 and w.getnchannels() == 1
+        sr = w.getframerate()
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+    return pcm.astype(np.float64) / 32767.0, float(sr)
+
+
+# ---- periodic.rs ---------------------------------------------------------
+
+def test_ac(oracle):
+    """src/periodic.rs:475-482 test_ac: autocorrelate == autocorrelate_mut (one routine here),
+    plus the Q1 seed quirk spelled out: r[lag] = x[0] + sum_{i>=1} x[i] x[i+lag]."""
+    x = oracle.sine(16, 16.0, 1.0)
+    r = oracle.autocorrelate(x, 16)
+    for lag in range(16):
+        exp = x[0]
+        for i in range(1, 16 - lag):
+            exp = exp + x[i] * x[i + lag]
+        assert r[lag] == exp
+    # stale doc example at src/periodic.rs:258-264: the real lag-0 value is 2.5, not -1.0
+    r2 = oracle.autocorrelate([1.0, 0.5, 0.0, -0.5, -1.0], 2)
+    assert r2[0] == 2.5
+
+
+def test_pitch(oracle):
+    """src/periodic.rs:484-499 test_pitch (same frame as examples/pitch_detection.rs:15-33):
+    150 Hz sine @44.1 kHz, Windower::hanning(2048, 1024) over 2049 samples -> one frame."""
+    sig = oracle.sine(2049, 44100.0, 150.0)
+    frames = oracle.frames_view(sig, 2048, 1024)
+    assert frames.shape[0] == 1
+    x = frames[0] * oracle.window("hanning", 2048)
+    st, cand, count = oracle.pitch(x, 44100.0, 0.2, 100.0, 500.0)
+    assert st == 0 and count >= 1
+    assert abs(cand[0, 0] - 150.0) < 1.0e-2
+    # restatement-derived values recorded in SURVEY.md 8c
+    assert abs(cand[0, 0] - 149.9999843470686) < 1e-7
+    assert abs(cand[0, 1] - 0.9997482091589159) < 1e-9
+    assert cand[-1, 0] == 0.0 and cand[-1, 1] == 0.2
+
+
+def test_pitch_48k_quantised(oracle):
+    """SURVEY.md 8c provisional value: 137.3 Hz sine @48 kHz, N=1200 -> 48000/350 (Q8)."""
+    sig = oracle.sine(1200, 48000.0, 137.3)
+    x = sig * oracle.window("hanning", 1200)
+    st, cand, _ = oracle.pitch(x, 48000.0, 0.2, 75.0, 600.0)
+    assert st == 0
+    assert abs(cand[0, 0] - 137.1428566729394) < 1e-6
+    assert abs(cand[0, 1] - 0.9985693856763005) < 1e-8
+
+
+def test_window_autocorr(oracle):
+    """src/waves.rs:120-136 test_window_autocorr: HanningLag(16) vs normalised autocorr of Hanning(16)."""
+    data = oracle.window("hanning_lag", 16)
+    manual = oracle.normalize(oracle.autocorrelate(oracle.window("hanning", 16), 16))
+    assert np.all(np.abs(manual - data) < 1e-1)
+
+
+def test_rms(oracle):
+    """src/waves.rs:138-144 test_rms."""
+    assert abs(oracle.rms(oracle.sine(64, 64.0, 1.0)) - 0.707) < 0.001
+
+
+def test_pe(oracle):
+    """src/waves.rs:114-118 test_pe (smoke) + the recurrence itself."""
+    x = oracle.sine(32, 32.0, 1.0)
+    y = oracle.preemphasis(x, 0.1)
+    exp = x.copy()
+    for i in range(30, -1, -1):
+        exp[i] = exp[i] + exp[i + 1] * (2.0 * math.pi * 0.1)
+    assert np.array_equal(y, exp)
+
+
+# ---- spectrum.rs: LPC ------------------------------------------------------
+
+def test_lpc(oracle):
+    """src/spectrum.rs:470-487 test_lpc."""
+    auto = oracle.normalize(oracle.autocorrelate(oracle.sine(8, 8.0, 1.0), 8))
+    auto_exp = [1.0, 0.7071, 0.1250, -0.3536, -0.5, -0.3536, -0.1250, 0.0]
+    lpc_exp = [1.0, -1.3122, 0.8660, -0.0875, -0.0103]
+    lpc = oracle.lpc(auto, 4)
+    assert np.all(np.abs(auto - auto_exp) < 0.0001)
+    assert np.all(np.abs(lpc - lpc_exp) < 0.0001)
+
+
+def test_lpc_praat(oracle):
+    """src/spectrum.rs:512-525 test_lpc_praat (Burg, 1e-10)."""
+    source = np.array(list(range(1, 11)) + list(range(10, 0, -1)), dtype=np.float64)
+    st, coeffs = oracle.lpc_burg(source, 5)
+    exp = [-2.529731754197289, 2.6138925001574935, -1.6951059551991234,
+           0.7776548472652218, -0.15008712022777612]
+    assert st == 0
+    assert np.all(np.abs(coeffs - exp) < 1.0e-10)
+
+
+def test_lpc_praat_zero_frame_is_error(oracle):
+    """src/spectrum.rs:123-125: denum <= 0 -> Err(LPC)."""
+    st, _ = oracle.lpc_burg(np.zeros(64), 4)
+    assert st == oracle.ERR_LPC
+
+
+def test_sine_resonances_praat(oracle):
+    """src/spectrum.rs:489-510 test_sine_resonances_praat."""
+    s = oracle.sine(512, 44100.0, 440.0)
+    st, coeffs = oracle.lpc_burg(s, 4)
+    assert st == 0
+    cc = np.array(([1.0] + list(coeffs))[::-1], dtype=np.complex128)
+    st, roots = oracle.find_roots(cc)
+    assert st == 0
+    sel = [r for r in roots if r.imag > 1.0e-8]
+    res = oracle.to_resonance(np.array(sel[:1]), 44100.0)
+    assert res.shape[0] == 1 and abs(res[0, 0] - 440.0) < 4.0
+
+
+def test_resonances(oracle):
+    """src/spectrum.rs:461-468 test_resonances."""
+    roots = np.array([complex(-0.5, 0.86602540378444), complex(-0.5, -0.86602540378444)])
+    res = oracle.to_resonance(roots, 300.0)
+    assert abs(res[0, 0] - 100.0) < 1e-8
+    assert abs(res[0, 1] - 0.0) < 1e-8
+
+
+def test_resonances_from_coeffs(oracle):
+    """src/spectrum.rs:615-633: because of the zip with 4 expectations only the 4th root found
+    is compared -- pins Laguerre root ORDER (Q11)."""
+    coeffs = [-0.80098309, 1.20869679, -1.61846677, 0.86630291,
+              -1.44203292, 0.93621726, -0.58772811, 0.65949051]
+    cc = np.array(([1.0] + coeffs)[::-1], dtype=np.complex128)
+    st, roots = oracle.find_roots(cc)
+    assert st == 0 and roots.size == 8
+    exp = [251.770, 2289.634, 3037.846, 4045.196]
+    checked = 0
+    for root, e in zip(roots, exp):
+        if root.imag > 0.0:
+            res = oracle.to_resonance(np.array([root]), 11025.0)
+            if res.shape[0]:
+                assert abs(res[0, 0] - e) < 1.0
+                checked += 1
+    assert checked == 1  # exactly the 4th root: -0.6311+0.6988i -> 4045.196 Hz
+    # and all four resonances exist among the roots
+    allres = oracle.to_resonance(roots, 11025.0)
+    assert np.all(np.abs(allres[:, 0] - exp) < 1.0)
+
+
+def test_formant_extractor(oracle):
+    """src/spectrum.rs:527-567 test_formant_extractor (exact)."""
+    frames = [[100.0, 150.0, 200.0, 240.0, 300.0],
+              [110.0, 180.0, 210.0, 230.0, 310.0],
+              [230.0, 270.0, 290.0, 350.0, 360.0]]
+    est = np.array([[140.0, 1.0], [230.0, 1.0], [320.0, 1.0]])
+    exp = [[150.0, 240.0, 300.0], [180.0, 230.0, 310.0], [230.0, 270.0, 290.0]]
+    for fr, e in zip(frames, exp):
+        est = oracle.estimate_formants(est, np.array([[f, 1.0] for f in fr]))
+        assert list(est[:, 0]) == e
+
+
+def test_hz_mel(oracle):
+    """src/spectrum.rs:569-577 test_hz_to_mel / test_mel_to_hz."""
+    assert abs(oracle.hz_to_mel(300.0) - 401.25) < 1.0e-2
+    assert abs(oracle.mel_to_hz(401.25) - 300.0) < 1.0e-2
+
+
+def test_dct(oracle):
+    """src/spectrum.rs:604-613 test_dct."""
+    d = oracle.dct([0.2, 0.3, 0.4, 0.3])
+    assert np.all(np.abs(d - [2.4, -0.26131, -0.28284, 0.10823]) < 1.0e-5)
+
+
+def test_mfcc_not_nan(oracle):
+    """src/spectrum.rs:592-602 test_mfcc_not_nan: zeros(512) -> finite (log clamp, Q14)."""
+    st, m = oracle.mfcc(np.zeros(512), 13, 100.0, 8000.0, 22050.0)
+    assert st == 0 and np.all(np.isfinite(m))
+    assert abs(m[0] - 2.6e-9) < 1e-15
+
+
+def test_mfcc_smoke_and_fft(oracle):
+    """src/spectrum.rs:579-590 test_mfcc (smoke, unseeded noise there; seeded here), and the
+    FFT stand-in for rustfft equals the mathematical DFT."""
+    rng = np.random.default_rng(7)
+    v = oracle.preemphasis(rng.uniform(-1, 1, 256), 0.1 * 22050.0)
+    with np.errstate(all="ignore"):   # factor 2205 overflows to inf, as in the reference's own test
+        v = v * oracle.window("hanning", 256)
+    st, m = oracle.mfcc(v, 26, 133.0, 6855.0, 22050.0)
+    assert st == 0 and m.size == 26 and np.all(np.isfinite(m))
+    for n in (256, 1200, 512, 1024, 2 * 3 * 5 * 7):
+        x = rng.standard_normal(n)
+        assert np.max(np.abs(oracle.fft(x) - np.fft.fft(x))) < 1e-10
+    x = rng.standard_normal(1200)
+    a = oracle.mfcc(x, 13, 100.0, 8000.0, 48000.0, use_fft=False)[1]
+    b = oracle.mfcc(x, 13, 100.0, 8000.0, 48000.0, use_fft=True)[1]
+    assert np.max(np.abs(a - b)) < 1e-10
+    assert list(oracle.mfcc_bins(1200, 13, 100.0, 8000.0, 48000.0)) == \
+        [2, 6, 11, 17, 24, 32, 42, 54, 69, 86, 107, 133, 163, 200, 244]
+
+
+# ---- polynomial.rs ---------------------------------------------------------
+
+def test_degree_off_low(oracle):
+    """src/polynomial.rs:269-279."""
+    assert oracle.degree([3.0, 2.0, 4.0, 0.0, 0.0]) == 2
+    assert oracle.off_low([0.0, 0.0, 3.0, 2.0, 4.0]) == 2
+
+
+def test_laguerre(oracle):
+    """src/polynomial.rs:281-292 test_laguerre."""
+    z = oracle.laguerre([1.0, 2.5, 2.0, 3.0], complex(-64.0, -64.0))
+    assert abs(z.real - -0.1070229535872) < 1e-8
+    assert abs(z.imag - -0.8514680262155) < 1e-8
+
+
+def test_1d_2d_roots(oracle):
+    """src/polynomial.rs:294-333 test_1d_roots, test_2d_roots, test_2d_complex_roots (1e-12, order)."""
+    st, r = oracle.find_roots([1.0, 2.5])
+    assert st == 0 and r.size == 1 and abs(r[0] - complex(-0.4, 0.0)) < 1e-12
+    st, r = oracle.find_roots([1.0, 2.5, -2.0])
+    exp = [complex(-0.31872930440884, 0.0), complex(1.5687293044088, 0.0)]
+    assert st == 0 and r.size == 2
+    for a, b in zip(r, exp):
+        assert abs(a.real - b.real) < 1e-12 and abs(a.imag - b.imag) < 1e-12
+    st, r = oracle.find_roots([1.0, -2.5, 2.0])
+    exp = [complex(0.625, -0.33071891388307), complex(0.625, 0.33071891388307)]
+    assert st == 0 and r.size == 2
+    for a, b in zip(r, exp):
+        assert abs(a.real - b.real) < 1e-12 and abs(a.imag - b.imag) < 1e-12
+
+
+def test_hi_d_roots(oracle):
+    """src/polynomial.rs:349-362 test_hi_d_roots (order pinned)."""
+    st, r = oracle.find_roots([1.0, 2.5, -2.0, -3.0])
+    exp = [-1.1409835232292, -0.35308705904629, 0.82740391560878]
+    assert st == 0 and r.size == 3
+    for a, b in zip(r, exp):
+        assert abs(a.real - b) < 1e-6 and abs(a.imag) < 1e-6
+
+
+def test_zero_degree_is_error(oracle):
+    """src/polynomial.rs:95."""
+    st, _ = oracle.find_roots([1.0, 0.0, 0.0])
+    assert st == oracle.ERR_POLYNOMIAL
+
+
+# ---- tests/lib.rs (integration smoke; the reference only prints) ------------
+
+def test_formant_calculation(oracle, golden_dir):
+    """tests/lib.rs:44-90 test_formant_calculation: short_sample.wav, rectangle Windower
+    1024/512 -> 4 frames, p=10, MALE estimates, bandwidth 1.0.  The reference asserts nothing;
+    expected values are restatement-derived and double as regression goldens."""
+    samples, sr = _read_wav16(os.path.join(golden_dir, "short_sample.wav"))
+    assert sr == 11025.0 and samples.size == 2878
+    frames = oracle.frames_view(samples, 1024, 512)
+    assert frames.shape[0] == 4
+    est = np.array([[f, 1.0] for f in (320.0, 1440.0, 2760.0, 3200.0)])
+    exp = [[1030.92, 2724.53, 3719.48, 3200.0],
+           [1032.08, 2689.09, 3705.75, 3200.0],
+           [1025.91, 2695.68, 2695.68, 3709.67],
+           [1042.90, 2696.43, 3704.22, 3709.67]]
+    for fr, e in zip(frames, exp):
+        st, est, _, _ = oracle.find_formants(fr, sr, 10, est)
+        assert st == 0
+        assert np.all(np.abs(est[:, 0] - e) < 0.01)
+
+
+def test_against_praat(oracle, golden_dir):
+    """tests/lib.rs:14-42 test_against_praat: the whole down_sampled.wav through find_formants, p=13."""
+    samples, sr = _read_wav16(os.path.join(golden_dir, "down_sampled.wav"))
+    assert samples.size == 31232
+    est = np.array([[f, 1.0] for f in (320.0, 1440.0, 2760.0, 3200.0)])
+    st, est, res, _ = oracle.find_formants(samples, sr, 13, est)
+    assert st == 0 and np.all(np.isfinite(est))
+    nz = res[res[:, 0] != 0.0, 0]
+    assert np.all(np.diff(nz) >= 0)
