@@ -1,0 +1,246 @@
+/*
+ * voxbox_hip.h -- C ABI of libvoxbox_hip.so: batched, MI355X-native (gfx950)
+ * replacement for the per-frame DSP hot path of the Rust crate vox_box 0.3.0.
+ *
+ * The reference exposes this path as extension traits on slices, called once
+ * per frame from a user loop (examples/pitch_detection.rs:23-30,
+ * tests/lib.rs:71-83).  It has no FFI of its own, so these
+ * entry points ARE what a Rust/cgo/ctypes binding of the path would bind:
+ * one call = the user's whole frame loop (F frames).  Each declaration cites
+ * the reference interface it replaces (file:line under /root/reference).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every data pointer is a DEVICE pointer
+ *    unless the parameter name starts with `h_` (host).  vbx_malloc/vbx_memcpy_*
+ *    are provided so a caller needs no HIP binding of its own; pointers from
+ *    hipMalloc / torch tensors (.data_ptr()) are equally valid.
+ *  - a frame batch is (x, n_frames, frame_len, stride, window): frame t is
+ *    x[t*stride .. t*stride+frame_len) -- stride == frame_len is the dense
+ *    [F, N] batch, stride == hop is the Windower view into contiguous audio
+ *    (sample 0.10 Windower: frame t exists while frame_len <= remaining).
+ *    `window` (device, frame_len doubles, or NULL) is multiplied onto the
+ *    samples on load: the batched form of window::Windower::hanning, whose
+ *    frames the reference's traits receive already windowed.
+ *  - all arithmetic is f64 ("Sample = f64" instantiation of the traits).
+ *  - calls are asynchronous on the context's HIP stream; vbx_sync() waits.
+ *  - return value: 0 ok, <0 API misuse / runtime failure (vbx_last_error()).
+ *    Per-frame conditions that make the reference return Err or panic are
+ *    reported in an int32 status[F] array (codes below) so one bad frame never
+ *    aborts a batch; outputs of such a frame are zero-filled and tracker state
+ *    passes through unchanged (src/lib.rs:75 `?`).
+ *  - there is NO CPU fallback: without a HIP device vbx_ctx_create fails.
+ */
+#ifndef VOXBOX_HIP_H
+#define VOXBOX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VBX_ABI_VERSION 1
+
+/* API return codes */
+#define VBX_SUCCESS 0
+#define VBX_E_INVALID (-1)      /* null pointer / bad size / unsupported shape */
+#define VBX_E_RUNTIME (-2)      /* HIP runtime error */
+#define VBX_E_NODEVICE (-3)     /* no usable gfx950 device */
+
+/* per-frame status codes (VoxBoxError, src/error.rs:4-16, and the panics of the path) */
+#define VBX_FRAME_OK 0
+#define VBX_FRAME_ERR_LPC 1         /* Err(LPC("Denum was <= 0.0")), src/spectrum.rs:123-125 */
+#define VBX_FRAME_ERR_POLYNOMIAL 2  /* Err(Polynomial(..)), src/polynomial.rs:95,123 */
+#define VBX_FRAME_ERR_NAN 3         /* partial_cmp().unwrap() on NaN, src/periodic.rs:453 */
+#define VBX_FRAME_ERR_PANIC 4       /* any other panic of the reference (index out of bounds, assert) */
+
+#define VBX_MAX_RESONANCES 32       /* MAX_RESONANCES, src/lib.rs:26 */
+#define VBX_FORMANT_SLOTS 6         /* FormantSlots, src/spectrum.rs:228 */
+#define VBX_MAX_LPC_ORDER 30        /* 2*order resonances must fit the tracker's fixed arrays */
+#define VBX_MAX_FRAME_LEN 4096      /* register/LDS-resident frame kernels */
+#define VBX_MAX_PITCH_CANDIDATES 64 /* kmax upper bound of vbx_pitch_f64 */
+
+typedef struct vbx_ctx vbx_ctx;
+
+/* #[repr(C)] Resonance<f64>, src/spectrum.rs:149-154 */
+typedef struct { double frequency; double bandwidth; } vbx_resonance;
+/* Pitch<f64>, src/periodic.rs:306-310 */
+typedef struct { double frequency; double strength; } vbx_pitch;
+/* num::Complex<f64> (repr(C): re, im) */
+typedef struct { double re; double im; } vbx_complex;
+
+/* MALE/FEMALE_FORMANT_ESTIMATES, src/lib.rs:27-28 */
+extern const double VBX_MALE_FORMANT_ESTIMATES[4];
+extern const double VBX_FEMALE_FORMANT_ESTIMATES[4];
+
+/* ------------------------------------------------------------------ context */
+
+int vbx_abi_version(void);
+/* device: HIP device ordinal.  hip_stream: a hipStream_t to launch on (e.g. torch's
+ * current stream), or NULL to let the context create and own one. */
+int vbx_ctx_create(vbx_ctx **out, int device, void *hip_stream);
+void vbx_ctx_destroy(vbx_ctx *ctx);
+int vbx_sync(vbx_ctx *ctx);
+const char *vbx_last_error(const vbx_ctx *ctx); /* ctx may be NULL: last global error */
+/* device name (e.g. "gfx950:sramecc+:xnack-"), CU count; any pointer may be NULL */
+int vbx_device_info(const vbx_ctx *ctx, char *h_name, size_t name_cap, int *h_cu_count);
+
+/* device memory helpers (synchronous w.r.t. the host for memcpy) */
+int vbx_malloc(vbx_ctx *ctx, void **out_dptr, size_t bytes);
+int vbx_free(vbx_ctx *ctx, void *dptr);
+int vbx_memcpy_h2d(vbx_ctx *ctx, void *dst, const void *h_src, size_t bytes);
+int vbx_memcpy_d2h(vbx_ctx *ctx, void *h_dst, const void *src, size_t bytes);
+int vbx_memset(vbx_ctx *ctx, void *dst, int value, size_t bytes);
+
+/* HIP-event timing on the context's stream (bench.py's roofline leg).
+ * vbx_timer_begin/end bracket a region; *h_ms is valid after the call returns. */
+int vbx_timer_begin(vbx_ctx *ctx);
+int vbx_timer_end(vbx_ctx *ctx, float *h_ms);
+/* Per-kernel event profile: when enabled every kernel launch is bracketed by
+ * events; vbx_profile_get sums them by kernel name (synchronises the stream). */
+int vbx_profile_enable(vbx_ctx *ctx, int on);
+int vbx_profile_reset(vbx_ctx *ctx);
+int vbx_profile_get(vbx_ctx *ctx, const char *kernel_name, double *h_total_ms, long *h_launches);
+/* names of profiled kernels, '\n'-separated, into h_buf */
+int vbx_profile_names(vbx_ctx *ctx, char *h_buf, size_t cap);
+
+/* ------------------------------------------------------------------ tables (host) */
+
+/* sample 0.10 window tables, built on the host with the reference's recurrences.
+ *  VBX_WINDOW_HANNING          Window::<Hanning>::new(n): phase accumulated by 1/(n-1), % 1.0
+ *                              (Windower::hanning, examples/pitch_detection.rs:23)
+ *  VBX_WINDOW_HANNING_LAG      HanningLag::at_phase over the same phases (src/periodic.rs:236-248,:400)
+ *  VBX_WINDOW_HANNING_PERIODIC Hanning::at_phase(idx/len) (src/lib.rs:66-70)
+ *  VBX_WINDOW_RECTANGLE        all ones (Windower::rectangle, tests/lib.rs:71) */
+#define VBX_WINDOW_HANNING 0
+#define VBX_WINDOW_HANNING_LAG 1
+#define VBX_WINDOW_HANNING_PERIODIC 2
+#define VBX_WINDOW_RECTANGLE 3
+int vbx_window_table_f64(int kind, size_t n, double *h_out);
+/* number of Windower frames: (n_samples - frame_len)/hop + 1 while frame_len <= remaining */
+size_t vbx_frame_count(size_t n_samples, size_t frame_len, size_t hop);
+
+/* hz_to_mel / mel_to_hz, src/spectrum.rs:375-381 (host scalars) */
+double vbx_hz_to_mel(double hz);
+double vbx_mel_to_hz(double mel);
+/* find_formants_real_work_size / _complex_work_size, src/lib.rs:30-36.  The library owns
+ * its workspaces; these exist so ported callers that size buffers keep compiling. */
+size_t vbx_find_formants_real_work_size(size_t buf_len, size_t n_coeffs);
+size_t vbx_find_formants_complex_work_size(size_t n_coeffs);
+
+/* ------------------------------------------------------------------ periodic.rs */
+
+/* Autocorrelate::autocorrelate(n_lags) per frame (src/periodic.rs:265-289), including the
+ * fold seed quirk r[lag] = x[0] + sum_{i>=1} x[i]*x[i+lag].  out: [F, n_lags]. */
+int vbx_autocorrelate_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
+                          size_t stride, const double *window, size_t n_lags, double *out);
+
+/* Normalize::normalize on each row (src/waves.rs:60-76): row *= 1/max|row|.  data: [F, n] in place. */
+int vbx_normalize_f64(vbx_ctx *ctx, double *data, size_t n_rows, size_t n);
+
+/* interpolate_sinc (src/periodic.rs:29-87) of one lag curve y[ylen] at M query points.
+ * status[M] (optional) receives VBX_FRAME_ERR_PANIC where the reference would index out of bounds. */
+int vbx_interpolate_sinc_f64(vbx_ctx *ctx, const double *y, size_t ylen, long offset, size_t nx,
+                             const double *xs, size_t m, size_t max_depth, double *out, int32_t *status);
+
+/* improve_extremum(.., Interpolation::Sinc(depth), is_max = true) (src/periodic.rs:192-229)
+ * at M starting points; out_xy: [M, 2] = (xmid, ymid). */
+int vbx_improve_extremum_f64(vbx_ctx *ctx, const double *y, size_t ylen, long offset, size_t nx,
+                             const double *ixmid, size_t m, size_t depth, double *out_xy, int32_t *status);
+
+/* Pitched::pitch::<Hanning>(sample_rate, threshold, _, _, min, max) per frame
+ * (src/periodic.rs:356-358,396-455; local_peak/global_peak are unused by the reference).
+ * out_cand: [F, kmax] candidates, stable-sorted by descending strength exactly as the
+ * reference's Vec (entries past count are zero); out_count[F] = full candidate count
+ * (may exceed kmax).  PitchExtractor (src/periodic.rs:337-353) output = out_cand[f*kmax + 0]. */
+int vbx_pitch_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
+                  const double *window, double sample_rate, double threshold, double fmin, double fmax,
+                  size_t kmax, vbx_pitch *out_cand, int32_t *out_count, int32_t *status);
+
+/* ------------------------------------------------------------------ spectrum.rs: LPC */
+
+/* LPC::lpc(n_coeffs) on autocorrelation rows (Levinson-Durbin, src/spectrum.rs:63-92).
+ * r: [F, r_stride] with r_stride >= n_coeffs+1; out: [F, n_coeffs+1] = [1, a1..ap]. */
+int vbx_lpc_f64(vbx_ctx *ctx, const double *r, size_t n_frames, size_t r_stride,
+                size_t n_coeffs, double *out);
+
+/* frame.autocorrelate(n_coeffs+1) [-> .normalize()] -> .lpc(n_coeffs) fused, one pass over the
+ * samples (LPCSolver usage, src/spectrum.rs:40-42,470-479).  out_r: [F, n_coeffs+1] (after the
+ * optional normalize), out_lpc: [F, n_coeffs+1]; either may be NULL. */
+int vbx_autocorr_lpc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
+                         size_t stride, const double *window, size_t n_coeffs, int normalize,
+                         double *out_r, double *out_lpc);
+
+/* LPC::lpc_praat(n_coeffs) per frame (Burg, src/spectrum.rs:94-146).  out: [F, n_coeffs]
+ * (no leading 1, sign-flipped as the reference); status[F]: VBX_FRAME_ERR_LPC when denum <= 0. */
+int vbx_lpc_burg_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
+                     size_t stride, const double *window, size_t n_coeffs, double *out, int32_t *status);
+
+/* ------------------------------------------------------------------ polynomial.rs */
+
+/* Polynomial::find_roots_mut on F polynomials of `len` coefficients (coefficient of x^j at
+ * index j), src/polynomial.rs:92-152: Laguerre from -2-2i with deflation, quadratic/linear
+ * tail; roots are written in discovery order, remainder zeroed.  polys: [F, len] in/out. */
+int vbx_find_roots_c64(vbx_ctx *ctx, vbx_complex *polys, size_t n_polys, size_t len, int32_t *status);
+
+/* Polynomial::laguerre(start) (src/polynomial.rs:34-72) on F polynomials; out: [F]. */
+int vbx_laguerre_c64(vbx_ctx *ctx, const vbx_complex *polys, size_t n_polys, size_t len,
+                     vbx_complex start, vbx_complex *out);
+
+/* ------------------------------------------------------------------ spectrum.rs: resonances, tracker */
+
+/* ToResonance::to_resonance(sample_rate) per row of roots (src/spectrum.rs:165-210): roots with
+ * im >= 0, reflected inside the unit circle, 50 Hz < f < nyquist-50, sorted by frequency.
+ * roots: [F, n_roots]; out_res: [F, n_roots] zero padded; out_count[F]. */
+int vbx_to_resonance_c64(vbx_ctx *ctx, const vbx_complex *roots, size_t n_rows, size_t n_roots,
+                         double sample_rate, vbx_resonance *out_res, int32_t *out_count);
+
+/* EstimateFormants::estimate_formants carried frame to frame = FormantExtractor
+ * (src/spectrum.rs:216-369).  The scan is sequential in the reference (the caller passes the
+ * previous frame's estimates back in, tests/lib.rs:75-79); it is batched per utterance:
+ * h_seg_start[n_segments] (HOST array) are the ascending frame indices at which the caller's
+ * state is reset to est_init (h_seg_start[0] must be 0; NULL/0 = one segment).  res: [F, n_res]
+ * resonance rows exactly as the reference passes them (zero padded); frame_status (optional):
+ * frames with status != 0 leave the state untouched.  out: [F, n_est] estimates after each frame. */
+int vbx_estimate_formants_f64(vbx_ctx *ctx, const vbx_resonance *res, size_t n_frames, size_t n_res,
+                              const int64_t *h_seg_start, size_t n_segments,
+                              const vbx_resonance *h_est_init, size_t n_est,
+                              const int32_t *frame_status, vbx_resonance *out);
+
+/* vox_box::find_formants(buf, sample_rate, 1.0, .., n_coeffs, .., formants) over F frames
+ * (src/lib.rs:40-116): periodic Hanning -> Burg -> reversed complex polynomial -> find_roots_mut
+ * -> Resonance::from_root (im > 0) -> sort -> estimate_formants.  `window` must be NULL for
+ * rectangular input frames as in tests/lib.rs:71 (the periodic Hanning is applied inside).
+ * out_formants: [F, n_est]; out_res (optional): [F, 32] zero padded; out_res_count (optional): [F];
+ * out_coeffs (optional): [F, n_coeffs] Burg coefficients; status[F]. */
+int vbx_find_formants_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
+                          size_t stride, double sample_rate, size_t n_coeffs,
+                          const int64_t *h_seg_start, size_t n_segments,
+                          const vbx_resonance *h_est_init, size_t n_est,
+                          vbx_resonance *out_formants, vbx_resonance *out_res, int32_t *out_res_count,
+                          double *out_coeffs, int32_t *status);
+
+/* ------------------------------------------------------------------ spectrum.rs: MFCC */
+
+/* MFCC::mfcc(num_coeffs, (lo, hi), sample_rate) per frame (src/spectrum.rs:401-441).
+ * out: [F, num_coeffs]; status[F]: VBX_FRAME_ERR_PANIC when a mel bin exceeds the spectrum. */
+int vbx_mfcc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
+                 const double *window, size_t num_coeffs, double lo_hz, double hi_hz,
+                 double sample_rate, double *out, int32_t *status);
+
+/* dct (src/spectrum.rs:384-398) on rows: in/out [F, n]. */
+int vbx_dct_f64(vbx_ctx *ctx, const double *in, size_t n_rows, size_t n, double *out);
+
+/* ------------------------------------------------------------------ bench utility */
+
+/* Deterministic speech-like synthetic audio (DESIGN.md "synthetic signal"): samples
+ * [sample_offset, sample_offset + n_samples) of an endless 48 kHz-style stream defined in
+ * closed form per sample, so any shard can be generated in place on its own GPU. */
+int vbx_synth_speech_f64(vbx_ctx *ctx, double *out, size_t n_samples, uint64_t sample_offset,
+                         double sample_rate, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOXBOX_HIP_H */

@@ -1,0 +1,89 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/voxbox_hip.h declares, refuses to run without a GPU (no CPU fallback), and its
+host-built tables equal the oracle's statement of the sample-crate recurrences."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.load_library()
+    names = pkg.exported_symbols()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), f"libvoxbox_hip.so lacks {n}"
+    assert lib.vbx_abi_version() == 1
+
+
+def test_no_cpu_fallback(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.VoxBoxError):
+        pkg.VoxBox(0)
+
+
+def test_product_does_not_touch_the_oracle():
+    """The shipped path must never import / link the oracle."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "vox_box.rs_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "pyoracle" not in text and "vbx_oracle" not in text and "vbxo_" not in text, f
+    out = subprocess.run(["ldd", os.path.join(root, "vox_box.rs_amd", "lib", "libvoxbox_hip.so")],
+                         capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
+@pytest.mark.parametrize("n", [2, 16, 512, 1200, 2048])
+def test_window_tables_match_oracle(pkg, oracle, n):
+    for kind, name in ((pkg.WINDOW_HANNING, "hanning"), (pkg.WINDOW_HANNING_LAG, "hanning_lag"),
+                       (pkg.WINDOW_HANNING_PERIODIC, "hanning_periodic")):
+        assert np.array_equal(pkg.window_table(kind, n), oracle.window(name, n)), (name, n)
+    assert np.all(pkg.window_table(pkg.WINDOW_RECTANGLE, n) == 1.0)
+
+
+def test_frame_count_is_windower_semantics(pkg, oracle):
+    # examples/pitch_detection.rs:23: 2049 samples, bin 2048, hop 1024 -> one frame
+    assert pkg.frame_count(2049, 2048, 1024) == 1
+    # tests/lib.rs:71: 2878 samples, bin 1024, hop 512 -> 4 frames
+    assert pkg.frame_count(2878, 1024, 512) == 4
+    assert pkg.frame_count(100, 1024, 512) == 0
+    for s, n, h in ((48000, 1200, 480), (1200, 1200, 480), (1679, 1200, 480), (1680, 1200, 480)):
+        assert pkg.frame_count(s, n, h) == oracle.frames_view(np.zeros(s), n, h).shape[0]
+
+
+def test_mel_scalars(pkg, oracle):
+    for hz in (0.0, 100.0, 300.0, 8000.0):
+        assert pkg.hz_to_mel(hz) == oracle.hz_to_mel(hz)
+        assert pkg.mel_to_hz(pkg.hz_to_mel(hz)) == oracle.mel_to_hz(oracle.hz_to_mel(hz))
+    lib = pkg.load_library()
+    assert lib.vbx_find_formants_real_work_size(1024, 10) == 1024 * 2 + 10 * 23 + 2   # src/lib.rs:30-32
+    assert lib.vbx_find_formants_complex_work_size(10) == 74                           # src/lib.rs:34-36
+
+
+def test_host_synth_is_deterministic(pkg):
+    import __graft_entry__ as g
+    synth = __import__("importlib").import_module(g.PKG_NAME + ".synth")
+    a = synth.synth_speech(4800, sample_offset=100)
+    b = synth.synth_speech(2400, sample_offset=2500)
+    assert np.array_equal(a[2400:], b)
+    assert np.max(np.abs(a)) < 1.0
+    un = synth.synth_speech(100, sample_offset=4 * 48000 + 10)
+    assert np.max(np.abs(un)) <= 0.05
+
+
+def test_cpp_host_mirror_compiles():
+    """host/voxbox.hpp (C++ mirror of the trait surface) compiles against the C ABI."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "vox_box.rs_amd", "host", "voxbox.hpp")
+    if not os.path.exists(hdr):
+        pytest.skip("host mirror not present")
+    src = '#include "voxbox.hpp"\nint main(){ return vbx_abi_version() == VBX_ABI_VERSION ? 0 : 1; }\n'
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(root, "include"),
+                        "-I", os.path.dirname(hdr), "-x", "c++", "-"], input=src, text=True, capture_output=True)
+    assert r.returncode == 0, r.stderr

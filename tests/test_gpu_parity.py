@@ -1,0 +1,421 @@
+"""Parity tests proper: every entry point of libvoxbox_hip.so (called through the C ABI)
+against the CPU oracle on identical inputs.  Tolerances are BASELINE.json's:
+autocorrelation / LPC 1e-6 relative (SURVEY 8d metric), pitch / formant Hz 1e-4 relative,
+candidate counts and statuses exact.  Needs a real MI355X: run with `-m gpu`.
+"""
+import os
+import wave
+
+import numpy as np
+import pytest
+
+from conftest import rel_close
+
+pytestmark = pytest.mark.gpu
+
+SR = 48000.0
+N48, H48 = 1200, 480
+
+
+def _read_wav16(path):
+    with wave.open(path, "rb") as w:
+        sr = w.getframerate()
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+    return pcm.astype(np.float64) / 32767.0, float(sr)
+
+
+@pytest.fixture(scope="module")
+def audio(vb):
+    """6 s of device-generated synthetic speech pulled back to the host: seconds 2..8 of the
+    stream, i.e. voiced glide + one fully unvoiced second (4..5)."""
+    d = vb.synth_speech(6 * 48000, sample_offset=2 * 48000)
+    a = d.numpy()
+    d.free()
+    return a
+
+
+def _frames(audio, n, hop, idx):
+    return np.stack([audio[t * hop:t * hop + n] for t in idx])
+
+
+# ---- cross-lane helpers -----------------------------------------------------------------
+
+def test_lane_helpers(vb):
+    o = vb.selftest_lanes()
+    v = 1.0 + 0.37 * np.arange(64) + 1e-3 * ((np.arange(64) * 7919) % 64)
+    assert np.array_equal(o[:, 0], o[:, 1]), "DPP wave_shl:1 != __shfl_down"
+    assert np.array_equal(o[:, 2], o[:, 3]), "DPP wave_shr:1 != __shfl_up"
+    assert np.array_equal(o[:-1, 0], v[1:]) and o[63, 0] == 0.0
+    assert np.all(np.abs(o[:, 4] - v.sum()) < 1e-10) and np.all(o[:, 4] == o[0, 4])
+    assert np.all(np.abs(o[:, 5] - v.sum()) < 1e-10)
+    assert np.all(o[:, 6] == v.max())
+    assert np.all(o[:, 7] == v[17])
+
+
+def test_synth_matches_host_statement(vb, pkg, audio):
+    import importlib
+    import __graft_entry__ as g
+    synth = importlib.import_module(g.PKG_NAME + ".synth")
+    host = synth.synth_speech(audio.size, sample_offset=2 * 48000)
+    assert np.max(np.abs(host - audio)) < 1e-9
+    assert np.max(np.abs(audio)) < 1.0 and np.std(audio) > 0.01
+
+
+# ---- autocorrelate / normalize / lpc --------------------------------------------------------
+
+@pytest.mark.parametrize("n,lags", [(512, 13), (512, 1), (16, 16), (100, 7), (1200, 13), (1200, 1200),
+                                    (333, 333), (2048, 17), (4096, 40), (640, 321), (64, 64), (5, 5)])
+def test_autocorrelate(vb, oracle, n, lags):
+    rng = np.random.default_rng(n * 1000 + lags)
+    x = rng.uniform(-1, 1, (9, n))          # rectangular frames: x[0] != 0 exercises the Q1 seed
+    got = vb.autocorrelate(x, lags)
+    for f in range(x.shape[0]):
+        exp = oracle.autocorrelate(x[f], lags)
+        assert np.all(rel_close(got[f], exp)), (f, np.max(np.abs(got[f] - exp)))
+
+
+def test_autocorrelate_strided_windowed(vb, oracle, pkg, audio):
+    F = pkg.frame_count(audio.size, N48, H48)
+    d = vb.to_device(audio)
+    w = vb.window(pkg.WINDOW_HANNING, N48)
+    got = vb.autocorrelate(d, 13, frame_len=N48, stride=H48, n_frames=F, window=w)
+    wh = oracle.window("hanning", N48)
+    for f in range(0, F, 37):
+        exp = oracle.autocorrelate(audio[f * H48:f * H48 + N48] * wh, 13)
+        assert np.all(rel_close(got[f], exp)), f
+    d.free()
+
+
+def test_empty_batch_is_a_noop(vb):
+    assert vb.autocorrelate(np.zeros((0, 512)), 13).shape == (0, 13)
+    c, cnt, st = vb.pitch(np.zeros((0, 512)), SR, 0.2, 75., 600.)
+    assert cnt.size == 0
+
+
+def test_normalize(vb, oracle):
+    rng = np.random.default_rng(3)
+    rows = rng.standard_normal((7, 100))
+    got = vb.normalize(rows)
+    for f in range(7):
+        assert np.all(rel_close(got[f], oracle.normalize(rows[f]), 1e-14))
+
+
+def test_lpc_kat(vb, oracle):
+    """src/spectrum.rs:470-487 test_lpc through the GPU path."""
+    s = oracle.sine(8, 8.0, 1.0)
+    r = vb.autocorrelate(s[None, :], 8)
+    auto = vb.normalize(r)
+    assert np.all(np.abs(auto[0] - [1.0, 0.7071, 0.1250, -0.3536, -0.5, -0.3536, -0.1250, 0.0]) < 1e-4)
+    lpc = vb.lpc(auto, 4)
+    assert np.all(np.abs(lpc[0] - [1.0, -1.3122, 0.8660, -0.0875, -0.0103]) < 1e-4)
+    r2, a2 = vb.autocorr_lpc(s[None, :], 4, normalize=True)
+    assert np.all(np.abs(a2[0] - lpc[0]) < 1e-12)
+
+
+@pytest.mark.parametrize("n,p,norm", [(512, 12, False), (512, 12, True), (1200, 12, False), (256, 8, False),
+                                      (700, 16, True), (512, 10, False), (300, 20, False)])
+def test_autocorr_lpc(vb, oracle, n, p, norm):
+    rng = np.random.default_rng(n + p)
+    t = np.arange(n)
+    x = np.stack([np.sin(2 * np.pi * (0.01 + 0.002 * k) * t) * 0.5 + 0.2 * rng.standard_normal(n) for k in range(8)])
+    x *= oracle.window("hanning", n)
+    r, a = vb.autocorr_lpc(x, p, normalize=norm)
+    for f in range(8):
+        er = oracle.autocorrelate(x[f], p + 1)
+        if norm:
+            er = oracle.normalize(er)
+        ea = oracle.lpc(er, p)
+        assert np.all(rel_close(r[f], er)), (f, "r")
+        assert np.all(rel_close(a[f], ea)), (f, "lpc", np.max(np.abs(a[f] - ea)))
+
+
+# ---- Burg -------------------------------------------------------------------------------------
+
+def test_lpc_praat_kat(vb, oracle):
+    """src/spectrum.rs:512-525 test_lpc_praat (1e-10) through the GPU path."""
+    src = np.array(list(range(1, 11)) + list(range(10, 0, -1)), dtype=np.float64)
+    co, st = vb.lpc_praat(src[None, :], 5)
+    exp = [-2.529731754197289, 2.6138925001574935, -1.6951059551991234, 0.7776548472652218, -0.15008712022777612]
+    assert st[0] == 0 and np.all(np.abs(co[0] - exp) < 1e-10)
+
+
+@pytest.mark.parametrize("n,p", [(512, 12), (1200, 12), (1024, 10), (100, 5), (2049, 13), (4096, 8), (30, 4), (513, 30)])
+def test_lpc_praat(vb, oracle, n, p):
+    rng = np.random.default_rng(n * 31 + p)
+    t = np.arange(n)
+    x = np.stack([0.6 * np.sin(2 * np.pi * (0.013 + 0.004 * k) * t) + 0.3 * np.sin(2 * np.pi * 0.11 * t + k)
+                  + 0.05 * rng.standard_normal(n) for k in range(6)])
+    x[5] = 0.0                                        # all-zero frame -> Err(LPC) (src/spectrum.rs:123-125)
+    co, st = vb.lpc_praat(x, p)
+    for f in range(6):
+        es, ec = oracle.lpc_burg(x[f], p)
+        assert st[f] == es, f
+        if es == 0:
+            assert np.all(rel_close(co[f], ec)), (f, np.max(np.abs(co[f] - ec)))
+        else:
+            assert np.all(co[f] == 0.0)
+
+
+# ---- polynomial ---------------------------------------------------------------------------------
+
+def test_roots_kats(vb, oracle):
+    """src/polynomial.rs:281-362 known answers through the GPU path (values AND discovery order)."""
+    z = vb.laguerre(np.array([[1.0, 2.5, 2.0, 3.0]]), complex(-64.0, -64.0))[0]
+    assert abs(z.real - -0.1070229535872) < 1e-8 and abs(z.imag - -0.8514680262155) < 1e-8
+    r, st = vb.find_roots(np.array([[1.0, 2.5]]))
+    assert st[0] == 0 and abs(r[0, 0] - (-0.4)) < 1e-12
+    r, st = vb.find_roots(np.array([[1.0, 2.5, -2.0]]))
+    assert st[0] == 0 and abs(r[0, 0] - (-0.31872930440884)) < 1e-12 and abs(r[0, 1] - 1.5687293044088) < 1e-12
+    r, st = vb.find_roots(np.array([[1.0, -2.5, 2.0]]))
+    assert abs(r[0, 0] - complex(0.625, -0.33071891388307)) < 1e-12
+    assert abs(r[0, 1] - complex(0.625, 0.33071891388307)) < 1e-12
+    r, st = vb.find_roots(np.array([[1.0, 2.5, -2.0, -3.0]]))
+    for a, b in zip(r[0, :3], [-1.1409835232292, -0.35308705904629, 0.82740391560878]):
+        assert abs(a - b) < 1e-6
+    r, st = vb.find_roots(np.array([[1.0, 0.0, 0.0]]))
+    assert st[0] == 2                                  # Err(Polynomial), src/polynomial.rs:95
+    # src/spectrum.rs:615-633: the 4th root found must be the 4045 Hz one
+    co = [-0.80098309, 1.20869679, -1.61846677, 0.86630291, -1.44203292, 0.93621726, -0.58772811, 0.65949051]
+    r, st = vb.find_roots(np.array([([1.0] + co)[::-1]]))
+    res, cnt = vb.to_resonance(r[:, 3:4], 11025.0)
+    assert cnt[0] == 1 and abs(res[0, 0, 0] - 4045.196) < 1.0
+
+
+def test_find_roots_random(vb, oracle):
+    rng = np.random.default_rng(11)
+    for deg in (3, 5, 8, 12, 13, 20):
+        polys = rng.standard_normal((40, deg + 1)) + 0j
+        polys[:, -1] = 1.0
+        polys[3, -1] = 0.0                              # lower effective degree (degree() < len-1)
+        polys[4, :] = 0.0; polys[4, 0] = 1.0            # zero-degree -> Err(Polynomial)
+        got, st = vb.find_roots(polys)
+        for f in range(polys.shape[0]):
+            es, er = oracle.find_roots_mut(polys[f])
+            assert st[f] == es, (deg, f, st[f], es)
+            if es == 0:
+                assert np.all(np.abs(got[f] - er) <= 1e-7 * np.maximum(1.0, np.abs(er))), (deg, f)
+
+
+def test_to_resonance(vb, oracle):
+    """src/spectrum.rs:461-468 test_resonances + random rows."""
+    res, cnt = vb.to_resonance(np.array([[complex(-0.5, 0.86602540378444), complex(-0.5, -0.86602540378444)]]), 300.0)
+    assert cnt[0] == 1 and abs(res[0, 0, 0] - 100.0) < 1e-8 and abs(res[0, 0, 1]) < 1e-8
+    rng = np.random.default_rng(5)
+    roots = (rng.uniform(0.3, 1.3, (50, 12)) * np.exp(1j * rng.uniform(-np.pi, np.pi, (50, 12))))
+    res, cnt = vb.to_resonance(roots, SR)
+    for f in range(50):
+        e = oracle.to_resonance(roots[f], SR)
+        assert cnt[f] == e.shape[0]
+        assert np.all(rel_close(res[f, :cnt[f]], e, 1e-10))
+        assert np.all(res[f, cnt[f]:] == 0.0)
+
+
+# ---- tracker -----------------------------------------------------------------------------------
+
+def test_formant_extractor_kat(vb):
+    """src/spectrum.rs:527-567 test_formant_extractor (exact) through the GPU scan."""
+    fr = np.array([[100.0, 150.0, 200.0, 240.0, 300.0], [110.0, 180.0, 210.0, 230.0, 310.0],
+                   [230.0, 270.0, 290.0, 350.0, 360.0]])
+    res = np.stack([fr, np.ones_like(fr)], axis=-1)
+    est = np.array([[140.0, 1.0], [230.0, 1.0], [320.0, 1.0]])
+    out = vb.estimate_formants(res, est)
+    assert out[:, :, 0].tolist() == [[150.0, 240.0, 300.0], [180.0, 230.0, 310.0], [230.0, 270.0, 290.0]]
+
+
+def test_estimate_formants_random_segments(vb, oracle):
+    rng = np.random.default_rng(17)
+    F, R = 400, 32
+    res = np.zeros((F, R, 2))
+    for f in range(F):
+        c = rng.integers(0, 7)
+        fr = np.sort(rng.uniform(60, 5000, c))
+        if c >= 2 and rng.random() < 0.3:
+            fr[1] = fr[0]                                # duplicates
+        res[f, :c, 0] = fr
+        res[f, :c, 1] = rng.uniform(10, 400, c)
+    est0 = np.array([[320.0, 1.0], [1440.0, 1.0], [2760.0, 1.0], [3200.0, 1.0]])
+    seg = np.array([0, 50, 51, 200, 399])
+    status = np.zeros(F, dtype=np.int32); status[[7, 120]] = 1
+    got = vb.estimate_formants(res, est0, seg_start=seg, frame_status=status)
+    est = None
+    for f in range(F):
+        if f in seg:
+            est = est0.copy()
+        if status[f] == 0:
+            est = oracle.estimate_formants(est, res[f])
+        assert np.array_equal(got[f], est), f
+
+
+# ---- find_formants ---------------------------------------------------------------------------------
+
+def test_find_formants_wav_fixture(vb, oracle, golden_dir):
+    """tests/lib.rs:44-90: short_sample.wav, rectangle Windower 1024/512, p = 10."""
+    samples, sr = _read_wav16(os.path.join(golden_dir, "short_sample.wav"))
+    est0 = np.array([[f, 1.0] for f in (320.0, 1440.0, 2760.0, 3200.0)])
+    out = vb.find_formants(samples, sr, 10, est0, frame_len=1024, stride=512)
+    assert out["formants"].shape == (4, 4, 2) and np.all(out["status"] == 0)
+    exp = [[1030.92, 2724.53, 3719.48, 3200.0], [1032.08, 2689.09, 3705.75, 3200.0],
+           [1025.91, 2695.68, 2695.68, 3709.67], [1042.90, 2696.43, 3704.22, 3709.67]]
+    assert np.all(np.abs(out["formants"][:, :, 0] - exp) < 0.01)
+    est = est0.copy()
+    for t in range(4):
+        st, est, res, co = oracle.find_formants(samples[t * 512:t * 512 + 1024], sr, 10, est)
+        assert np.all(rel_close(out["coeffs"][t], co))
+        assert np.all(np.abs(out["res"][t] - res) <= 1e-4 * np.abs(res) + 1e-9)
+        assert np.all(np.abs(out["formants"][t] - est) <= 1e-4 * np.abs(est))
+
+
+@pytest.mark.parametrize("n,hop,p", [(N48, H48, 12), (512, 480, 12), (1024, 512, 10)])
+def test_find_formants_synthetic(vb, oracle, audio, pkg, n, hop, p):
+    F = min(pkg.frame_count(audio.size, n, hop), 420)
+    est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+    seg = np.array([0, 100, 250])
+    d = vb.to_device(audio)
+    out = vb.find_formants(d, SR, p, est0, seg_start=seg, frame_len=n, stride=hop, n_frames=F)
+    d.free()
+    est = None
+    bad = 0
+    for t in range(F):
+        if t in seg:
+            est = est0.copy()
+        st, est, res, co = oracle.find_formants(audio[t * hop:t * hop + n], SR, p, est)
+        assert out["status"][t] == st
+        assert np.all(rel_close(out["coeffs"][t], co)), t
+        assert out["count"][t] == int(np.sum(res[:, 0] != 0.0)), t
+        ok = np.all(np.abs(out["res"][t] - res) <= 1e-4 * np.abs(res) + 1e-9) and \
+            np.all(np.abs(out["formants"][t] - est) <= 1e-4 * np.abs(est))
+        bad += 0 if ok else 1
+    assert bad == 0, f"{bad} of {F} frames outside 1e-4"
+
+
+# ---- sinc / Brent ------------------------------------------------------------------------------
+
+def _lag_curve(oracle, x):
+    n = x.size
+    r = oracle.normalize(oracle.autocorrelate(x, n)) / oracle.window("hanning_lag", n)
+    return np.concatenate([r, np.zeros(n)])
+
+
+def test_interpolate_sinc_points(vb, oracle, audio):
+    x = audio[1000:1000 + N48] * oracle.window("hanning", N48)
+    y = _lag_curve(oracle, x)
+    b = N48 // 2
+    offset, nx = -b - 1, 2 * b + 1
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([rng.uniform(b + 2, 2 * b, 300), [b + 1 + 100.0, b + 1 + 100.0 + 5e-11, -1.0, nx + 5.0, b + 1.5]])
+    for depth in (30, 1200):
+        got, st = vb.interpolate_sinc(y, offset, nx, xs, depth)
+        for i, xv in enumerate(xs):
+            es, ev = oracle.interpolate_sinc(y, offset, nx, xv, depth)
+            assert st[i] == es
+            assert abs(got[i] - ev) <= 1e-9 * max(1.0, abs(ev)), (depth, xv, got[i], ev)
+
+
+def test_improve_extremum_points(vb, oracle, audio):
+    x = audio[20000:20000 + N48] * oracle.window("hanning", N48)
+    y = _lag_curve(oracle, x)
+    b = N48 // 2
+    offset, nx = -b - 1, 2 * b + 1
+    peaks = [k for k in range(1, b - 1) if y[k - 1] < y[k] > y[k + 1] and 80 < k < 590]
+    ix = np.array([k + 0.01 * ((k * 7) % 10) - offset for k in peaks] + [0.0, float(nx), nx + 3.0])
+    got, st = vb.improve_extremum(y, offset, nx, ix, 1200)
+    for i, v in enumerate(ix):
+        es, ex, ey = oracle.improve_extremum_sinc(y, offset, nx, v, 1200)
+        assert st[i] == es
+        assert abs(got[i, 0] - ex) <= 1e-6 * max(1.0, abs(ex)), (v, got[i], ex, ey)
+        assert abs(got[i, 1] - ey) <= 1e-6 * max(1.0, abs(ey)), (v, got[i], ex, ey)
+
+
+# ---- pitch ----------------------------------------------------------------------------------------
+
+def test_pitch_kat(vb, oracle, pkg):
+    """src/periodic.rs:484-499 test_pitch / examples/pitch_detection.rs: 150 Hz sine @44.1 kHz."""
+    sig = oracle.sine(2049, 44100.0, 150.0)
+    d = vb.to_device(sig)
+    w = vb.window(pkg.WINDOW_HANNING, 2048)
+    cand, cnt, st = vb.pitch(d, 44100.0, 0.2, 100.0, 500.0, kmax=4, frame_len=2048, stride=1024, n_frames=1, window=w)
+    assert st[0] == 0 and cnt[0] == 2
+    assert abs(cand[0, 0, 0] - 150.0) < 1e-2
+    assert abs(cand[0, 0, 0] - 149.9999843470686) < 1e-4 * 150 and abs(cand[0, 0, 1] - 0.9997482091589159) < 1e-6
+    assert cand[0, 1, 0] == 0.0 and cand[0, 1, 1] == 0.2
+    # Q8 quantisation: 137.3 Hz @ 48 kHz -> 48000/350
+    s2 = oracle.sine(1200, 48000.0, 137.3)
+    cand, cnt, st = vb.pitch(s2[None, :] * oracle.window("hanning", 1200), 48000.0, 0.2, 75.0, 600.0)
+    assert abs(cand[0, 0, 0] - 137.1428566729394) < 1e-4 * 137 and abs(cand[0, 0, 1] - 0.9985693856763005) < 1e-6
+
+
+def _check_pitch(vb, oracle, frames_windowed, sr, thr, fmin, fmax, kmax):
+    cand, cnt, st = vb.pitch(frames_windowed, sr, thr, fmin, fmax, kmax=kmax)
+    n_bad = 0
+    for f in range(frames_windowed.shape[0]):
+        es, ec, en = oracle.pitch(frames_windowed[f], sr, thr, fmin, fmax)
+        assert st[f] == es, (f, st[f], es)
+        assert cnt[f] == en, (f, cnt[f], en)
+        k = min(kmax, en)
+        ok = np.all(np.abs(cand[f, :k, 0] - ec[:k, 0]) <= 1e-4 * np.abs(ec[:k, 0])) and \
+            np.all(np.abs(cand[f, :k, 1] - ec[:k, 1]) <= 1e-6 * np.maximum(np.abs(ec[:k, 1]), 1e-3))
+        if not ok:
+            n_bad += 1
+        assert np.all(cand[f, k:] == 0.0)
+    return n_bad
+
+
+def test_pitch_synthetic_voiced_and_unvoiced(vb, oracle, audio, pkg):
+    F = pkg.frame_count(audio.size, N48, H48)
+    idx = list(range(0, F, 9))                          # spans the voiced glide and the noise-only second
+    x = _frames(audio, N48, H48, idx) * oracle.window("hanning", N48)
+    assert _check_pitch(vb, oracle, x, SR, 0.2, 75.0, 600.0, 8) == 0
+
+
+def test_pitch_full_candidate_list(vb, oracle, audio):
+    x = _frames(audio, N48, H48, [5, 150, 260, 300]) * oracle.window("hanning", N48)   # 260/300: unvoiced
+    assert _check_pitch(vb, oracle, x, SR, 0.2, 75.0, 600.0, 64) == 0
+
+
+@pytest.mark.parametrize("n", [64, 100, 256, 513, 2048])
+def test_pitch_other_frame_lengths(vb, oracle, audio, n):
+    x = _frames(audio, n, 211, range(0, 40, 3)) * oracle.window("hanning", n)
+    assert _check_pitch(vb, oracle, x, SR, 0.45, 60.0, 2000.0, 8) == 0
+
+
+def test_pitch_edge_frames(vb, oracle):
+    z = np.zeros((2, 512))
+    z[1, :] = 1e-3                                        # constant frame
+    cand, cnt, st = vb.pitch(z, SR, 0.2, 75.0, 600.0, kmax=4)
+    for f in range(2):
+        es, ec, en = oracle.pitch(z[f], SR, 0.2, 75.0, 600.0)
+        assert st[f] == es and cnt[f] == en
+        if es == 0:
+            assert np.all(np.abs(cand[f, :min(4, en)] - ec[:4]) <= 1e-9)
+
+
+# ---- MFCC --------------------------------------------------------------------------------------------
+
+def test_dct_kat(vb):
+    """src/spectrum.rs:604-613 test_dct."""
+    d = vb.dct(np.array([[0.2, 0.3, 0.4, 0.3]]))
+    assert np.all(np.abs(d[0] - [2.4, -0.26131, -0.28284, 0.10823]) < 1e-5)
+
+
+def test_mfcc_not_nan(vb):
+    """src/spectrum.rs:592-602 test_mfcc_not_nan."""
+    m, st = vb.mfcc(np.zeros((1, 512)), 13, (100.0, 8000.0), 22050.0)
+    assert st[0] == 0 and np.all(np.isfinite(m)) and abs(m[0, 0] - 2.6e-9) < 1e-15
+
+
+@pytest.mark.parametrize("n,k,lo,hi,sr", [(1200, 13, 100.0, 8000.0, 48000.0), (256, 26, 133.0, 6855.0, 22050.0),
+                                          (512, 13, 100.0, 8000.0, 22050.0), (1024, 20, 0.0, 4000.0, 16000.0)])
+def test_mfcc(vb, oracle, audio, n, k, lo, hi, sr):
+    x = _frames(audio, n, 977, range(0, 60, 4)) * oracle.window("hanning", n) * 40.0
+    m, st = vb.mfcc(x, k, (lo, hi), sr)
+    for f in range(x.shape[0]):
+        es, em = oracle.mfcc(x[f], k, lo, hi, sr)
+        assert st[f] == es
+        assert np.all(rel_close(m[f], em, 1e-6)), (f, np.max(np.abs(m[f] - em)))
+
+
+def test_mfcc_bins_beyond_spectrum_is_panic_status(vb, oracle):
+    x = np.ones((2, 64))
+    m, st = vb.mfcc(x, 13, (100.0, 30000.0), 22050.0)      # mel points beyond the spectrum length
+    es, _ = oracle.mfcc(x[0], 13, 100.0, 30000.0, 22050.0)
+    assert es == oracle.ERR_PANIC and np.all(st == 4) and np.all(m == 0.0)

@@ -1,0 +1,223 @@
+// k_lpc.hip -- autocorrelation (few lags / all lags), normalize, Levinson-Durbin, and the
+// fused autocorrelate -> [normalize] -> lpc kernel (BASELINE config 2: HBM-bound).
+//
+// Reference: src/periodic.rs:276-289 (autocorrelate_mut), src/waves.rs:60-76 (normalize),
+//            src/spectrum.rs:63-92 (lpc_mut / lpc).
+#include "vbx_autocorr.hpp"
+#include "vbx_kernels.hpp"
+
+namespace vbx {
+
+// ------------------------------------------------------------------------------------------
+// Few-lag path: one wavefront per frame, EPL contiguous samples per lane held in registers,
+// neighbour lanes' samples fetched with DPP wave shifts (no LDS), lag sums reduced with
+// row rotations + v_readlane.  HBM-bound: 8 B/sample in, (2 * n_lags) * 8 B out.
+// ------------------------------------------------------------------------------------------
+
+// Levinson-Durbin on wave-uniform r[0..p] (src/spectrum.rs:63-84): every lane runs the same
+// recursion; lane 0 stores.  ac has P+1 entries.
+template <int P>
+__device__ __forceinline__ void levinson_uniform(const double (&r)[P + 1], double (&ac)[P + 1]) {
+    double tmp[P + 1];
+    double err = r[0];
+    ac[0] = 1.0;
+#pragma unroll
+    for (int i = 1; i <= P; i++) ac[i] = 0.0;
+#pragma unroll
+    for (int i = 1; i <= P; i++) {
+        double acc = r[i];
+#pragma unroll
+        for (int j = 1; j < i; j++) acc = acc + ac[j] * r[i - j];
+        const double k = -acc / err;
+        ac[i] = k;
+#pragma unroll
+        for (int j = 0; j < P; j++) tmp[j] = ac[j];
+#pragma unroll
+        for (int j = 1; j < i; j++) ac[j] = ac[j] + k * tmp[i - j];
+        err = err * (1.0 - k * k);
+    }
+}
+
+// EPL: samples per lane (frame_len <= 64*EPL).  NL: number of lags computed (n_lags <= NL).
+template <int EPL, int NL>
+__global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
+    const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
+    int n_lags, int normalize, double *__restrict__ out_r, double *__restrict__ out_lpc) {
+    const long f = blockIdx.x;
+    if (f >= n_frames) return;
+    const int lane = lane_id();
+    const double *xf = x + f * stride;
+
+    // ext[0..EPL) own samples, ext[EPL..EPL+NL-1) the following samples (from lanes l+1, l+2, ..)
+    double ext[EPL + NL - 1];
+#pragma unroll
+    for (int e = 0; e < EPL; e++) {
+        const int i = lane * EPL + e;
+        double v = (i < n) ? xf[i] : 0.0;
+        if (window != nullptr && i < n) v *= window[i];
+        ext[e] = v;
+    }
+    const double x0 = readlane_f64(ext[0], 0);
+#pragma unroll
+    for (int e = EPL; e < EPL + NL - 1; e++) ext[e] = from_next_lane(ext[e - EPL]);
+
+    double r[NL];
+#pragma unroll
+    for (int lag = 0; lag < NL; lag++) {
+        double s = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) s = fma(ext[e], ext[e + lag], s);
+        r[lag] = s;
+    }
+    // x[lag] (uniform) for the Q1 correction:  r = S - x0*x[lag] + x0
+#pragma unroll
+    for (int lag = 0; lag < NL; lag++) {
+        const int src_lane = lag / EPL, src_e = lag % EPL;
+        const double xl = readlane_f64(ext[src_e], src_lane);
+        const double s = wave_sum(r[lag]);
+        r[lag] = (lag < n) ? (s - x0 * xl) + x0 : x0;
+    }
+    if (normalize) {   // Normalize::normalize over the n_lags coefficients (max |.| over all, Q2)
+        double m = fabs(r[0]);
+#pragma unroll
+        for (int lag = 1; lag < NL; lag++) if (lag < n_lags) { double a = fabs(r[lag]); m = (a > m) ? a : m; }
+        const double scale = 1.0 / m;
+#pragma unroll
+        for (int lag = 0; lag < NL; lag++) r[lag] = r[lag] * scale;
+    }
+    if (out_r != nullptr) {
+#pragma unroll
+        for (int lag = 0; lag < NL; lag++)
+            if (lane == lag && lag < n_lags) out_r[f * n_lags + lag] = r[lag];
+    }
+    if (out_lpc != nullptr) {   // only instantiated/called with n_lags == NL
+        double ac[NL];
+        levinson_uniform<NL - 1>(r, ac);
+#pragma unroll
+        for (int j = 0; j < NL; j++)
+            if (lane == j) out_lpc[f * NL + j] = ac[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// All-lag path (n_lags up to frame_len): frame staged in LDS, lag tiles (vbx_autocorr.hpp).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void autocorr_tiles_kernel(
+    const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
+    int n_lags, double *__restrict__ out) {
+    extern __shared__ double smem[];
+    const long f = blockIdx.x;
+    if (f >= n_frames) return;
+    const int lane = lane_id();
+    const double *xf = x + f * stride;
+    const int total = n + autocorr_pad(n);
+    for (int i = lane; i < total; i += 64) {
+        double v = 0.0;
+        if (i < n) { v = xf[i]; if (window != nullptr) v *= window[i]; }
+        smem[i] = v;
+    }
+    __syncthreads();
+    const double x0 = smem[0];
+    double *o = out + f * (long)n_lags;
+    autocorr_tiles(smem, n, n_lags, [&](int lag, double s) {
+        o[lag] = (s - x0 * smem[lag]) + x0;
+    });
+}
+
+// Normalize::normalize on rows (src/waves.rs:68-75): one wavefront per row.
+__global__ __launch_bounds__(64) void normalize_rows_kernel(double *__restrict__ data, long n_rows, int n) {
+    const long row = blockIdx.x;
+    if (row >= n_rows) return;
+    const int lane = lane_id();
+    double *d = data + row * (long)n;
+    // max_amplitude: fold keeps acc unless amp is strictly greater (NaN never wins)
+    double m = -1.0;
+    for (int i = lane; i < n; i += 64) { double a = fabs(d[i]); m = (a > m) ? a : m; }
+    m = wave_max(m);
+    const double scale = 1.0 / m;
+    for (int i = lane; i < n; i += 64) d[i] = d[i] * scale;
+}
+
+// LPC::lpc on autocorrelation rows: one thread per row (src/spectrum.rs:63-92).
+__global__ void levinson_rows_kernel(const double *__restrict__ r, long n_rows, long r_stride, int p,
+                                     double *__restrict__ out) {
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    const double *rr = r + row * r_stride;
+    double *ac = out + row * (long)(p + 1);
+    double tmp[VBX_MAX_LPC_ORDER_K + 1];
+    double err = rr[0];
+    ac[0] = 1.0;
+    for (int i = 1; i <= p; i++) ac[i] = 0.0;
+    for (int i = 1; i <= p; i++) {
+        double acc = rr[i];
+        for (int j = 1; j < i; j++) acc = acc + ac[j] * rr[i - j];
+        const double k = -acc / err;
+        ac[i] = k;
+        for (int j = 0; j < p; j++) tmp[j] = ac[j];
+        for (int j = 1; j < i; j++) ac[j] = ac[j] + k * tmp[i - j];
+        err = err * (1.0 - k * k);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------
+
+template <int EPL, int NL>
+static void launch_fewlags(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
+                           int n_lags, int normalize, double *out_r, double *out_lpc) {
+    hipLaunchKernelGGL((autocorr_fewlags_kernel<EPL, NL>), dim3((unsigned)F), dim3(64), 0, s,
+                       x, F, n, stride, window, n_lags, normalize, out_r, out_lpc);
+}
+
+template <int NL>
+static bool dispatch_epl(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
+                         int n_lags, int normalize, double *out_r, double *out_lpc) {
+    if (n <= 64 * 8) launch_fewlags<8, NL>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc);
+    else if (n <= 64 * 16) launch_fewlags<16, NL>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc);
+    else if (n <= 64 * 20) launch_fewlags<20, NL>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc);
+    else if (n <= 64 * 32) launch_fewlags<32, NL>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc);
+    else return false;
+    return true;
+}
+
+// true if a register-resident few-lag kernel exists for this shape
+bool fewlags_supported(int n, int n_lags, bool want_lpc) {
+    if (n > 64 * 32 || n < 1) return false;
+    if (want_lpc) return n_lags == 9 || n_lags == 11 || n_lags == 13 || n_lags == 17;
+    return n_lags <= 17;
+}
+
+void launch_autocorr_fewlags(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
+                             int n_lags, int normalize, double *out_r, double *out_lpc) {
+    if (out_lpc != nullptr) {
+        switch (n_lags) {
+            case 9:  dispatch_epl<9>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc); break;
+            case 11: dispatch_epl<11>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc); break;
+            case 13: dispatch_epl<13>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc); break;
+            case 17: dispatch_epl<17>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc); break;
+        }
+        return;
+    }
+    if (n_lags <= 9) dispatch_epl<9>(s, x, F, n, stride, window, n_lags, normalize, out_r, nullptr);
+    else if (n_lags <= 13) dispatch_epl<13>(s, x, F, n, stride, window, n_lags, normalize, out_r, nullptr);
+    else dispatch_epl<17>(s, x, F, n, stride, window, n_lags, normalize, out_r, nullptr);
+}
+
+void launch_autocorr_tiles(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
+                           int n_lags, double *out) {
+    const size_t lds = (size_t)(n + autocorr_pad(n)) * sizeof(double);
+    hipLaunchKernelGGL(autocorr_tiles_kernel, dim3((unsigned)F), dim3(64), lds, s, x, F, n, stride, window, n_lags, out);
+}
+
+void launch_normalize_rows(hipStream_t s, double *data, long rows, int n) {
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)rows), dim3(64), 0, s, data, rows, n);
+}
+
+void launch_levinson_rows(hipStream_t s, const double *r, long rows, long r_stride, int p, double *out) {
+    const int bs = 64;
+    hipLaunchKernelGGL(levinson_rows_kernel, dim3((unsigned)((rows + bs - 1) / bs)), dim3(bs), 0, s, r, rows, r_stride, p, out);
+}
+
+}  // namespace vbx

@@ -1,0 +1,258 @@
+// k_roots.hip -- Laguerre root finding with deflation, resonances from roots.
+//
+// Reference: src/polynomial.rs:26-195 (degree, off_low, laguerre, find_roots_mut,
+//            div_polynomial_mut; Q11), src/spectrum.rs:165-210 (Resonance::from_root,
+//            to_resonance), src/lib.rs:80-110 (find_formants: polynomial build, im > 0 filter, sort).
+//
+// The per-polynomial work is a short, strictly sequential recurrence (20 fixed Laguerre
+// iterations x 3 Horner chains, then synthetic division), so the mapping is ONE LANE PER
+// POLYNOMIAL: 64 frames per wavefront, every lane busy, control flow almost uniform.
+// Per-lane polynomial/roots arrays live in LDS as [index][lane] (16-byte elements, lane
+// fastest) so dynamic indexing costs one conflict-free ds_read_b128, never scratch memory.
+#include "vbx_device.hpp"
+#include "vbx_kernels.hpp"
+
+namespace vbx {
+
+constexpr int ROOTS_BLOCK = 64;
+
+struct lds_poly {
+    c64 *base;   // element j of this lane at base[j * ROOTS_BLOCK]
+    __device__ __forceinline__ c64 get(int j) const { return base[j * ROOTS_BLOCK]; }
+    __device__ __forceinline__ void set(int j, c64 v) const { base[j * ROOTS_BLOCK] = v; }
+};
+
+// src/polynomial.rs:26-32
+__device__ __forceinline__ int poly_degree(const lds_poly &p, int len) {
+    int d = 0;
+    for (int j = 0; j < len; j++) if (!ciszero(p.get(j))) d = j;
+    return d;
+}
+__device__ __forceinline__ int poly_off_low(const lds_poly &p, int len) {
+    int d = -1;
+    for (int j = len - 1; j >= 0; j--) if (!ciszero(p.get(j))) d = j;
+    return d < 0 ? 0 : d;
+}
+
+// src/polynomial.rs:34-72.  n = len - 1 stays fixed across deflations (Q11).
+__device__ __forceinline__ c64 laguerre(const lds_poly &p, int len, c64 start) {
+    const int n = len - 1;
+    const double dn = (double)n, dnn1 = (double)(n - 1) * (double)n;
+    c64 z = start;
+    bool done = false;
+    for (int it = 0; it < 20; it++) {
+        c64 a0 = p.get(n), a1 = cmk(0.0, 0.0), a2 = cmk(0.0, 0.0);
+        for (int j = n - 1; j >= 0; j--) {
+            a2 = cmad(a2, z, a1);
+            a1 = cmad(a1, z, a0);
+            a0 = cmad(a0, z, p.get(j));
+        }
+        // |p(z)| <= 1e-16  (compared on squared norms)
+        const double n0 = a0.re * a0.re + a0.im * a0.im;
+        if (!done && n0 <= 1.0e-32) done = true;
+        if (__all(done)) break;
+        const c64 ca = cdiv(cneg(a1), a0);
+        const c64 ca2 = cmul(ca, ca);
+        const c64 cb = csub(ca2, cdiv(cmk(2.0 * a2.re, 2.0 * a2.im), a0));
+        const c64 c1 = csqrt(csub(cmk(dnn1 * cb.re, dnn1 * cb.im), ca2));
+        const c64 cc1 = cadd(ca, c1), cc2 = csub(ca, c1);
+        const double m1 = cc1.re * cc1.re + cc1.im * cc1.im, m2 = cc2.re * cc2.re + cc2.im * cc2.im;
+        const c64 den = (m1 > m2) ? cc1 : cc2;
+        const c64 cc = cdiv(cmk(dn, 0.0), den);
+        if (!done) z = cadd(z, cc);
+    }
+    return z;
+}
+
+// src/polynomial.rs:92-152 (+ div_polynomial_mut :155-195 inlined as in-place synthetic division).
+// co: polynomial in / scratch; zr: roots out (len entries, zero filled past the roots).
+__device__ __forceinline__ int find_roots_lane(const lds_poly &co, const lds_poly &zr, int len) {
+    for (int j = 0; j < len; j++) zr.set(j, cmk(0.0, 0.0));
+    const int coeff_high = poly_degree(co, len);
+    if (coeff_high < 1) return 2;                       // Err(Polynomial), :95
+    const int coeff_low = poly_off_low(co, len);
+    if (coeff_low > 0) return 4;                        // coeffs[co] out of bounds, :110-112
+    int m = coeff_high;
+    const int clen = coeff_high + 1;
+    int zi = 0;
+    for (int k = m; k >= 3; k--) {                      // (3..m+1).rev()
+        const c64 z = laguerre(co, clen, cmk(-2.0, -2.0));
+        zr.set(zi++, z);
+        if (ciszero(z)) return 2;                       // div by zero -> Err, :123,:192
+        // divide by (x - z): other = -z; q[i] = c[i+1] - q[i+1]*other
+        const int ns = poly_degree(co, clen);
+        c64 t = co.get(ns);
+        for (int i = ns - 1; i >= 0; i--) {
+            const c64 old = co.get(i);
+            co.set(i, t);
+            t = cmad(t, z, old);                        // old - t*(-z)
+        }
+        co.set(ns, cmk(0.0, 0.0));
+        m -= 1;
+    }
+    if (m == 2) {                                       // :131-139
+        const c64 c0 = co.get(0), c1 = co.get(1), c2 = co.get(2);
+        const c64 a2 = cadd(c2, c2);
+        const c64 four_ac = cmul(cmk(4.0 * c2.re, 4.0 * c2.im), c0);
+        const c64 d = csqrt(csub(cmul(c1, c1), four_ac));
+        const c64 xx = cneg(c1);
+        zr.set(zi, cdiv(cadd(xx, d), a2));
+        zr.set(zi + 1, cdiv(csub(xx, d), a2));
+        zi += 2;
+    } else if (m == 1) {                                // :141-144
+        zr.set(zi, cdiv(cneg(co.get(0)), co.get(1)));
+        zi += 1;
+    }
+    return 0;
+}
+
+// src/spectrum.rs:166-192
+__device__ __forceinline__ bool resonance_from_root(c64 root, double sample_rate, res_t &out) {
+    const double freq_mul = sample_rate / (M_PI * 2.0);
+    if (!(root.im >= 0.0)) return false;
+    double r = hypot(root.re, root.im), theta = atan2(root.im, root.re);
+    if (r > 1.0) {      // root.conj().inv() = (re, im) / |root|^2
+        const double ns = root.re * root.re + root.im * root.im;
+        const double ire = root.re / ns, iim = root.im / ns;
+        r = hypot(ire, iim); theta = atan2(iim, ire);
+    }
+    const double frequency = freq_mul * theta;
+    const double bandwidth = -2.0 * freq_mul * log(r);
+    if (frequency > 50.0 && frequency < sample_rate * 0.5 - 50.0) {
+        out.frequency = frequency; out.bandwidth = bandwidth;
+        return true;
+    }
+    return false;
+}
+
+// ---- kernels ---------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(ROOTS_BLOCK) void find_roots_kernel(cplx_t *__restrict__ polys, long n_polys, int len,
+                                                                 int32_t *__restrict__ status) {
+    extern __shared__ c64 lds[];
+    const long f = (long)blockIdx.x * ROOTS_BLOCK + threadIdx.x;
+    const bool active = f < n_polys;
+    lds_poly co{lds + threadIdx.x}, zr{lds + (size_t)len * ROOTS_BLOCK + threadIdx.x};
+    const long fr = active ? f : n_polys - 1;           // idle lanes shadow the last polynomial
+    cplx_t *pp = polys + fr * (long)len;
+    for (int j = 0; j < len; j++) co.set(j, cmk(pp[j].re, pp[j].im));
+    const int st = find_roots_lane(co, zr, len);
+    if (active) {
+        if (st == 0) {
+            for (int j = 0; j < len; j++) { const c64 v = zr.get(j); pp[j].re = v.re; pp[j].im = v.im; }
+        }
+        if (status != nullptr) status[f] = st;
+    }
+}
+
+__global__ __launch_bounds__(ROOTS_BLOCK) void laguerre_kernel(const cplx_t *__restrict__ polys, long n_polys, int len,
+                                                               cplx_t start, cplx_t *__restrict__ out) {
+    extern __shared__ c64 lds[];
+    const long f = (long)blockIdx.x * ROOTS_BLOCK + threadIdx.x;
+    const bool active = f < n_polys;
+    lds_poly co{lds + threadIdx.x};
+    const long fr = active ? f : n_polys - 1;
+    const cplx_t *pp = polys + fr * (long)len;
+    for (int j = 0; j < len; j++) co.set(j, cmk(pp[j].re, pp[j].im));
+    const c64 z = laguerre(co, len, cmk(start.re, start.im));
+    if (active) { out[f].re = z.re; out[f].im = z.im; }
+}
+
+// insertion of one resonance into a frequency-sorted row (stable: equal keys keep arrival order)
+__device__ __forceinline__ void res_insert_sorted(res_t *row, int count, res_t v) {
+    int j = count;
+    while (j > 0 && row[j - 1].frequency > v.frequency) { row[j] = row[j - 1]; j--; }
+    row[j] = v;
+}
+
+// to_resonance (strict_im = 0: roots with im >= 0, src/spectrum.rs:204-209) or the find_formants
+// variant (strict_im = 1: im > 0 first, src/lib.rs:94-104).  One lane per row.
+__global__ void to_resonance_kernel(const cplx_t *__restrict__ roots, long n_rows, int n_roots, double sample_rate,
+                                    int strict_im, res_t *__restrict__ out, int out_stride,
+                                    int32_t *__restrict__ out_count, const int32_t *__restrict__ status) {
+    const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_rows) return;
+    res_t *row = out + f * (long)out_stride;
+    int count = 0;
+    const bool ok = (status == nullptr) || status[f] == 0;
+    if (ok) {
+        const cplx_t *rr = roots + f * (long)n_roots;
+        for (int j = 0; j < n_roots && count < out_stride; j++) {
+            const c64 z = cmk(rr[j].re, rr[j].im);
+            if (strict_im && !(z.im > 0.0)) continue;
+            res_t v;
+            if (resonance_from_root(z, sample_rate, v)) { res_insert_sorted(row, count, v); count++; }
+        }
+    }
+    for (int j = count; j < out_stride; j++) { row[j].frequency = 0.0; row[j].bandwidth = 0.0; }
+    if (out_count != nullptr) out_count[f] = count;
+}
+
+// find_formants core (src/lib.rs:80-110): Burg coefficients -> rev([1, a1..ap]) -> roots ->
+// resonances [32] sorted, zero padded.  One lane per frame.
+__global__ __launch_bounds__(ROOTS_BLOCK) void formant_resonances_kernel(
+    const double *__restrict__ coeffs, long n_frames, int p, double sample_rate,
+    res_t *__restrict__ out_res, int32_t *__restrict__ out_count, int32_t *__restrict__ status) {
+    extern __shared__ c64 lds[];
+    const long f = (long)blockIdx.x * ROOTS_BLOCK + threadIdx.x;
+    const bool active = f < n_frames;
+    const int len = p + 1;
+    lds_poly co{lds + threadIdx.x}, zr{lds + (size_t)len * ROOTS_BLOCK + threadIdx.x};
+    const long fr = active ? f : n_frames - 1;
+    const double *a = coeffs + fr * (long)p;
+    int st = (status != nullptr) ? status[fr] : 0;
+    // complex_lpc = rev([1, a1..ap]): index j < p holds a[p-1-j], index p holds 1 (src/lib.rs:80-91)
+    for (int j = 0; j < p; j++) co.set(j, cmk(a[p - 1 - j], 0.0));
+    co.set(p, cmk(1.0, 0.0));
+    int rst = 0;
+    if (st == 0) rst = find_roots_lane(co, zr, len);
+    if (!active) return;
+    res_t *row = out_res + f * (long)VBX_MAX_RESONANCES_K;
+    int count = 0;
+    if (st == 0 && rst == 0) {
+        for (int j = 0; j < len; j++) {                 // iterates p+1 entries; the last is always 0
+            const c64 z = zr.get(j);
+            if (!(z.im > 0.0)) continue;
+            res_t v;
+            if (count < VBX_MAX_RESONANCES_K && resonance_from_root(z, sample_rate, v)) {
+                // the reference appends then sorts [0..=rpos] by frequency (stable, :105-110);
+                // all stored frequencies are > 50 so rpos = count-1: equivalent to sorted insertion
+                res_insert_sorted(row, count, v);
+                count++;
+            }
+        }
+    }
+    for (int j = count; j < VBX_MAX_RESONANCES_K; j++) { row[j].frequency = 0.0; row[j].bandwidth = 0.0; }
+    if (out_count != nullptr) out_count[f] = count;
+    if (status != nullptr && st == 0 && rst != 0) status[f] = rst;
+}
+
+// ---- launchers -----------------------------------------------------------------------------
+
+void launch_find_roots(hipStream_t s, cplx_t *polys, long F, int len, int32_t *status) {
+    const size_t lds = (size_t)2 * len * ROOTS_BLOCK * sizeof(c64);
+    hipLaunchKernelGGL(find_roots_kernel, dim3((unsigned)((F + ROOTS_BLOCK - 1) / ROOTS_BLOCK)), dim3(ROOTS_BLOCK), lds, s,
+                       polys, F, len, status);
+}
+
+void launch_laguerre(hipStream_t s, const cplx_t *polys, long F, int len, cplx_t start, cplx_t *out) {
+    const size_t lds = (size_t)len * ROOTS_BLOCK * sizeof(c64);
+    hipLaunchKernelGGL(laguerre_kernel, dim3((unsigned)((F + ROOTS_BLOCK - 1) / ROOTS_BLOCK)), dim3(ROOTS_BLOCK), lds, s,
+                       polys, F, len, start, out);
+}
+
+void launch_to_resonance(hipStream_t s, const cplx_t *roots, long F, int n_roots, double sample_rate,
+                         int strict_im, res_t *out, int out_stride, int32_t *out_count, const int32_t *status) {
+    const int bs = 64;
+    hipLaunchKernelGGL(to_resonance_kernel, dim3((unsigned)((F + bs - 1) / bs)), dim3(bs), 0, s,
+                       roots, F, n_roots, sample_rate, strict_im, out, out_stride, out_count, status);
+}
+
+void launch_formant_resonances(hipStream_t s, const double *coeffs, long F, int p, double sample_rate,
+                               res_t *out_res, int32_t *out_count, int32_t *status) {
+    const size_t lds = (size_t)2 * (p + 1) * ROOTS_BLOCK * sizeof(c64);
+    hipLaunchKernelGGL(formant_resonances_kernel, dim3((unsigned)((F + ROOTS_BLOCK - 1) / ROOTS_BLOCK)), dim3(ROOTS_BLOCK), lds, s,
+                       coeffs, F, p, sample_rate, out_res, out_count, status);
+}
+
+}  // namespace vbx

@@ -1,0 +1,731 @@
+// vbx_api.hip -- host side of libvoxbox_hip.so: context, workspaces, host-built tables and
+// the extern "C" entry points declared in include/voxbox_hip.h.  No CPU fallback: every
+// numeric entry point launches gfx950 kernels on the context's stream.
+#include "../../include/voxbox_hip.h"
+#include "vbx_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+using namespace vbx;
+
+extern "C" const double VBX_MALE_FORMANT_ESTIMATES[4] = {320., 1440., 2760., 3200.};     // src/lib.rs:27
+extern "C" const double VBX_FEMALE_FORMANT_ESTIMATES[4] = {480., 1760., 3200., 3520.};   // src/lib.rs:28
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct ProfRec { std::string name; hipEvent_t a, b; };
+
+}  // namespace
+
+struct vbx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    std::string last_error;
+    std::string arch;
+    int cu_count = 0;
+    // workspaces (grown on demand, never shrunk)
+    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_N };
+    void *ws[WS_N] = {nullptr};
+    size_t ws_bytes[WS_N] = {0};
+    // cached device tables
+    std::map<std::pair<int, size_t>, double *> windows;   // (kind, n)
+    std::map<size_t, double *> twiddles;                  // n -> [n][2]
+    std::map<size_t, double *> dct_tables;                // K -> [K][K]
+    std::map<std::tuple<size_t, size_t, double, double, double>, int32_t *> bins_cache;
+    // timing
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    std::map<std::string, std::pair<double, long>> prof_acc;
+    std::mutex mu;
+};
+
+namespace {
+
+int fail(vbx_ctx *ctx, int code, const std::string &msg) {
+    g_last_error = msg;
+    if (ctx) ctx->last_error = msg;
+    return code;
+}
+
+#define VBX_HIP(ctx, expr)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(ctx, VBX_E_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+#define VBX_REQUIRE(ctx, cond, msg) \
+    do { if (!(cond)) return fail(ctx, VBX_E_INVALID, std::string(__func__) + ": " + (msg)); } while (0)
+
+int check_launch(vbx_ctx *ctx, const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, VBX_E_RUNTIME, std::string(what) + " launch: " + hipGetErrorString(e));
+    return VBX_SUCCESS;
+}
+
+struct Prof {
+    vbx_ctx *ctx; const char *name; hipEvent_t a = nullptr, b = nullptr;
+    Prof(vbx_ctx *c, const char *n) : ctx(c), name(n) {
+        if (ctx->prof) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, ctx->stream); }
+    }
+    ~Prof() {
+        if (ctx->prof) { hipEventRecord(b, ctx->stream); ctx->recs.push_back({name, a, b}); }
+    }
+};
+
+int ws_get(vbx_ctx *ctx, int slot, size_t bytes, void **out) {
+    if (bytes == 0) bytes = 16;
+    if (ctx->ws_bytes[slot] < bytes) {
+        if (ctx->ws[slot]) {
+            VBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            VBX_HIP(ctx, hipFree(ctx->ws[slot]));
+            ctx->ws[slot] = nullptr; ctx->ws_bytes[slot] = 0;
+        }
+        size_t cap = bytes + bytes / 8;
+        VBX_HIP(ctx, hipMalloc(&ctx->ws[slot], cap));
+        ctx->ws_bytes[slot] = cap;
+    }
+    *out = ctx->ws[slot];
+    return VBX_SUCCESS;
+}
+
+// ---- host-built tables (the library's own statement of the sample-crate recurrences) --------
+
+// sample 0.10 signal::Phase: yields phase, then phase = (phase + step) % 1.0
+void phase_ramp(std::vector<double> &ph, size_t n, double step) {
+    ph.resize(n);
+    double next = 0.0;
+    for (size_t i = 0; i < n; i++) { ph[i] = next; next = std::fmod(next + step, 1.0); }
+}
+
+int window_table_host(int kind, size_t n, double *out) {
+    const double pi2 = M_PI * 2.0;
+    std::vector<double> ph;
+    switch (kind) {
+        case VBX_WINDOW_HANNING:            // Window::<Hanning>::new(n)
+            phase_ramp(ph, n, 1.0 / ((double)n - 1.0));
+            for (size_t i = 0; i < n; i++) out[i] = 0.5 * (1.0 - std::cos(ph[i] * pi2));
+            return VBX_SUCCESS;
+        case VBX_WINDOW_HANNING_LAG:        // HanningLag::at_phase, src/periodic.rs:239-247 (Q3)
+            phase_ramp(ph, n, 1.0 / ((double)n - 1.0));
+            for (size_t i = 0; i < n; i++) {
+                const double v = ph[i] * pi2;
+                out[i] = (1.0 - ph[i]) * (2.0 / 3.0 + (1.0 / 3.0) * std::cos(v)) + (1.0 / pi2) * std::sin(v);
+            }
+            return VBX_SUCCESS;
+        case VBX_WINDOW_HANNING_PERIODIC: { // src/lib.rs:65-70
+            const double len_inv = 1.0 / (double)n;
+            for (size_t i = 0; i < n; i++) out[i] = 0.5 * (1.0 - std::cos(((double)i * len_inv) * pi2));
+            return VBX_SUCCESS;
+        }
+        case VBX_WINDOW_RECTANGLE:
+            for (size_t i = 0; i < n; i++) out[i] = 1.0;
+            return VBX_SUCCESS;
+    }
+    return VBX_E_INVALID;
+}
+
+int get_window_dev(vbx_ctx *ctx, int kind, size_t n, const double **out) {
+    auto key = std::make_pair(kind, n);
+    auto it = ctx->windows.find(key);
+    if (it == ctx->windows.end()) {
+        std::vector<double> h(n);
+        if (window_table_host(kind, n, h.data()) != VBX_SUCCESS) return fail(ctx, VBX_E_INVALID, "bad window kind");
+        double *d = nullptr;
+        VBX_HIP(ctx, hipMalloc((void **)&d, n * sizeof(double)));
+        VBX_HIP(ctx, hipMemcpy(d, h.data(), n * sizeof(double), hipMemcpyHostToDevice));
+        it = ctx->windows.emplace(key, d).first;
+    }
+    *out = it->second;
+    return VBX_SUCCESS;
+}
+
+int get_twiddle_dev(vbx_ctx *ctx, size_t n, const double **out) {
+    auto it = ctx->twiddles.find(n);
+    if (it == ctx->twiddles.end()) {
+        std::vector<double> h(2 * n);
+        for (size_t i = 0; i < n; i++) {
+            const double ang = 2.0 * M_PI * (double)i / (double)n;
+            h[2 * i] = std::cos(ang); h[2 * i + 1] = std::sin(ang);
+        }
+        double *d = nullptr;
+        VBX_HIP(ctx, hipMalloc((void **)&d, 2 * n * sizeof(double)));
+        VBX_HIP(ctx, hipMemcpy(d, h.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice));
+        it = ctx->twiddles.emplace(n, d).first;
+    }
+    *out = it->second;
+    return VBX_SUCCESS;
+}
+
+int get_dct_dev(vbx_ctx *ctx, size_t k, const double **out) {
+    auto it = ctx->dct_tables.find(k);
+    if (it == ctx->dct_tables.end()) {
+        std::vector<double> h(k * k);
+        for (size_t kk = 0; kk < k; kk++)          // src/spectrum.rs:395
+            for (size_t n = 0; n < k; n++)
+                h[kk * k + n] = std::cos(M_PI * (double)kk * (2. * (double)n + 1.) / (2. * (double)k));
+        double *d = nullptr;
+        VBX_HIP(ctx, hipMalloc((void **)&d, k * k * sizeof(double)));
+        VBX_HIP(ctx, hipMemcpy(d, h.data(), k * k * sizeof(double), hipMemcpyHostToDevice));
+        it = ctx->dct_tables.emplace(k, d).first;
+    }
+    *out = it->second;
+    return VBX_SUCCESS;
+}
+
+// src/spectrum.rs:411-414 (Q14)
+void mel_bins_host(size_t n, size_t k, double lo, double hi, double sr, std::vector<int32_t> &bins, bool &overflow) {
+    const double mlo = vbx_hz_to_mel(lo), mel_range = vbx_hz_to_mel(hi) - mlo;
+    bins.resize(k + 2);
+    overflow = false;
+    for (size_t i = 0; i < k + 2; i++) {
+        const double point = ((double)i / (double)k) * mel_range + mlo;
+        const double b = std::floor((double)(n + 1) * vbx_mel_to_hz(point) / sr);
+        if (!(b >= 0.0)) { bins[i] = 0; }
+        else if (b > 1.0e9) { bins[i] = 1000000000; overflow = true; }
+        else bins[i] = (int32_t)b;
+    }
+}
+
+int get_bins_dev(vbx_ctx *ctx, size_t n, size_t k, double lo, double hi, double sr,
+                 const int32_t **out, std::vector<int32_t> &host_bins, bool &bad) {
+    mel_bins_host(n, k, lo, hi, sr, host_bins, bad);
+    for (size_t i = 0; i + 1 < host_bins.size(); i++) if (host_bins[i + 1] < host_bins[i]) bad = true;   // usize underflow panics
+    if (host_bins.back() > (int32_t)n) bad = true;                                                    // spectrum[bin] out of bounds
+    auto key = std::make_tuple(n, k, lo, hi, sr);
+    auto it = ctx->bins_cache.find(key);
+    if (it == ctx->bins_cache.end()) {
+        int32_t *d = nullptr;
+        VBX_HIP(ctx, hipMalloc((void **)&d, host_bins.size() * sizeof(int32_t)));
+        VBX_HIP(ctx, hipMemcpy(d, host_bins.data(), host_bins.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        it = ctx->bins_cache.emplace(key, d).first;
+    }
+    *out = it->second;
+    return VBX_SUCCESS;
+}
+
+int check_frames(vbx_ctx *ctx, const char *fn, const void *x, size_t n_frames, size_t frame_len, size_t stride) {
+    if (!ctx) return fail(nullptr, VBX_E_INVALID, std::string(fn) + ": null context");
+    if (n_frames == 0) return 1;   // empty batch: nothing to do
+    if (!x) return fail(ctx, VBX_E_INVALID, std::string(fn) + ": null frame pointer");
+    if (frame_len < 1 || frame_len > VBX_MAX_FRAME_LEN)
+        return fail(ctx, VBX_E_INVALID, std::string(fn) + ": frame_len must be in [1, 4096]");
+    if (stride < 1) return fail(ctx, VBX_E_INVALID, std::string(fn) + ": stride must be >= 1");
+    if (n_frames > 0x7fffffffull) return fail(ctx, VBX_E_INVALID, std::string(fn) + ": too many frames for one launch");
+    return VBX_SUCCESS;
+}
+
+int upload_segments(vbx_ctx *ctx, const int64_t *h_seg, size_t n_seg, size_t n_frames, const int64_t **d_seg, size_t *n_out) {
+    if (h_seg == nullptr || n_seg == 0) { *d_seg = nullptr; *n_out = 1; return VBX_SUCCESS; }
+    if (h_seg[0] != 0) return fail(ctx, VBX_E_INVALID, "seg_start[0] must be 0");
+    for (size_t i = 1; i < n_seg; i++)
+        if (h_seg[i] < h_seg[i - 1] || (size_t)h_seg[i] > n_frames) return fail(ctx, VBX_E_INVALID, "seg_start must ascend within [0, n_frames]");
+    void *d = nullptr;
+    int rc = ws_get(ctx, vbx_ctx::WS_SEG, n_seg * sizeof(int64_t), &d);
+    if (rc != VBX_SUCCESS) return rc;
+    VBX_HIP(ctx, hipMemcpyAsync(d, h_seg, n_seg * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    *d_seg = (const int64_t *)d; *n_out = n_seg;
+    return VBX_SUCCESS;
+}
+
+int upload_estimates(vbx_ctx *ctx, const vbx_resonance *h_est, size_t n_est, const res_t **d_est) {
+    void *d = nullptr;
+    int rc = ws_get(ctx, vbx_ctx::WS_EST, n_est * sizeof(vbx_resonance), &d);
+    if (rc != VBX_SUCCESS) return rc;
+    VBX_HIP(ctx, hipMemcpyAsync(d, h_est, n_est * sizeof(vbx_resonance), hipMemcpyHostToDevice, ctx->stream));
+    *d_est = (const res_t *)d;
+    return VBX_SUCCESS;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int vbx_abi_version(void) { return VBX_ABI_VERSION; }
+
+int vbx_ctx_create(vbx_ctx **out, int device, void *hip_stream) {
+    if (!out) return fail(nullptr, VBX_E_INVALID, "vbx_ctx_create: null out");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, VBX_E_NODEVICE, "vbx_ctx_create: no HIP device (this library has no CPU fallback)");
+    if (device < 0 || device >= count) return fail(nullptr, VBX_E_INVALID, "vbx_ctx_create: bad device ordinal");
+    VBX_HIP(nullptr, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    VBX_HIP(nullptr, hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, VBX_E_NODEVICE, std::string("vbx_ctx_create: device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    vbx_ctx *ctx = new vbx_ctx();
+    ctx->device = device;
+    ctx->arch = prop.gcnArchName;
+    ctx->cu_count = prop.multiProcessorCount;
+    if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->owns_stream = false; }
+    else {
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete ctx; return fail(nullptr, VBX_E_RUNTIME, "hipStreamCreate failed"); }
+        ctx->owns_stream = true;
+    }
+    hipEventCreate(&ctx->t0);
+    hipEventCreate(&ctx->t1);
+    *out = ctx;
+    return VBX_SUCCESS;
+}
+
+void vbx_ctx_destroy(vbx_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < vbx_ctx::WS_N; i++) if (ctx->ws[i]) hipFree(ctx->ws[i]);
+    for (auto &kv : ctx->windows) hipFree(kv.second);
+    for (auto &kv : ctx->twiddles) hipFree(kv.second);
+    for (auto &kv : ctx->dct_tables) hipFree(kv.second);
+    for (auto &kv : ctx->bins_cache) hipFree(kv.second);
+    for (auto &r : ctx->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    if (ctx->t0) hipEventDestroy(ctx->t0);
+    if (ctx->t1) hipEventDestroy(ctx->t1);
+    if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int vbx_sync(vbx_ctx *ctx) {
+    if (!ctx) return fail(nullptr, VBX_E_INVALID, "vbx_sync: null context");
+    VBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VBX_SUCCESS;
+}
+
+const char *vbx_last_error(const vbx_ctx *ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
+
+int vbx_device_info(const vbx_ctx *ctx, char *h_name, size_t name_cap, int *h_cu_count) {
+    if (!ctx) return fail(nullptr, VBX_E_INVALID, "vbx_device_info: null context");
+    if (h_name && name_cap) { std::strncpy(h_name, ctx->arch.c_str(), name_cap - 1); h_name[name_cap - 1] = 0; }
+    if (h_cu_count) *h_cu_count = ctx->cu_count;
+    return VBX_SUCCESS;
+}
+
+int vbx_malloc(vbx_ctx *ctx, void **out_dptr, size_t bytes) {
+    VBX_REQUIRE(ctx, ctx && out_dptr, "null argument");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    VBX_HIP(ctx, hipMalloc(out_dptr, bytes ? bytes : 16));
+    return VBX_SUCCESS;
+}
+int vbx_free(vbx_ctx *ctx, void *dptr) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    if (dptr) { VBX_HIP(ctx, hipStreamSynchronize(ctx->stream)); VBX_HIP(ctx, hipFree(dptr)); }
+    return VBX_SUCCESS;
+}
+int vbx_memcpy_h2d(vbx_ctx *ctx, void *dst, const void *h_src, size_t bytes) {
+    VBX_REQUIRE(ctx, ctx && (bytes == 0 || (dst && h_src)), "null argument");
+    if (bytes == 0) return VBX_SUCCESS;
+    VBX_HIP(ctx, hipMemcpyAsync(dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VBX_SUCCESS;
+}
+int vbx_memcpy_d2h(vbx_ctx *ctx, void *h_dst, const void *src, size_t bytes) {
+    VBX_REQUIRE(ctx, ctx && (bytes == 0 || (h_dst && src)), "null argument");
+    if (bytes == 0) return VBX_SUCCESS;
+    VBX_HIP(ctx, hipMemcpyAsync(h_dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VBX_SUCCESS;
+}
+int vbx_memset(vbx_ctx *ctx, void *dst, int value, size_t bytes) {
+    VBX_REQUIRE(ctx, ctx && (bytes == 0 || dst), "null argument");
+    if (bytes == 0) return VBX_SUCCESS;
+    VBX_HIP(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return VBX_SUCCESS;
+}
+
+int vbx_timer_begin(vbx_ctx *ctx) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    VBX_HIP(ctx, hipEventRecord(ctx->t0, ctx->stream));
+    return VBX_SUCCESS;
+}
+int vbx_timer_end(vbx_ctx *ctx, float *h_ms) {
+    VBX_REQUIRE(ctx, ctx && h_ms, "null argument");
+    VBX_HIP(ctx, hipEventRecord(ctx->t1, ctx->stream));
+    VBX_HIP(ctx, hipEventSynchronize(ctx->t1));
+    VBX_HIP(ctx, hipEventElapsedTime(h_ms, ctx->t0, ctx->t1));
+    return VBX_SUCCESS;
+}
+
+static int prof_flush(vbx_ctx *ctx) {
+    if (ctx->recs.empty()) return VBX_SUCCESS;
+    VBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &r : ctx->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            auto &acc = ctx->prof_acc[r.name];
+            acc.first += ms; acc.second += 1;
+        }
+        hipEventDestroy(r.a); hipEventDestroy(r.b);
+    }
+    ctx->recs.clear();
+    return VBX_SUCCESS;
+}
+int vbx_profile_enable(vbx_ctx *ctx, int on) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    int rc = prof_flush(ctx);
+    ctx->prof = on != 0;
+    return rc;
+}
+int vbx_profile_reset(vbx_ctx *ctx) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    int rc = prof_flush(ctx);
+    ctx->prof_acc.clear();
+    return rc;
+}
+int vbx_profile_get(vbx_ctx *ctx, const char *kernel_name, double *h_total_ms, long *h_launches) {
+    VBX_REQUIRE(ctx, ctx && kernel_name, "null argument");
+    int rc = prof_flush(ctx);
+    if (rc != VBX_SUCCESS) return rc;
+    auto it = ctx->prof_acc.find(kernel_name);
+    if (h_total_ms) *h_total_ms = (it == ctx->prof_acc.end()) ? 0.0 : it->second.first;
+    if (h_launches) *h_launches = (it == ctx->prof_acc.end()) ? 0 : it->second.second;
+    return VBX_SUCCESS;
+}
+int vbx_profile_names(vbx_ctx *ctx, char *h_buf, size_t cap) {
+    VBX_REQUIRE(ctx, ctx && h_buf && cap, "null argument");
+    int rc = prof_flush(ctx);
+    if (rc != VBX_SUCCESS) return rc;
+    std::string s;
+    for (auto &kv : ctx->prof_acc) { s += kv.first; s += '\n'; }
+    std::strncpy(h_buf, s.c_str(), cap - 1); h_buf[cap - 1] = 0;
+    return VBX_SUCCESS;
+}
+
+// ---- tables -------------------------------------------------------------------------------
+
+int vbx_window_table_f64(int kind, size_t n, double *h_out) {
+    if (!h_out || n < 1) return fail(nullptr, VBX_E_INVALID, "vbx_window_table_f64: bad argument");
+    int rc = window_table_host(kind, n, h_out);
+    if (rc != VBX_SUCCESS) return fail(nullptr, rc, "vbx_window_table_f64: unknown window kind");
+    return rc;
+}
+
+size_t vbx_frame_count(size_t n_samples, size_t frame_len, size_t hop) {
+    if (frame_len == 0 || hop == 0 || n_samples < frame_len) return 0;
+    return (n_samples - frame_len) / hop + 1;
+}
+
+double vbx_hz_to_mel(double hz) { return 1125. * std::log1p(hz / 700.); }       // src/spectrum.rs:375-377
+double vbx_mel_to_hz(double mel) { return 700. * (std::exp(mel / 1125.) - 1.); } // src/spectrum.rs:379-381
+size_t vbx_find_formants_real_work_size(size_t buf_len, size_t n_coeffs) { return buf_len * 2 + n_coeffs * 23 + 2; }
+size_t vbx_find_formants_complex_work_size(size_t n_coeffs) { return n_coeffs * 7 + 4; }
+
+// ---- periodic.rs --------------------------------------------------------------------------
+
+int vbx_autocorrelate_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
+                          size_t stride, const double *window, size_t n_lags, double *out) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_REQUIRE(ctx, out != nullptr, "null output");
+    VBX_REQUIRE(ctx, n_lags >= 1 && n_lags <= frame_len, "n_lags must be in [1, frame_len] (the reference panics beyond)");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    if (fewlags_supported((int)frame_len, (int)n_lags, false)) {
+        Prof p(ctx, "autocorr_fewlags");
+        launch_autocorr_fewlags(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_lags, 0, out, nullptr);
+    } else {
+        Prof p(ctx, "autocorr_tiles");
+        launch_autocorr_tiles(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_lags, out);
+    }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_normalize_f64(vbx_ctx *ctx, double *data, size_t n_rows, size_t n) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    if (n_rows == 0) return VBX_SUCCESS;
+    VBX_REQUIRE(ctx, data && n >= 1 && n <= 0x7fffffff && n_rows <= 0x7fffffff, "bad argument");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    { Prof p(ctx, "normalize_rows"); launch_normalize_rows(ctx->stream, data, (long)n_rows, (int)n); }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_interpolate_sinc_f64(vbx_ctx *ctx, const double *y, size_t ylen, long offset, size_t nx,
+                             const double *xs, size_t m, size_t max_depth, double *out, int32_t *status) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    if (m == 0) return VBX_SUCCESS;
+    VBX_REQUIRE(ctx, y && xs && out && ylen >= 1 && ylen <= 0x7fffffff && m <= 0x7fffffff, "bad argument");
+    VBX_REQUIRE(ctx, max_depth <= 0x7fffffff && nx <= 0x7fffffff, "depth / nx too large");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    { Prof p(ctx, "sinc_points"); launch_sinc_points(ctx->stream, y, (int)ylen, offset, (long)nx, xs, (long)m, (long)max_depth, out, status); }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_improve_extremum_f64(vbx_ctx *ctx, const double *y, size_t ylen, long offset, size_t nx,
+                             const double *ixmid, size_t m, size_t depth, double *out_xy, int32_t *status) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    if (m == 0) return VBX_SUCCESS;
+    VBX_REQUIRE(ctx, y && ixmid && out_xy && ylen >= 1 && ylen <= 0x7fffffff && m <= 0x7fffffff, "bad argument");
+    VBX_REQUIRE(ctx, depth <= 0x7fffffff && nx <= 0x7fffffff, "depth / nx too large");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    { Prof p(ctx, "extremum_points"); launch_extremum_points(ctx->stream, y, (int)ylen, offset, (long)nx, ixmid, (long)m, (long)depth, out_xy, status); }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_pitch_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
+                  const double *window, double sample_rate, double threshold, double fmin, double fmax,
+                  size_t kmax, vbx_pitch *out_cand, int32_t *out_count, int32_t *status) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_REQUIRE(ctx, out_cand != nullptr, "null output");
+    VBX_REQUIRE(ctx, kmax >= 1 && kmax <= VBX_MAX_PITCH_CANDIDATES, "kmax must be in [1, 64]");
+    VBX_REQUIRE(ctx, frame_len >= 4, "frame_len must be >= 4");
+    VBX_REQUIRE(ctx, pitch_lds_bytes((int)frame_len) <= 160 * 1024, "frame does not fit the LDS");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    const double *lagw = nullptr;
+    rc = get_window_dev(ctx, VBX_WINDOW_HANNING_LAG, frame_len, &lagw);
+    if (rc != VBX_SUCCESS) return rc;
+    {
+        Prof p(ctx, "pitch");
+        launch_pitch(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, lagw, sample_rate, threshold,
+                     fmin, fmax, (int)kmax, (pitch_t *)out_cand, out_count, status);
+    }
+    return check_launch(ctx, __func__);
+}
+
+// ---- spectrum.rs: LPC ---------------------------------------------------------------------
+
+int vbx_lpc_f64(vbx_ctx *ctx, const double *r, size_t n_frames, size_t r_stride, size_t n_coeffs, double *out) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    if (n_frames == 0) return VBX_SUCCESS;
+    VBX_REQUIRE(ctx, r && out, "null argument");
+    VBX_REQUIRE(ctx, n_coeffs >= 1 && n_coeffs <= VBX_MAX_LPC_ORDER && r_stride >= n_coeffs + 1, "bad order / stride");
+    VBX_REQUIRE(ctx, n_frames <= 0x7fffffffull, "too many rows");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    { Prof p(ctx, "levinson_rows"); launch_levinson_rows(ctx->stream, r, (long)n_frames, (long)r_stride, (int)n_coeffs, out); }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_autocorr_lpc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
+                         size_t stride, const double *window, size_t n_coeffs, int normalize,
+                         double *out_r, double *out_lpc) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_REQUIRE(ctx, out_r || out_lpc, "both outputs null");
+    VBX_REQUIRE(ctx, n_coeffs >= 1 && n_coeffs <= VBX_MAX_LPC_ORDER && n_coeffs + 1 <= frame_len, "bad order");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    const int n_lags = (int)n_coeffs + 1;
+    if (fewlags_supported((int)frame_len, n_lags, out_lpc != nullptr)) {
+        Prof p(ctx, "autocorr_lpc");
+        launch_autocorr_fewlags(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, n_lags, normalize, out_r, out_lpc);
+        return check_launch(ctx, __func__);
+    }
+    // general shapes: autocorrelate -> [normalize] -> Levinson as three launches
+    double *r = out_r;
+    if (!r) {
+        void *w = nullptr;
+        rc = ws_get(ctx, vbx_ctx::WS_MISC, n_frames * (size_t)n_lags * sizeof(double), &w);
+        if (rc != VBX_SUCCESS) return rc;
+        r = (double *)w;
+    }
+    if (fewlags_supported((int)frame_len, n_lags, false)) {
+        Prof p(ctx, "autocorr_fewlags");
+        launch_autocorr_fewlags(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, n_lags, 0, r, nullptr);
+    } else {
+        Prof p(ctx, "autocorr_tiles");
+        launch_autocorr_tiles(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, n_lags, r);
+    }
+    if (normalize) { Prof p(ctx, "normalize_rows"); launch_normalize_rows(ctx->stream, r, (long)n_frames, n_lags); }
+    if (out_lpc) { Prof p(ctx, "levinson_rows"); launch_levinson_rows(ctx->stream, r, (long)n_frames, n_lags, (int)n_coeffs, out_lpc); }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_lpc_burg_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
+                     size_t stride, const double *window, size_t n_coeffs, double *out, int32_t *status) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_REQUIRE(ctx, out != nullptr, "null output");
+    VBX_REQUIRE(ctx, burg_supported((int)frame_len, (int)n_coeffs), "frame_len must be in [2, 4096], order in [1, 30]");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    { Prof p(ctx, "burg"); launch_burg(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_coeffs, out, status); }
+    return check_launch(ctx, __func__);
+}
+
+// ---- polynomial.rs ------------------------------------------------------------------------
+
+int vbx_find_roots_c64(vbx_ctx *ctx, vbx_complex *polys, size_t n_polys, size_t len, int32_t *status) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    if (n_polys == 0) return VBX_SUCCESS;
+    VBX_REQUIRE(ctx, polys != nullptr, "null polynomials");
+    VBX_REQUIRE(ctx, len >= 1 && len <= 2 * VBX_MAX_LPC_ORDER + 4, "len must be in [1, 64]");
+    VBX_REQUIRE(ctx, n_polys <= 0x7fffffffull, "too many polynomials");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    { Prof p(ctx, "find_roots"); launch_find_roots(ctx->stream, (cplx_t *)polys, (long)n_polys, (int)len, status); }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_laguerre_c64(vbx_ctx *ctx, const vbx_complex *polys, size_t n_polys, size_t len,
+                     vbx_complex start, vbx_complex *out) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    if (n_polys == 0) return VBX_SUCCESS;
+    VBX_REQUIRE(ctx, polys && out, "null argument");
+    VBX_REQUIRE(ctx, len >= 2 && len <= 2 * VBX_MAX_LPC_ORDER + 4, "len must be in [2, 64]");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    cplx_t s; s.re = start.re; s.im = start.im;
+    { Prof p(ctx, "laguerre"); launch_laguerre(ctx->stream, (const cplx_t *)polys, (long)n_polys, (int)len, s, (cplx_t *)out); }
+    return check_launch(ctx, __func__);
+}
+
+// ---- spectrum.rs: resonances, tracker -----------------------------------------------------
+
+int vbx_to_resonance_c64(vbx_ctx *ctx, const vbx_complex *roots, size_t n_rows, size_t n_roots,
+                         double sample_rate, vbx_resonance *out_res, int32_t *out_count) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    if (n_rows == 0) return VBX_SUCCESS;
+    VBX_REQUIRE(ctx, roots && out_res && n_roots >= 1 && n_roots <= 0x7fffffff, "bad argument");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    {
+        Prof p(ctx, "to_resonance");
+        launch_to_resonance(ctx->stream, (const cplx_t *)roots, (long)n_rows, (int)n_roots, sample_rate, 0,
+                            (res_t *)out_res, (int)n_roots, out_count, nullptr);
+    }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_estimate_formants_f64(vbx_ctx *ctx, const vbx_resonance *res, size_t n_frames, size_t n_res,
+                              const int64_t *h_seg_start, size_t n_segments,
+                              const vbx_resonance *h_est_init, size_t n_est,
+                              const int32_t *frame_status, vbx_resonance *out) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    if (n_frames == 0) return VBX_SUCCESS;
+    VBX_REQUIRE(ctx, res && h_est_init && out, "null argument");
+    VBX_REQUIRE(ctx, n_res >= 1 && n_res <= 0x7fffffff, "n_res must be >= 1 (the reference indexes resonances[0])");
+    VBX_REQUIRE(ctx, n_est >= 1 && n_est <= VBX_FORMANT_SLOTS, "n_est must be in [1, 6]");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t *d_seg = nullptr; size_t nseg = 1; const res_t *d_est = nullptr;
+    int rc = upload_segments(ctx, h_seg_start, n_segments, n_frames, &d_seg, &nseg);
+    if (rc != VBX_SUCCESS) return rc;
+    rc = upload_estimates(ctx, h_est_init, n_est, &d_est);
+    if (rc != VBX_SUCCESS) return rc;
+    {
+        Prof p(ctx, "tracker");
+        launch_tracker(ctx->stream, (const res_t *)res, (long)n_frames, (int)n_res, nullptr, d_seg, (long)nseg, d_est,
+                       (int)n_est, frame_status, (res_t *)out);
+    }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_find_formants_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
+                          size_t stride, double sample_rate, size_t n_coeffs,
+                          const int64_t *h_seg_start, size_t n_segments,
+                          const vbx_resonance *h_est_init, size_t n_est,
+                          vbx_resonance *out_formants, vbx_resonance *out_res, int32_t *out_res_count,
+                          double *out_coeffs, int32_t *status) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_REQUIRE(ctx, h_est_init && out_formants, "null argument");
+    VBX_REQUIRE(ctx, burg_supported((int)frame_len, (int)n_coeffs), "frame_len must be in [2, 4096], order in [1, 30]");
+    VBX_REQUIRE(ctx, n_est >= 1 && n_est <= VBX_FORMANT_SLOTS, "n_est must be in [1, 6]");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    const long F = (long)n_frames; const int p = (int)n_coeffs;
+    void *w = nullptr;
+    double *coeffs = out_coeffs;
+    if (!coeffs) { rc = ws_get(ctx, vbx_ctx::WS_COEFFS, n_frames * n_coeffs * sizeof(double), &w); if (rc) return rc; coeffs = (double *)w; }
+    res_t *res = (res_t *)out_res;
+    if (!res) { rc = ws_get(ctx, vbx_ctx::WS_RES, n_frames * VBX_MAX_RESONANCES * sizeof(vbx_resonance), &w); if (rc) return rc; res = (res_t *)w; }
+    int32_t *cnt = out_res_count;
+    if (!cnt) { rc = ws_get(ctx, vbx_ctx::WS_COUNT, n_frames * sizeof(int32_t), &w); if (rc) return rc; cnt = (int32_t *)w; }
+    int32_t *st = status;
+    if (!st) { rc = ws_get(ctx, vbx_ctx::WS_STATUS, n_frames * sizeof(int32_t), &w); if (rc) return rc; st = (int32_t *)w; }
+    const double *hann = nullptr;
+    rc = get_window_dev(ctx, VBX_WINDOW_HANNING_PERIODIC, frame_len, &hann);   // src/lib.rs:65-70
+    if (rc != VBX_SUCCESS) return rc;
+    const int64_t *d_seg = nullptr; size_t nseg = 1; const res_t *d_est = nullptr;
+    rc = upload_segments(ctx, h_seg_start, n_segments, n_frames, &d_seg, &nseg);
+    if (rc != VBX_SUCCESS) return rc;
+    rc = upload_estimates(ctx, h_est_init, n_est, &d_est);
+    if (rc != VBX_SUCCESS) return rc;
+    { Prof pr(ctx, "burg"); launch_burg(ctx->stream, x, F, (int)frame_len, (long)stride, hann, p, coeffs, st); }                 // :75
+    { Prof pr(ctx, "formant_resonances"); launch_formant_resonances(ctx->stream, coeffs, F, p, sample_rate, res, cnt, st); }      // :80-110
+    { Prof pr(ctx, "tracker"); launch_tracker(ctx->stream, res, F, VBX_MAX_RESONANCES, cnt, d_seg, (long)nseg, d_est, (int)n_est, st, (res_t *)out_formants); }  // :114
+    return check_launch(ctx, __func__);
+}
+
+// ---- spectrum.rs: MFCC --------------------------------------------------------------------
+
+int vbx_mfcc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
+                 const double *window, size_t num_coeffs, double lo_hz, double hi_hz,
+                 double sample_rate, double *out, int32_t *status) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_REQUIRE(ctx, out != nullptr, "null output");
+    VBX_REQUIRE(ctx, num_coeffs >= 1 && num_coeffs <= 64, "num_coeffs must be in [1, 64]");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<int32_t> hb; bool bad = false; const int32_t *d_bins = nullptr;
+    rc = get_bins_dev(ctx, frame_len, num_coeffs, lo_hz, hi_hz, sample_rate, &d_bins, hb, bad);
+    if (rc != VBX_SUCCESS) return rc;
+    if (bad) {   // the reference panics on every frame (bins do not depend on the data)
+        VBX_HIP(ctx, hipMemsetAsync(out, 0, n_frames * num_coeffs * sizeof(double), ctx->stream));
+        if (status) {
+            std::vector<int32_t> h(n_frames, VBX_FRAME_ERR_PANIC);
+            VBX_HIP(ctx, hipMemcpyAsync(status, h.data(), n_frames * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+            VBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        return VBX_SUCCESS;
+    }
+    const int nb = hb.back() - hb.front();
+    VBX_REQUIRE(ctx, mfcc_fits((int)frame_len, nb), "frame / bin range does not fit the LDS");
+    const double *tw = nullptr, *dct = nullptr;
+    rc = get_twiddle_dev(ctx, frame_len, &tw); if (rc != VBX_SUCCESS) return rc;
+    rc = get_dct_dev(ctx, num_coeffs, &dct); if (rc != VBX_SUCCESS) return rc;
+    if (status) VBX_HIP(ctx, hipMemsetAsync(status, 0, n_frames * sizeof(int32_t), ctx->stream));
+    {
+        Prof p(ctx, "mfcc");
+        launch_mfcc(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, tw, d_bins, dct, (int)num_coeffs, out, status, nb);
+    }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_dct_f64(vbx_ctx *ctx, const double *in, size_t n_rows, size_t n, double *out) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    if (n_rows == 0) return VBX_SUCCESS;
+    VBX_REQUIRE(ctx, in && out && n >= 1 && n <= 4096 && n_rows <= 0x7fffffffull, "bad argument");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    const double *dct = nullptr;
+    int rc = get_dct_dev(ctx, n, &dct); if (rc != VBX_SUCCESS) return rc;
+    { Prof p(ctx, "dct_rows"); launch_dct_rows(ctx->stream, in, (long)n_rows, (int)n, dct, out); }
+    return check_launch(ctx, __func__);
+}
+
+// ---- bench utility ------------------------------------------------------------------------
+
+int vbx_synth_speech_f64(vbx_ctx *ctx, double *out, size_t n_samples, uint64_t sample_offset,
+                         double sample_rate, uint64_t seed) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    if (n_samples == 0) return VBX_SUCCESS;
+    VBX_REQUIRE(ctx, out != nullptr && sample_rate > 0.0, "bad argument");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    { Prof p(ctx, "synth"); launch_synth(ctx->stream, out, n_samples, sample_offset, sample_rate, seed); }
+    return check_launch(ctx, __func__);
+}
+
+// internal: cross-lane helper self-test (tests only; not part of the public header)
+int vbx_selftest_lanes(vbx_ctx *ctx, double *h_out512) {
+    VBX_REQUIRE(ctx, ctx && h_out512, "null argument");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    void *d = nullptr;
+    int rc = ws_get(ctx, vbx_ctx::WS_MISC, 512 * sizeof(double), &d);
+    if (rc != VBX_SUCCESS) return rc;
+    launch_selftest(ctx->stream, (double *)d);
+    rc = check_launch(ctx, __func__);
+    if (rc != VBX_SUCCESS) return rc;
+    VBX_HIP(ctx, hipMemcpyAsync(h_out512, d, 512 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    VBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VBX_SUCCESS;
+}
+
+}  // extern "C"

@@ -1,0 +1,120 @@
+// vbx_device.hpp -- wave64 device helpers shared by the gfx950 kernels.
+// CDNA4 only: 64-lane wavefronts, DPP row rotations, v_readlane broadcasts.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VBX_WAVE 64
+
+namespace vbx {
+
+// ---- lane broadcast / shuffles on f64 (two 32-bit halves) ---------------------------
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double readfirstlane_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    return __hiloint2double(hi, lo);
+}
+
+// DPP move of one f64 (both halves).  CTRL is a gfx9 dpp_ctrl immediate; lanes whose
+// source is out of range receive 0 (bound_ctrl).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int DPP_ROW_ROR1 = 0x121, DPP_ROW_ROR2 = 0x122, DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
+constexpr int DPP_WAVE_SHL1 = 0x130;  // lane i <- lane i+1 (lane 63 <- 0)
+constexpr int DPP_WAVE_SHR1 = 0x138;  // lane i <- lane i-1 (lane 0 <- 0)
+
+// value of lane+1 (lane 63 receives 0)
+__device__ __forceinline__ double from_next_lane(double v) { return dpp_f64<DPP_WAVE_SHL1>(v); }
+// value of lane-1 (lane 0 receives 0)
+__device__ __forceinline__ double from_prev_lane(double v) { return dpp_f64<DPP_WAVE_SHR1>(v); }
+
+// Sum over the 64 lanes; the result is bit-identical in every lane (it is broadcast from
+// scalar registers), which keeps data-dependent control flow wave-uniform.
+__device__ __forceinline__ double wave_sum(double v) {
+    // all-reduce inside each 16-lane row by rotations (full-rate DPP moves)
+    v += dpp_f64<DPP_ROW_ROR8>(v);
+    v += dpp_f64<DPP_ROW_ROR4>(v);
+    v += dpp_f64<DPP_ROW_ROR2>(v);
+    v += dpp_f64<DPP_ROW_ROR1>(v);
+    // one lane per row -> scalar registers -> uniform sum
+    double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32), d = readlane_f64(v, 48);
+    return (a + b) + (c + d);
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+    v = fmax(v, dpp_f64<DPP_ROW_ROR8>(v));
+    v = fmax(v, dpp_f64<DPP_ROW_ROR4>(v));
+    v = fmax(v, dpp_f64<DPP_ROW_ROR2>(v));
+    v = fmax(v, dpp_f64<DPP_ROW_ROR1>(v));
+    double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32), d = readlane_f64(v, 48);
+    return fmax(fmax(a, b), fmax(c, d));
+}
+
+// reference-model variants through ds_bpermute (used by the self-test to validate the DPP forms)
+__device__ __forceinline__ double wave_sum_shfl(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return readfirstlane_f64(v);
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// Orders LDS traffic between the lanes of ONE wavefront (LDS executes a wave's instructions in
+// order; this only stops the compiler from moving accesses across the point).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- complex arithmetic (num-complex 0.2 formulas; FMA contraction allowed) -------
+
+struct c64 { double re, im; };
+
+__device__ __forceinline__ c64 cmk(double re, double im) { c64 z; z.re = re; z.im = im; return z; }
+__device__ __forceinline__ c64 cadd(c64 a, c64 b) { return cmk(a.re + b.re, a.im + b.im); }
+__device__ __forceinline__ c64 csub(c64 a, c64 b) { return cmk(a.re - b.re, a.im - b.im); }
+__device__ __forceinline__ c64 cneg(c64 a) { return cmk(-a.re, -a.im); }
+__device__ __forceinline__ c64 cmul(c64 a, c64 b) {
+    return cmk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re);
+}
+// a*b + c
+__device__ __forceinline__ c64 cmad(c64 a, c64 b, c64 c) {
+    return cmk(fma(a.re, b.re, fma(-a.im, b.im, c.re)), fma(a.re, b.im, fma(a.im, b.re, c.im)));
+}
+__device__ __forceinline__ c64 cdiv(c64 a, c64 b) {
+    double ns = b.re * b.re + b.im * b.im;
+    double inv = 1.0 / ns;
+    double re = a.re * b.re + a.im * b.im;
+    double im = a.im * b.re - a.re * b.im;
+    return cmk(re * inv, im * inv);
+}
+__device__ __forceinline__ double cnorm(c64 a) { return hypot(a.re, a.im); }
+__device__ __forceinline__ bool ciszero(c64 a) { return a.re == 0.0 && a.im == 0.0; }
+// principal square root, algebraic form (equals the polar form of num-complex up to rounding)
+__device__ __forceinline__ c64 csqrt(c64 z) {
+    double r = hypot(z.re, z.im);
+    if (r == 0.0) return cmk(0.0, z.im);
+    if (z.re >= 0.0) {
+        double t = sqrt(0.5 * (r + z.re));
+        return cmk(t, z.im / (2.0 * t));
+    }
+    double t = sqrt(0.5 * (r - z.re));
+    return cmk(fabs(z.im) / (2.0 * t), copysign(t, z.im));
+}
+
+}  // namespace vbx

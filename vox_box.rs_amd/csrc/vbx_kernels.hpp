@@ -1,0 +1,69 @@
+// vbx_kernels.hpp -- host-side launcher declarations (one per kernel family).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VBX_MAX_LPC_ORDER_K 30   // == VBX_MAX_LPC_ORDER (include/voxbox_hip.h)
+#define VBX_MAX_FRAME_LEN_K 4096
+#define VBX_MAX_RESONANCES_K 32
+#define VBX_FORMANT_SLOTS_K 6
+
+namespace vbx {
+
+struct res_t { double frequency, bandwidth; };
+struct pitch_t { double frequency, strength; };
+struct cplx_t { double re, im; };
+
+// k_lpc.hip
+bool fewlags_supported(int n, int n_lags, bool want_lpc);
+void launch_autocorr_fewlags(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
+                             int n_lags, int normalize, double *out_r, double *out_lpc);
+void launch_autocorr_tiles(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
+                           int n_lags, double *out);
+void launch_normalize_rows(hipStream_t s, double *data, long rows, int n);
+void launch_levinson_rows(hipStream_t s, const double *r, long rows, long r_stride, int p, double *out);
+
+// k_burg.hip
+bool burg_supported(int n, int p);
+void launch_burg(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
+                 int p, double *out, int32_t *status);
+
+// k_roots.hip
+void launch_find_roots(hipStream_t s, cplx_t *polys, long F, int len, int32_t *status);
+void launch_laguerre(hipStream_t s, const cplx_t *polys, long F, int len, cplx_t start, cplx_t *out);
+void launch_to_resonance(hipStream_t s, const cplx_t *roots, long F, int n_roots, double sample_rate,
+                         int strict_im, res_t *out, int out_stride, int32_t *out_count, const int32_t *status);
+// Burg coefficients [F,p] -> reversed complex polynomial -> roots -> resonances [F,32] (find_formants core)
+void launch_formant_resonances(hipStream_t s, const double *coeffs, long F, int p, double sample_rate,
+                               res_t *out_res, int32_t *out_count, int32_t *status);
+
+// k_tracker.hip
+void launch_tracker(hipStream_t s, const res_t *res, long F, int n_res, const int32_t *res_count,
+                    const int64_t *seg_start, long n_seg, const res_t *est_init, int n_est,
+                    const int32_t *frame_status, res_t *out);
+
+// k_pitch.hip
+size_t pitch_lds_bytes(int n);
+void launch_pitch(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
+                  const double *inv_lag_window, double sample_rate, double threshold, double fmin, double fmax,
+                  int kmax, pitch_t *out_cand, int32_t *out_count, int32_t *status);
+void launch_sinc_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *xs, long m,
+                        long depth, double *out, int32_t *status);
+void launch_extremum_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *ix, long m,
+                            long depth, double *out_xy, int32_t *status);
+
+// k_mfcc.hip
+bool mfcc_fits(int n, int nb);
+void launch_mfcc(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
+                 const double *twiddle /* [n][2] cos,sin */, const int32_t *bins /* K+2 */, const double *dct_table /* [K][K] */,
+                 int num_coeffs, double *out, int32_t *status, int nb /* bins[K+1]-bins[0] */);
+void launch_dct_rows(hipStream_t s, const double *in, long rows, int n, const double *dct_table, double *out);
+
+// k_synth.hip
+void launch_synth(hipStream_t s, double *out, size_t n_samples, uint64_t sample_offset, double sample_rate, uint64_t seed);
+
+// k_selftest.hip
+void launch_selftest(hipStream_t s, double *out /* 64*8 */);
+
+}  // namespace vbx

@@ -1,0 +1,503 @@
+"""ctypes binding of libvoxbox_hip.so (include/voxbox_hip.h).
+
+Method names follow the reference crate's traits (Autocorrelate::autocorrelate, LPC::lpc /
+lpc_praat, Pitched::pitch, Polynomial::find_roots, ToResonance::to_resonance,
+EstimateFormants / FormantExtractor, MFCC::mfcc, vox_box::find_formants); each takes a whole
+batch of frames instead of one slice.  Arguments named ``x`` may be a host numpy array
+(uploaded for the call) or a DeviceArray / raw device pointer (used in place).
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvoxbox_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "voxbox_hip.h")
+
+WINDOW_HANNING, WINDOW_HANNING_LAG, WINDOW_HANNING_PERIODIC, WINDOW_RECTANGLE = 0, 1, 2, 3
+FRAME_OK, FRAME_ERR_LPC, FRAME_ERR_POLYNOMIAL, FRAME_ERR_NAN, FRAME_ERR_PANIC = 0, 1, 2, 3, 4
+MALE_FORMANT_ESTIMATES = (320.0, 1440.0, 2760.0, 3200.0)      # src/lib.rs:27
+FEMALE_FORMANT_ESTIMATES = (480.0, 1760.0, 3200.0, 3520.0)    # src/lib.rs:28
+MAX_RESONANCES = 32
+
+
+class VoxBoxError(RuntimeError):
+    pass
+
+
+class _Complex(C.Structure):
+    _fields_ = [("re", C.c_double), ("im", C.c_double)]
+
+
+_lib = None
+
+
+def exported_symbols():
+    """Function names declared in include/voxbox_hip.h (the ABI the library must export)."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vbx_[a-z0-9_]+)\s*\(", text)))
+
+
+def load_library():
+    """Loads libvoxbox_hip.so.  Fails loudly if it was not built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VoxBoxError(
+            f"{LIB_PATH} is missing: build it with `make -C {_HERE}` (or __graft_entry__.build()); "
+            "there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, dbl, i32, i64 = C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.c_int64
+    sig = {
+        "vbx_abi_version": (C.c_int, []),
+        "vbx_ctx_create": (C.c_int, [C.POINTER(vp), i32, vp]),
+        "vbx_ctx_destroy": (None, [vp]),
+        "vbx_sync": (C.c_int, [vp]),
+        "vbx_last_error": (C.c_char_p, [vp]),
+        "vbx_device_info": (C.c_int, [vp, C.c_char_p, sz, C.POINTER(C.c_int)]),
+        "vbx_malloc": (C.c_int, [vp, C.POINTER(vp), sz]),
+        "vbx_free": (C.c_int, [vp, vp]),
+        "vbx_memcpy_h2d": (C.c_int, [vp, vp, vp, sz]),
+        "vbx_memcpy_d2h": (C.c_int, [vp, vp, vp, sz]),
+        "vbx_memset": (C.c_int, [vp, vp, i32, sz]),
+        "vbx_timer_begin": (C.c_int, [vp]),
+        "vbx_timer_end": (C.c_int, [vp, C.POINTER(C.c_float)]),
+        "vbx_profile_enable": (C.c_int, [vp, i32]),
+        "vbx_profile_reset": (C.c_int, [vp]),
+        "vbx_profile_get": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+        "vbx_profile_names": (C.c_int, [vp, C.c_char_p, sz]),
+        "vbx_window_table_f64": (C.c_int, [i32, sz, vp]),
+        "vbx_frame_count": (sz, [sz, sz, sz]),
+        "vbx_hz_to_mel": (dbl, [dbl]),
+        "vbx_mel_to_hz": (dbl, [dbl]),
+        "vbx_find_formants_real_work_size": (sz, [sz, sz]),
+        "vbx_find_formants_complex_work_size": (sz, [sz]),
+        "vbx_autocorrelate_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, vp]),
+        "vbx_normalize_f64": (C.c_int, [vp, vp, sz, sz]),
+        "vbx_interpolate_sinc_f64": (C.c_int, [vp, vp, sz, C.c_long, sz, vp, sz, sz, vp, vp]),
+        "vbx_improve_extremum_f64": (C.c_int, [vp, vp, sz, C.c_long, sz, vp, sz, sz, vp, vp]),
+        "vbx_pitch_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, dbl, dbl, dbl, dbl, sz, vp, vp, vp]),
+        "vbx_lpc_f64": (C.c_int, [vp, vp, sz, sz, sz, vp]),
+        "vbx_autocorr_lpc_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, i32, vp, vp]),
+        "vbx_lpc_burg_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, vp, vp]),
+        "vbx_find_roots_c64": (C.c_int, [vp, vp, sz, sz, vp]),
+        "vbx_laguerre_c64": (C.c_int, [vp, vp, sz, sz, _Complex, vp]),
+        "vbx_to_resonance_c64": (C.c_int, [vp, vp, sz, sz, dbl, vp, vp]),
+        "vbx_estimate_formants_f64": (C.c_int, [vp, vp, sz, sz, vp, sz, vp, sz, vp, vp]),
+        "vbx_find_formants_f64": (C.c_int, [vp, vp, sz, sz, sz, dbl, sz, vp, sz, vp, sz, vp, vp, vp, vp, vp]),
+        "vbx_mfcc_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, dbl, dbl, dbl, vp, vp]),
+        "vbx_dct_f64": (C.c_int, [vp, vp, sz, sz, vp]),
+        "vbx_synth_speech_f64": (C.c_int, [vp, vp, sz, C.c_uint64, dbl, C.c_uint64]),
+        "vbx_selftest_lanes": (C.c_int, [vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)          # AttributeError here = symbol missing from the build
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+# ---- host-only helpers (no GPU needed) --------------------------------------------------
+
+def window_table(kind, n):
+    out = np.empty(n, dtype=np.float64)
+    rc = load_library().vbx_window_table_f64(kind, n, out.ctypes.data)
+    if rc != 0:
+        raise VoxBoxError("vbx_window_table_f64 failed")
+    return out
+
+
+def frame_count(n_samples, frame_len, hop):
+    return int(load_library().vbx_frame_count(n_samples, frame_len, hop))
+
+
+def hz_to_mel(hz):
+    return load_library().vbx_hz_to_mel(hz)
+
+
+def mel_to_hz(mel):
+    return load_library().vbx_mel_to_hz(mel)
+
+
+class DeviceArray:
+    """A device allocation owned by a VoxBox context (freed with it or via .free())."""
+
+    def __init__(self, vb, nbytes, dtype=np.float64, shape=None):
+        self.vb, self.nbytes, self.dtype = vb, int(nbytes), np.dtype(dtype)
+        self.shape = shape if shape is not None else (self.nbytes // self.dtype.itemsize,)
+        p = C.c_void_p()
+        vb._check(vb.L.vbx_malloc(vb.ctx, C.byref(p), self.nbytes))
+        self.ptr = p.value
+        vb._allocs.add(self)
+
+    def numpy(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        self.vb._check(self.vb.L.vbx_memcpy_d2h(self.vb.ctx, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.vb.L.vbx_free(self.vb.ctx, self.ptr)
+            self.ptr = None
+            self.vb._allocs.discard(self)
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, DeviceArray):
+        return a.ptr
+    if isinstance(a, int):
+        return a
+    if hasattr(a, "data_ptr"):          # torch tensor on the device
+        return a.data_ptr()
+    raise TypeError(f"not a device buffer: {type(a)}")
+
+
+class VoxBox:
+    """One libvoxbox_hip context = one GPU + one HIP stream."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = load_library()
+        self._allocs = set()
+        ctx = C.c_void_p()
+        rc = self.L.vbx_ctx_create(C.byref(ctx), device, stream)
+        if rc != 0:
+            msg = self.L.vbx_last_error(None)
+            raise VoxBoxError(f"vbx_ctx_create failed ({rc}): {msg.decode() if msg else ''}")
+        self.ctx = ctx
+        self._tables = {}
+
+    # -- plumbing ---------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.L.vbx_last_error(self.ctx)
+            raise VoxBoxError(f"libvoxbox_hip error {rc}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            for a in list(self._allocs):
+                a.free()
+            self.L.vbx_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def sync(self):
+        self._check(self.L.vbx_sync(self.ctx))
+
+    def device_info(self):
+        buf = C.create_string_buffer(128)
+        cu = C.c_int()
+        self._check(self.L.vbx_device_info(self.ctx, buf, 128, C.byref(cu)))
+        return buf.value.decode(), cu.value
+
+    def empty(self, shape, dtype=np.float64):
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        n = int(np.prod(shape)) if shape else 1
+        return DeviceArray(self, max(n, 1) * np.dtype(dtype).itemsize, dtype, shape)
+
+    def to_device(self, a, dtype=None):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        d = DeviceArray(self, max(a.nbytes, 16), a.dtype, a.shape)
+        if a.nbytes:
+            self._check(self.L.vbx_memcpy_h2d(self.ctx, d.ptr, a.ctypes.data, a.nbytes))
+        return d
+
+    def zeros(self, shape, dtype=np.float64):
+        d = self.empty(shape, dtype)
+        self._check(self.L.vbx_memset(self.ctx, d.ptr, 0, d.nbytes))
+        return d
+
+    def window(self, kind, n):
+        """device copy of a host-built window table (cached)."""
+        key = (kind, n)
+        if key not in self._tables:
+            self._tables[key] = self.to_device(window_table(kind, n))
+        return self._tables[key]
+
+    def timer_begin(self):
+        self._check(self.L.vbx_timer_begin(self.ctx))
+
+    def timer_end(self):
+        ms = C.c_float()
+        self._check(self.L.vbx_timer_end(self.ctx, C.byref(ms)))
+        return ms.value
+
+    def profile(self, on=True):
+        self._check(self.L.vbx_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self.L.vbx_profile_reset(self.ctx))
+
+    def profile_report(self):
+        buf = C.create_string_buffer(4096)
+        self._check(self.L.vbx_profile_names(self.ctx, buf, 4096))
+        out = {}
+        for name in buf.value.decode().split("\n"):
+            if not name:
+                continue
+            ms, cnt = C.c_double(), C.c_long()
+            self._check(self.L.vbx_profile_get(self.ctx, name.encode(), C.byref(ms), C.byref(cnt)))
+            out[name] = (ms.value, cnt.value)
+        return out
+
+    def _frames(self, x, frame_len=None, stride=None, n_frames=None):
+        """Resolves a frame batch: 2-D host array = dense [F, N]; 1-D host array + (frame_len,
+        stride) = Windower view; device buffers need all of frame_len/stride/n_frames."""
+        tmp = None
+        if isinstance(x, np.ndarray):
+            if x.ndim == 2:
+                n_frames, frame_len = x.shape
+                stride = frame_len
+            else:
+                assert frame_len and stride
+                n_frames = frame_count(x.size, frame_len, stride) if n_frames is None else n_frames
+            tmp = self.to_device(x, np.float64)
+            ptr = tmp.ptr
+        else:
+            assert frame_len and stride and n_frames is not None
+            ptr = _ptr(x)
+        return ptr, int(n_frames), int(frame_len), int(stride), tmp
+
+    # -- periodic.rs ------------------------------------------------------------------
+    def autocorrelate(self, x, n_lags, frame_len=None, stride=None, n_frames=None, window=None, out=None):
+        ptr, F, N, S, tmp = self._frames(x, frame_len, stride, n_frames)
+        o = out if out is not None else self.empty((F, n_lags))
+        self._check(self.L.vbx_autocorrelate_f64(self.ctx, ptr, F, N, S, _ptr(window), n_lags, _ptr(o)))
+        return self._finish(o, out, tmp)
+
+    def normalize(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        d = self.to_device(rows)
+        self._check(self.L.vbx_normalize_f64(self.ctx, d.ptr, rows.shape[0], rows.shape[1]))
+        r = d.numpy()
+        d.free()
+        return r
+
+    def interpolate_sinc(self, y, offset, nx, xs, depth):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        xs = np.ascontiguousarray(xs, dtype=np.float64)
+        dy, dx = self.to_device(y), self.to_device(xs)
+        o, st = self.empty(xs.size), self.empty(xs.size, np.int32)
+        self._check(self.L.vbx_interpolate_sinc_f64(self.ctx, dy.ptr, y.size, offset, nx, dx.ptr, xs.size, depth, o.ptr, st.ptr))
+        r = (o.numpy(), st.numpy())
+        for d in (dy, dx, o, st):
+            d.free()
+        return r
+
+    def improve_extremum(self, y, offset, nx, ixmid, depth):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        ix = np.ascontiguousarray(ixmid, dtype=np.float64)
+        dy, dx = self.to_device(y), self.to_device(ix)
+        o, st = self.empty((ix.size, 2)), self.empty(ix.size, np.int32)
+        self._check(self.L.vbx_improve_extremum_f64(self.ctx, dy.ptr, y.size, offset, nx, dx.ptr, ix.size, depth, o.ptr, st.ptr))
+        r = (o.numpy(), st.numpy())
+        for d in (dy, dx, o, st):
+            d.free()
+        return r
+
+    def pitch(self, x, sample_rate, threshold, fmin, fmax, kmax=8, frame_len=None, stride=None, n_frames=None,
+              window=None, out=None):
+        """Returns (cand[F, kmax, 2], count[F], status[F]) as numpy, or writes into `out`
+        = (cand, count, status) device buffers and returns None."""
+        ptr, F, N, S, tmp = self._frames(x, frame_len, stride, n_frames)
+        if out is None:
+            cand, cnt, st = self.empty((F, kmax, 2)), self.empty(F, np.int32), self.empty(F, np.int32)
+        else:
+            cand, cnt, st = out
+        self._check(self.L.vbx_pitch_f64(self.ctx, ptr, F, N, S, _ptr(window), sample_rate, threshold, fmin, fmax,
+                                         kmax, _ptr(cand), _ptr(cnt), _ptr(st)))
+        if out is not None:
+            return None
+        r = (cand.numpy(), cnt.numpy(), st.numpy())
+        for d in (cand, cnt, st, tmp):
+            if d is not None:
+                d.free()
+        return r
+
+    # -- spectrum.rs: LPC -------------------------------------------------------------
+    def lpc(self, r, n_coeffs):
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        d = self.to_device(r)
+        o = self.empty((r.shape[0], n_coeffs + 1))
+        self._check(self.L.vbx_lpc_f64(self.ctx, d.ptr, r.shape[0], r.shape[1], n_coeffs, o.ptr))
+        res = o.numpy()
+        d.free(); o.free()
+        return res
+
+    def autocorr_lpc(self, x, n_coeffs, normalize=False, frame_len=None, stride=None, n_frames=None, window=None,
+                     out=None):
+        ptr, F, N, S, tmp = self._frames(x, frame_len, stride, n_frames)
+        if out is None:
+            r, a = self.empty((F, n_coeffs + 1)), self.empty((F, n_coeffs + 1))
+        else:
+            r, a = out
+        self._check(self.L.vbx_autocorr_lpc_f64(self.ctx, ptr, F, N, S, _ptr(window), n_coeffs, 1 if normalize else 0,
+                                                _ptr(r), _ptr(a)))
+        if out is not None:
+            return None
+        res = (r.numpy(), a.numpy())
+        for d in (r, a, tmp):
+            if d is not None:
+                d.free()
+        return res
+
+    def lpc_praat(self, x, n_coeffs, frame_len=None, stride=None, n_frames=None, window=None, out=None):
+        """Burg (LPC::lpc_praat).  Returns (coeffs[F, p], status[F])."""
+        ptr, F, N, S, tmp = self._frames(x, frame_len, stride, n_frames)
+        if out is None:
+            co, st = self.empty((F, n_coeffs)), self.empty(F, np.int32)
+        else:
+            co, st = out
+        self._check(self.L.vbx_lpc_burg_f64(self.ctx, ptr, F, N, S, _ptr(window), n_coeffs, _ptr(co), _ptr(st)))
+        if out is not None:
+            return None
+        res = (co.numpy(), st.numpy())
+        for d in (co, st, tmp):
+            if d is not None:
+                d.free()
+        return res
+
+    # -- polynomial.rs ----------------------------------------------------------------
+    def find_roots(self, polys):
+        """polys: [F, len] complex (coefficient of x^j at index j).  Returns (roots[F, len], status[F]);
+        row layout as find_roots_mut leaves `self`: roots in discovery order, then zeros."""
+        p = np.ascontiguousarray(polys, dtype=np.complex128)
+        d = self.to_device(p)
+        st = self.empty(p.shape[0], np.int32)
+        self._check(self.L.vbx_find_roots_c64(self.ctx, d.ptr, p.shape[0], p.shape[1], st.ptr))
+        res = (d.numpy(), st.numpy())
+        d.free(); st.free()
+        return res
+
+    def laguerre(self, polys, start):
+        p = np.ascontiguousarray(polys, dtype=np.complex128)
+        d = self.to_device(p)
+        o = self.empty(p.shape[0], np.complex128)
+        self._check(self.L.vbx_laguerre_c64(self.ctx, d.ptr, p.shape[0], p.shape[1], _Complex(start.real, start.imag), o.ptr))
+        res = o.numpy()
+        d.free(); o.free()
+        return res
+
+    # -- spectrum.rs: resonances / tracker ---------------------------------------------
+    def to_resonance(self, roots, sample_rate):
+        r = np.ascontiguousarray(roots, dtype=np.complex128)
+        d = self.to_device(r)
+        o, c = self.empty((r.shape[0], r.shape[1], 2)), self.empty(r.shape[0], np.int32)
+        self._check(self.L.vbx_to_resonance_c64(self.ctx, d.ptr, r.shape[0], r.shape[1], sample_rate, o.ptr, c.ptr))
+        res = (o.numpy(), c.numpy())
+        for b in (d, o, c):
+            b.free()
+        return res
+
+    def estimate_formants(self, res, est_init, seg_start=None, frame_status=None):
+        """FormantExtractor over [F, n_res, 2] resonance rows; returns estimates [F, n_est, 2]."""
+        r = np.ascontiguousarray(res, dtype=np.float64)
+        e = np.ascontiguousarray(est_init, dtype=np.float64)
+        F, n_res, n_est = r.shape[0], r.shape[1], e.shape[0]
+        d = self.to_device(r)
+        o = self.empty((F, n_est, 2))
+        seg = None if seg_start is None else np.ascontiguousarray(seg_start, dtype=np.int64)
+        fs = None if frame_status is None else self.to_device(np.ascontiguousarray(frame_status, dtype=np.int32))
+        self._check(self.L.vbx_estimate_formants_f64(
+            self.ctx, d.ptr, F, n_res, None if seg is None else seg.ctypes.data, 0 if seg is None else seg.size,
+            e.ctypes.data, n_est, _ptr(fs), o.ptr))
+        out = o.numpy()
+        for b in (d, o, fs):
+            if b is not None:
+                b.free()
+        return out
+
+    def find_formants(self, x, sample_rate, n_coeffs, est_init, seg_start=None, frame_len=None, stride=None,
+                      n_frames=None, out=None, want=("formants", "res", "count", "coeffs", "status")):
+        """vox_box::find_formants over a batch (resample_ratio = 1.0).  est_init: [n_est, 2]."""
+        ptr, F, N, S, tmp = self._frames(x, frame_len, stride, n_frames)
+        e = np.ascontiguousarray(est_init, dtype=np.float64)
+        n_est = e.shape[0]
+        seg = None if seg_start is None else np.ascontiguousarray(seg_start, dtype=np.int64)
+        if out is None:
+            bufs = {
+                "formants": self.empty((F, n_est, 2)),
+                "res": self.empty((F, MAX_RESONANCES, 2)) if "res" in want else None,
+                "count": self.empty(F, np.int32) if "count" in want else None,
+                "coeffs": self.empty((F, n_coeffs)) if "coeffs" in want else None,
+                "status": self.empty(F, np.int32) if "status" in want else None,
+            }
+        else:
+            bufs = out
+        self._check(self.L.vbx_find_formants_f64(
+            self.ctx, ptr, F, N, S, sample_rate, n_coeffs,
+            None if seg is None else seg.ctypes.data, 0 if seg is None else seg.size,
+            e.ctypes.data, n_est, _ptr(bufs["formants"]), _ptr(bufs.get("res")), _ptr(bufs.get("count")),
+            _ptr(bufs.get("coeffs")), _ptr(bufs.get("status"))))
+        if out is not None:
+            return None
+        res = {k: (v.numpy() if v is not None else None) for k, v in bufs.items()}
+        for v in list(bufs.values()) + [tmp]:
+            if v is not None:
+                v.free()
+        return res
+
+    # -- spectrum.rs: MFCC ------------------------------------------------------------
+    def mfcc(self, x, num_coeffs, freq_bounds, sample_rate, frame_len=None, stride=None, n_frames=None,
+             window=None, out=None):
+        ptr, F, N, S, tmp = self._frames(x, frame_len, stride, n_frames)
+        if out is None:
+            o, st = self.empty((F, num_coeffs)), self.empty(F, np.int32)
+        else:
+            o, st = out
+        self._check(self.L.vbx_mfcc_f64(self.ctx, ptr, F, N, S, _ptr(window), num_coeffs, freq_bounds[0],
+                                        freq_bounds[1], sample_rate, _ptr(o), _ptr(st)))
+        if out is not None:
+            return None
+        res = (o.numpy(), st.numpy())
+        for d in (o, st, tmp):
+            if d is not None:
+                d.free()
+        return res
+
+    def dct(self, rows):
+        r = np.ascontiguousarray(rows, dtype=np.float64)
+        d = self.to_device(r)
+        o = self.empty(r.shape)
+        self._check(self.L.vbx_dct_f64(self.ctx, d.ptr, r.shape[0], r.shape[1], o.ptr))
+        res = o.numpy()
+        d.free(); o.free()
+        return res
+
+    # -- utilities ----------------------------------------------------------------------
+    def synth_speech(self, n_samples, sample_offset=0, sample_rate=48000.0, seed=0x5EED0001, out=None):
+        o = out if out is not None else self.empty(n_samples)
+        self._check(self.L.vbx_synth_speech_f64(self.ctx, _ptr(o), n_samples, sample_offset, sample_rate, seed))
+        return o
+
+    def selftest_lanes(self):
+        out = np.zeros((64, 8), dtype=np.float64)
+        self._check(self.L.vbx_selftest_lanes(self.ctx, out.ctypes.data))
+        return out
+
+    def _finish(self, o, out, tmp):
+        if out is not None:
+            return None
+        r = o.numpy()
+        o.free()
+        if tmp is not None:
+            tmp.free()
+        return r
