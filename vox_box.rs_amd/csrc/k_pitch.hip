@@ -4,66 +4,139 @@
 //            :192-229 (improve_extremum), :362-375 (local_maxima), :396-455 (pitch),
 //            src/waves.rs:44-75 (max_amplitude / normalize).  Quirks Q1-Q10 reproduced.
 //
-// One wavefront per frame.  The windowed frame is staged in LDS, the all-lag autocorrelation
-// runs as lag tiles (vbx_autocorr.hpp), the normalised / lag-window-divided curve y stays in
-// LDS, and every candidate peak is refined by the reference's Brent iteration whose scalar
-// control flow is executed identically by all 64 lanes while each sinc evaluation -- the
-// dominant cost, 2*(depth+1) terms -- is spread over the lanes and reduced with DPP.
-//
-// Sinc term algebra (exact identities, no change of the reference's formula):
-//   sin(pi*(phi+n)) = (-1)^n * sin(pi*phi)                       -> one sinpi per evaluation
-//   cos(a/(phi+D)) with a/(phi+D) in [0, pi]                      -> odd polynomial in (theta - pi/2)
-//   1/a                                                            -> v_rcp_f64 + 2 Newton steps
-// This kernel is FP64-VALU bound (hundreds of flop per byte); HBM traffic is the 3.8 KB of
-// new samples per frame.
+// Two kernels, one wavefront per frame each: (1) the windowed frame is staged in LDS and the
+// all-lag autocorrelation runs as lag tiles (vbx_autocorr.hpp), giving the normalised /
+// lag-window-divided curve y; (2) y sits in LDS and every candidate peak is refined by the
+// reference's Brent iteration, whose scalar control flow is executed identically by all 64 lanes
+// while each sinc evaluation -- the dominant cost, 2*(depth+1) terms -- is spread over the lanes
+// and reduced with DPP.  The path is FP64-VALU bound (hundreds of flop per byte); HBM traffic
+// is the 3.8 KB of new samples per frame plus the 19 KB round trip of y between the kernels.
 #include "vbx_autocorr.hpp"
 #include "vbx_kernels.hpp"
 
 namespace vbx {
 
-// reciprocal of a normal, well-scaled double
-__device__ __forceinline__ double fast_rcp(double a) {
+// reciprocal of a normal, well-scaled double: v_rcp_f64 (4.6e-8) + Newton steps
+__device__ __forceinline__ double rcp_nr1(double a) {       // ~2e-15 relative
+    double r = __builtin_amdgcn_rcp(a);
+    return fma(fma(-a, r, 1.0), r, r);
+}
+__device__ __forceinline__ double rcp_nr2(double a) {       // correctly rounded in practice
     double r = __builtin_amdgcn_rcp(a);
     r = fma(fma(-a, r, 1.0), r, r);
-    r = fma(fma(-a, r, 1.0), r, r);
-    return r;
+    return fma(fma(-a, r, 1.0), r, r);
 }
 
-// cos(theta) for theta in [0, pi] (slightly outside is fine): -sin(theta - pi/2), Taylor to u^21
-__device__ __forceinline__ double cos_0_pi(double theta) {
-    const double u = theta - 1.57079632679489661923;
-    const double u2 = u * u;
+// sin(x), cos(x) for |x| <= pi/2 (a little beyond is fine): Taylor to x^21 / x^22 (< 2e-18 truncation)
+__device__ __forceinline__ double sin_poly(double x) {
+    const double x2 = x * x;
     double p = -1.9572941063391261231e-20;           // -1/21!
-    p = fma(p, u2, 8.2206352466243297170e-18);       //  1/19!
-    p = fma(p, u2, -2.8114572543455207632e-15);      // -1/17!
-    p = fma(p, u2, 7.6471637318198164759e-13);       //  1/15!
-    p = fma(p, u2, -1.6059043836821614599e-10);      // -1/13!
-    p = fma(p, u2, 2.5052108385441718775e-08);       //  1/11!
-    p = fma(p, u2, -2.7557319223985890653e-06);      // -1/9!
-    p = fma(p, u2, 1.9841269841269841270e-04);       //  1/7!
-    p = fma(p, u2, -8.3333333333333333333e-03);      // -1/5!
-    p = fma(p, u2, 1.6666666666666666667e-01);       //  1/3!   (sign folded below)
-    // sin(u) = u - u^3/6 + ... = u * (1 - u2*(1/6 - u2*(1/120 - ...)))
-    const double s = u * fma(-u2, p, 1.0);
-    return -s;
+    p = fma(p, x2, 8.2206352466243297170e-18);       //  1/19!
+    p = fma(p, x2, -2.8114572543455207632e-15);      // -1/17!
+    p = fma(p, x2, 7.6471637318198164759e-13);       //  1/15!
+    p = fma(p, x2, -1.6059043836821614599e-10);      // -1/13!
+    p = fma(p, x2, 2.5052108385441718775e-08);       //  1/11!
+    p = fma(p, x2, -2.7557319223985890653e-06);      // -1/9!
+    p = fma(p, x2, 1.9841269841269841270e-04);       //  1/7!
+    p = fma(p, x2, -8.3333333333333333333e-03);      // -1/5!
+    p = fma(p, x2, 1.6666666666666666667e-01);       //  1/3!
+    return x * fma(-x2, p, 1.0);
+}
+__device__ __forceinline__ double cos_poly(double x) {
+    const double x2 = x * x;
+    double p = 8.8967913924505732867e-22;            //  1/22!
+    p = fma(p, x2, -4.1103176233121648585e-19);      // -1/20!
+    p = fma(p, x2, 1.5619206968586226462e-16);       //  1/18!
+    p = fma(p, x2, -4.7794773323873852974e-14);      // -1/16!
+    p = fma(p, x2, 1.1470745597729724714e-11);       //  1/14!
+    p = fma(p, x2, -2.0876756987868098979e-09);      // -1/12!
+    p = fma(p, x2, 2.7557319223985890653e-07);       //  1/10!
+    p = fma(p, x2, -2.4801587301587301587e-05);      // -1/8!
+    p = fma(p, x2, 1.3888888888888888889e-03);       //  1/6!
+    p = fma(p, x2, -4.1666666666666666667e-02);      // -1/4!
+    p = fma(p, x2, 0.5);                             //  1/2!
+    return fma(-x2, p, 1.0);
 }
 
-// y lookup: entries [nstore, ylen) are the zeros of self_lag.resize(2N, 0) (src/periodic.rs:411)
-__device__ __forceinline__ double y_at(const double *y, int nstore, long idx) {
-    return (idx < nstore) ? y[idx] : 0.0;
+// cos(theta) for theta in [0, pi]: -sin(theta - pi/2)
+__device__ __forceinline__ double cos_0_pi(double theta) { return -sin_poly(theta - 1.57079632679489661923); }
+
+// y lookup: entries [nvalid, ylen) are the zeros of self_lag.resize(2N, 0) (src/periodic.rs:411)
+__device__ __forceinline__ double y_at(const double *y, int nvalid, long idx) {
+    return (idx < nvalid) ? y[idx] : 0.0;
+}
+
+// Sum of the 2*(D+1) sinc terms (src/periodic.rs:59-84), general form: any index may need the
+// reference's clamps.  Even lanes take "left" terms, odd lanes "right" terms.
+__device__ __forceinline__ double sinc_sum_general(const double *y, int nvalid, long ylen, long offset, long nl, long nr,
+                                                   double phil, double phir, long max_depth) {
+    const int lane = lane_id();
+    const int side = lane & 1;
+    const double ph = side ? phir : phil;
+    const double s0 = sinpi(ph);               // sin(pi*(ph+n)) = (-1)^n * s0
+    const double inv_dd = 1.0 / (ph + (double)max_depth);
+    const long ibase = side ? (offset + nl) : (offset + nr);
+    double acc = 0.0;
+    for (long n = (lane >> 1); n <= max_depth; n += 32) {
+        const double a = M_PI * (ph + (double)n);
+        long idx = side ? (ibase + n) : (ibase - n);
+        idx = (idx < 0) ? 0 : idx;
+        idx = (idx >= ylen) ? (ylen - 1) : idx;          // only reachable on the right side (:78)
+        const double r_lag = y_at(y, nvalid, idx);
+        const double sgn_s0 = (n & 1) ? -s0 : s0;
+        const double first = sgn_s0 * rcp_nr2(a);
+        const double second = fma(0.5, cos_0_pi(a * inv_dd), 0.5);
+        acc = fma(r_lag * first, second, acc);
+    }
+    return wave_sum(acc);
+}
+
+// The same sum when every index is known to be in [0, nvalid): no clamps, and the per-term work is
+// reduced with exact identities (no change of the reference's formula):
+//   sin(pi*(ph+n))              = (-1)^n * sin(pi*ph)              one polynomial per evaluation
+//   0.5 + 0.5*cos(a/(ph+D))     = cos^2(h*(ph+n)),  h = pi/(2*(ph+D))  angle in [0, pi/2]; successive
+//                                 terms of a lane (n += 32) by one plane rotation instead of a cosine
+//   1/a                         = v_rcp_f64 + one Newton step
+__device__ __forceinline__ double sinc_sum_fast(const double *y, int ibase_l, int ibase_r,
+                                                double phil, double phir, int max_depth) {
+    const int lane = lane_id();
+    const int side = lane & 1;
+    const int n0 = lane >> 1;
+    const double ph = side ? phir : phil;
+    const double s0 = sin_poly(M_PI * fmin(phil, phir));      // sin(pi*phil) == sin(pi*phir)
+    const double h = 1.57079632679489661923 * rcp_nr2(ph + (double)max_depth);
+    double pn = ph + (double)n0;
+    double c = cos_poly(h * pn), s = sin_poly(h * pn);
+    const double rc = cos_poly(32.0 * h), rs = sin_poly(32.0 * h);
+    int idx = side ? (ibase_r + n0) : (ibase_l - n0);
+    const int step = side ? 32 : -32;
+    double acc = 0.0;
+    for (int n = n0; n <= max_depth; n += 32) {
+        const double yv = y[idx];
+        const double r = rcp_nr1(pn);
+        acc = fma(yv * r, c * c, acc);
+        const double cn = fma(c, rc, -(s * rs));
+        s = fma(s, rc, c * rs);
+        c = cn;
+        pn += 32.0;
+        idx += step;
+    }
+    acc = (n0 & 1) ? -acc : acc;
+    return wave_sum(acc) * (s0 * 0.31830988618379067154);
 }
 
 // interpolate_sinc, wave-cooperative; result identical in all lanes.  st |= 4 where the
-// reference would index out of bounds.
-__device__ __forceinline__ double sinc_interp(const double *y, int nstore, long ylen, long offset, long nx,
+// reference would index out of bounds.  y[0..nvalid) is readable; logical length ylen >= nvalid
+// with zeros beyond nvalid... (entries in [n_data, nvalid) must already be zero).
+__device__ __forceinline__ double sinc_interp(const double *y, int nvalid, long ylen, long offset, long nx,
                                               double x, long max_depth, int &st) {
     if (nx < 1) return __builtin_nan("");                                     // :38
     if (x > (double)nx) {                                                      // :39
         const long idx = offset + nx - 1;
         if (idx < 0 || idx >= ylen) { st |= 4; return 0.0; }
-        return y_at(y, nstore, idx);
+        return y_at(y, nvalid, idx);
     }
-    if (x < 0.0) return y_at(y, nstore, 0);                                   // :40
+    if (x < 0.0) return y_at(y, nvalid, 0);                                   // :40
     const double fl = floor(x);
     const long nl = (fl > 0.0) ? (long)fl : 0;                                // NaN -> 0
     const long nr = nl + 1;
@@ -72,12 +145,12 @@ __device__ __forceinline__ double sinc_interp(const double *y, int nstore, long 
     if (fabs(x - (double)nl) < 1.0e-10) {                                      // :41
         const long idx = offset + nl;
         if (idx < 0 || idx >= ylen) { st |= 4; return 0.0; }
-        return y_at(y, nstore, idx);
+        return y_at(y, nvalid, idx);
     }
     if (fabs(x - (double)nr) < 1.0e-10) {                                      // :42
         const long idx = offset + nr;
         if (idx < 0 || idx >= ylen) { st |= 4; return 0.0; }
-        return y_at(y, nstore, idx);
+        return y_at(y, nvalid, idx);
     }
     if ((offset + nr) < max_depth) max_depth = ((offset + nr) < 0) ? 0 : (offset + nr);    // :46-52
     if ((offset + nl + max_depth) >= nx) {                                                    // :55-57
@@ -85,28 +158,11 @@ __device__ __forceinline__ double sinc_interp(const double *y, int nstore, long 
         if (max_depth < 0) { st |= 4; return 0.0; }
     }
     if (offset + nr >= ylen) { st |= 4; return 0.0; }    // left index at n = 0 (:67) out of bounds
-
-    const int lane = lane_id();
-    const int side = lane & 1;                 // even lanes: "left" terms, odd lanes: "right" terms
-    const double ph = side ? phir : phil;
-    const double s0 = sinpi(ph);               // sin(pi*(ph+n)) = (-1)^n * s0
-    const double dd = ph + (double)max_depth;
-    const double inv_dd = 1.0 / dd;
-    const long ibase = side ? (offset + nl) : (offset + nr);
-    const long nterms = max_depth + 1;
-    double acc = 0.0;
-    for (long n = (lane >> 1); n < nterms; n += 32) {
-        const double a = M_PI * (ph + (double)n);
-        long idx = side ? (ibase + n) : (ibase - n);
-        idx = (idx < 0) ? 0 : idx;
-        idx = (idx >= ylen) ? (ylen - 1) : idx;          // only reachable on the right side (:78)
-        const double r_lag = y_at(y, nstore, idx);
-        const double sgn_s0 = (n & 1) ? -s0 : s0;
-        const double first = sgn_s0 * fast_rcp(a);
-        const double second = fma(0.5, cos_0_pi(a * inv_dd), 0.5);
-        acc = fma(r_lag * first, second, acc);
-    }
-    return wave_sum(acc);
+    // fast path: left indices [offset+nr-D, offset+nr] and right indices [offset+nl, offset+nl+D] all valid
+    if (!(x != x) && max_depth <= offset + nr && offset + nl >= 0 && offset + nl + max_depth < (long)nvalid &&
+        offset + nr < (long)nvalid && max_depth < 0x3fffffff)
+        return sinc_sum_fast(y, (int)(offset + nr), (int)(offset + nl), phil, phir, (int)max_depth);
+    return sinc_sum_general(y, nvalid, ylen, offset, nl, nr, phil, phir, max_depth);
 }
 
 // brent_maximize (src/periodic.rs:103-188) over f(x) = interpolate_sinc(.., x, depth): a MINIMISER
@@ -174,18 +230,21 @@ __device__ __forceinline__ void improve_extremum_sinc(const double *y, int nstor
 }
 
 // ------------------------------------------------------------------------------------------
-// pitch kernel
+// pitch, kernel 1: frame -> lag curve y (src/periodic.rs:400-408)
+//   y[i] = (r[i] / max|r|) / w_lag[i],  r = self.autocorrelate(self.len())
+// One wavefront per frame, frame staged in LDS, lag tiles (vbx_autocorr.hpp); the finished row
+// is written coalesced to a chunk-sized scratch in HBM for kernel 2.  (This phase is < 4 % of the
+// pitch time; splitting it off lets the refinement kernel run at 16 waves/CU.)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void pitch_kernel(
+__global__ __launch_bounds__(64) void pitch_lag_kernel(
     const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
-    const double *__restrict__ lag_window, double sample_rate, double threshold, double fmin, double fmax,
-    int kmax, pitch_t *__restrict__ out_cand, int32_t *__restrict__ out_count, int32_t *__restrict__ status) {
+    const double *__restrict__ lag_window, double *__restrict__ y_out) {
     extern __shared__ double smem[];
     const long f = blockIdx.x;
     if (f >= n_frames) return;
     const int lane = lane_id();
     double *xs = smem;                              // [n + pad] windowed samples, zero padded
-    double *ys = smem + n + autocorr_pad(n);        // [n] lag curve
+    double *ys = smem + n + autocorr_pad(n);        // [n] raw autocorrelation
     const double *xf = x + f * stride;
     const int total = n + autocorr_pad(n);
     for (int i = lane; i < total; i += 64) {
@@ -194,11 +253,9 @@ __global__ __launch_bounds__(64) void pitch_kernel(
         xs[i] = v;
     }
     __syncthreads();
-
-    // self.autocorrelate(self.len()), :403
     const double x0 = xs[0];
     double amax = -1.0;
-    autocorr_tiles(xs, n, n, [&](int lag, double s) {
+    autocorr_tiles(xs, n, n, [&](int lag, double s) {          // :403
         const double r = (s - x0 * xs[lag]) + x0;
         ys[lag] = r;
         const double a = fabs(r);
@@ -206,15 +263,34 @@ __global__ __launch_bounds__(64) void pitch_kernel(
     });
     amax = wave_max(amax);                          // max_amplitude over ALL lags (Q2)
     __syncthreads();
-    // normalize (:404) then divide by the lag window (:406-408)
-    const double scale = 1.0 / amax;
-    for (int i = lane; i < n; i += 64) ys[i] = (ys[i] * scale) / lag_window[i];
+    const double scale = 1.0 / amax;                // normalize (:404), then / lag window (:406-408)
+    double *yo = y_out + f * (long)n;
+    for (int i = lane; i < n; i += 64) yo[i] = (ys[i] * scale) / lag_window[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// pitch, kernel 2: lag curve -> candidates (src/periodic.rs:411-455)
+// One wavefront per frame; y row in LDS (zero padded, standing for resize(2N, 0)); peaks found
+// with ballots and processed in index order; each sinc evaluation spread over the 64 lanes.
+// ------------------------------------------------------------------------------------------
+constexpr int Y_PAD = 64;
+
+__global__ __launch_bounds__(64) void pitch_refine_kernel(
+    const double *__restrict__ y_in, long n_frames, int n, double sample_rate, double threshold, double fmin, double fmax,
+    int kmax, pitch_t *__restrict__ out_cand, int32_t *__restrict__ out_count, int32_t *__restrict__ status) {
+    extern __shared__ double ys[];                  // [n + Y_PAD]
+    const long f = blockIdx.x;
+    if (f >= n_frames) return;
+    const int lane = lane_id();
+    const double *yi = y_in + f * (long)n;
+    for (int i = lane; i < n + Y_PAD; i += 64) ys[i] = (i < n) ? yi[i] : 0.0;
     __syncthreads();
 
     const long b = (long)floor(0.5 * (double)n);    // brent_ixmax, :414
     const long offset = -b - 1;                     // :429
     const long nx = b - offset;                     // :430
     const long ylen = 2L * n;                       // :411
+    const int nvalid = n + Y_PAD;
 
     int st = 0;
     int total_cand = 0, kept = 0;
@@ -238,11 +314,11 @@ __global__ __launch_bounds__(64) void pitch_kernel(
             const double d2r = 2. * peak - (peak_rev - peak_fwd);             // :424 (Q5)
             const double freq = sample_rate / ((double)kk + dr / d2r);        // :425
             const double nn = sample_rate / freq - (double)offset;            // :432
-            double strn = sinc_interp(ys, n, ylen, offset, nx, nn, 30, st);   // :433
+            double strn = sinc_interp(ys, nvalid, ylen, offset, nx, nn, 30, st);   // :433
             if (strn > 1.) strn = 1. / strn;                                  // :435
             if (!((freq == 0.0) || (freq > fmin && freq < fmax))) continue;   // :439
             double xmid, ymid;
-            improve_extremum_sinc(ys, n, ylen, offset, nx, nn, 1200, xmid, ymid, st);   // :444
+            improve_extremum_sinc(ys, nvalid, ylen, offset, nx, nn, 1200, xmid, ymid, st);   // :444
             xmid += (double)offset;                                           // :445
             if (ymid > 1.) ymid = 1. / ymid;                                  // :446
             const double cf = sample_rate / xmid, cs = ymid;                  // :447-448
@@ -313,12 +389,24 @@ __global__ __launch_bounds__(64) void extremum_points_kernel(const double *__res
 
 size_t pitch_lds_bytes(int n) { return (size_t)(2 * n + autocorr_pad(n)) * sizeof(double); }
 
+// frames per chunk of the lag-curve scratch (about 2.5 GB of HBM, at least 4096 frames)
+long pitch_chunk_frames(int n, long n_frames) {
+    long c = (long)(2.5e9 / (8.0 * (double)n));
+    if (c < 4096) c = 4096;
+    return c < n_frames ? c : n_frames;
+}
+
 void launch_pitch(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                   const double *lag_window, double sample_rate, double threshold, double fmin, double fmax,
-                  int kmax, pitch_t *out_cand, int32_t *out_count, int32_t *status) {
-    hipLaunchKernelGGL(pitch_kernel, dim3((unsigned)F), dim3(64), pitch_lds_bytes(n), s,
-                       x, F, n, stride, window, lag_window, sample_rate, threshold, fmin, fmax, kmax,
-                       out_cand, out_count, status);
+                  int kmax, pitch_t *out_cand, int32_t *out_count, int32_t *status, double *lag_ws, long chunk) {
+    for (long f0 = 0; f0 < F; f0 += chunk) {
+        const long fc = (F - f0 < chunk) ? (F - f0) : chunk;
+        hipLaunchKernelGGL(pitch_lag_kernel, dim3((unsigned)fc), dim3(64), pitch_lds_bytes(n), s,
+                           x + f0 * stride, fc, n, stride, window, lag_window, lag_ws);
+        hipLaunchKernelGGL(pitch_refine_kernel, dim3((unsigned)fc), dim3(64), (size_t)(n + Y_PAD) * sizeof(double), s,
+                           lag_ws, fc, n, sample_rate, threshold, fmin, fmax, kmax,
+                           out_cand + f0 * (long)kmax, out_count ? out_count + f0 : nullptr, status ? status + f0 : nullptr);
+    }
 }
 
 void launch_sinc_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *xs, long m,

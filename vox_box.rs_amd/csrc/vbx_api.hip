@@ -36,7 +36,7 @@ struct vbx_ctx {
     std::string arch;
     int cu_count = 0;
     // workspaces (grown on demand, never shrunk)
-    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_N };
+    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_LAG, WS_N };
     void *ws[WS_N] = {nullptr};
     size_t ws_bytes[WS_N] = {0};
     // cached device tables
@@ -489,10 +489,14 @@ int vbx_pitch_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_l
     const double *lagw = nullptr;
     rc = get_window_dev(ctx, VBX_WINDOW_HANNING_LAG, frame_len, &lagw);
     if (rc != VBX_SUCCESS) return rc;
+    const long chunk = pitch_chunk_frames((int)frame_len, (long)n_frames);
+    void *lag_ws = nullptr;
+    rc = ws_get(ctx, vbx_ctx::WS_LAG, (size_t)chunk * frame_len * sizeof(double), &lag_ws);
+    if (rc != VBX_SUCCESS) return rc;
     {
         Prof p(ctx, "pitch");
         launch_pitch(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, lagw, sample_rate, threshold,
-                     fmin, fmax, (int)kmax, (pitch_t *)out_cand, out_count, status);
+                     fmin, fmax, (int)kmax, (pitch_t *)out_cand, out_count, status, (double *)lag_ws, chunk);
     }
     return check_launch(ctx, __func__);
 }
