@@ -41,7 +41,8 @@ def _frames(audio, n, hop, idx):
 # ---- cross-lane helpers -----------------------------------------------------------------
 
 def test_lane_helpers(vb):
-    o = vb.selftest_lanes()
+    both = vb.selftest_lanes()
+    o, gsum = both[0], both[1]
     v = 1.0 + 0.37 * np.arange(64) + 1e-3 * ((np.arange(64) * 7919) % 64)
     assert np.array_equal(o[:, 0], o[:, 1]), "DPP wave_shl:1 != __shfl_down"
     assert np.array_equal(o[:, 2], o[:, 3]), "DPP wave_shr:1 != __shfl_up"
@@ -51,6 +52,10 @@ def test_lane_helpers(vb):
     assert np.all(np.abs(o[:, 5] - v.sum()) < 1e-10)
     assert np.allclose(o[:, 6], v.max(), rtol=1e-14) and np.all(o[:, 6] == o[0, 6])
     assert np.allclose(o[:, 7], v[17], rtol=1e-14) and np.all(o[:, 7] == o[0, 7])
+    for j, g in enumerate((4, 8, 16, 32, 64)):        # group sums: right value, bit-identical inside a group
+        col = gsum[:, j].reshape(64 // g, g)
+        assert np.allclose(col[:, 0], v.reshape(64 // g, g).sum(axis=1), rtol=1e-13), g
+        assert np.all(col == col[:, :1]), g
 
 
 def test_synth_matches_host_statement(vb, pkg, audio):

@@ -6,11 +6,13 @@
 //
 // Two kernels, one wavefront per frame each: (1) the windowed frame is staged in LDS and the
 // all-lag autocorrelation runs as lag tiles (vbx_autocorr.hpp), giving the normalised /
-// lag-window-divided curve y; (2) y sits in LDS and every candidate peak is refined by the
-// reference's Brent iteration, whose scalar control flow is executed identically by all 64 lanes
-// while each sinc evaluation -- the dominant cost, 2*(depth+1) terms -- is spread over the lanes
-// and reduced with DPP.  The path is FP64-VALU bound (hundreds of flop per byte); HBM traffic
-// is the 3.8 KB of new samples per frame plus the 19 KB round trip of y between the kernels.
+// lag-window-divided curve y; (2) y sits in LDS, the candidate peaks are compacted in index
+// order, and they are refined PG lanes per candidate, 64/PG candidates at a time: every lane of
+// a group runs the reference's Brent iteration on identical values (group sums are made
+// bit-identical across the group), while each sinc evaluation -- the dominant cost,
+// 2*(depth+1) terms -- is spread over the group's lanes and reduced with DPP.  The path is
+// FP64-VALU bound (hundreds of flop per byte); HBM traffic is the 3.8 KB of new samples per
+// frame plus the 19 KB round trip of y between the kernels.
 #include "vbx_autocorr.hpp"
 #include "vbx_kernels.hpp"
 
@@ -62,24 +64,30 @@ __device__ __forceinline__ double cos_poly(double x) {
 __device__ __forceinline__ double cos_0_pi(double theta) { return -sin_poly(theta - 1.57079632679489661923); }
 
 // y lookup: entries [nvalid, ylen) are the zeros of self_lag.resize(2N, 0) (src/periodic.rs:411)
-__device__ __forceinline__ double y_at(const double *y, int nvalid, long idx) {
+__device__ __forceinline__ double y_at(const double *y, int nvalid, int idx) {
     return (idx < nvalid) ? y[idx] : 0.0;
 }
 
-// Sum of the 2*(D+1) sinc terms (src/periodic.rs:59-84), general form: any index may need the
-// reference's clamps.  Even lanes take "left" terms, odd lanes "right" terms.
-__device__ __forceinline__ double sinc_sum_general(const double *y, int nvalid, long ylen, long offset, long nl, long nr,
-                                                   double phil, double phir, long max_depth) {
-    const int lane = lane_id();
-    const int side = lane & 1;
+
+// ------------------------------------------------------------------------------------------
+// lane groups: G consecutive lanes cooperate on one candidate / query point (group_sum<G> in
+// vbx_device.hpp)
+// ------------------------------------------------------------------------------------------
+// General form of the sinc sum (src/periodic.rs:59-84): any index may need the reference's
+// clamps.  Even lanes of a group take "left" terms, odd lanes "right" terms.  No cross-lane ops.
+template <int G>
+__device__ __forceinline__ double sinc_terms_general(const double *y, int nvalid, int ylen, int offset, int nl, int nr,
+                                                     double phil, double phir, int max_depth) {
+    const int lig = lane_id() & (G - 1);
+    const int side = lig & 1;
     const double ph = side ? phir : phil;
     const double s0 = sinpi(ph);               // sin(pi*(ph+n)) = (-1)^n * s0
     const double inv_dd = 1.0 / (ph + (double)max_depth);
-    const long ibase = side ? (offset + nl) : (offset + nr);
+    const int ibase = side ? (offset + nl) : (offset + nr);
     double acc = 0.0;
-    for (long n = (lane >> 1); n <= max_depth; n += 32) {
+    for (int n = (lig >> 1); n <= max_depth; n += G / 2) {
         const double a = M_PI * (ph + (double)n);
-        long idx = side ? (ibase + n) : (ibase - n);
+        int idx = side ? (ibase + n) : (ibase - n);
         idx = (idx < 0) ? 0 : idx;
         idx = (idx >= ylen) ? (ylen - 1) : idx;          // only reachable on the right side (:78)
         const double r_lag = y_at(y, nvalid, idx);
@@ -88,101 +96,130 @@ __device__ __forceinline__ double sinc_sum_general(const double *y, int nvalid, 
         const double second = fma(0.5, cos_0_pi(a * inv_dd), 0.5);
         acc = fma(r_lag * first, second, acc);
     }
-    return wave_sum(acc);
+    return acc;
 }
 
-// The same sum when every index is known to be in [0, nvalid): no clamps, and the per-term work is
-// reduced with exact identities (no change of the reference's formula):
-//   sin(pi*(ph+n))              = (-1)^n * sin(pi*ph)              one polynomial per evaluation
-//   0.5 + 0.5*cos(a/(ph+D))     = cos^2(h*(ph+n)),  h = pi/(2*(ph+D))  angle in [0, pi/2]; successive
-//                                 terms of a lane (n += 32) by one plane rotation instead of a cosine
+// The same terms when every index is known to be in [0, nvalid): no clamps, and the per-term work
+// is reduced with exact identities (no change of the reference's formula):
+//   sin(pi*(ph+n))              = (-1)^n * sin(pi*ph)               one polynomial per evaluation
+//   0.5 + 0.5*cos(a/(ph+D))     = cos^2(h*(ph+n)),  h = pi/(2*(ph+D))   angle in [0, pi/2]; successive
+//                                 terms of a lane (n += G/2) by one plane rotation instead of a cosine
 //   1/a                         = v_rcp_f64 + one Newton step
-__device__ __forceinline__ double sinc_sum_fast(const double *y, int ibase_l, int ibase_r,
-                                                double phil, double phir, int max_depth) {
-    const int lane = lane_id();
-    const int side = lane & 1;
-    const int n0 = lane >> 1;
+// Returns the lane's partial sum already scaled (sum over the group = interpolate_sinc).
+template <int G>
+__device__ __forceinline__ double sinc_terms_fast(const double *y, int ibase_l, int ibase_r,
+                                                  double phil, double phir, int max_depth) {
+    constexpr int NSTEP = G / 2;
+    const int lig = lane_id() & (G - 1);
+    const int side = lig & 1;
+    const int n0 = lig >> 1;
     const double ph = side ? phir : phil;
     const double s0 = sin_poly(M_PI * fmin(phil, phir));      // sin(pi*phil) == sin(pi*phir)
     const double h = 1.57079632679489661923 * rcp_nr2(ph + (double)max_depth);
     double pn = ph + (double)n0;
     double c = cos_poly(h * pn), s = sin_poly(h * pn);
-    const double rc = cos_poly(32.0 * h), rs = sin_poly(32.0 * h);
+    const double rc = cos_poly((double)NSTEP * h), rs = sin_poly((double)NSTEP * h);
     int idx = side ? (ibase_r + n0) : (ibase_l - n0);
-    const int step = side ? 32 : -32;
+    const int step = side ? NSTEP : -NSTEP;
     double acc = 0.0;
-    for (int n = n0; n <= max_depth; n += 32) {
+    for (int n = n0; n <= max_depth; n += NSTEP) {
         const double yv = y[idx];
         const double r = rcp_nr1(pn);
         acc = fma(yv * r, c * c, acc);
         const double cn = fma(c, rc, -(s * rs));
         s = fma(s, rc, c * rs);
         c = cn;
-        pn += 32.0;
+        pn += (double)NSTEP;
         idx += step;
     }
-    acc = (n0 & 1) ? -acc : acc;
-    return wave_sum(acc) * (s0 * 0.31830988618379067154);
+    const double k = s0 * 0.31830988618379067154;             // sin(pi*ph) / pi
+    return ((n0 & 1) ? -acc : acc) * k;
 }
 
-// interpolate_sinc, wave-cooperative; result identical in all lanes.  st |= 4 where the
-// reference would index out of bounds.  y[0..nvalid) is readable; logical length ylen >= nvalid
-// with zeros beyond nvalid... (entries in [n_data, nvalid) must already be zero).
-__device__ __forceinline__ double sinc_interp(const double *y, int nvalid, long ylen, long offset, long nx,
-                                              double x, long max_depth, int &st) {
-    if (nx < 1) return __builtin_nan("");                                     // :38
-    if (x > (double)nx) {                                                      // :39
-        const long idx = offset + nx - 1;
-        if (idx < 0 || idx >= ylen) { st |= 4; return 0.0; }
-        return y_at(y, nvalid, idx);
+// interpolate_sinc (src/periodic.rs:29-87), cooperative over groups of G lanes; the arguments are
+// uniform inside a group and the result is bit-identical in all its lanes.  Lanes with
+// active == false contribute nothing.  st |= 4 where the reference would index out of bounds.
+// y[0..nvalid) is readable (entries past the data are zero), ylen >= nvalid is the logical length
+// after self_lag.resize(2N, 0).  Must be called from converged code.
+template <int G>
+__device__ __forceinline__ double sinc_interp(const double *y, int nvalid, int ylen, int offset, int nx,
+                                              double x, int max_depth, bool active, int &st) {
+    bool summed = false, fast = false;
+    double special = 0.0, phil = 0.5, phir = 0.5;
+    int nl = 0, nr = 1;
+    if (active) {
+        if (nx < 1) special = __builtin_nan("");                                   // :38
+        else if (x > (double)nx) {                                                 // :39
+            const int idx = offset + nx - 1;
+            if (idx < 0 || idx >= ylen) st |= 4; else special = y_at(y, nvalid, idx);
+        } else if (x < 0.0) special = y_at(y, nvalid, 0);                          // :40
+        else {
+            const double fl = floor(x);
+            nl = (fl > 0.0) ? (int)fl : 0;                                          // NaN -> 0
+            nr = nl + 1;
+            phil = x - (double)nl;
+            phir = 1.0 - phil;
+            if (fabs(x - (double)nl) < 1.0e-10) {                                   // :41
+                const int idx = offset + nl;
+                if (idx < 0 || idx >= ylen) st |= 4; else special = y_at(y, nvalid, idx);
+            } else if (fabs(x - (double)nr) < 1.0e-10) {                            // :42
+                const int idx = offset + nr;
+                if (idx < 0 || idx >= ylen) st |= 4; else special = y_at(y, nvalid, idx);
+            } else {
+                if ((offset + nr) < max_depth) max_depth = ((offset + nr) < 0) ? 0 : (offset + nr);   // :46-52
+                if ((offset + nl + max_depth) >= nx) max_depth = nx - offset + nl - 1;                  // :55-57
+                if (max_depth < 0 || offset + nr >= ylen) st |= 4;   // usize wrap / left index at n = 0 out of bounds
+                else {
+                    summed = true;
+                    // all left indices [offset+nr-D, offset+nr] and right indices [offset+nl, offset+nl+D] readable
+                    fast = !(x != x) && max_depth <= offset + nr && offset + nl >= 0 &&
+                           offset + nl + max_depth < nvalid && offset + nr < nvalid;
+                }
+            }
+        }
     }
-    if (x < 0.0) return y_at(y, nvalid, 0);                                   // :40
-    const double fl = floor(x);
-    const long nl = (fl > 0.0) ? (long)fl : 0;                                // NaN -> 0
-    const long nr = nl + 1;
-    const double phil = x - (double)nl;
-    const double phir = 1.0 - phil;
-    if (fabs(x - (double)nl) < 1.0e-10) {                                      // :41
-        const long idx = offset + nl;
-        if (idx < 0 || idx >= ylen) { st |= 4; return 0.0; }
-        return y_at(y, nvalid, idx);
+    double acc = 0.0;
+    if (summed) {
+        if (fast) acc = sinc_terms_fast<G>(y, offset + nr, offset + nl, phil, phir, max_depth);
+        else acc = sinc_terms_general<G>(y, nvalid, ylen, offset, nl, nr, phil, phir, max_depth);
     }
-    if (fabs(x - (double)nr) < 1.0e-10) {                                      // :42
-        const long idx = offset + nr;
-        if (idx < 0 || idx >= ylen) { st |= 4; return 0.0; }
-        return y_at(y, nvalid, idx);
-    }
-    if ((offset + nr) < max_depth) max_depth = ((offset + nr) < 0) ? 0 : (offset + nr);    // :46-52
-    if ((offset + nl + max_depth) >= nx) {                                                    // :55-57
-        max_depth = nx - offset + nl - 1;
-        if (max_depth < 0) { st |= 4; return 0.0; }
-    }
-    if (offset + nr >= ylen) { st |= 4; return 0.0; }    // left index at n = 0 (:67) out of bounds
-    // fast path: left indices [offset+nr-D, offset+nr] and right indices [offset+nl, offset+nl+D] all valid
-    if (!(x != x) && max_depth <= offset + nr && offset + nl >= 0 && offset + nl + max_depth < (long)nvalid &&
-        offset + nr < (long)nvalid && max_depth < 0x3fffffff)
-        return sinc_sum_fast(y, (int)(offset + nr), (int)(offset + nl), phil, phir, (int)max_depth);
-    return sinc_sum_general(y, nvalid, ylen, offset, nl, nr, phil, phir, max_depth);
+    const double total = group_sum<G>(acc);
+    return summed ? total : special;
 }
 
-// brent_maximize (src/periodic.rs:103-188) over f(x) = interpolate_sinc(.., x, depth): a MINIMISER
-// of the un-negated interpolant (Q8).  All lanes run the same scalar iteration.
-__device__ __forceinline__ double brent_sinc(const double *y, int nstore, long ylen, long offset, long nx, long depth,
-                                             double a, double b, double tol, double &fx, int &st) {
+// improve_extremum(.., Interpolation::Sinc(depth), true) (src/periodic.rs:192-229) around
+// brent_maximize (:103-188): a MINIMISER of the un-negated interpolant (Q8).  One candidate per
+// group of G lanes; `active` lanes carry a candidate.  Must be called from converged code.
+template <int G>
+__device__ __forceinline__ void improve_extremum_sinc(const double *y, int nvalid, int ylen, int offset, int nx,
+                                                      double ixmid, int depth, bool active,
+                                                      double &xmid, double &ymid, int &st) {
 #pragma clang fp contract(off)   // keep the scalar iteration bit-identical to the unfused CPU arithmetic
     const double golden = 1. - 0.6180339887498948482045868343656381177203091798057628621;
     const double sqrt_epsilon = 1.4901161193847656e-08;   // sqrt(f64::EPSILON)
     const double eps = 2.220446049250313e-16;
+    const double tol = 1e-10;
+    xmid = 0.; ymid = 0.;
+    bool run = active;
+    if (active) {
+        if (ixmid == 0.) { xmid = 0.; ymid = y_at(y, nvalid, 0); run = false; }                 // :193
+        else if (ixmid >= (double)nx) {                                                          // :194
+            run = false;
+            if (nx < 1 || nx - 1 >= ylen) st |= 4;
+            else { xmid = (double)nx; ymid = y_at(y, nvalid, nx - 1); }
+        } else if (!(ixmid - 1. < ixmid + 1.)) { st |= 4; run = false; }                        // assert!(a < b), :113
+    }
+    double a = ixmid - 1., b = ixmid + 1.;
     double v = a + golden * (b - a);
-    double fv = sinc_interp(y, nstore, ylen, offset, nx, v, depth, st);
-    double x = v, w = v;
-    fx = fv;
-    double fw = fv;
+    double fv = sinc_interp<G>(y, nvalid, ylen, offset, nx, v, depth, run, st);
+    double x = v, w = v, fx = fv, fw = fv;
+    bool done = !run;
     for (int it = 1; it <= 60; it++) {
         const double range = b - a;
         const double middle_range = (a + b) * 0.5;
         const double tol_act = sqrt_epsilon * fabs(x) + tol / 3.;
-        if (fabs(x - middle_range) + range * 0.5 <= 2. * tol_act) return x;
+        if (!done && fabs(x - middle_range) + range * 0.5 <= 2. * tol_act) done = true;
+        if (!__any(!done)) break;
         double new_step = (x < middle_range) ? golden * (b - x) : golden * (a - x);
         if (fabs(x - w) >= tol_act) {
             const double t = (x - w) * (fx - fv);
@@ -195,38 +232,25 @@ __device__ __forceinline__ double brent_sinc(const double *y, int nstore, long y
         }
         if (fabs(new_step) < tol_act) new_step = (new_step > 0.) ? tol_act : -tol_act;
         const double t = x + new_step;
-        const double ft = sinc_interp(y, nstore, ylen, offset, nx, t, depth, st);
-        if (ft <= fx) {
-            if (t < x) b = x; else a = x;
-            v = w; w = x; x = t;
-            fv = fw; fw = fx; fx = ft;
-        } else {
-            if (t < x) a = t; else b = t;
-            if (ft <= fw || fabs(w - x) < eps) {
-                v = w; w = t;
-                fv = fw; fw = ft;
-            } else if (ft <= fv || fabs(v - x) < eps || fabs(v - w) < eps) {
-                v = t;
-                fv = ft;
+        const double ft = sinc_interp<G>(y, nvalid, ylen, offset, nx, t, depth, !done, st);
+        if (!done) {
+            if (ft <= fx) {
+                if (t < x) b = x; else a = x;
+                v = w; w = x; x = t;
+                fv = fw; fw = fx; fx = ft;
+            } else {
+                if (t < x) a = t; else b = t;
+                if (ft <= fw || fabs(w - x) < eps) {
+                    v = w; w = t;
+                    fv = fw; fw = ft;
+                } else if (ft <= fv || fabs(v - x) < eps || fabs(v - w) < eps) {
+                    v = t;
+                    fv = ft;
+                }
             }
         }
     }
-    return x;
-}
-
-// improve_extremum(.., Sinc(depth), true), src/periodic.rs:192-229
-__device__ __forceinline__ void improve_extremum_sinc(const double *y, int nstore, long ylen, long offset, long nx,
-                                                      double ixmid, long depth, double &xmid, double &ymid, int &st) {
-    if (ixmid == 0.) { xmid = 0.; ymid = y_at(y, nstore, 0); return; }                        // :193
-    if (ixmid >= (double)nx) {                                                                  // :194
-        if (nx < 1 || nx - 1 >= ylen) { st |= 4; xmid = 0.; ymid = 0.; return; }
-        xmid = (double)nx; ymid = y_at(y, nstore, nx - 1); return;
-    }
-    const double a = ixmid - 1., b = ixmid + 1.;
-    if (!(a < b)) { st |= 4; xmid = 0.; ymid = 0.; return; }                                   // assert!(a < b), :113
-    double fx = 0.;
-    xmid = brent_sinc(y, nstore, ylen, offset, nx, depth, a, b, 1e-10, fx, st);
-    ymid = fx;
+    if (run) { xmid = x; ymid = fx; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -270,68 +294,98 @@ __global__ __launch_bounds__(64) void pitch_lag_kernel(
 
 // ------------------------------------------------------------------------------------------
 // pitch, kernel 2: lag curve -> candidates (src/periodic.rs:411-455)
-// One wavefront per frame; y row in LDS (zero padded, standing for resize(2N, 0)); peaks found
-// with ballots and processed in index order; each sinc evaluation spread over the 64 lanes.
+// One wavefront per frame; y row in LDS (zero padded, standing for resize(2N, 0)).
+//  a) peak scan, lane-parallel: strict local maxima of y[0..N/2) (Q4), the "parabolic" lag (Q5) and
+//     the frequency filter (:439); survivors are compacted in index order into an LDS list.
+//     The sinc(30) strength of :433 is dead in the reference (overwritten at :448 for every
+//     candidate that passes the filter, dropped otherwise) and is not evaluated.
+//  b) refinement in rounds of 64/PG candidates, PG lanes each (improve_extremum_sinc).
+//  c) results inserted in candidate order into a lane-resident list kept sorted by descending
+//     strength == the reference's stable sort (:453); the unvoiced candidate goes in last (:452).
 // ------------------------------------------------------------------------------------------
 constexpr int Y_PAD = 64;
+constexpr int PG = 16;                          // lanes per candidate
+constexpr int PNG = 64 / PG;                    // candidates per round
+
+__device__ __forceinline__ void cand_from_peak(const double *ys, int kk, double sample_rate, int offset,
+                                               double &freq, double &nn) {
+    const double peak = ys[kk], peak_rev = ys[kk - 1], peak_fwd = ys[kk + 1];
+    const double dr = 0.5 * (peak_fwd - peak_rev);                    // :423
+    const double d2r = 2. * peak - (peak_rev - peak_fwd);             // :424 (Q5)
+    freq = sample_rate / ((double)kk + dr / d2r);                     // :425
+    nn = sample_rate / freq - (double)offset;                         // :432, :443
+}
 
 __global__ __launch_bounds__(64) void pitch_refine_kernel(
     const double *__restrict__ y_in, long n_frames, int n, double sample_rate, double threshold, double fmin, double fmax,
     int kmax, pitch_t *__restrict__ out_cand, int32_t *__restrict__ out_count, int32_t *__restrict__ status) {
-    extern __shared__ double ys[];                  // [n + Y_PAD]
+    extern __shared__ double ys[];                  // [n + Y_PAD] doubles, then the candidate list (ints)
     const long f = blockIdx.x;
     if (f >= n_frames) return;
     const int lane = lane_id();
+    int *cand_list = reinterpret_cast<int *>(ys + n + Y_PAD);
     const double *yi = y_in + f * (long)n;
     for (int i = lane; i < n + Y_PAD; i += 64) ys[i] = (i < n) ? yi[i] : 0.0;
     __syncthreads();
 
-    const long b = (long)floor(0.5 * (double)n);    // brent_ixmax, :414
-    const long offset = -b - 1;                     // :429
-    const long nx = b - offset;                     // :430
-    const long ylen = 2L * n;                       // :411
+    const int b = (int)floor(0.5 * (double)n);      // brent_ixmax, :414
+    const int offset = -b - 1;                      // :429
+    const int nx = b - offset;                      // :430
+    const int ylen = 2 * n;                         // :411
     const int nvalid = n + Y_PAD;
 
-    int st = 0;
-    int total_cand = 0, kept = 0;
-    double lf = 0.0, ls = 0.0;                      // lane j holds sorted candidate j
-    bool any_nan = false;
-
-    for (long base = 0; base < b; base += 64) {
-        const long k = base + lane;
-        bool ispeak = false;
+    // a) peaks -> filtered candidate list
+    int ncand = 0;
+    for (int base = 0; base < b; base += 64) {
+        const int k = base + lane;
+        bool pass = false;
         if (k >= 1 && k + 1 < b) {                  // windows(3) over self_lag[0..b] (Q4)
             const double c = ys[k];
-            ispeak = (ys[k - 1] < c) && (ys[k + 1] < c);
+            if ((ys[k - 1] < c) && (ys[k + 1] < c)) {
+                double freq, nn;
+                cand_from_peak(ys, k, sample_rate, offset, freq, nn);
+                pass = (freq == 0.0) || (freq > fmin && freq < fmax);         // :439
+            }
         }
-        unsigned long long mask = __ballot(ispeak);
-        while (mask) {
-            const int bit = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const long kk = base + bit;
-            const double peak = ys[kk], peak_rev = ys[kk - 1], peak_fwd = ys[kk + 1];
-            const double dr = 0.5 * (peak_fwd - peak_rev);                    // :423
-            const double d2r = 2. * peak - (peak_rev - peak_fwd);             // :424 (Q5)
-            const double freq = sample_rate / ((double)kk + dr / d2r);        // :425
-            const double nn = sample_rate / freq - (double)offset;            // :432
-            double strn = sinc_interp(ys, nvalid, ylen, offset, nx, nn, 30, st);   // :433
-            if (strn > 1.) strn = 1. / strn;                                  // :435
-            if (!((freq == 0.0) || (freq > fmin && freq < fmax))) continue;   // :439
-            double xmid, ymid;
-            improve_extremum_sinc(ys, nvalid, ylen, offset, nx, nn, 1200, xmid, ymid, st);   // :444
-            xmid += (double)offset;                                           // :445
-            if (ymid > 1.) ymid = 1. / ymid;                                  // :446
-            const double cf = sample_rate / xmid, cs = ymid;                  // :447-448
-            if (cs != cs) any_nan = true;
-            // stable descending insertion == prefix of the reference's stable sort (:453)
-            const int pos = __popcll(__ballot(lane < kept && ls >= cs));
-            const double pf = from_prev_lane(lf), ps = from_prev_lane(ls);
-            if (lane > pos) { lf = pf; ls = ps; }
-            if (lane == pos) { lf = cf; ls = cs; }
-            kept = (kept + 1 < kmax) ? kept + 1 : kmax;
-            total_cand++;
+        const unsigned long long mask = __ballot(pass);
+        if (pass) cand_list[ncand + __popcll(mask & ((1ull << lane) - 1ull))] = k;
+        ncand += __popcll(mask);
+    }
+    __syncthreads();
+
+    int st = 0;
+    int kept = 0;
+    double lf = 0.0, ls = 0.0;                      // lane j holds sorted candidate j
+    bool any_nan = false;
+    const int gid = lane / PG;
+
+    for (int r0 = 0; r0 < ncand; r0 += PNG) {
+        // b) one candidate per group
+        const int ci = r0 + gid;
+        const bool have = ci < ncand;
+        const int kk = have ? cand_list[ci] : 1;
+        double freq, nn;
+        cand_from_peak(ys, kk, sample_rate, offset, freq, nn);
+        double xmid, ymid;
+        improve_extremum_sinc<PG>(ys, nvalid, ylen, offset, nx, nn, 1200, have, xmid, ymid, st);   // :444
+        xmid += (double)offset;                                           // :445
+        if (ymid > 1.) ymid = 1. / ymid;                                  // :446
+        const double cf = sample_rate / xmid, cs = ymid;                  // :447-448
+        // c) stable descending insertion, in candidate order
+#pragma unroll
+        for (int g = 0; g < PNG; g++) {
+            if (r0 + g < ncand) {
+                const double f_g = readlane_f64(cf, g * PG), s_g = readlane_f64(cs, g * PG);
+                if (s_g != s_g) any_nan = true;
+                const int pos = __popcll(__ballot(lane < kept && ls >= s_g));
+                const double pf = from_prev_lane(lf), ps = from_prev_lane(ls);
+                if (lane > pos) { lf = pf; ls = ps; }
+                if (lane == pos) { lf = f_g; ls = s_g; }
+                kept = (kept + 1 < kmax) ? kept + 1 : kmax;
+            }
         }
     }
+    int total_cand = ncand;
     {   // maxima.push(Pitch::new(0, threshold)), :452
         const int pos = __popcll(__ballot(lane < kept && ls >= threshold));
         const double pf = from_prev_lane(lf), ps = from_prev_lane(ls);
@@ -340,6 +394,7 @@ __global__ __launch_bounds__(64) void pitch_refine_kernel(
         kept = (kept + 1 < kmax) ? kept + 1 : kmax;
         total_cand++;
     }
+    st = __any(st & 4) ? 4 : 0;                     // a panic in any group is a panic of the frame
     if (total_cand > 1 && (any_nan || threshold != threshold)) st |= 8;   // partial_cmp().unwrap() panics (Q10)
     int code = 0;
     if (st & 4) code = 4; else if (st & 8) code = 3;
@@ -357,30 +412,30 @@ __global__ __launch_bounds__(64) void pitch_refine_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// interpolate_sinc / improve_extremum at M query points of one curve (one wavefront per point)
+// interpolate_sinc / improve_extremum at M query points of one curve (PG lanes per point)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void sinc_points_kernel(const double *__restrict__ y, int ylen, long offset, long nx,
-                                                         const double *__restrict__ xs, long m, long depth,
+__global__ __launch_bounds__(64) void sinc_points_kernel(const double *__restrict__ y, int ylen, int offset, int nx,
+                                                         const double *__restrict__ xs, long m, int depth,
                                                          double *__restrict__ out, int32_t *__restrict__ status) {
-    const long q = blockIdx.x;
-    if (q >= m) return;
+    const long q = (long)blockIdx.x * PNG + lane_id() / PG;
+    const bool have = q < m;
     int st = 0;
-    const double v = sinc_interp(y, ylen, ylen, offset, nx, xs[q], depth, st);
-    if (lane_id() == 0) {
+    const double v = sinc_interp<PG>(y, ylen, ylen, offset, nx, have ? xs[q] : 0.0, depth, have, st);
+    if (have && (lane_id() & (PG - 1)) == 0) {
         out[q] = (st & 4) ? 0.0 : v;
         if (status != nullptr) status[q] = (st & 4) ? 4 : 0;
     }
 }
 
-__global__ __launch_bounds__(64) void extremum_points_kernel(const double *__restrict__ y, int ylen, long offset, long nx,
-                                                             const double *__restrict__ ix, long m, long depth,
+__global__ __launch_bounds__(64) void extremum_points_kernel(const double *__restrict__ y, int ylen, int offset, int nx,
+                                                             const double *__restrict__ ix, long m, int depth,
                                                              double *__restrict__ out_xy, int32_t *__restrict__ status) {
-    const long q = blockIdx.x;
-    if (q >= m) return;
+    const long q = (long)blockIdx.x * PNG + lane_id() / PG;
+    const bool have = q < m;
     int st = 0;
     double xmid, ymid;
-    improve_extremum_sinc(y, ylen, ylen, offset, nx, ix[q], depth, xmid, ymid, st);
-    if (lane_id() == 0) {
+    improve_extremum_sinc<PG>(y, ylen, ylen, offset, nx, have ? ix[q] : 1.0, depth, have, xmid, ymid, st);
+    if (have && (lane_id() & (PG - 1)) == 0) {
         out_xy[2 * q] = (st & 4) ? 0.0 : xmid;
         out_xy[2 * q + 1] = (st & 4) ? 0.0 : ymid;
         if (status != nullptr) status[q] = (st & 4) ? 4 : 0;
@@ -388,6 +443,7 @@ __global__ __launch_bounds__(64) void extremum_points_kernel(const double *__res
 }
 
 size_t pitch_lds_bytes(int n) { return (size_t)(2 * n + autocorr_pad(n)) * sizeof(double); }
+static size_t refine_lds_bytes(int n) { return (size_t)(n + Y_PAD) * sizeof(double) + (size_t)(n / 4 + 8) * sizeof(int); }
 
 // frames per chunk of the lag-curve scratch (about 2.5 GB of HBM, at least 4096 frames)
 long pitch_chunk_frames(int n, long n_frames) {
@@ -403,7 +459,7 @@ void launch_pitch(hipStream_t s, const double *x, long F, int n, long stride, co
         const long fc = (F - f0 < chunk) ? (F - f0) : chunk;
         hipLaunchKernelGGL(pitch_lag_kernel, dim3((unsigned)fc), dim3(64), pitch_lds_bytes(n), s,
                            x + f0 * stride, fc, n, stride, window, lag_window, lag_ws);
-        hipLaunchKernelGGL(pitch_refine_kernel, dim3((unsigned)fc), dim3(64), (size_t)(n + Y_PAD) * sizeof(double), s,
+        hipLaunchKernelGGL(pitch_refine_kernel, dim3((unsigned)fc), dim3(64), refine_lds_bytes(n), s,
                            lag_ws, fc, n, sample_rate, threshold, fmin, fmax, kmax,
                            out_cand + f0 * (long)kmax, out_count ? out_count + f0 : nullptr, status ? status + f0 : nullptr);
     }
@@ -411,12 +467,14 @@ void launch_pitch(hipStream_t s, const double *x, long F, int n, long stride, co
 
 void launch_sinc_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *xs, long m,
                         long depth, double *out, int32_t *status) {
-    hipLaunchKernelGGL(sinc_points_kernel, dim3((unsigned)m), dim3(64), 0, s, y, ylen, offset, nx, xs, m, depth, out, status);
+    hipLaunchKernelGGL(sinc_points_kernel, dim3((unsigned)((m + PNG - 1) / PNG)), dim3(64), 0, s,
+                       y, ylen, (int)offset, (int)nx, xs, m, (int)depth, out, status);
 }
 
 void launch_extremum_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *ix, long m,
                             long depth, double *out_xy, int32_t *status) {
-    hipLaunchKernelGGL(extremum_points_kernel, dim3((unsigned)m), dim3(64), 0, s, y, ylen, offset, nx, ix, m, depth, out_xy, status);
+    hipLaunchKernelGGL(extremum_points_kernel, dim3((unsigned)((m + PNG - 1) / PNG)), dim3(64), 0, s,
+                       y, ylen, (int)offset, (int)nx, ix, m, (int)depth, out_xy, status);
 }
 
 }  // namespace vbx

@@ -459,7 +459,8 @@ int vbx_interpolate_sinc_f64(vbx_ctx *ctx, const double *y, size_t ylen, long of
     VBX_REQUIRE(ctx, ctx != nullptr, "null context");
     if (m == 0) return VBX_SUCCESS;
     VBX_REQUIRE(ctx, y && xs && out && ylen >= 1 && ylen <= 0x7fffffff && m <= 0x7fffffff, "bad argument");
-    VBX_REQUIRE(ctx, max_depth <= 0x7fffffff && nx <= 0x7fffffff, "depth / nx too large");
+    VBX_REQUIRE(ctx, max_depth <= 0x3fffffff && nx <= 0x3fffffff && ylen <= 0x3fffffff &&
+                offset > -0x3fffffffL && offset < 0x3fffffffL, "depth / nx / offset / ylen too large");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     { Prof p(ctx, "sinc_points"); launch_sinc_points(ctx->stream, y, (int)ylen, offset, (long)nx, xs, (long)m, (long)max_depth, out, status); }
     return check_launch(ctx, __func__);
@@ -470,7 +471,8 @@ int vbx_improve_extremum_f64(vbx_ctx *ctx, const double *y, size_t ylen, long of
     VBX_REQUIRE(ctx, ctx != nullptr, "null context");
     if (m == 0) return VBX_SUCCESS;
     VBX_REQUIRE(ctx, y && ixmid && out_xy && ylen >= 1 && ylen <= 0x7fffffff && m <= 0x7fffffff, "bad argument");
-    VBX_REQUIRE(ctx, depth <= 0x7fffffff && nx <= 0x7fffffff, "depth / nx too large");
+    VBX_REQUIRE(ctx, depth <= 0x3fffffff && nx <= 0x3fffffff && ylen <= 0x3fffffff &&
+                offset > -0x3fffffffL && offset < 0x3fffffffL, "depth / nx / offset / ylen too large");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     { Prof p(ctx, "extremum_points"); launch_extremum_points(ctx->stream, y, (int)ylen, offset, (long)nx, ixmid, (long)m, (long)depth, out_xy, status); }
     return check_launch(ctx, __func__);
@@ -718,16 +720,16 @@ int vbx_synth_speech_f64(vbx_ctx *ctx, double *out, size_t n_samples, uint64_t s
 }
 
 // internal: cross-lane helper self-test (tests only; not part of the public header)
-int vbx_selftest_lanes(vbx_ctx *ctx, double *h_out512) {
+int vbx_selftest_lanes(vbx_ctx *ctx, double *h_out512) {   // h_out512: 1024 doubles
     VBX_REQUIRE(ctx, ctx && h_out512, "null argument");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     void *d = nullptr;
-    int rc = ws_get(ctx, vbx_ctx::WS_MISC, 512 * sizeof(double), &d);
+    int rc = ws_get(ctx, vbx_ctx::WS_MISC, 1024 * sizeof(double), &d);
     if (rc != VBX_SUCCESS) return rc;
     launch_selftest(ctx->stream, (double *)d);
     rc = check_launch(ctx, __func__);
     if (rc != VBX_SUCCESS) return rc;
-    VBX_HIP(ctx, hipMemcpyAsync(h_out512, d, 512 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    VBX_HIP(ctx, hipMemcpyAsync(h_out512, d, 1024 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     VBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VBX_SUCCESS;
 }

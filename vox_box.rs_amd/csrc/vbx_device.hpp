@@ -74,6 +74,29 @@ __device__ __forceinline__ double wave_sum_shfl(double v) {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
+constexpr int DPP_QUAD_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_QUAD_REV = 0x1B;          // quad_perm [3,2,1,0]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;  // i <-> 7-i inside each 8 lanes
+constexpr int DPP_ROW_MIRROR = 0x140;       // i <-> 15-i inside each 16 lanes
+
+// Sum over each group of G lanes.  Every step pairs lanes by an involution, and fp addition is
+// commutative, so all lanes of a group end with bit-identical results: data-dependent control flow
+// stays uniform inside a group.  Must be called from converged code.
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+    static_assert(G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "group size");
+    v += dpp_f64<DPP_QUAD_XOR1>(v);
+    v += dpp_f64<DPP_QUAD_REV>(v);
+    if (G >= 8) v += dpp_f64<DPP_ROW_HALF_MIRROR>(v);
+    if (G >= 16) v += dpp_f64<DPP_ROW_MIRROR>(v);
+    if (G >= 32) {
+        const double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32), d = readlane_f64(v, 48);
+        if (G == 64) return (a + b) + (c + d);
+        return (lane_id() < 32) ? (a + b) : (c + d);
+    }
+    return v;
+}
+
 // Orders LDS traffic between the lanes of ONE wavefront (LDS executes a wave's instructions in
 // order; this only stops the compiler from moving accesses across the point).
 __device__ __forceinline__ void wave_sync() {

@@ -489,7 +489,7 @@ class VoxBox:
         return o
 
     def selftest_lanes(self):
-        out = np.zeros((64, 8), dtype=np.float64)
+        out = np.zeros((2, 64, 8), dtype=np.float64)
         self._check(self.L.vbx_selftest_lanes(self.ctx, out.ctypes.data))
         return out
 
