@@ -1,65 +1,72 @@
 // k_mfcc.hip -- MFCC::mfcc (src/spectrum.rs:401-441, Q14) and dct (:384-398).
 //
-// The reference takes a full complex FFT (rustfft) but only reads the bins below the last mel
-// point (< 245 of 1200 at 48 kHz / (100, 8000) Hz).  The kernel evaluates exactly those DFT
-// bins: one wavefront per frame, one lane per bin, the frame broadcast through v_readlane and
-// the twiddles e^{-2 pi i k n / N} read from an LDS table (exact index k*n mod N, so there is
-// no recurrence error).  Mel energies are then summed per filter in the reference's order
-// (rising |X|^2 slope, then the "falling" slope that also rises and uses |X|), log10 clamped
-// from below at 1e-10, and the K x K DCT-II (x2) is applied from a host-built cosine table.
+// The reference takes a full complex FFT (rustfft) but only reads |X_k| of the bins below the
+// last mel point (< 245 of 1200 at 48 kHz / (100, 8000) Hz), and only their magnitudes.  The
+// kernel evaluates exactly those bins with the Goertzel recurrence in Reinsch's numerically
+// stable form: one wavefront per frame, lane <-> bin (BPL bins per lane), the samples read
+// coalesced from HBM 64 at a time and broadcast through v_readlane, no twiddle table, no LDS
+// traffic in the loop.  Per bin and sample:  t = d - kappa*s;  d = sigma*t + x;  s = sigma*s + d
+// (kappa = 4 sin^2(w/2), sigma = +1 when cos w > 0, else kappa = 4 cos^2(w/2), sigma = -1), and
+//   |X_k|^2 = d^2 + sigma*kappa*s_{N-1}*s_{N-2}     (error grows only linearly in N).
+// Mel energies are then summed per filter in the reference's order (rising |X|^2 slope, then
+// the "falling" slope that also rises and uses |X|), log10 clamped from below at 1e-10, and the
+// K x K DCT-II (x2) is applied from a host-built cosine table.
 #include "vbx_device.hpp"
 #include "vbx_kernels.hpp"
 
 namespace vbx {
 
-// LDS layout per block (W waves): twiddle[n] (double2) | per wave: xs[n] | mag2[nb] | mag[nb] | en[64]
+constexpr int MFCC_BPL = 4;                 // bins per lane and pass
+constexpr int MFCC_PASS = 64 * MFCC_BPL;    // bins per pass over the frame
+
+// LDS per wave: mag2[nb] | mag[nb] | en[64]
 template <int W>
 __global__ __launch_bounds__(64 * W) void mfcc_kernel(
     const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
-    const double *__restrict__ twiddle, const int32_t *__restrict__ bins, const double *__restrict__ dct_table,
-    int num_coeffs, double *__restrict__ out) {
+    const double *__restrict__ kappa_sigma /* [nb][2] */, const int32_t *__restrict__ bins,
+    const double *__restrict__ dct_table, int num_coeffs, int nb, double *__restrict__ out) {
     extern __shared__ double smem[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
-    const int b_lo = bins[0], b_hi = bins[num_coeffs + 1];
-    const int nb = b_hi - b_lo;
-    double *tw = smem;                                   // [n][2]
-    double *wbase = smem + 2 * (size_t)n + (size_t)wave * ((size_t)n + 2 * (size_t)nb + 64);
-    double *xs = wbase, *mag2 = wbase + n, *mag = mag2 + nb, *en = mag + nb;
-    for (int i = threadIdx.x; i < 2 * n; i += 64 * W) tw[i] = twiddle[i];
     const long f = (long)blockIdx.x * W + wave;
-    const bool active = f < n_frames;
-    if (active) {
-        const double *xf = x + f * stride;
-        for (int i = lane; i < n; i += 64) {
-            double v = xf[i];
-            if (window != nullptr) v *= window[i];
-            xs[i] = v;
-        }
-    }
-    __syncthreads();
-    if (!active) return;
+    if (f >= n_frames) return;
+    const int b_lo = bins[0];
+    double *mag2 = smem + (size_t)wave * (2 * (size_t)nb + 64), *mag = mag2 + nb, *en = mag + nb;
+    const double *xf = x + f * stride;
 
-    // DFT of bins [b_lo, b_hi): lane <-> bin
-    for (int g = 0; g < nb; g += 64) {
-        const int k = b_lo + g + lane;
-        const int kk = (k < b_hi) ? (k % n) : 0;
-        double re = 0.0, im = 0.0;
-        int idx = 0;
+    for (int p0 = 0; p0 < nb; p0 += MFCC_PASS) {
+        double kap[MFCC_BPL], sig[MFCC_BPL], s[MFCC_BPL], d[MFCC_BPL];
+#pragma unroll
+        for (int j = 0; j < MFCC_BPL; j++) {
+            const int bi = p0 + j * 64 + lane;
+            const bool ok = bi < nb;
+            kap[j] = ok ? kappa_sigma[2 * bi] : 0.0;
+            sig[j] = ok ? kappa_sigma[2 * bi + 1] : 1.0;
+            s[j] = 0.0; d[j] = 0.0;
+        }
         for (int i0 = 0; i0 < n; i0 += 64) {
-            const double chunk = (i0 + lane < n) ? xs[i0 + lane] : 0.0;
+            double chunk = 0.0;
+            if (i0 + lane < n) { chunk = xf[i0 + lane]; if (window != nullptr) chunk *= window[i0 + lane]; }
             const int steps = min(64, n - i0);
-            for (int s = 0; s < steps; s++) {
-                const double xi = readlane_f64(chunk, s);
-                const double2 cs = *reinterpret_cast<const double2 *>(tw + 2 * idx);
-                re = fma(xi, cs.x, re);
-                im = fma(-xi, cs.y, im);
-                idx += kk; idx = (idx >= n) ? idx - n : idx;
+            for (int q = 0; q < steps; q++) {
+                const double xi = readlane_f64(chunk, q);
+#pragma unroll
+                for (int j = 0; j < MFCC_BPL; j++) {
+                    const double t = fma(-kap[j], s[j], d[j]);
+                    d[j] = fma(sig[j], t, xi);
+                    s[j] = fma(sig[j], s[j], d[j]);
+                }
             }
         }
-        if (k < b_hi) {
-            const double m2 = re * re + im * im;          // norm_sqr (:426)
-            mag2[k - b_lo] = m2;
-            mag[k - b_lo] = hypot(re, im);                // norm (:432)
+#pragma unroll
+        for (int j = 0; j < MFCC_BPL; j++) {
+            const int bi = p0 + j * 64 + lane;
+            if (bi < nb) {
+                const double s2 = sig[j] * (s[j] - d[j]);
+                double m2 = fma(d[j], d[j], sig[j] * kap[j] * s[j] * s2);     // norm_sqr (:426)
+                m2 = (m2 < 0.0) ? 0.0 : m2;
+                mag2[bi] = m2;
+                mag[bi] = sqrt(m2);                                           // norm (:432)
+            }
         }
     }
     wave_sync();       // mag2/mag are produced and consumed inside this wavefront
@@ -94,26 +101,19 @@ __global__ void dct_rows_kernel(const double *__restrict__ in, long rows, int n,
     }
 }
 
-static size_t mfcc_lds(int n, int nb, int w) {
-    return ((size_t)2 * n + (size_t)w * ((size_t)n + 2 * (size_t)nb + 64)) * sizeof(double);
-}
+static size_t mfcc_lds(int nb, int w) { return (size_t)w * (2 * (size_t)nb + 64) * sizeof(double); }
 
-// returns false if the shape does not fit the LDS
-bool mfcc_fits(int n, int nb) { return mfcc_lds(n, nb, 1) <= 160 * 1024; }
+bool mfcc_fits(int /*n*/, int nb) { return mfcc_lds(nb, 1) <= 160 * 1024; }
 
 void launch_mfcc(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
-                 const double *twiddle, const int32_t *bins_dev, const double *dct_table,
+                 const double *kappa_sigma, const int32_t *bins_dev, const double *dct_table,
                  int num_coeffs, double *out, int32_t * /*status*/, int nb) {
-    // pick the widest block whose LDS still allows >= 2 blocks per CU
-    if (mfcc_lds(n, nb, 4) <= 80 * 1024) {
-        hipLaunchKernelGGL((mfcc_kernel<4>), dim3((unsigned)((F + 3) / 4)), dim3(256), mfcc_lds(n, nb, 4), s,
-                           x, F, n, stride, window, twiddle, bins_dev, dct_table, num_coeffs, out);
-    } else if (mfcc_lds(n, nb, 2) <= 80 * 1024) {
-        hipLaunchKernelGGL((mfcc_kernel<2>), dim3((unsigned)((F + 1) / 2)), dim3(128), mfcc_lds(n, nb, 2), s,
-                           x, F, n, stride, window, twiddle, bins_dev, dct_table, num_coeffs, out);
+    if (mfcc_lds(nb, 4) <= 40 * 1024) {
+        hipLaunchKernelGGL((mfcc_kernel<4>), dim3((unsigned)((F + 3) / 4)), dim3(256), mfcc_lds(nb, 4), s,
+                           x, F, n, stride, window, kappa_sigma, bins_dev, dct_table, num_coeffs, nb, out);
     } else {
-        hipLaunchKernelGGL((mfcc_kernel<1>), dim3((unsigned)F), dim3(64), mfcc_lds(n, nb, 1), s,
-                           x, F, n, stride, window, twiddle, bins_dev, dct_table, num_coeffs, out);
+        hipLaunchKernelGGL((mfcc_kernel<1>), dim3((unsigned)F), dim3(64), mfcc_lds(nb, 1), s,
+                           x, F, n, stride, window, kappa_sigma, bins_dev, dct_table, num_coeffs, nb, out);
     }
 }
 

@@ -3,105 +3,124 @@
 //
 // The only cross-frame dependency of the whole hot path: the estimates after frame t feed
 // frame t+1 (tests/lib.rs:75-79).  The scan is therefore sequential WITHIN an utterance and
-// parallel ACROSS utterances: one lane per segment, segments given by the caller.
+// parallel ACROSS utterances: one lane per segment, segments given by the caller.  All per-lane
+// state (6 slots, <= 6 estimates) lives in registers: every loop over slots is fully unrolled
+// so no array is ever indexed dynamically (no scratch memory on the serial path).
 #include "vbx_device.hpp"
 #include "vbx_kernels.hpp"
 
 namespace vbx {
 
-struct opt_res { int some; res_t v; };
+constexpr int NS = VBX_FORMANT_SLOTS_K;   // 6
 
-__device__ __forceinline__ bool res_eq(const res_t &a, const res_t &b) {   // derive(PartialEq), :149
-    return a.frequency == b.frequency && a.bandwidth == b.bandwidth;
+struct slot_t { bool some; double f, bw; };
+
+__device__ __forceinline__ bool same_res(double f1, double b1, double f2, double b2) {   // derive(PartialEq), :149
+    return f1 == f2 && b1 == b2;
 }
-__device__ __forceinline__ bool slots_contains(const opt_res *slots, const res_t &peak) {
-    for (int i = 0; i < VBX_FORMANT_SLOTS_K; i++) if (slots[i].some && res_eq(slots[i].v, peak)) return true;
+
+// comparator of :312-324 (None < Some, then frequency; incomparable -> Equal): a > b ?
+__device__ __forceinline__ bool slot_greater(const slot_t &a, const slot_t &b) {
+    if (a.some) return b.some ? (a.f > b.f) : true;
     return false;
 }
-// comparator of :312-324 (None < Some, then frequency; incomparable -> Equal)
-__device__ __forceinline__ int slot_cmp(const opt_res &a, const opt_res &b) {
-    if (a.some) {
-        if (b.some) {
-            if (a.v.frequency < b.v.frequency) return -1;
-            if (a.v.frequency > b.v.frequency) return 1;
-            return 0;
-        }
-        return 1;
-    }
-    return -1;
-}
 
-// one estimate_formants step.  res row has n_res entries of which the first `cnt` are read
-// from memory and the rest are the zero padding the reference passes along (src/lib.rs:55,114).
-__device__ void estimate_formants_step(res_t *est, int n_est, const res_t *__restrict__ row, int n_res, int cnt) {
-    opt_res slots[VBX_FORMANT_SLOTS_K];
-    for (int i = 0; i < VBX_FORMANT_SLOTS_K; i++) { slots[i].some = 0; slots[i].v.frequency = 0.0; slots[i].v.bandwidth = 0.0; }
-    const res_t zero = {0.0, 0.0};
-    const int n_zip = n_est < VBX_FORMANT_SLOTS_K ? n_est : VBX_FORMANT_SLOTS_K;
+// One estimate_formants step.  The row has n_res entries of which the first `cnt` are read from
+// memory; the rest are the zero padding the reference passes along (src/lib.rs:55,114).
+__device__ __forceinline__ void estimate_formants_step(double (&ef)[NS], double (&eb)[NS], int n_est,
+                                                       const res_t *__restrict__ row, int n_res, int cnt) {
+    slot_t s[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) { s[i].some = false; s[i].f = 0.0; s[i].bw = 0.0; }
 
-    // Step 2 (:235-245)
-    for (int e = 0; e < n_zip; e++) {
-        res_t best = (cnt > 0) ? row[0] : zero;
-        double bestd = fabs(best.frequency - est[e].frequency);
-        for (int i = 1; i < n_res; i++) {
-            const res_t it = (i < cnt) ? row[i] : zero;
-            const double d = fabs(it.frequency - est[e].frequency);
-            if (d < bestd) { best = it; bestd = d; }
-            if (i >= cnt) break;        // all further entries equal this zero: strict '<' never fires again
+    // Step 2 (:235-245): nearest resonance per estimate, strict '<' (first wins ties).  One pass over
+    // the row serves all estimates.  Entries >= cnt are zeros: the first of them may win, the rest tie.
+    {
+        double bf[NS], bb[NS], bd[NS];
+        const res_t r0 = (cnt > 0) ? row[0] : res_t{0.0, 0.0};
+#pragma unroll
+        for (int e = 0; e < NS; e++) { bf[e] = r0.frequency; bb[e] = r0.bandwidth; bd[e] = fabs(r0.frequency - ef[e]); }
+        const int lim = (cnt < n_res) ? cnt + 1 : n_res;      // real entries + one representative zero
+        for (int i = 1; i < lim; i++) {
+            const res_t it = (i < cnt) ? row[i] : res_t{0.0, 0.0};
+#pragma unroll
+            for (int e = 0; e < NS; e++) {
+                const double d = fabs(it.frequency - ef[e]);
+                if (d < bd[e]) { bf[e] = it.frequency; bb[e] = it.bandwidth; bd[e] = d; }
+            }
         }
-        slots[e].some = 1; slots[e].v = best;
+#pragma unroll
+        for (int e = 0; e < NS; e++) if (e < n_est) { s[e].some = true; s[e].f = bf[e]; s[e].bw = bb[e]; }
     }
 
-    // Step 3 (:250-272)
-    int w = 0;
+    // Step 3 (:250-272): w tracks the last surviving slot; all accesses by unrolled select
     bool has_unassigned = false;
-    for (int r = 1; r < VBX_FORMANT_SLOTS_K; r++) {
-        if (!slots[r].some) continue;
-        const res_t v = slots[r].v;
-        if (res_eq(v, slots[w].v)) {
-            if (fabs(v.frequency - est[r].frequency) < fabs(v.frequency - est[w].frequency)) {
-                slots[w].some = 0; has_unassigned = true; w = r;
-            } else {
-                slots[r].some = 0; has_unassigned = true;
-            }
-        } else {
-            w = r;
-        }
-    }
-
-    // Step 4 (:274-310)
-    if (has_unassigned) {
-        for (int j = 0; j < n_res; j++) {
-            const res_t peak = (j < cnt) ? row[j] : zero;
-            if (slots_contains(slots, peak)) {
-                if (j >= cnt) break;    // once the zero peak is contained it stays contained
-                continue;
-            }
-            if (j < VBX_FORMANT_SLOTS_K && !slots[j].some) { slots[j].some = 1; slots[j].v = peak; continue; }
-            if (j > 0 && j < VBX_FORMANT_SLOTS_K) {
-                if (!slots[j - 1].some) {
-                    const opt_res t = slots[j]; slots[j] = slots[j - 1]; slots[j - 1] = t;
-                    slots[j].some = 1; slots[j].v = peak; continue;
+    {
+        int w = 0;
+#pragma unroll
+        for (int r = 1; r < NS; r++) {
+            if (s[r].some) {
+                double wf = 0.0, wb = 0.0, we = 0.0;
+#pragma unroll
+                for (int q = 0; q < NS; q++) if (q == w) { wf = s[q].f; wb = s[q].bw; we = ef[q]; }
+                if (same_res(s[r].f, s[r].bw, wf, wb)) {
+                    if (fabs(s[r].f - ef[r]) < fabs(s[r].f - we)) {
+#pragma unroll
+                        for (int q = 0; q < NS; q++) if (q == w) s[q].some = false;
+                        has_unassigned = true; w = r;
+                    } else {
+                        s[r].some = false; has_unassigned = true;
+                    }
+                } else {
+                    w = r;
                 }
             }
-            if (j + 1 < VBX_FORMANT_SLOTS_K && !slots[j + 1].some) {
-                const opt_res t = slots[j]; slots[j] = slots[j + 1]; slots[j + 1] = t;
-                slots[j].some = 1; slots[j].v = peak; continue;
-            }
-            if (j >= VBX_FORMANT_SLOTS_K && j >= cnt) break;   // zero peaks beyond the slots can never be placed
         }
     }
 
-    // :312-324 stable sort
-    for (int i = 1; i < VBX_FORMANT_SLOTS_K; i++) {
-        const opt_res key = slots[i]; int j = i;
-        while (j > 0 && slot_cmp(slots[j - 1], key) > 0) { slots[j] = slots[j - 1]; j--; }
-        slots[j] = key;
+    // Step 4 (:274-310).  For j >= 6 no branch of the reference can place a peak, so j stops at 6.
+    if (has_unassigned) {
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            if (j < n_res) {
+                const res_t pk = (j < cnt) ? row[j] : res_t{0.0, 0.0};
+                bool contained = false;
+#pragma unroll
+                for (int q = 0; q < NS; q++) contained = contained || (s[q].some && same_res(s[q].f, s[q].bw, pk.frequency, pk.bandwidth));
+                if (!contained) {
+                    if (!s[j].some) {
+                        s[j].some = true; s[j].f = pk.frequency; s[j].bw = pk.bandwidth;
+                    } else if (j > 0 && !s[j > 0 ? j - 1 : 0].some) {
+                        s[j - 1] = s[j];                               // swap(j, j-1); slots[j] = peak
+                        s[j].some = true; s[j].f = pk.frequency; s[j].bw = pk.bandwidth;
+                    } else if (j + 1 < NS && !s[j + 1 < NS ? j + 1 : j].some) {
+                        s[j + 1] = s[j];                               // swap(j, j+1); slots[j] = peak
+                        s[j].some = true; s[j].f = pk.frequency; s[j].bw = pk.bandwidth;
+                    }
+                }
+            }
+        }
     }
-    // :327-332
+
+    // :312-324 stable sort (None first, then ascending frequency): adjacent exchanges on strict '>'
+#pragma unroll
+    for (int pass = 0; pass < NS - 1; pass++) {
+#pragma unroll
+        for (int i = 0; i + 1 < NS - pass; i++) {
+            if (slot_greater(s[i], s[i + 1])) { const slot_t t = s[i]; s[i] = s[i + 1]; s[i + 1] = t; }
+        }
+    }
+
+    // :327-332 winners with frequency > 0 overwrite the leading estimates
     int e = 0;
-    for (int i = 0; i < VBX_FORMANT_SLOTS_K && e < n_est; i++)
-        if (slots[i].some && slots[i].v.frequency > 0.0) est[e++] = slots[i].v;
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        if (s[i].some && s[i].f > 0.0 && e < n_est) {
+#pragma unroll
+            for (int q = 0; q < NS; q++) if (q == e) { ef[q] = s[i].f; eb[q] = s[i].bw; }
+            e++;
+        }
+    }
 }
 
 __global__ void tracker_kernel(const res_t *__restrict__ res, long n_frames, int n_res,
@@ -113,15 +132,21 @@ __global__ void tracker_kernel(const res_t *__restrict__ res, long n_frames, int
     if (sg >= n_seg) return;
     const long f0 = (seg_start != nullptr) ? seg_start[sg] : 0;
     const long f1 = (seg_start != nullptr && sg + 1 < n_seg) ? seg_start[sg + 1] : n_frames;
-    res_t est[VBX_FORMANT_SLOTS_K];
-    for (int e = 0; e < n_est; e++) est[e] = est_init[e];
+    double ef[NS], eb[NS];
+#pragma unroll
+    for (int e = 0; e < NS; e++) {
+        ef[e] = (e < n_est) ? est_init[e].frequency : 0.0;
+        eb[e] = (e < n_est) ? est_init[e].bandwidth : 0.0;
+    }
     for (long f = f0; f < f1; f++) {
         const bool ok = (frame_status == nullptr) || frame_status[f] == 0;
         if (ok) {
             const int cnt = (res_count != nullptr) ? res_count[f] : n_res;
-            estimate_formants_step(est, n_est, res + f * (long)n_res, n_res, cnt);
+            estimate_formants_step(ef, eb, n_est, res + f * (long)n_res, n_res, cnt);
         }
-        for (int e = 0; e < n_est; e++) out[f * (long)n_est + e] = est[e];
+#pragma unroll
+        for (int e = 0; e < NS; e++)
+            if (e < n_est) { res_t o; o.frequency = ef[e]; o.bandwidth = eb[e]; out[f * (long)n_est + e] = o; }
     }
 }
 

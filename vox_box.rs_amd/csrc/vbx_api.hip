@@ -41,7 +41,7 @@ struct vbx_ctx {
     size_t ws_bytes[WS_N] = {0};
     // cached device tables
     std::map<std::pair<int, size_t>, double *> windows;   // (kind, n)
-    std::map<size_t, double *> twiddles;                  // n -> [n][2]
+    std::map<std::tuple<size_t, int, int>, double *> goertzel;   // (n, b_lo, nb) -> [nb][2] kappa, sigma
     std::map<size_t, double *> dct_tables;                // K -> [K][K]
     std::map<std::tuple<size_t, size_t, double, double, double>, int32_t *> bins_cache;
     // timing
@@ -153,18 +153,21 @@ int get_window_dev(vbx_ctx *ctx, int kind, size_t n, const double **out) {
     return VBX_SUCCESS;
 }
 
-int get_twiddle_dev(vbx_ctx *ctx, size_t n, const double **out) {
-    auto it = ctx->twiddles.find(n);
-    if (it == ctx->twiddles.end()) {
-        std::vector<double> h(2 * n);
-        for (size_t i = 0; i < n; i++) {
-            const double ang = 2.0 * M_PI * (double)i / (double)n;
-            h[2 * i] = std::cos(ang); h[2 * i + 1] = std::sin(ang);
+// Goertzel-Reinsch constants of bins [b_lo, b_lo + nb) of an n-point DFT (k_mfcc.hip)
+int get_goertzel_dev(vbx_ctx *ctx, size_t n, int b_lo, int nb, const double **out) {
+    auto key = std::make_tuple(n, b_lo, nb);
+    auto it = ctx->goertzel.find(key);
+    if (it == ctx->goertzel.end()) {
+        std::vector<double> h(2 * (size_t)(nb > 0 ? nb : 1));
+        for (int i = 0; i < nb; i++) {
+            const double w = 2.0 * M_PI * (double)((size_t)(b_lo + i) % n) / (double)n;
+            if (std::cos(w) > 0.0) { const double sh = std::sin(0.5 * w); h[2 * i] = 4.0 * sh * sh; h[2 * i + 1] = 1.0; }
+            else { const double ch = std::cos(0.5 * w); h[2 * i] = 4.0 * ch * ch; h[2 * i + 1] = -1.0; }
         }
         double *d = nullptr;
-        VBX_HIP(ctx, hipMalloc((void **)&d, 2 * n * sizeof(double)));
-        VBX_HIP(ctx, hipMemcpy(d, h.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice));
-        it = ctx->twiddles.emplace(n, d).first;
+        VBX_HIP(ctx, hipMalloc((void **)&d, h.size() * sizeof(double)));
+        VBX_HIP(ctx, hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+        it = ctx->goertzel.emplace(key, d).first;
     }
     *out = it->second;
     return VBX_SUCCESS;
@@ -292,7 +295,7 @@ void vbx_ctx_destroy(vbx_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < vbx_ctx::WS_N; i++) if (ctx->ws[i]) hipFree(ctx->ws[i]);
     for (auto &kv : ctx->windows) hipFree(kv.second);
-    for (auto &kv : ctx->twiddles) hipFree(kv.second);
+    for (auto &kv : ctx->goertzel) hipFree(kv.second);
     for (auto &kv : ctx->dct_tables) hipFree(kv.second);
     for (auto &kv : ctx->bins_cache) hipFree(kv.second);
     for (auto &r : ctx->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -686,7 +689,7 @@ int vbx_mfcc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_le
     const int nb = hb.back() - hb.front();
     VBX_REQUIRE(ctx, mfcc_fits((int)frame_len, nb), "frame / bin range does not fit the LDS");
     const double *tw = nullptr, *dct = nullptr;
-    rc = get_twiddle_dev(ctx, frame_len, &tw); if (rc != VBX_SUCCESS) return rc;
+    rc = get_goertzel_dev(ctx, frame_len, hb.front(), nb, &tw); if (rc != VBX_SUCCESS) return rc;
     rc = get_dct_dev(ctx, num_coeffs, &dct); if (rc != VBX_SUCCESS) return rc;
     if (status) VBX_HIP(ctx, hipMemsetAsync(status, 0, n_frames * sizeof(int32_t), ctx->stream));
     {

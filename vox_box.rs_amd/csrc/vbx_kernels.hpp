@@ -58,7 +58,7 @@ void launch_extremum_points(hipStream_t s, const double *y, int ylen, long offse
 // k_mfcc.hip
 bool mfcc_fits(int n, int nb);
 void launch_mfcc(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
-                 const double *twiddle /* [n][2] cos,sin */, const int32_t *bins /* K+2 */, const double *dct_table /* [K][K] */,
+                 const double *kappa_sigma /* [nb][2] Goertzel-Reinsch constants */, const int32_t *bins /* K+2 */, const double *dct_table /* [K][K] */,
                  int num_coeffs, double *out, int32_t *status, int nb /* bins[K+1]-bins[0] */);
 void launch_dct_rows(hipStream_t s, const double *in, long rows, int n, const double *dct_table, double *out);
 
