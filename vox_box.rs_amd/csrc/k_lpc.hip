@@ -9,13 +9,11 @@
 namespace vbx {
 
 // ------------------------------------------------------------------------------------------
-// Few-lag path: one wavefront per frame, EPL contiguous samples per lane held in registers,
-// neighbour lanes' samples fetched with DPP wave shifts (no LDS), lag sums reduced with
-// row rotations + v_readlane.  HBM-bound: 8 B/sample in, (2 * n_lags) * 8 B out.
+// Few-lag path: EPL contiguous samples per lane held in registers, neighbour lanes' samples
+// fetched with DPP wave shifts.  HBM-bound: 8 B/sample in, (2 * n_lags) * 8 B out.
 // ------------------------------------------------------------------------------------------
 
-// Levinson-Durbin on wave-uniform r[0..p] (src/spectrum.rs:63-84): every lane runs the same
-// recursion; lane 0 stores.  ac has P+1 entries.
+// Levinson-Durbin on r[0..p] held in registers (src/spectrum.rs:63-84); ac has P+1 entries.
 template <int P>
 __device__ __forceinline__ void levinson_uniform(const double (&r)[P + 1], double (&ac)[P + 1]) {
     double tmp[P + 1];
@@ -39,63 +37,128 @@ __device__ __forceinline__ void levinson_uniform(const double (&r)[P + 1], doubl
 }
 
 // EPL: samples per lane (frame_len <= 64*EPL).  NL: number of lags computed (n_lags <= NL).
+//
+// One wavefront works through FPW = 64 consecutive frames:
+//   per frame   coalesced 16-B loads of the lane's EPL samples (next frame prefetched), neighbour
+//               samples by DPP wave shifts, NL lag products per lane in registers (EPL*NL FMAs),
+//               then ONE transposing reduction through LDS for all NL sums together (a lane's NL
+//               partials are written as a row, 4 lanes per lag each add 16 of the 64 partials,
+//               a quad butterfly finishes) instead of NL separate 64-lane reductions;
+//   per 64 frames  lane f runs Levinson-Durbin for frame f (one division chain per 64 frames, not
+//               per frame) and the [64, NL] result blocks leave through LDS as coalesced stores.
 template <int EPL, int NL>
 __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
     const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
     int n_lags, int normalize, double *__restrict__ out_r, double *__restrict__ out_lpc) {
-    const long f = blockIdx.x;
-    if (f >= n_frames) return;
+    constexpr int FPW = 64;
+    constexpr int TS = NL | 1;                       // odd row stride: conflict-free column reads
+    __shared__ double T[64 * TS];                    // per-frame transpose buffer [lane][lag]
+    __shared__ double R[FPW * TS];                   // results of the wave's frames [frame][lag]
     const int lane = lane_id();
-    const double *xf = x + f * stride;
+    const long f0 = (long)blockIdx.x * FPW;
+    if (f0 >= n_frames) return;
+    const int nf = (int)((n_frames - f0 < FPW) ? (n_frames - f0) : FPW);
 
-    // ext[0..EPL) own samples, ext[EPL..EPL+NL-1) the following samples (from lanes l+1, l+2, ..)
-    double ext[EPL + NL - 1];
+    double wreg[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; e++) {
         const int i = lane * EPL + e;
-        double v = (i < n) ? xf[i] : 0.0;
-        if (window != nullptr && i < n) v *= window[i];
-        ext[e] = v;
+        wreg[e] = (i < n) ? ((window != nullptr) ? window[i] : 1.0) : 0.0;
     }
-    const double x0 = readlane_f64(ext[0], 0);
+    const bool full = (n == 64 * EPL);               // uniform: unguarded, mergeable loads
+    auto load_frame = [&](int g, double (&dst)[EPL]) {
+        const double *xf = x + (f0 + g) * stride + lane * EPL;
+        if (full) {
 #pragma unroll
-    for (int e = EPL; e < EPL + NL - 1; e++) ext[e] = from_next_lane(ext[e - EPL]);
+            for (int e = 0; e < EPL; e++) dst[e] = xf[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPL; e++) dst[e] = (lane * EPL + e < n) ? xf[e] : 0.0;
+        }
+    };
+    double cur[EPL], nxt[EPL];
+    load_frame(0, cur);
+    const int red_lag = lane >> 2, red_part = lane & 3;
 
+    for (int g = 0; g < nf; g++) {
+        if (g + 1 < nf) load_frame(g + 1, nxt);
+        // ext[0..EPL) own samples, ext[EPL..EPL+NL-1) the following samples (from lanes l+1, l+2, ..)
+        double ext[EPL + NL - 1];
+#pragma unroll
+        for (int e = 0; e < EPL; e++) ext[e] = cur[e] * wreg[e];
+#pragma unroll
+        for (int e = EPL; e < EPL + NL - 1; e++) ext[e] = from_next_lane(ext[e - EPL]);
+        double part[NL];
+#pragma unroll
+        for (int lag = 0; lag < NL; lag++) {
+            double s = 0.0;
+#pragma unroll
+            for (int e = 0; e < EPL; e++) s = fma(ext[e], ext[e + lag], s);
+            part[lag] = s;
+        }
+        // Q1: r[lag] = x[0] + sum_{i>=1} x[i]x[i+lag]  ==  S[lag] - x0*x[lag] + x0 ; lane 0 owns the i = 0 term
+        const double x0 = readlane_f64(ext[0], 0);
+        if (x0 != 0.0) {
+            if (lane == 0) {
+#pragma unroll
+                for (int lag = 0; lag < NL; lag++) part[lag] = (part[lag] - x0 * ext[lag]) + x0;
+            }
+        }
+#pragma unroll
+        for (int lag = 0; lag < NL; lag++) T[lane * TS + lag] = part[lag];
+        wave_sync();
+#pragma unroll
+        for (int lbase = 0; lbase < NL; lbase += 16) {   // 16 lags per sweep (4 lanes per lag)
+            const int rl = lbase + red_lag;
+            double tot = 0.0;
+            if (rl < NL) {
+#pragma unroll
+                for (int t = 0; t < 16; t++) tot += T[(red_part * 16 + t) * TS + rl];
+            }
+            tot += dpp_f64<DPP_QUAD_XOR1>(tot);
+            tot += dpp_f64<0x4E>(tot);               // quad_perm [2,3,0,1]
+            if (red_part == 0 && rl < NL) R[g * TS + rl] = tot;
+        }
+        wave_sync();
+#pragma unroll
+        for (int e = 0; e < EPL; e++) cur[e] = nxt[e];
+    }
+
+    // lane f <-> frame f0 + f
     double r[NL];
 #pragma unroll
-    for (int lag = 0; lag < NL; lag++) {
-        double s = 0.0;
-#pragma unroll
-        for (int e = 0; e < EPL; e++) s = fma(ext[e], ext[e + lag], s);
-        r[lag] = s;
-    }
-    // x[lag] (uniform) for the Q1 correction:  r = S - x0*x[lag] + x0
-#pragma unroll
-    for (int lag = 0; lag < NL; lag++) {
-        const int src_lane = lag / EPL, src_e = lag % EPL;
-        const double xl = readlane_f64(ext[src_e], src_lane);
-        const double s = wave_sum(r[lag]);
-        r[lag] = (lag < n) ? (s - x0 * xl) + x0 : x0;
-    }
+    for (int k = 0; k < NL; k++) r[k] = (lane < nf) ? R[lane * TS + k] : 1.0;
     if (normalize) {   // Normalize::normalize over the n_lags coefficients (max |.| over all, Q2)
         double m = fabs(r[0]);
 #pragma unroll
-        for (int lag = 1; lag < NL; lag++) if (lag < n_lags) { double a = fabs(r[lag]); m = (a > m) ? a : m; }
+        for (int k = 1; k < NL; k++) if (k < n_lags) { const double a = fabs(r[k]); m = (a > m) ? a : m; }
         const double scale = 1.0 / m;
 #pragma unroll
-        for (int lag = 0; lag < NL; lag++) r[lag] = r[lag] * scale;
-    }
-    if (out_r != nullptr) {
+        for (int k = 0; k < NL; k++) r[k] = r[k] * scale;
+        wave_sync();
 #pragma unroll
-        for (int lag = 0; lag < NL; lag++)
-            if (lane == lag && lag < n_lags) out_r[f * n_lags + lag] = r[lag];
+        for (int k = 0; k < NL; k++) R[lane * TS + k] = r[k];
+        wave_sync();
     }
-    if (out_lpc != nullptr) {   // only instantiated/called with n_lags == NL
+    if (out_r != nullptr) {          // [nf, n_lags] block, contiguous in the output
+        double *o = out_r + f0 * (long)n_lags;
+        for (int idx = lane; idx < nf * n_lags; idx += 64) {
+            const int fr = idx / n_lags, k = idx - fr * n_lags;
+            o[idx] = R[fr * TS + k];
+        }
+    }
+    if (out_lpc != nullptr) {        // only instantiated/called with n_lags == NL
         double ac[NL];
         levinson_uniform<NL - 1>(r, ac);
+        wave_sync();
 #pragma unroll
-        for (int j = 0; j < NL; j++)
-            if (lane == j) out_lpc[f * NL + j] = ac[j];
+        for (int k = 0; k < NL; k++) R[lane * TS + k] = ac[k];
+        wave_sync();
+        double *o = out_lpc + f0 * (long)NL;
+        for (int idx = lane; idx < nf * NL; idx += 64) {
+            const int fr = idx / NL, k = idx - fr * NL;
+            o[idx] = R[fr * TS + k];
+        }
     }
 }
 
@@ -167,7 +230,7 @@ __global__ void levinson_rows_kernel(const double *__restrict__ r, long n_rows, 
 template <int EPL, int NL>
 static void launch_fewlags(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                            int n_lags, int normalize, double *out_r, double *out_lpc) {
-    hipLaunchKernelGGL((autocorr_fewlags_kernel<EPL, NL>), dim3((unsigned)F), dim3(64), 0, s,
+    hipLaunchKernelGGL((autocorr_fewlags_kernel<EPL, NL>), dim3((unsigned)((F + 63) / 64)), dim3(64), 0, s,
                        x, F, n, stride, window, n_lags, normalize, out_r, out_lpc);
 }
 
