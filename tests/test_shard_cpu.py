@@ -1,0 +1,129 @@
+"""CPU tests of the multi-GPU host logic: frame-range split with the window halo,
+utterance-aligned tracker segments, and the per-frame record gather to rank 0 -- exercised with
+world_size 2 over gloo.  The per-shard compute stand-in here is the CPU oracle (allowed: tests
+may call the oracle); on the GPU box the same helpers feed libvoxbox_hip (bench.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N, H, SR, P = 1200, 480, 48000.0, 12
+
+
+def test_frame_range_partitions_everything(pkg):
+    sh = pkg.shard
+    for n_frames in (0, 1, 7, 8, 1000, 35999998):
+        for world in (1, 2, 3, 8):
+            ranges = [sh.frame_range(r, world, n_frames) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n_frames
+            for (a, b), (c, d) in zip(ranges, ranges[1:]):
+                assert b == c and a <= b
+            sizes = [b - a for a, b in ranges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_sample_range_has_the_window_halo(pkg):
+    sh = pkg.shard
+    # rank g needs samples [start*H, (end-1)*H + N): a halo of N-H = 720 samples
+    s0, s1 = sh.sample_range(100, 200, N, H)
+    assert s0 == 100 * H and s1 == 199 * H + N
+    nxt0, _ = sh.sample_range(200, 300, N, H)
+    assert s1 - nxt0 == N - H
+    assert pkg.frame_count(s1 - s0, N, H) == 100
+    assert sh.sample_range(5, 5, N, H) == (5 * H, 5 * H)
+
+
+def test_segment_aligned_ranges(pkg):
+    sh = pkg.shard
+    seg = np.arange(0, 10000, 1000)
+    rr = sh.segment_aligned_ranges(4, seg, 10000)
+    assert rr[0][0] == 0 and rr[-1][1] == 10000
+    for (a, b), (c, d) in zip(rr, rr[1:]):
+        assert b == c
+    for a, b in rr:
+        assert a % 1000 == 0 and (b % 1000 == 0 or b == 10000)
+    ls = sh.local_segments(seg, 3000, 6000)
+    assert list(ls) == [0, 1000, 2000]
+    assert list(sh.local_segments(seg, 2500, 4200)) == [0, 500, 1500]
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import importlib
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    o = g.load_oracle()
+    synth = importlib.import_module(g.PKG_NAME + ".synth")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_samples = 2 * 48000 + 777
+    F = pkg.frame_count(n_samples, N, H)
+    seg = np.array([0, 60, 131], dtype=np.int64)
+    ranges = pkg.shard.segment_aligned_ranges(world, seg, F)
+    lo, hi = ranges[rank]
+    s0, s1 = pkg.shard.sample_range(lo, hi, N, H)
+    audio = synth.synth_speech(s1 - s0, sample_offset=s0)          # each rank generates ITS shard only
+    w = o.window("hanning", N)
+    lseg = pkg.shard.local_segments(seg, lo, hi)
+    rec = np.zeros((hi - lo, 2 + 8 + 13), dtype=np.float64)
+    est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+    est = None
+    for t in range(hi - lo):
+        fr = audio[t * H:t * H + N]
+        _, c, _ = o.pitch(fr * w, SR, 0.2, 75.0, 600.0, cap=1)
+        if t in lseg:
+            est = est0.copy()
+        _, est, _, _ = o.find_formants(fr, SR, P, est)
+        rec[t, 0:2] = c[0]
+        rec[t, 2:10] = est.reshape(-1)
+        rec[t, 10:] = o.lpc(o.autocorrelate(fr * w, P + 1), P)
+    counts = [b - a for a, b in ranges]
+    full = pkg.shard.gather_records(torch.from_numpy(rec), counts, dst=0)
+    if rank == 0:
+        np.save(out_path, full.numpy())
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gloo_gather_equals_single_process(tmp_path, pkg, oracle):
+    import importlib
+    import torch.multiprocessing as mp
+    import __graft_entry__ as g
+    synth = importlib.import_module(g.PKG_NAME + ".synth")
+    out = str(tmp_path / "gathered.npy")
+    mp.start_processes(_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    got = np.load(out)
+    # single-process reference over the whole recording
+    n_samples = 2 * 48000 + 777
+    audio = synth.synth_speech(n_samples)
+    F = pkg.frame_count(n_samples, N, H)
+    assert got.shape == (F, 23)
+    w = oracle.window("hanning", N)
+    seg = [0, 60, 131]
+    est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+    est = None
+    for t in range(F):
+        fr = audio[t * H:t * H + N]
+        _, c, _ = oracle.pitch(fr * w, SR, 0.2, 75.0, 600.0, cap=1)
+        if t in seg:
+            est = est0.copy()
+        _, est, _, _ = oracle.find_formants(fr, SR, P, est)
+        exp = np.concatenate([c[0], est.reshape(-1), oracle.lpc(oracle.autocorrelate(fr * w, P + 1), P)])
+        assert np.array_equal(got[t], exp), t
