@@ -1,0 +1,17 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; cd $R
+mkdir -p gpurun_out/prof2
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/prof2/pmc1 -- python3 bench.py --workload config3 --hours 0.25 --steps 1 --warmup 0 --no-cpu > gpurun_out/prof2/pmc1.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/prof2/pmc2 -- python3 bench.py --workload config3 --hours 0.25 --steps 1 --warmup 0 --no-cpu > gpurun_out/prof2/pmc2.log 2>&1
+python3 - <<'PY'
+import csv,glob,collections
+for name in ('pmc1','pmc2'):
+    for f in glob.glob(f'gpurun_out/prof2/{name}/*/*counter_collection.csv'):
+        acc=collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            acc[(r['Kernel_Name'][:40], r['Counter_Name'])].append(float(r['Counter_Value']))
+        for k,v in sorted(acc.items()):
+            if 'pitch' in k[0]: print(name,k,len(v),sum(v)/len(v))
+PY
+tail -3 gpurun_out/prof2/pmc2.log | cut -c1-300

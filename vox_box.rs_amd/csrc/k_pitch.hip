@@ -101,38 +101,62 @@ __device__ __forceinline__ double sinc_terms_general(const double *y, int nvalid
 
 // The same terms when every index is known to be in [0, nvalid): no clamps, and the per-term work
 // is reduced with exact identities (no change of the reference's formula):
-//   sin(pi*(ph+n))              = (-1)^n * sin(pi*ph)               one polynomial per evaluation
-//   0.5 + 0.5*cos(a/(ph+D))     = cos^2(h*(ph+n)),  h = pi/(2*(ph+D))   angle in [0, pi/2]; successive
-//                                 terms of a lane (n += G/2) by one plane rotation instead of a cosine
-//   1/a                         = v_rcp_f64 + one Newton step
+//   sin(pi*(ph+n))          = (-1)^n * sin(pi*ph)                       one polynomial per evaluation
+//   0.5 + 0.5*cos(a/(ph+D)) = 0.5 + 0.5*cos(theta0 + j*delta)           a lane's terms (n = n0 + j*G/2) are
+//                             equally spaced in angle: Reinsch's stable cosine recurrence
+//                             d += -kappa*C; C += d  (kappa = 4 sin^2(delta/2)) replaces the cosine
+//   1/(ph+n)                = four terms share ONE v_rcp_f64 (+ a Newton step): 1/(p0 p1 p2 p3), then products
 // Returns the lane's partial sum already scaled (sum over the group = interpolate_sinc).
 template <int G>
 __device__ __forceinline__ double sinc_terms_fast(const double *y, int ibase_l, int ibase_r,
                                                   double phil, double phir, int max_depth) {
     constexpr int NSTEP = G / 2;
+    constexpr double S = (double)NSTEP;
     const int lig = lane_id() & (G - 1);
     const int side = lig & 1;
     const int n0 = lig >> 1;
     const double ph = side ? phir : phil;
     const double s0 = sin_poly(M_PI * fmin(phil, phir));      // sin(pi*phil) == sin(pi*phir)
-    const double h = 1.57079632679489661923 * rcp_nr2(ph + (double)max_depth);
+    const double h2 = M_PI * rcp_nr2(ph + (double)max_depth); // theta = h2 * (ph + n)  in [0, pi]
     double pn = ph + (double)n0;
-    double c = cos_poly(h * pn), s = sin_poly(h * pn);
-    const double rc = cos_poly((double)NSTEP * h), rs = sin_poly((double)NSTEP * h);
-    int idx = side ? (ibase_r + n0) : (ibase_l - n0);
+    const int nterms = (n0 <= max_depth) ? (max_depth - n0) / NSTEP + 1 : 0;
+    // cosine recurrence state: C = cos(theta_j), d = C_j - C_{j-1}
+    const double theta0 = h2 * pn, delta = h2 * S;
+    double C = cos_0_pi(theta0);
+    double d = cos_0_pi(theta0 + delta) - C;                   // only used when the lane has >= 2 terms
+    const double sh = sin_poly(0.5 * delta);
+    const double kappa = 4.0 * sh * sh;
     const int step = side ? NSTEP : -NSTEP;
-    double acc = 0.0;
-    for (int n = n0; n <= max_depth; n += NSTEP) {
-        const double yv = y[idx];
-        const double r = rcp_nr1(pn);
-        acc = fma(yv * r, c * c, acc);
-        const double cn = fma(c, rc, -(s * rs));
-        s = fma(s, rc, c * rs);
-        c = cn;
-        pn += (double)NSTEP;
-        idx += step;
+    const double *yp = y + (side ? (ibase_r + n0) : (ibase_l - n0));
+    double acc0 = 0.0, acc1 = 0.0;                             // sum t, sum t*C   (t = y/(ph+n))
+    int j = 0;
+    for (; j + 4 <= nterms; j += 4) {
+        const double y0 = yp[0], y1 = yp[step], y2 = yp[2 * step], y3 = yp[3 * step];
+        const double p0 = pn, p1 = pn + S, p2 = pn + 2.0 * S, p3 = pn + 3.0 * S;
+        const double q01 = p0 * p1, q23 = p2 * p3;
+        const double r = rcp_nr1(q01 * q23);
+        const double r01 = r * q23, r23 = r * q01;
+        const double t0 = y0 * (r01 * p1), t1 = y1 * (r01 * p0), t2 = y2 * (r23 * p3), t3 = y3 * (r23 * p2);
+        acc0 += t0; acc1 = fma(t0, C, acc1);
+        C += d; d = fma(-kappa, C, d);                         // after the first step d_1 was preset: see below
+        acc0 += t1; acc1 = fma(t1, C, acc1);
+        C += d; d = fma(-kappa, C, d);
+        acc0 += t2; acc1 = fma(t2, C, acc1);
+        C += d; d = fma(-kappa, C, d);
+        acc0 += t3; acc1 = fma(t3, C, acc1);
+        C += d; d = fma(-kappa, C, d);
+        pn += 4.0 * S;
+        yp += 4 * step;
     }
-    const double k = s0 * 0.31830988618379067154;             // sin(pi*ph) / pi
+    for (; j < nterms; j++) {
+        const double t = yp[0] * rcp_nr1(pn);
+        acc0 += t; acc1 = fma(t, C, acc1);
+        C += d; d = fma(-kappa, C, d);
+        pn += S;
+        yp += step;
+    }
+    const double k = s0 * (0.5 * 0.31830988618379067154);     // sin(pi*ph) / pi, and the 0.5 of the taper
+    const double acc = acc0 + acc1;
     return ((n0 & 1) ? -acc : acc) * k;
 }
 
