@@ -1,0 +1,103 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (the oracle cannot walk
+millions of frames): layout independence (hop-strided view == dense copy), batch/chunk independence,
+run-to-run determinism, exact power-of-two scaling laws, plus random spot checks against the oracle
+inside the big batch.  Needs a real MI355X."""
+import numpy as np
+import pytest
+
+from conftest import rel_close
+
+pytestmark = pytest.mark.gpu
+SR, N, H, P = 48000.0, 1200, 480, 12
+
+
+def test_config2_one_million_dense_frames(vb, oracle, pkg):
+    """BASELINE config 2: 1M x 512 f64 frames, autocorrelate(13) -> lpc(12)."""
+    F, n = 1_000_000, 512
+    x = vb.synth_speech(F * n, sample_offset=12345)
+    w = vb.window(pkg.WINDOW_HANNING, n)
+    r, a = vb.empty((F, 13)), vb.empty((F, 13))
+    vb.autocorr_lpc(x, P, frame_len=n, stride=n, n_frames=F, window=w, out=(r, a))
+    R, A = r.numpy(), a.numpy()
+    assert np.all(np.isfinite(R)) and np.all(np.isfinite(A)) and np.all(A[:, 0] == 1.0)
+    assert np.all(R[:, 0] >= np.abs(R).max(axis=1) * (1 - 1e-12))       # windowed frames: r[0] is the maximum
+    # determinism
+    r2, a2 = vb.empty((F, 13)), vb.empty((F, 13))
+    vb.autocorr_lpc(x, P, frame_len=n, stride=n, n_frames=F, window=w, out=(r2, a2))
+    assert np.array_equal(R, r2.numpy()) and np.array_equal(A, a2.numpy())
+    # chunk independence: a sub-batch that starts mid-way (different wave/frame alignment) gives the same bits
+    lo, cnt = 333_337, 10_001
+    xs = x.numpy()[lo * n:(lo + cnt) * n]
+    rs, as_ = vb.autocorr_lpc(xs.reshape(cnt, n), P, window=w)
+    assert np.array_equal(rs, R[lo:lo + cnt]) and np.array_equal(as_, A[lo:lo + cnt])
+    # exact scaling law: x -> 4x gives r -> 16 r bit for bit, and the same LPC coefficients
+    r4, a4 = vb.autocorr_lpc(4.0 * xs.reshape(cnt, n), P, window=w)
+    assert np.array_equal(r4, 16.0 * rs) and np.array_equal(a4, as_)
+    # spot checks against the oracle
+    wh = oracle.window("hanning", n)
+    xh = xs.reshape(cnt, n)
+    for t in np.random.default_rng(0).integers(0, cnt, 40):
+        er = oracle.autocorrelate(xh[t] * wh, 13)
+        assert np.all(rel_close(rs[t], er)) and np.all(rel_close(as_[t], oracle.lpc(er, P)))
+    for d in (x, r, a, r2, a2):
+        d.free()
+
+
+def test_pipeline_one_hour_strided(vb, oracle, pkg):
+    """1 h of 48 kHz audio, 25 ms / 10 ms hop (359,998 frames): pitch + find_formants + MFCC."""
+    ns = 3600 * 48000
+    audio = vb.synth_speech(ns, sample_offset=7 * 48000)
+    F = pkg.frame_count(ns, N, H)
+    assert F == 359_998
+    han = vb.window(pkg.WINDOW_HANNING, N)
+    cand, cnt, st = vb.empty((F, 2, 2)), vb.empty(F, np.int32), vb.empty(F, np.int32)
+    vb.pitch(audio, SR, 0.2, 75.0, 600.0, kmax=2, frame_len=N, stride=H, n_frames=F, window=han, out=(cand, cnt, st))
+    C, K, S = cand.numpy(), cnt.numpy(), st.numpy()
+    assert np.all(S == 0) and np.all(K >= 1)
+    top = C[:, 0, :]
+    # the filter (src/periodic.rs:439) acts on the parabolic estimate; Brent may then move the lag by < 1
+    assert np.all((top[:, 0] == 0.0) | ((top[:, 0] > SR / (SR / 75.0 + 1.0)) & (top[:, 0] < SR / (SR / 600.0 - 1.0))))
+    assert np.all(top[:, 1] >= 0.2) and np.all(top[:, 1] <= 1.0)          # strength >= threshold; reflected at 1
+    assert np.all(C[:, 0, 1] >= C[:, 1, 1])                                # sorted by descending strength
+    sec = ((np.arange(F) * H + 7 * 48000) // 48000) % 5
+    inner = (np.arange(F) * H + N + 7 * 48000) // 48000 % 5                 # frame entirely inside the second
+    voiced = (sec != 4) & (inner != 4) & (sec == inner)
+    unvoiced = (sec == 4) & (inner == 4)
+    assert np.mean(top[voiced, 0] > 0) > 0.99 and np.mean(top[unvoiced, 0] == 0.0) > 0.99
+    # the synthetic f0 glides 90..250 Hz: voiced estimates must sit on it (or its octave neighbours at most rarely)
+    fv = top[voiced, 0]
+    assert np.mean((fv > 85) & (fv < 260)) > 0.97
+    # layout independence: dense copies of frames give bit-identical results to the strided view
+    idx = np.sort(np.random.default_rng(1).integers(0, F, 300))
+    ah = audio.numpy()
+    dense = np.stack([ah[t * H:t * H + N] for t in idx])
+    c2, k2, s2 = vb.pitch(dense, SR, 0.2, 75.0, 600.0, kmax=2, window=han)
+    assert np.array_equal(c2, C[idx]) and np.array_equal(k2, K[idx])
+    # spot checks against the oracle inside the big batch (top candidate, BASELINE tolerance)
+    wh = oracle.window("hanning", N)
+    bad = 0
+    for j in range(0, 300, 6):
+        es, ec, en = oracle.pitch(dense[j] * wh, SR, 0.2, 75.0, 600.0)
+        assert es == 0 and en == K[idx[j]]
+        tie = en > 1 and abs(ec[0, 1] - ec[1, 1]) < 1e-3
+        ok = abs(C[idx[j], 0, 0] - ec[0, 0]) <= 1e-4 * abs(ec[0, 0]) and abs(C[idx[j], 0, 1] - ec[0, 1]) <= 1e-4
+        bad += 0 if (ok or tie) else 1
+    assert bad == 0
+    # find_formants + MFCC: finite, deterministic, chunk-independent at a segment boundary
+    est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+    seg = np.arange(0, F, 1000, dtype=np.int64)
+    ff = vb.find_formants(audio, SR, P, est0, seg_start=seg, frame_len=N, stride=H, n_frames=F, want=("formants", "status", "count"))
+    assert np.all(ff["status"] == 0) and np.all(np.isfinite(ff["formants"]))
+    assert np.all(ff["count"] >= 1) and np.all(ff["count"] <= 6)
+    lo = 200_000
+    sub = ah[lo * H:(lo + 999) * H + N]
+    f2 = vb.find_formants(sub, SR, P, est0, frame_len=N, stride=H, want=("formants", "status"))
+    assert np.array_equal(f2["formants"], ff["formants"][lo:lo + 1000])
+    m, ms = vb.mfcc(audio, 13, (100.0, 8000.0), SR, frame_len=N, stride=H, n_frames=F, window=han)
+    assert np.all(ms == 0) and np.all(np.isfinite(m))
+    m2, _ = vb.mfcc(sub, 13, (100.0, 8000.0), SR, frame_len=N, stride=H, window=han)
+    assert np.array_equal(m2, m[lo:lo + 1000])
+    for t in (0, 417, 999):
+        _, em = oracle.mfcc(sub[t * H:t * H + N] * wh, 13, 100.0, 8000.0, SR)
+        assert np.all(rel_close(m2[t], em, 1e-6))
+    audio.free()
