@@ -148,12 +148,19 @@ __device__ __forceinline__ double sinc_terms_fast(const double *y, int ibase_l, 
         pn += 4.0 * S;
         yp += 4 * step;
     }
-    for (; j < nterms; j++) {
-        const double t = yp[0] * rcp_nr1(pn);
-        acc0 += t; acc1 = fma(t, C, acc1);
+    if (j < nterms) {      // 1..3 terms left: one more block, padded with zero-weight terms
+        const int rem = nterms - j;
+        const double y0 = yp[0], y1 = (rem > 1) ? yp[step] : 0.0, y2 = (rem > 2) ? yp[2 * step] : 0.0;
+        const double p0 = pn, p1 = pn + S, p2 = pn + 2.0 * S;
+        const double q01 = p0 * p1;
+        const double r = rcp_nr1(q01 * p2);
+        const double r01 = r * p2;
+        const double t0 = y0 * (r01 * p1), t1 = y1 * (r01 * p0), t2 = y2 * (r * q01);
+        acc0 += t0; acc1 = fma(t0, C, acc1);
         C += d; d = fma(-kappa, C, d);
-        pn += S;
-        yp += step;
+        acc0 += t1; acc1 = fma(t1, C, acc1);
+        C += d;
+        acc0 += t2; acc1 = fma(t2, C, acc1);
     }
     const double k = s0 * (0.5 * 0.31830988618379067154);     // sin(pi*ph) / pi, and the 0.5 of the taper
     const double acc = acc0 + acc1;
@@ -383,35 +390,113 @@ __global__ __launch_bounds__(64) void pitch_refine_kernel(
     bool any_nan = false;
     const int gid = lane / PG;
 
-    for (int r0 = 0; r0 < ncand; r0 += PNG) {
-        // b) one candidate per group
-        const int ci = r0 + gid;
-        const bool have = ci < ncand;
-        const int kk = have ? cand_list[ci] : 1;
-        double freq, nn;
-        cand_from_peak(ys, kk, sample_rate, offset, freq, nn);
-        double xmid, ymid;
-        improve_extremum_sinc<PG>(ys, nvalid, ylen, offset, nx, nn, 1200, have, xmid, ymid, st);   // :444
-        xmid += (double)offset;                                           // :445
-        if (ymid > 1.) ymid = 1. / ymid;                                  // :446
-        const double cf = sample_rate / xmid, cs = ymid;                  // :447-448
-        // c) stable descending insertion, in candidate order
-#pragma unroll
-        for (int g = 0; g < PNG; g++) {
-            if (r0 + g < ncand) {
-                const double f_g = readlane_f64(cf, g * PG), s_g = readlane_f64(cs, g * PG);
+    // b) + c): the 64/PG lane groups run improve_extremum (src/periodic.rs:192-229, brent_maximize
+    // :103-188) on one candidate each and take the NEXT candidate as soon as theirs has converged, so
+    // a slow refinement never idles the other groups.  Finished candidates enter the lane-resident
+    // list ordered by (strength desc, candidate index asc) == the reference's stable sort (:453).
+    int li = 0;                                     // candidate index of the list entry held by this lane
+    int ci = -1, it = 0, next = 0;
+    bool special = false;
+    double ba = 0., bb = 0., v = 0., w = 0., x = 0., fv = 0., fw = 0., fx = 0., xmid = 0., ymid = 0.;
+    constexpr unsigned long long LEADERS = (PG == 16) ? 0x0001000100010001ull : (PG == 8) ? 0x0101010101010101ull
+                                         : (PG == 32) ? 0x0000000100000001ull : (PG == 4) ? 0x1111111111111111ull : 1ull;
+    for (;;) {
+#pragma clang fp contract(off)   // the scalar Brent arithmetic stays bit-identical to the unfused CPU arithmetic
+        {   // hand out candidates to idle groups, in group order
+            const bool idle = ci < 0;
+            const unsigned long long im = __ballot(idle) & LEADERS;
+            const int rank = __popcll(im & ((1ull << (gid * PG)) - 1ull));
+            if (idle && next + rank < ncand) {
+                ci = next + rank;
+                double freq, nn;
+                cand_from_peak(ys, cand_list[ci], sample_rate, offset, freq, nn);
+                it = 0; special = false; xmid = 0.; ymid = 0.;
+                if (nn == 0.) { special = true; xmid = 0.; ymid = ys[0]; }                              // :193
+                else if (nn >= (double)nx) { special = true; xmid = (double)nx; ymid = y_at(ys, nvalid, nx - 1); }   // :194
+                else if (!(nn - 1. < nn + 1.)) { special = true; st |= 4; }                             // assert!(a < b), :113
+                ba = nn - 1.; bb = nn + 1.;
+            }
+            const int handed = __popcll(im);
+            next = (next + handed < ncand) ? next + handed : ncand;
+        }
+        if (!__any(ci >= 0)) break;
+
+        const double golden = 1. - 0.6180339887498948482045868343656381177203091798057628621;
+        const double sqrt_epsilon = 1.4901161193847656e-08, eps = 2.220446049250313e-16, tol = 1e-10;
+        bool finished = false, need = false;
+        double t = 0.;
+        if (ci >= 0) {
+            if (special) finished = true;
+            else if (it == 0) { v = ba + golden * (bb - ba); t = v; need = true; }
+            else {
+                const double range = bb - ba;
+                const double middle_range = (ba + bb) * 0.5;
+                const double tol_act = sqrt_epsilon * fabs(x) + tol / 3.;
+                if (it > 60 || fabs(x - middle_range) + range * 0.5 <= 2. * tol_act) { finished = true; xmid = x; ymid = fx; }
+                else {
+                    double new_step = (x < middle_range) ? golden * (bb - x) : golden * (ba - x);
+                    if (fabs(x - w) >= tol_act) {
+                        const double tt = (x - w) * (fx - fv);
+                        double q = (x - v) * (fx - fw);
+                        double pp = (x - v) * q - (x - w) * tt;
+                        q = 2. * q - tt;
+                        if (q > 0.) pp = -pp; else q = -q;
+                        if (fabs(pp) < fabs(new_step * q) && pp > q * (ba - x + 2. * tol_act) && pp < q * (bb - x - 2. * tol_act))
+                            new_step = pp / q;
+                    }
+                    if (fabs(new_step) < tol_act) new_step = (new_step > 0.) ? tol_act : -tol_act;
+                    t = x + new_step;
+                    need = true;
+                }
+            }
+        }
+        const double ft = sinc_interp<PG>(ys, nvalid, ylen, offset, nx, t, 1200, need, st);
+        if (need) {
+            if (it == 0) { x = v; w = v; fv = ft; fx = ft; fw = ft; it = 1; }
+            else {
+                if (ft <= fx) {
+                    if (t < x) bb = x; else ba = x;
+                    v = w; w = x; x = t;
+                    fv = fw; fw = fx; fx = ft;
+                } else {
+                    if (t < x) ba = t; else bb = t;
+                    if (ft <= fw || fabs(w - x) < eps) {
+                        v = w; w = t;
+                        fv = fw; fw = ft;
+                    } else if (ft <= fv || fabs(v - x) < eps || fabs(v - w) < eps) {
+                        v = t;
+                        fv = ft;
+                    }
+                }
+                it++;
+            }
+        }
+        // finished candidates -> sorted list
+        unsigned long long fm = __ballot(finished) & LEADERS;
+        if (fm) {
+            double xm = xmid + (double)offset;                                // :445
+            double ym = ymid;
+            if (ym > 1.) ym = 1. / ym;                                        // :446
+            const double cf = sample_rate / xm, cs = ym;                      // :447-448
+            while (fm) {
+                const int ld = __builtin_ctzll(fm);
+                fm &= fm - 1;
+                const double f_g = readlane_f64(cf, ld), s_g = readlane_f64(cs, ld);
+                const int c_g = __builtin_amdgcn_readlane(ci, ld);
                 if (s_g != s_g) any_nan = true;
-                const int pos = __popcll(__ballot(lane < kept && ls >= s_g));
+                const int pos = __popcll(__ballot(lane < kept && (ls > s_g || (ls == s_g && li < c_g))));
                 const double pf = from_prev_lane(lf), ps = from_prev_lane(ls);
-                if (lane > pos) { lf = pf; ls = ps; }
-                if (lane == pos) { lf = f_g; ls = s_g; }
+                const int pi = __builtin_amdgcn_update_dpp(0, li, DPP_WAVE_SHR1, 0xf, 0xf, true);
+                if (lane > pos) { lf = pf; ls = ps; li = pi; }
+                if (lane == pos) { lf = f_g; ls = s_g; li = c_g; }
                 kept = (kept + 1 < kmax) ? kept + 1 : kmax;
             }
+            if (finished) ci = -1;
         }
     }
     int total_cand = ncand;
     {   // maxima.push(Pitch::new(0, threshold)), :452
-        const int pos = __popcll(__ballot(lane < kept && ls >= threshold));
+        const int pos = __popcll(__ballot(lane < kept && ls >= threshold));   // it carries the largest index
         const double pf = from_prev_lane(lf), ps = from_prev_lane(ls);
         if (lane > pos) { lf = pf; ls = ps; }
         if (lane == pos) { lf = 0.0; ls = threshold; }
