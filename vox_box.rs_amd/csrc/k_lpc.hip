@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
 __global__ __launch_bounds__(64) void autocorr_tiles_kernel(
     const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
     int n_lags, double *__restrict__ out) {
-    extern __shared__ double smem[];
+    extern __shared__ __attribute__((aligned(16))) double smem[];
     const long f = blockIdx.x;
     if (f >= n_frames) return;
     const int lane = lane_id();

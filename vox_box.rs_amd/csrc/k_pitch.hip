@@ -294,7 +294,7 @@ __device__ __forceinline__ void improve_extremum_sinc(const double *y, int nvali
 __global__ __launch_bounds__(64) void pitch_lag_kernel(
     const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
     const double *__restrict__ lag_window, double *__restrict__ y_out) {
-    extern __shared__ double smem[];
+    extern __shared__ __attribute__((aligned(16))) double smem[];
     const long f = blockIdx.x;
     if (f >= n_frames) return;
     const int lane = lane_id();

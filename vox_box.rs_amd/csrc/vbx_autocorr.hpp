@@ -8,8 +8,8 @@
 // Mapping ("lag tiles"): lags are processed in passes of 64*KT consecutive lags; in a pass
 // lane l owns the KT consecutive lags  base + l*KT + k.  Stepping i by one slides each lane's
 // KT-wide sample window by one element, so a step costs ONE ds_read_b64 (stride KT doubles
-// across lanes: conflict-free for odd KT) and KT FMAs; x[i] itself is broadcast from a
-// register through v_readlane (no LDS traffic).  Pass g only runs i < N - g*64*KT, which
+// across lanes: conflict-free for odd KT) and KT FMAs; x[i], x[i+1] come from one broadcast
+// ds_read_b128 (all lanes read the same address).  Pass g only runs i < N - g*64*KT, which
 // trims most of the triangle's empty half.
 #pragma once
 
@@ -23,11 +23,12 @@ constexpr int AC_PASS = VBX_WAVE * AC_KT;   // lags per pass (320)
 // number of zero doubles that must follow the N samples in LDS
 __host__ __device__ constexpr int autocorr_pad(int /*n*/) { return AC_PASS + VBX_WAVE; }
 
-// xs: LDS, samples [0,N) followed by >= autocorr_pad(N) zeros.
+// xs: LDS (16-byte aligned), samples [0,N) followed by >= autocorr_pad(N) zeros.
 // Calls emit(lag, S_lag) for every lag in [0, n_lags) from the lane that owns it.
 template <typename Emit>
 __device__ __forceinline__ void autocorr_tiles(const double *xs, int n, int n_lags, Emit emit) {
     const int lane = lane_id();
+    constexpr int UN = 2 * AC_KT;                    // steps per unrolled group (two window rotations)
     for (int base = 0; base < n_lags; base += AC_PASS) {
         const int trips = n - base;                  // i < N - base contributes to some lag of this pass
         const int lag0 = base + lane * AC_KT;
@@ -35,19 +36,18 @@ __device__ __forceinline__ void autocorr_tiles(const double *xs, int n, int n_la
         double win[AC_KT];
 #pragma unroll
         for (int k = 0; k < AC_KT; k++) { acc[k] = 0.0; win[k] = xs[lag0 + k]; }
-        for (int i0 = 0; i0 < trips; i0 += 60) {     // 60 = 12 * AC_KT steps per broadcast chunk
-            const double xchunk = xs[i0 + lane];     // lanes 0..59 are used (reads past N hit the zero pad)
-            const int steps = min(60, trips - i0);
-            for (int s0 = 0; s0 < steps; s0 += AC_KT) {
-                // AC_KT unrolled steps; the window rotates through the registers by renaming
+        const double *wp = xs + lag0 + AC_KT;        // next window sample of this lane
+        for (int i0 = 0; i0 < trips; i0 += UN) {     // steps past `trips` only meet the zero pad
+            double2 xb[AC_KT];
 #pragma unroll
-                for (int u = 0; u < AC_KT; u++) {
-                    const double xi = readlane_f64(xchunk, s0 + u);
-                    const double nxt = xs[i0 + s0 + u + lag0 + AC_KT];
+            for (int q = 0; q < AC_KT; q++) xb[q] = *reinterpret_cast<const double2 *>(xs + i0 + 2 * q);
 #pragma unroll
-                    for (int k = 0; k < AC_KT; k++) acc[k] = fma(xi, win[(k + u) % AC_KT], acc[k]);
-                    win[u] = nxt;                    // slot u is the oldest after this step
-                }
+            for (int u = 0; u < UN; u++) {
+                const double xi = (u & 1) ? xb[u >> 1].y : xb[u >> 1].x;
+                const double nxt = wp[i0 + u];
+#pragma unroll
+                for (int k = 0; k < AC_KT; k++) acc[k] = fma(xi, win[(k + u) % AC_KT], acc[k]);
+                win[u % AC_KT] = nxt;                // that slot held the oldest sample
             }
         }
 #pragma unroll
