@@ -1,44 +1,52 @@
 // k_burg.hip -- Burg LPC (LPC::lpc_praat_mut, src/spectrum.rs:101-146, Q12).
 //
-// One wavefront per frame.  Lane l keeps b1/b2 elements [l*EPL, (l+1)*EPL) in registers, so
-// the reference's shift  b2[j] <- b2[j+1] - a*b1[j+1]  needs ONE neighbour-lane fetch per order
-// (DPP wave_shl) instead of a pass through memory.  Per order: two wave reductions (num, denum),
-// the coefficient recursion (tiny, LDS-resident, lane 0), one fused update sweep.
+// G lanes per frame, 64/G frames per wavefront.  A lane keeps b1/b2 elements
+// [lig*EPL, (lig+1)*EPL) of its frame in registers, so the reference's shift
+//   b2[j] <- b2[j+1] - a*b1[j+1]
+// needs ONE neighbour-lane fetch per order (DPP wave_shl) instead of a pass through memory.
+// Per order: two group reductions (num, denum; DPP, bit-identical inside the group), the
+// coefficient recursion (tiny, LDS-resident, group leader), one fused update sweep.
 // The shrinking valid range [0, N-i) is kept by zeroing exactly the element that drops out.
+// Short frames use small groups so that the per-order overhead is shared by several frames.
 #include "vbx_device.hpp"
 #include "vbx_kernels.hpp"
 
 namespace vbx {
 
-template <int EPL>
+template <int G, int EPL>
 __global__ __launch_bounds__(64) void burg_kernel(
     const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
     int p, double *__restrict__ out, int32_t *__restrict__ status) {
-    __shared__ double aa[VBX_MAX_LPC_ORDER_K + 2];
-    __shared__ double co[VBX_MAX_LPC_ORDER_K + 2];
-    const long f = blockIdx.x;
-    if (f >= n_frames) return;
+    constexpr int NG = 64 / G;
+    constexpr int CS = VBX_MAX_LPC_ORDER_K + 2;
+    __shared__ double aa[NG][CS];
+    __shared__ double co[NG][CS];
     const int lane = lane_id();
-    const double *xf = x + f * stride;
+    const int gid = lane / G, lig = lane % G;
+    const long f = (long)blockIdx.x * NG + gid;
+    const bool have = f < n_frames;
+    const double *xf = x + (have ? f : 0) * stride;
 
     double b1[EPL], b2[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; e++) {
-        const int j = lane * EPL + e;
-        double v = (j < n) ? xf[j] : 0.0;
+        const int j = lig * EPL + e;
+        double v = (have && j < n) ? xf[j] : 0.0;
         if (window != nullptr && j < n) v *= window[j];
         b1[e] = v;
     }
+    const bool last_lane = (lig == G - 1);          // its "next lane" belongs to another frame
     // b2[j] = x[j+1]  (zero past the frame);  b1[j] = x[j] for j <= n-2  (src/spectrum.rs:108-114)
     {
-        const double nxt = from_next_lane(b1[0]);
+        const double fetched = from_next_lane(b1[0]);   // DPP outside any lane-dependent branch
+        const double nxt = last_lane ? 0.0 : fetched;
 #pragma unroll
         for (int e = 0; e < EPL - 1; e++) b2[e] = b1[e + 1];
         b2[EPL - 1] = nxt;
         const int last = n - 1;
         const int kb = last % EPL, lb = last / EPL;
 #pragma unroll
-        for (int e = 0; e < EPL; e++) if (e == kb && lane == lb) b1[e] = 0.0;
+        for (int e = 0; e < EPL; e++) if (e == kb && lig == lb) b1[e] = 0.0;
     }
 
     int st = 0;
@@ -50,21 +58,22 @@ __global__ __launch_bounds__(64) void burg_kernel(
             den = fma(b1[e], b1[e], den);
             den = fma(b2[e], b2[e], den);
         }
-        num = wave_sum(num);
-        den = wave_sum(den);
-        if (den <= 0.0) { st = 1; break; }          // Err(LPC), src/spectrum.rs:123-125 (NaN falls through)
+        num = group_sum<G>(num);
+        den = group_sum<G>(den);
+        if (st == 0 && den <= 0.0) st = 1;           // Err(LPC), src/spectrum.rs:123-125 (NaN falls through)
         const double c = 2.0 * num / den;
-        __syncthreads();
-        if (lane == 0) {
-            co[i - 1] = c;
-            for (int j = 1; j < i; j++) co[j - 1] = aa[j - 1] - c * aa[i - j - 1];
+        wave_sync();
+        if (lig == 0) {
+            co[gid][i - 1] = c;
+            for (int j = 1; j < i; j++) co[gid][j - 1] = aa[gid][j - 1] - c * aa[gid][i - j - 1];
         }
-        __syncthreads();
+        wave_sync();
         if (i < p) {
-            if (lane == 0) for (int j = 1; j <= i; j++) aa[j - 1] = co[j - 1];
+            if (lig == 0) for (int j = 1; j <= i; j++) aa[gid][j - 1] = co[gid][j - 1];
             const double a = c;                      // aa[i-1] == coeffs[i-1]
-            const double nb1 = from_next_lane(b1[0]);
-            const double nb2 = from_next_lane(b2[0]);
+            const double f1 = from_next_lane(b1[0]), f2 = from_next_lane(b2[0]);
+            const double nb1 = last_lane ? 0.0 : f1;
+            const double nb2 = last_lane ? 0.0 : f2;
 #pragma unroll
             for (int e = 0; e < EPL; e++) {
                 const double b1n = (e + 1 < EPL) ? b1[e + 1] : nb1;   // old b1[j+1]
@@ -79,13 +88,15 @@ __global__ __launch_bounds__(64) void burg_kernel(
             if (drop >= 0) {
                 const int kb = drop % EPL, lb = drop / EPL;
 #pragma unroll
-                for (int e = 0; e < EPL; e++) if (e == kb && lane == lb) { b1[e] = 0.0; b2[e] = 0.0; }
+                for (int e = 0; e < EPL; e++) if (e == kb && lig == lb) { b1[e] = 0.0; b2[e] = 0.0; }
             }
         }
     }
-    __syncthreads();
-    if (lane < p) out[f * (long)p + lane] = (st == 0) ? co[lane] * -1.0 : 0.0;   // src/spectrum.rs:142-144
-    if (status != nullptr && lane == 0) status[f] = st;
+    wave_sync();
+    if (have) {
+        for (int j = lig; j < p; j += G) out[f * (long)p + j] = (st == 0) ? co[gid][j] * -1.0 : 0.0;   // :142-144
+        if (status != nullptr && lig == 0) status[f] = st;
+    }
 }
 
 bool burg_supported(int n, int p) {
@@ -94,13 +105,17 @@ bool burg_supported(int n, int p) {
 
 void launch_burg(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                  int p, double *out, int32_t *status) {
-    dim3 g((unsigned)F), b(64);
-#define VBX_BURG(E) hipLaunchKernelGGL((burg_kernel<E>), g, b, 0, s, x, F, n, stride, window, p, out, status)
-    if (n <= 64 * 8) VBX_BURG(8);
-    else if (n <= 64 * 16) VBX_BURG(16);
-    else if (n <= 64 * 20) VBX_BURG(20);
-    else if (n <= 64 * 32) VBX_BURG(32);
-    else VBX_BURG(64);
+    dim3 b(64);
+#define VBX_BURG(GG, E)                                                                                   \
+    hipLaunchKernelGGL((burg_kernel<GG, E>), dim3((unsigned)((F + (64 / GG) - 1) / (64 / GG))), b, 0, s, \
+                       x, F, n, stride, window, p, out, status)
+    if (n <= 16 * 8) VBX_BURG(16, 8);
+    else if (n <= 16 * 16) VBX_BURG(16, 16);
+    else if (n <= 16 * 32) VBX_BURG(16, 32);
+    else if (n <= 32 * 32) VBX_BURG(32, 32);
+    else if (n <= 64 * 20) VBX_BURG(64, 20);
+    else if (n <= 64 * 32) VBX_BURG(64, 32);
+    else VBX_BURG(64, 64);
 #undef VBX_BURG
 }
 
