@@ -259,6 +259,38 @@ def test_estimate_formants_random_segments(vb, oracle):
         assert np.array_equal(got[f], est), f
 
 
+def test_estimate_formants_long_scan(vb, oracle):
+    """A long scan must equal the
+    sequential reference scan exactly, also where the state does not forget: rows with 0-2 resonances leave
+    stale estimates alive for hundreds of frames (Q13)."""
+    rng = np.random.default_rng(23)
+    F, R = 6000, 32
+    res = np.zeros((F, R, 2))
+    for f in range(F):
+        sparse = (f // 700) % 2 == 1                      # alternating stretches of rich and nearly empty rows
+        c = int(rng.integers(0, 3)) if sparse else int(rng.integers(3, 7))
+        fr = np.sort(rng.uniform(60, 5000, c))
+        res[f, :c, 0] = fr
+        res[f, :c, 1] = rng.uniform(10, 400, c)
+    est0 = np.array([[320.0, 1.0], [1440.0, 1.0], [2760.0, 1.0], [3200.0, 1.0]])
+    seg = np.array([0, 17, 40, 1000, 1031, 1032, 2500, 5999])
+    status = np.zeros(F, dtype=np.int32)
+    status[rng.integers(0, F, 60)] = 1
+    got = vb.estimate_formants(res, est0, seg_start=seg, frame_status=status)
+    est = None
+    for f in range(F):
+        if f in seg:
+            est = est0.copy()
+        if status[f] == 0:
+            est = oracle.estimate_formants(est, res[f])
+        assert np.array_equal(got[f], est), f
+    one = vb.estimate_formants(res, est0)                 # one 6000-frame utterance
+    est = est0.copy()
+    for f in range(F):
+        est = oracle.estimate_formants(est, res[f])
+        assert np.array_equal(one[f], est), f
+
+
 # ---- find_formants ---------------------------------------------------------------------------------
 
 def test_find_formants_wav_fixture(vb, oracle, golden_dir):
