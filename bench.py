@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--hours", type=float, default=12.5, help="hours of 48 kHz audio PER GPU (pipeline / config3)")
     ap.add_argument("--frames", type=int, default=1_000_000, help="dense frames per GPU (config2 / config4)")
-    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "config2", "config3", "config4"])
+    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "config2", "config3", "config4", "frontend"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
@@ -133,6 +133,48 @@ def flop_model(workload):
             "flops": (2.0 * c["autocorr_macs"] + FLOPS_PER_SINC_TERM * c["sinc_terms"]) / n}
 
 
+def bench_frontend(args, torch, dev, vb, vb2, pkg):
+    """PCM16 ingestion -> Windower view -> RMS and pre-emphasis per frame (HBM-bound)."""
+    hours = min(args.hours, 2.0)
+    n = int(hours * 3600 * 48000)
+    pcm = torch.randint(-32768, 32767, (n,), dtype=torch.int16, device=dev)
+    audio = torch.empty(n, dtype=torch.float64, device=dev)
+    F = pkg.frame_count(n, N48, H48)
+    rms = torch.empty(F, dtype=torch.float64, device=dev)
+    Fp = min(F, 200_000)
+    pe = torch.empty((Fp, N48), dtype=torch.float64, device=dev)
+    win = vb.window(pkg.WINDOW_HANNING, N48)
+
+    def step():
+        vb.pcm16_to_f64(pcm, out=audio)
+        vb.L.vbx_rms_f64(vb.ctx, audio.data_ptr(), F, N48, H48, win.ptr, rms.data_ptr())
+        vb.preemphasis(audio, 0.1, frame_len=N48, stride=H48, n_frames=Fp, out=pe)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    vb.profile_reset(); vb.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = vb.profile_report(); vb.profile(False)
+    k = {name: ms / max(c, 1) for name, (ms, c) in prof.items()}
+    ach = n * 10 / (k["pcm16"] * 1e-3) / 1e9
+    out = {"metric": "frames/sec (frontend: pcm16 ingestion + rms + preemphasis)", "value": F * args.steps / dt,
+           "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"frontend, {hours:g} h 48 kHz int16 PCM -> f64, rms over {F} frames, preemphasis over {Fp}"},
+           "roofline": {"bound": "hbm", "kernel": "pcm16", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_sample": 10, "ms_avg": k["pcm16"]},
+           "kernels_ms": {a: round(b, 3) for a, b in k.items()},
+           "gbs": {"rms": F * (H48 * 8 + 8) / (k["rms"] * 1e-3) / 1e9,
+                   "preemphasis": Fp * (H48 * 8 + N48 * 8) / (k["preemphasis"] * 1e-3) / 1e9}}
+    print(json.dumps(out), flush=True)
+    vb2.close(); vb.close()
+
+
 # ------------------------------------------------------------------------------------------------
 def main():
     args = parse()
@@ -163,6 +205,8 @@ def main():
 
     wl = args.workload
     f64 = torch.float64
+    if wl == "frontend":
+        return bench_frontend(args, torch, dev, vb, vb2, pkg)
     est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
     if wl in ("pipeline", "config3"):
         total_frames_per_gpu = int(round(args.hours * 3600 * 100))            # 100 frames per second

@@ -232,6 +232,23 @@ int vbx_mfcc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_le
 /* dct (src/spectrum.rs:384-398) on rows: in/out [F, n]. */
 int vbx_dct_f64(vbx_ctx *ctx, const double *in, size_t n_rows, size_t n, double *out);
 
+/* ------------------------------------------------------------------ front end (N2, N3) */
+
+/* 16-bit PCM -> f64 as the reference's tests read WAV data: sample / (i32::MAX >> (32 - bits)) = / 32767
+ * (tests/lib.rs:17-19).  pcm: n int16 samples on the device; out: n doubles.  Framing is then the
+ * (stride = hop) view of `out`: window::Windower::{rectangle,hanning} without copying frames. */
+int vbx_pcm16_to_f64(vbx_ctx *ctx, const int16_t *pcm, size_t n_samples, double *out);
+
+/* RMS::rms per frame (src/waves.rs:10-23).  out: [F]. */
+int vbx_rms_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
+                const double *window, double *out);
+
+/* Filter::preemphasis(factor) per frame (src/waves.rs:82-96): x[i] += 2*pi*factor * x[i+1], backwards.
+ * The reference filters in place; frames of a hop-strided view overlap, so the result is written to the
+ * dense batch out: [F, frame_len] (out may equal x when stride == frame_len). */
+int vbx_preemphasis_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
+                        double factor, double *out);
+
 /* ------------------------------------------------------------------ bench utility */
 
 /* Deterministic speech-like synthetic audio (DESIGN.md "synthetic signal"): samples

@@ -1,0 +1,106 @@
+// k_front.hip -- the steps either side of the hot path:
+//   PCM ingestion   i16 -> f64 / 32767  (hound reader as used at tests/lib.rs:17-19)
+//   RMS::rms        src/waves.rs:10-23
+//   Filter::preemphasis  src/waves.rs:82-96: backwards recurrence y[i] = x[i] + c*y[i+1], c = 2*pi*factor
+// All three are HBM-bound byte/stream work: coalesced loads, one pass.
+#include "vbx_device.hpp"
+#include "vbx_kernels.hpp"
+
+namespace vbx {
+
+// x / denom for |x| <= 32768: reciprocal multiply + one Markstein correction step.  Correctly rounded
+// (== true division, which is what the reference computes) -- checked exhaustively over all 65536
+// int16 values in tests/test_gpu_frontend.py.
+__device__ __forceinline__ double div_exact_small(double x, double denom, double r) {
+    const double q = x * r;
+    const double rem = fma(-q, denom, x);
+    return fma(rem, r, q);
+}
+
+// two samples per lane and step: one 4-B load, one 16-B store -- every wave instruction touches one
+// contiguous span (256 B in, 1 KiB out)
+__global__ void pcm16_kernel(const int16_t *__restrict__ pcm, size_t n, double denom, double *__restrict__ out) {
+    const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(pcm) & 3) | (reinterpret_cast<uintptr_t>(out) & 15)) == 0;
+    const size_t n2 = aligned ? n / 2 : 0;
+    const double r = 1.0 / denom;
+    for (size_t v = t0; v < n2; v += step) {
+        const int w = reinterpret_cast<const int *>(pcm)[v];
+        const double lo = (double)(short)(w & 0xffff), hi = (double)(short)(w >> 16);
+        reinterpret_cast<double2 *>(out)[v] = make_double2(div_exact_small(lo, denom, r), div_exact_small(hi, denom, r));
+    }
+    for (size_t i = n2 * 2 + t0; i < n; i += step) out[i] = div_exact_small((double)pcm[i], denom, r);
+}
+
+// rms: one wavefront per frame
+__global__ __launch_bounds__(64) void rms_kernel(const double *__restrict__ x, long n_frames, int n, long stride,
+                                                 const double *__restrict__ window, double *__restrict__ out) {
+    const long f = blockIdx.x;
+    if (f >= n_frames) return;
+    const int lane = lane_id();
+    const double *xf = x + f * stride;
+    double s = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        double v = xf[i];
+        if (window != nullptr) v *= window[i];
+        s = fma(v, v, s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[f] = sqrt(s / (double)n);
+}
+
+// preemphasis: one wavefront per frame; lane l owns elements [l*E, (l+1)*E) (E = ceil(n/64)), kept in LDS.
+//   local pass   y_loc[e] = x[e] + c*y_loc[e+1]   (carry-in 0)
+//   lane scan    Y_l = y_loc_first(l) + c^E * Y_{l+1}    (backward Hillis-Steele over the 64 lanes)
+//   fix-up       y[e] = y_loc[e] + c^(E-e) * Y_{l+1}
+__global__ __launch_bounds__(64) void preemphasis_kernel(const double *__restrict__ x, long n_frames, int n, long stride,
+                                                         double c, double *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const long f = blockIdx.x;
+    if (f >= n_frames) return;
+    const int lane = lane_id();
+    const double *xf = x + f * stride;
+    double *yo = out + f * (long)n;
+    const int E = (n + 63) / 64;
+    for (int i = lane; i < 64 * E; i += 64) smem[i] = (i < n) ? xf[i] : 0.0;
+    __syncthreads();
+    double *mine = smem + lane * E;
+    double carry = 0.0;
+    for (int e = E - 1; e >= 0; e--) { carry = fma(c, carry, mine[e]); mine[e] = carry; }
+    // A = c^E
+    double A = 1.0;
+    for (int e = 0; e < E; e++) A *= c;
+    double Y = carry;                                   // value at the lane's first element, carry-in 0
+    double Ad = A;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double other = __shfl_down(Y, d, 64);
+        if (lane + d < 64) Y = fma(Ad, other, Y);
+        Ad *= Ad;
+    }
+    const double cin = __shfl_down(Y, 1, 64);           // Y_{l+1}
+    const double carry_in = (lane < 63) ? cin : 0.0;
+    double pw = c;                                      // c^(E-e) for e = E-1 .. 0
+    for (int e = E - 1; e >= 0; e--) { mine[e] = fma(pw, carry_in, mine[e]); pw *= c; }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) yo[i] = smem[i];
+}
+
+void launch_pcm16(hipStream_t s, const int16_t *pcm, size_t n, double denom, double *out) {
+    size_t blocks = (n / 2 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pcm16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pcm, n, denom, out);
+}
+
+void launch_rms(hipStream_t s, const double *x, long F, int n, long stride, const double *window, double *out) {
+    hipLaunchKernelGGL(rms_kernel, dim3((unsigned)F), dim3(64), 0, s, x, F, n, stride, window, out);
+}
+
+void launch_preemphasis(hipStream_t s, const double *x, long F, int n, long stride, double c, double *out) {
+    const size_t lds = (size_t)(64 * ((n + 63) / 64)) * sizeof(double);
+    hipLaunchKernelGGL(preemphasis_kernel, dim3((unsigned)F), dim3(64), lds, s, x, F, n, stride, c, out);
+}
+
+}  // namespace vbx

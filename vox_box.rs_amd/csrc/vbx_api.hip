@@ -710,6 +710,38 @@ int vbx_dct_f64(vbx_ctx *ctx, const double *in, size_t n_rows, size_t n, double 
     return check_launch(ctx, __func__);
 }
 
+// ---- front end (N2, N3) ---------------------------------------------------------------------
+
+int vbx_pcm16_to_f64(vbx_ctx *ctx, const int16_t *pcm, size_t n_samples, double *out) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    if (n_samples == 0) return VBX_SUCCESS;
+    VBX_REQUIRE(ctx, pcm && out, "null argument");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    { Prof p(ctx, "pcm16"); launch_pcm16(ctx->stream, pcm, n_samples, 32767.0, out); }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_rms_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
+                const double *window, double *out) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_REQUIRE(ctx, out != nullptr, "null output");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    { Prof p(ctx, "rms"); launch_rms(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, out); }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_preemphasis_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
+                        double factor, double *out) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_REQUIRE(ctx, out != nullptr, "null output");
+    VBX_REQUIRE(ctx, out != x || stride == frame_len, "in-place filtering needs a dense batch (stride == frame_len)");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    { Prof p(ctx, "preemphasis"); launch_preemphasis(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, 2.0 * M_PI * factor, out); }
+    return check_launch(ctx, __func__);
+}
+
 // ---- bench utility ------------------------------------------------------------------------
 
 int vbx_synth_speech_f64(vbx_ctx *ctx, double *out, size_t n_samples, uint64_t sample_offset,

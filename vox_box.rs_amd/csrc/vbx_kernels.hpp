@@ -62,6 +62,11 @@ void launch_mfcc(hipStream_t s, const double *x, long F, int n, long stride, con
                  int num_coeffs, double *out, int32_t *status, int nb /* bins[K+1]-bins[0] */);
 void launch_dct_rows(hipStream_t s, const double *in, long rows, int n, const double *dct_table, double *out);
 
+// k_front.hip
+void launch_pcm16(hipStream_t s, const int16_t *pcm, size_t n, double denom, double *out);
+void launch_rms(hipStream_t s, const double *x, long F, int n, long stride, const double *window, double *out);
+void launch_preemphasis(hipStream_t s, const double *x, long F, int n, long stride, double c, double *out);
+
 // k_synth.hip
 void launch_synth(hipStream_t s, double *out, size_t n_samples, uint64_t sample_offset, double sample_rate, uint64_t seed);
 

@@ -122,6 +122,21 @@ struct Autocorrelate {   // periodic.rs:265-274
     }
 };
 
+struct RMS {             // waves.rs:10-23
+    static void rms(Context &c, const Frames &f, double *out /* [F] */) {
+        c.check(vbx_rms_f64(c.get(), f.x, f.n_frames, f.frame_len, f.stride, f.window, out));
+    }
+};
+
+struct Filter {          // waves.rs:82-96 (result in a dense [F, N] batch: strided frames overlap)
+    static void preemphasis(Context &c, const Frames &f, double factor, double *out) {
+        c.check(vbx_preemphasis_f64(c.get(), f.x, f.n_frames, f.frame_len, f.stride, factor, out));
+    }
+};
+
+// hound-style ingestion of 16-bit PCM (tests/lib.rs:17-19): sample / 32767
+inline void pcm16_to_f64(Context &c, const int16_t *pcm, size_t n, double *out) { c.check(vbx_pcm16_to_f64(c.get(), pcm, n, out)); }
+
 struct Normalize {       // waves.rs:60-76
     static void normalize(Context &c, double *rows, size_t n_rows, size_t n) { c.check(vbx_normalize_f64(c.get(), rows, n_rows, n)); }
 };

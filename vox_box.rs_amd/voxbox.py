@@ -92,6 +92,9 @@ def load_library():
         "vbx_find_formants_f64": (C.c_int, [vp, vp, sz, sz, sz, dbl, sz, vp, sz, vp, sz, vp, vp, vp, vp, vp]),
         "vbx_mfcc_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, dbl, dbl, dbl, vp, vp]),
         "vbx_dct_f64": (C.c_int, [vp, vp, sz, sz, vp]),
+        "vbx_pcm16_to_f64": (C.c_int, [vp, vp, sz, vp]),
+        "vbx_rms_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, vp]),
+        "vbx_preemphasis_f64": (C.c_int, [vp, vp, sz, sz, sz, dbl, vp]),
         "vbx_synth_speech_f64": (C.c_int, [vp, vp, sz, C.c_uint64, dbl, C.c_uint64]),
         "vbx_selftest_lanes": (C.c_int, [vp, vp]),
     }
@@ -481,6 +484,34 @@ class VoxBox:
         res = o.numpy()
         d.free(); o.free()
         return res
+
+    # -- front end (waves.rs, WAV ingestion) ----------------------------------------------------
+    def pcm16_to_f64(self, pcm, out=None):
+        """int16 PCM (host array or device buffer + n via `out`) -> f64 / 32767 on the device."""
+        tmp = None
+        if isinstance(pcm, np.ndarray):
+            tmp = self.to_device(pcm, np.int16)
+            n, ptr = pcm.size, tmp.ptr
+        else:
+            n, ptr = out.shape[0], _ptr(pcm)
+        o = out if out is not None else self.empty(n)
+        self._check(self.L.vbx_pcm16_to_f64(self.ctx, ptr, n, _ptr(o)))
+        if tmp is not None:
+            self.sync()
+            tmp.free()
+        return o
+
+    def rms(self, x, frame_len=None, stride=None, n_frames=None, window=None):
+        ptr, F, N, S, tmp = self._frames(x, frame_len, stride, n_frames)
+        o = self.empty(F)
+        self._check(self.L.vbx_rms_f64(self.ctx, ptr, F, N, S, _ptr(window), o.ptr))
+        return self._finish(o, None, tmp)
+
+    def preemphasis(self, x, factor, frame_len=None, stride=None, n_frames=None, out=None):
+        ptr, F, N, S, tmp = self._frames(x, frame_len, stride, n_frames)
+        o = out if out is not None else self.empty((F, N))
+        self._check(self.L.vbx_preemphasis_f64(self.ctx, ptr, F, N, S, factor, _ptr(o)))
+        return self._finish(o, out, tmp)
 
     # -- utilities ----------------------------------------------------------------------
     def synth_speech(self, n_samples, sample_offset=0, sample_rate=48000.0, seed=0x5EED0001, out=None):
