@@ -65,9 +65,9 @@ __device__ __forceinline__ c64 laguerre(const lds_poly &p, int len, c64 start) {
 }
 
 // src/polynomial.rs:92-152 (+ div_polynomial_mut :155-195 inlined as in-place synthetic division).
-// co: polynomial in / scratch; zr: roots out (len entries, zero filled past the roots).
-__device__ __forceinline__ int find_roots_lane(const lds_poly &co, const lds_poly &zr, int len) {
-    for (int j = 0; j < len; j++) zr.set(j, cmk(0.0, 0.0));
+// co: polynomial in / scratch; emit(index, root) receives the roots in discovery order.
+template <typename Emit>
+__device__ __forceinline__ int find_roots_emit(const lds_poly &co, int len, Emit emit) {
     const int coeff_high = poly_degree(co, len);
     if (coeff_high < 1) return 2;                       // Err(Polynomial), :95
     const int coeff_low = poly_off_low(co, len);
@@ -77,7 +77,7 @@ __device__ __forceinline__ int find_roots_lane(const lds_poly &co, const lds_pol
     int zi = 0;
     for (int k = m; k >= 3; k--) {                      // (3..m+1).rev()
         const c64 z = laguerre(co, clen, cmk(-2.0, -2.0));
-        zr.set(zi++, z);
+        emit(zi++, z);
         if (ciszero(z)) return 2;                       // div by zero -> Err, :123,:192
         // divide by (x - z): other = -z; q[i] = c[i+1] - q[i+1]*other
         const int ns = poly_degree(co, clen);
@@ -96,14 +96,20 @@ __device__ __forceinline__ int find_roots_lane(const lds_poly &co, const lds_pol
         const c64 four_ac = cmul(cmk(4.0 * c2.re, 4.0 * c2.im), c0);
         const c64 d = csqrt(csub(cmul(c1, c1), four_ac));
         const c64 xx = cneg(c1);
-        zr.set(zi, cdiv(cadd(xx, d), a2));
-        zr.set(zi + 1, cdiv(csub(xx, d), a2));
+        emit(zi, cdiv(cadd(xx, d), a2));
+        emit(zi + 1, cdiv(csub(xx, d), a2));
         zi += 2;
     } else if (m == 1) {                                // :141-144
-        zr.set(zi, cdiv(cneg(co.get(0)), co.get(1)));
+        emit(zi, cdiv(cneg(co.get(0)), co.get(1)));
         zi += 1;
     }
     return 0;
+}
+
+// roots into an LDS array (len entries, zero filled past the roots)
+__device__ __forceinline__ int find_roots_lane(const lds_poly &co, const lds_poly &zr, int len) {
+    for (int j = 0; j < len; j++) zr.set(j, cmk(0.0, 0.0));
+    return find_roots_emit(co, len, [&](int i, c64 z) { zr.set(i, z); });
 }
 
 // src/spectrum.rs:166-192
@@ -197,31 +203,30 @@ __global__ __launch_bounds__(ROOTS_BLOCK) void formant_resonances_kernel(
     const long f = (long)blockIdx.x * ROOTS_BLOCK + threadIdx.x;
     const bool active = f < n_frames;
     const int len = p + 1;
-    lds_poly co{lds + threadIdx.x}, zr{lds + (size_t)len * ROOTS_BLOCK + threadIdx.x};
+    lds_poly co{lds + threadIdx.x};
     const long fr = active ? f : n_frames - 1;
     const double *a = coeffs + fr * (long)p;
     int st = (status != nullptr) ? status[fr] : 0;
     // complex_lpc = rev([1, a1..ap]): index j < p holds a[p-1-j], index p holds 1 (src/lib.rs:80-91)
     for (int j = 0; j < p; j++) co.set(j, cmk(a[p - 1 - j], 0.0));
     co.set(p, cmk(1.0, 0.0));
-    int rst = 0;
-    if (st == 0) rst = find_roots_lane(co, zr, len);
-    if (!active) return;
-    res_t *row = out_res + f * (long)VBX_MAX_RESONANCES_K;
+    res_t *row = out_res + fr * (long)VBX_MAX_RESONANCES_K;    // idle lanes shadow the last frame (same values)
     int count = 0;
-    if (st == 0 && rst == 0) {
-        for (int j = 0; j < len; j++) {                 // iterates p+1 entries; the last is always 0
-            const c64 z = zr.get(j);
-            if (!(z.im > 0.0)) continue;
+    int rst = 0;
+    if (st == 0) {
+        // every root goes straight through Resonance::from_root (im > 0 only, src/lib.rs:94-104); the
+        // reference appends and then sorts [0..=rpos] by frequency (stable, :105-110) -- all stored
+        // frequencies are > 50, so that is a sorted insertion.  No root array is kept.
+        rst = find_roots_emit(co, len, [&](int, c64 z) {
             res_t v;
-            if (count < VBX_MAX_RESONANCES_K && resonance_from_root(z, sample_rate, v)) {
-                // the reference appends then sorts [0..=rpos] by frequency (stable, :105-110);
-                // all stored frequencies are > 50 so rpos = count-1: equivalent to sorted insertion
-                res_insert_sorted(row, count, v);
+            if (z.im > 0.0 && count < VBX_MAX_RESONANCES_K && resonance_from_root(z, sample_rate, v)) {
+                if (active) res_insert_sorted(row, count, v);
                 count++;
             }
-        }
+        });
     }
+    if (!active) return;
+    if (rst != 0) count = 0;
     for (int j = count; j < VBX_MAX_RESONANCES_K; j++) { row[j].frequency = 0.0; row[j].bandwidth = 0.0; }
     if (out_count != nullptr) out_count[f] = count;
     if (status != nullptr && st == 0 && rst != 0) status[f] = rst;
@@ -250,7 +255,7 @@ void launch_to_resonance(hipStream_t s, const cplx_t *roots, long F, int n_roots
 
 void launch_formant_resonances(hipStream_t s, const double *coeffs, long F, int p, double sample_rate,
                                res_t *out_res, int32_t *out_count, int32_t *status) {
-    const size_t lds = (size_t)2 * (p + 1) * ROOTS_BLOCK * sizeof(c64);
+    const size_t lds = (size_t)(p + 1) * ROOTS_BLOCK * sizeof(c64);
     hipLaunchKernelGGL(formant_resonances_kernel, dim3((unsigned)((F + ROOTS_BLOCK - 1) / ROOTS_BLOCK)), dim3(ROOTS_BLOCK), lds, s,
                        coeffs, F, p, sample_rate, out_res, out_count, status);
 }
