@@ -36,21 +36,24 @@ __device__ __forceinline__ void levinson_uniform(const double (&r)[P + 1], doubl
     }
 }
 
+constexpr int AC_FPW = 16;   // frames per wavefront: short enough that the last round of waves is a small tail
+
 // EPL: samples per lane (frame_len <= 64*EPL).  NL: number of lags computed (n_lags <= NL).
 //
-// One wavefront works through FPW = 64 consecutive frames:
+// One wavefront works through FPW consecutive frames:
 //   per frame   coalesced 16-B loads of the lane's EPL samples (next frame prefetched), neighbour
 //               samples by DPP wave shifts, NL lag products per lane in registers (EPL*NL FMAs),
 //               then ONE transposing reduction through LDS for all NL sums together (a lane's NL
 //               partials are written as a row, 4 lanes per lag each add 16 of the 64 partials,
 //               a quad butterfly finishes) instead of NL separate 64-lane reductions;
-//   per 64 frames  lane f runs Levinson-Durbin for frame f (one division chain per 64 frames, not
-//               per frame) and the [64, NL] result blocks leave through LDS as coalesced stores.
+//   per FPW frames  lane f runs Levinson-Durbin for frame f (one division chain per FPW frames, not
+//               per frame) and the [FPW, NL] result blocks leave through LDS as coalesced stores.
+// Two frames are kept in flight ahead of the one being reduced.
 template <int EPL, int NL>
 __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
     const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
     int n_lags, int normalize, double *__restrict__ out_r, double *__restrict__ out_lpc) {
-    constexpr int FPW = 64;
+    constexpr int FPW = AC_FPW;
     constexpr int TS = NL | 1;                       // odd row stride: conflict-free column reads
     __shared__ double T[64 * TS];                    // per-frame transpose buffer [lane][lag]
     __shared__ double R[FPW * TS];                   // results of the wave's frames [frame][lag]
@@ -76,12 +79,13 @@ __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
             for (int e = 0; e < EPL; e++) dst[e] = (lane * EPL + e < n) ? xf[e] : 0.0;
         }
     };
-    double cur[EPL], nxt[EPL];
+    double cur[EPL], nxt[EPL], nx2[EPL];
     load_frame(0, cur);
+    if (nf > 1) load_frame(1, nxt);
     const int red_lag = lane >> 2, red_part = lane & 3;
 
     for (int g = 0; g < nf; g++) {
-        if (g + 1 < nf) load_frame(g + 1, nxt);
+        if (g + 2 < nf) load_frame(g + 2, nx2);
         // ext[0..EPL) own samples, ext[EPL..EPL+NL-1) the following samples (from lanes l+1, l+2, ..)
         double ext[EPL + NL - 1];
 #pragma unroll
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
         }
         wave_sync();
 #pragma unroll
-        for (int e = 0; e < EPL; e++) cur[e] = nxt[e];
+        for (int e = 0; e < EPL; e++) { cur[e] = nxt[e]; nxt[e] = nx2[e]; }
     }
 
     // lane f <-> frame f0 + f
@@ -230,7 +234,7 @@ __global__ void levinson_rows_kernel(const double *__restrict__ r, long n_rows, 
 template <int EPL, int NL>
 static void launch_fewlags(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                            int n_lags, int normalize, double *out_r, double *out_lpc) {
-    hipLaunchKernelGGL((autocorr_fewlags_kernel<EPL, NL>), dim3((unsigned)((F + 63) / 64)), dim3(64), 0, s,
+    hipLaunchKernelGGL((autocorr_fewlags_kernel<EPL, NL>), dim3((unsigned)((F + AC_FPW - 1) / AC_FPW)), dim3(64), 0, s,
                        x, F, n, stride, window, n_lags, normalize, out_r, out_lpc);
 }
 
