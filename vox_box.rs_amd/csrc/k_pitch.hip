@@ -285,21 +285,19 @@ __device__ __forceinline__ void improve_extremum_sinc(const double *y, int nvali
 }
 
 // ------------------------------------------------------------------------------------------
-// pitch, kernel 1: frame -> lag curve y (src/periodic.rs:400-408)
-//   y[i] = (r[i] / max|r|) / w_lag[i],  r = self.autocorrelate(self.len())
-// One wavefront per frame, frame staged in LDS, lag tiles (vbx_autocorr.hpp); the finished row
-// is written coalesced to a chunk-sized scratch in HBM for kernel 2.  (This phase is < 4 % of the
-// pitch time; splitting it off lets the refinement kernel run at 16 waves/CU.)
+// pitch, kernel 1: frame -> raw autocorrelation r = self.autocorrelate(self.len()) (src/periodic.rs:403)
+// One wavefront per frame, frame staged in LDS (the only LDS user: 12 waves/CU), lag tiles
+// (vbx_autocorr.hpp); each lane stores its lags straight to a chunk-sized scratch in HBM.  Kernel 2
+// normalises while it loads the row:  y[i] = (r[i] / max|r|) / w_lag[i]  (:404-408).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void pitch_lag_kernel(
     const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
-    const double *__restrict__ lag_window, double *__restrict__ y_out) {
+    double *__restrict__ r_out) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const long f = blockIdx.x;
     if (f >= n_frames) return;
     const int lane = lane_id();
     double *xs = smem;                              // [n + pad] windowed samples, zero padded
-    double *ys = smem + n + autocorr_pad(n);        // [n] raw autocorrelation
     const double *xf = x + f * stride;
     const int total = n + autocorr_pad(n);
     for (int i = lane; i < total; i += 64) {
@@ -309,18 +307,10 @@ __global__ __launch_bounds__(64) void pitch_lag_kernel(
     }
     __syncthreads();
     const double x0 = xs[0];
-    double amax = -1.0;
-    autocorr_tiles(xs, n, n, [&](int lag, double s) {          // :403
-        const double r = (s - x0 * xs[lag]) + x0;
-        ys[lag] = r;
-        const double a = fabs(r);
-        amax = (a > amax) ? a : amax;
+    double *ro = r_out + f * (long)n;
+    autocorr_tiles(xs, n, n, [&](int lag, double s) {          // self.autocorrelate(self.len()), :403
+        ro[lag] = (s - x0 * xs[lag]) + x0;
     });
-    amax = wave_max(amax);                          // max_amplitude over ALL lags (Q2)
-    __syncthreads();
-    const double scale = 1.0 / amax;                // normalize (:404), then / lag window (:406-408)
-    double *yo = y_out + f * (long)n;
-    for (int i = lane; i < n; i += 64) yo[i] = (ys[i] * scale) / lag_window[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -348,15 +338,25 @@ __device__ __forceinline__ void cand_from_peak(const double *ys, int kk, double 
 }
 
 __global__ __launch_bounds__(64) void pitch_refine_kernel(
-    const double *__restrict__ y_in, long n_frames, int n, double sample_rate, double threshold, double fmin, double fmax,
+    const double *__restrict__ r_in, const double *__restrict__ lag_window, long n_frames, int n,
+    double sample_rate, double threshold, double fmin, double fmax,
     int kmax, pitch_t *__restrict__ out_cand, int32_t *__restrict__ out_count, int32_t *__restrict__ status) {
     extern __shared__ double ys[];                  // [n + Y_PAD] doubles, then the candidate list (ints)
     const long f = blockIdx.x;
     if (f >= n_frames) return;
     const int lane = lane_id();
     int *cand_list = reinterpret_cast<int *>(ys + n + Y_PAD);
-    const double *yi = y_in + f * (long)n;
-    for (int i = lane; i < n + Y_PAD; i += 64) ys[i] = (i < n) ? yi[i] : 0.0;
+    const double *ri = r_in + f * (long)n;
+    double amax = -1.0;                             // max_amplitude over ALL lags (Q2; NaN never wins)
+    for (int i = lane; i < n + Y_PAD; i += 64) {
+        const double r = (i < n) ? ri[i] : 0.0;
+        ys[i] = r;
+        const double a = fabs(r);
+        amax = (a > amax) ? a : amax;
+    }
+    amax = wave_max(amax);
+    const double scale = 1.0 / amax;                // normalize (:404), then / lag window (:406-408)
+    for (int i = lane; i < n; i += 64) ys[i] = (ys[i] * scale) / lag_window[i];
     __syncthreads();
 
     const int b = (int)floor(0.5 * (double)n);      // brent_ixmax, :414
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(64) void extremum_points_kernel(const double *__res
     }
 }
 
-size_t pitch_lds_bytes(int n) { return (size_t)(2 * n + autocorr_pad(n)) * sizeof(double); }
+size_t pitch_lds_bytes(int n) { return (size_t)(n + autocorr_pad(n)) * sizeof(double); }
 static size_t refine_lds_bytes(int n) { return (size_t)(n + Y_PAD) * sizeof(double) + (size_t)(n / 4 + 8) * sizeof(int); }
 
 // frames per chunk of the lag-curve scratch (about 2.5 GB of HBM, at least 4096 frames)
@@ -567,9 +567,9 @@ void launch_pitch(hipStream_t s, const double *x, long F, int n, long stride, co
     for (long f0 = 0; f0 < F; f0 += chunk) {
         const long fc = (F - f0 < chunk) ? (F - f0) : chunk;
         hipLaunchKernelGGL(pitch_lag_kernel, dim3((unsigned)fc), dim3(64), pitch_lds_bytes(n), s,
-                           x + f0 * stride, fc, n, stride, window, lag_window, lag_ws);
+                           x + f0 * stride, fc, n, stride, window, lag_ws);
         hipLaunchKernelGGL(pitch_refine_kernel, dim3((unsigned)fc), dim3(64), refine_lds_bytes(n), s,
-                           lag_ws, fc, n, sample_rate, threshold, fmin, fmax, kmax,
+                           lag_ws, lag_window, fc, n, sample_rate, threshold, fmin, fmax, kmax,
                            out_cand + f0 * (long)kmax, out_count ? out_count + f0 : nullptr, status ? status + f0 : nullptr);
     }
 }
