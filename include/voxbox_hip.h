@@ -249,6 +249,16 @@ int vbx_rms_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len
 int vbx_preemphasis_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
                         double factor, double *out);
 
+/* The resample front end of find_formants (resample_ratio != 1.0, src/lib.rs:42,57-61):
+ * sample 0.10's Linear::new(buf[0], buf[1]) + Converter::scale_sample_hz(.., ratio), take(ceil(ratio*len)).
+ * That arithmetic lives in the un-vendored `sample` crate and no reference test runs this branch, so this
+ * entry point is "parity unpinned" (it is bit-identical to the oracle's restatement of the crate).
+ * out: dense [F, vbx_resampled_len(frame_len, ratio)].  find_formants with a ratio is then
+ * vbx_find_formants_f64 on that dense batch (frame_len = stride = resampled length). */
+size_t vbx_resampled_len(size_t frame_len, double resample_ratio);
+int vbx_resample_linear_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
+                            double resample_ratio, double *out);
+
 /* ------------------------------------------------------------------ bench utility */
 
 /* Deterministic speech-like synthetic audio (DESIGN.md "synthetic signal"): samples

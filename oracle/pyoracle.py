@@ -213,6 +213,27 @@ def find_formants(x, sample_rate, n_coeffs, formants):
     return st, f, res, co
 
 
+def resampled_len(n, ratio):
+    L = lib()
+    L.vbxo_resampled_len.restype = C.c_size_t
+    return L.vbxo_resampled_len(C.c_size_t(n), C.c_double(ratio))
+
+
+def resample_linear(x, ratio):
+    x = _f64(x)
+    out = np.zeros(resampled_len(x.size, ratio), dtype=np.float64)
+    lib().vbxo_resample_linear(_p(x), C.c_size_t(x.size), C.c_double(ratio), _p(out))
+    return out
+
+
+def find_formants_ratio(x, sample_rate, ratio, n_coeffs, formants):
+    x = _f64(x)
+    f = _f64(formants).copy()
+    st = lib().vbxo_find_formants_ratio(_p(x), C.c_size_t(x.size), C.c_double(sample_rate), C.c_double(ratio),
+                                        C.c_size_t(n_coeffs), _p(f), C.c_size_t(f.shape[0]))
+    return st, f
+
+
 def hz_to_mel(hz):
     return lib().vbxo_hz_to_mel(hz)
 

@@ -763,6 +763,39 @@ int vbxo_find_formants(const double *x, size_t n, double sample_rate, size_t n_c
     return status;
 }
 
+/* lib.rs:42,57-61 (resample_ratio != 1.0); sample 0.10 Converter + Linear restated -- parity unpinned. */
+size_t vbxo_resampled_len(size_t n, double ratio) { return (size_t)ceil(ratio * (double)n); }
+
+void vbxo_resample_linear(const double *x, size_t n, double ratio, double *out) {
+    size_t m = vbxo_resampled_len(n, ratio);
+    size_t next = 0;                                   /* signal::from_iter: equilibrium after the end */
+    double left = (next < n) ? x[next] : 0.0; next++;  /* Linear::new(buf_iter.next(), buf_iter.next()) */
+    double right = (next < n) ? x[next] : 0.0; next++;
+    double interpolation_value = 0.0;
+    double source_to_target_ratio = 1.0 / ratio;       /* scale_sample_hz(.., scale) = scale_playback_hz(.., 1/scale) */
+    for (size_t k = 0; k < m; k++) {
+        while (interpolation_value >= 1.0) {
+            left = right;
+            right = (next < n) ? x[next] : 0.0; next++;
+            interpolation_value -= 1.0;
+        }
+        double diff = right - left;
+        out[k] = (diff * interpolation_value) + left;
+        interpolation_value += source_to_target_ratio;
+    }
+}
+
+int vbxo_find_formants_ratio(const double *x, size_t n, double sample_rate, double ratio, size_t n_coeffs,
+                             vbxo_resonance_t *formants, size_t n_formants) {
+    if (ratio == 1.0) return vbxo_find_formants(x, n, sample_rate, n_coeffs, formants, n_formants, NULL, NULL);
+    size_t m = vbxo_resampled_len(n, ratio);
+    double *buf = (double *)malloc((m ? m : 1) * sizeof(double));
+    vbxo_resample_linear(x, n, ratio, buf);
+    int st = vbxo_find_formants(buf, m, sample_rate, n_coeffs, formants, n_formants, NULL, NULL);
+    free(buf);
+    return st;
+}
+
 /* ------------------------------------------------------------------------ */
 /* spectrum.rs: MFCC                                                         */
 /* ------------------------------------------------------------------------ */

@@ -96,6 +96,18 @@ int vbxo_find_formants(const double *x, size_t n, double sample_rate, size_t n_c
                        vbxo_resonance_t *formants, size_t n_formants,
                        vbxo_resonance_t *res_out, double *coeffs_out);
 
+/* lib.rs:57-61: the resample front end of find_formants (resample_ratio != 1.0):
+ *   Linear::new(buf[0], buf[1]) + Converter::scale_sample_hz(rest, linear, ratio), take(ceil(ratio*len)).
+ * sample 0.10 arithmetic restated from the crate (NOT in /root/reference, and no reference test runs this
+ * branch: PARITY UNPINNED): interpolation_value accumulates 1/ratio, whole steps advance (left,right),
+ * out = (right-left)*value + left, equilibrium (0) once the source is exhausted.
+ * out must hold vbxo_resampled_len(n, ratio) samples. */
+size_t vbxo_resampled_len(size_t n, double ratio);
+void vbxo_resample_linear(const double *x, size_t n, double ratio, double *out);
+/* find_formants with any ratio (ratio == 1.0 -> vbxo_find_formants) */
+int vbxo_find_formants_ratio(const double *x, size_t n, double sample_rate, double ratio, size_t n_coeffs,
+                             vbxo_resonance_t *formants, size_t n_formants);
+
 /* ---- spectrum.rs: MFCC ---- */
 double vbxo_hz_to_mel(double hz);                                                  /* :375-377 */
 double vbxo_mel_to_hz(double mel);                                                 /* :379-381 */

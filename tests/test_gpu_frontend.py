@@ -68,3 +68,33 @@ def test_preemphasis_strided_view(vb, oracle, pkg):
     got = vb.preemphasis(audio, 0.1, frame_len=1200, stride=480, n_frames=F)
     for t in (0, 1, F // 2, F - 1):
         assert np.all(rel_close(got[t], oracle.preemphasis(a[t * 480:t * 480 + 1200], 0.1), 1e-12, 1e-3))
+
+
+@pytest.mark.parametrize("n,ratio", [(1200, 10000.0 / 48000.0), (1024, 0.5), (512, 11025.0 / 44100.0), (100, 2.0), (333, 0.37), (7, 1.7)])
+def test_resample_linear_is_bit_identical_to_the_oracle(vb, oracle, n, ratio):
+    """src/lib.rs:57-61 (sample 0.10 Linear + Converter; parity unpinned by the reference)."""
+    x = np.random.default_rng(n).uniform(-1, 1, (5, n))
+    got = vb.resample_linear(x, ratio)
+    assert got.shape[1] == oracle.resampled_len(n, ratio)
+    for f in range(5):
+        assert np.array_equal(got[f], oracle.resample_linear(x[f], ratio)), f
+
+
+def test_find_formants_with_resample_ratio(vb, oracle, pkg):
+    """examples/formant_extraction usage: down-sample to 10 kHz, then find_formants at the new rate."""
+    audio = vb.synth_speech(3 * 48000, sample_offset=48000)
+    a = audio.numpy()
+    N, H, ratio, sr2, p = 1200, 480, 10000.0 / 48000.0, 10000.0, 10
+    F = pkg.frame_count(a.size, N, H)
+    dense = vb.empty((F, int(oracle.resampled_len(N, ratio))))
+    vb.resample_linear(audio, ratio, frame_len=N, stride=H, n_frames=F, out=dense)
+    est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+    M = dense.shape[1]
+    out = vb.find_formants(dense, sr2, p, est0, frame_len=M, stride=M, n_frames=F)
+    est = est0.copy()
+    bad = 0
+    for t in range(F):
+        st, est = oracle.find_formants_ratio(a[t * H:t * H + N], sr2, ratio, p, est)
+        assert st == out["status"][t]
+        bad += 0 if np.all(np.abs(out["formants"][t] - est) <= 1e-4 * np.abs(est)) else 1
+    assert bad == 0

@@ -87,6 +87,35 @@ __global__ __launch_bounds__(64) void preemphasis_kernel(const double *__restric
     for (int i = lane; i < n; i += 64) yo[i] = smem[i];
 }
 
+// resample front end of find_formants (src/lib.rs:57-61): sample 0.10's Linear + Converter reduce to
+//   out[k] = (x[li+1] - x[li]) * frac + x[li]   with (li, frac) a frame-independent table built on the host by
+// the crate's own recurrence (interpolation_value += 1/ratio; whole steps advance the source), zeros past the end.
+__global__ void resample_kernel(const double *__restrict__ x, long n_frames, int n, long stride,
+                                const int32_t *__restrict__ tab_idx, const double *__restrict__ tab_frac, int m,
+                                double *__restrict__ out) {
+#pragma clang fp contract(off)   // (diff * value) + left, two roundings as on the CPU
+    const long total = n_frames * (long)m;
+    const long step = (long)gridDim.x * blockDim.x;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += step) {
+        const long f = idx / m;
+        const int k = (int)(idx - f * m);
+        const int li = tab_idx[k];
+        const double *xf = x + f * stride;
+        const double left = (li < n) ? xf[li] : 0.0;
+        const double right = (li + 1 < n) ? xf[li + 1] : 0.0;
+        const double diff = right - left;
+        out[idx] = (diff * tab_frac[k]) + left;
+    }
+}
+
+void launch_resample(hipStream_t s, const double *x, long F, int n, long stride, const int32_t *tab_idx,
+                     const double *tab_frac, int m, double *out) {
+    long blocks = (F * (long)m + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(resample_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, F, n, stride, tab_idx, tab_frac, m, out);
+}
+
 void launch_pcm16(hipStream_t s, const int16_t *pcm, size_t n, double denom, double *out) {
     size_t blocks = (n / 2 + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;

@@ -44,6 +44,7 @@ struct vbx_ctx {
     std::map<std::tuple<size_t, int, int>, double *> goertzel;   // (n, b_lo, nb) -> [nb][2] kappa, sigma
     std::map<size_t, double *> dct_tables;                // K -> [K][K]
     std::map<std::tuple<size_t, size_t, double, double, double>, int32_t *> bins_cache;
+    std::map<std::pair<size_t, double>, std::pair<int32_t *, double *>> resample_tabs;   // (n, ratio) -> (index, fraction)
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool prof = false;
@@ -298,6 +299,7 @@ void vbx_ctx_destroy(vbx_ctx *ctx) {
     for (auto &kv : ctx->goertzel) hipFree(kv.second);
     for (auto &kv : ctx->dct_tables) hipFree(kv.second);
     for (auto &kv : ctx->bins_cache) hipFree(kv.second);
+    for (auto &kv : ctx->resample_tabs) { hipFree(kv.second.first); hipFree(kv.second.second); }
     for (auto &r : ctx->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (ctx->t0) hipEventDestroy(ctx->t0);
     if (ctx->t1) hipEventDestroy(ctx->t1);
@@ -739,6 +741,46 @@ int vbx_preemphasis_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t f
     VBX_REQUIRE(ctx, out != x || stride == frame_len, "in-place filtering needs a dense batch (stride == frame_len)");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     { Prof p(ctx, "preemphasis"); launch_preemphasis(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, 2.0 * M_PI * factor, out); }
+    return check_launch(ctx, __func__);
+}
+
+size_t vbx_resampled_len(size_t frame_len, double resample_ratio) {
+    return (size_t)std::ceil(resample_ratio * (double)frame_len);          // src/lib.rs:42
+}
+
+int vbx_resample_linear_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
+                            double resample_ratio, double *out) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_REQUIRE(ctx, out != nullptr, "null output");
+    VBX_REQUIRE(ctx, resample_ratio > 0.0 && resample_ratio <= 64.0, "resample_ratio must be in (0, 64]");
+    const size_t m = vbx_resampled_len(frame_len, resample_ratio);
+    VBX_REQUIRE(ctx, m >= 1 && m <= 0x3fffffff, "bad resampled length");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    auto key = std::make_pair(frame_len, resample_ratio);
+    auto it = ctx->resample_tabs.find(key);
+    if (it == ctx->resample_tabs.end()) {
+        // sample 0.10 Converter: interpolation_value starts at 0, grows by 1/ratio per output, and every whole
+        // unit advances the (left, right) pair by one source sample; left starts at source index 0
+        std::vector<int32_t> hi(m);
+        std::vector<double> hf(m);
+        double value = 0.0;
+        const double step = 1.0 / resample_ratio;
+        long left = 0;
+        for (size_t k = 0; k < m; k++) {
+            while (value >= 1.0) { left++; value -= 1.0; }
+            hi[k] = (left > 0x3fffffff) ? 0x3fffffff : (int32_t)left;
+            hf[k] = value;
+            value += step;
+        }
+        int32_t *di = nullptr; double *df = nullptr;
+        VBX_HIP(ctx, hipMalloc((void **)&di, m * sizeof(int32_t)));
+        VBX_HIP(ctx, hipMalloc((void **)&df, m * sizeof(double)));
+        VBX_HIP(ctx, hipMemcpy(di, hi.data(), m * sizeof(int32_t), hipMemcpyHostToDevice));
+        VBX_HIP(ctx, hipMemcpy(df, hf.data(), m * sizeof(double), hipMemcpyHostToDevice));
+        it = ctx->resample_tabs.emplace(key, std::make_pair(di, df)).first;
+    }
+    { Prof p(ctx, "resample"); launch_resample(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, it->second.first, it->second.second, (int)m, out); }
     return check_launch(ctx, __func__);
 }
 

@@ -63,6 +63,8 @@ void launch_mfcc(hipStream_t s, const double *x, long F, int n, long stride, con
 void launch_dct_rows(hipStream_t s, const double *in, long rows, int n, const double *dct_table, double *out);
 
 // k_front.hip
+void launch_resample(hipStream_t s, const double *x, long F, int n, long stride, const int32_t *tab_idx,
+                     const double *tab_frac, int m, double *out);
 void launch_pcm16(hipStream_t s, const int16_t *pcm, size_t n, double denom, double *out);
 void launch_rms(hipStream_t s, const double *x, long F, int n, long stride, const double *window, double *out);
 void launch_preemphasis(hipStream_t s, const double *x, long F, int n, long stride, double c, double *out);

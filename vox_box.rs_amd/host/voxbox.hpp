@@ -220,13 +220,23 @@ struct MFCC {            // spectrum.rs:371-373
 inline size_t find_formants_real_work_size(size_t buf_len, size_t n_coeffs) { return vbx_find_formants_real_work_size(buf_len, n_coeffs); }
 inline size_t find_formants_complex_work_size(size_t n_coeffs) { return vbx_find_formants_complex_work_size(n_coeffs); }
 
-// vox_box::find_formants (lib.rs:40) with resample_ratio == 1.0 over a batch.  `formants` receives the
+// vox_box::find_formants (lib.rs:40) over a batch.  `formants` receives the
 // estimates after every frame ([F, n_est]); frames whose status != Ok leave the state untouched.
 inline void find_formants(Context &c, const Frames &f, double sample_rate, size_t n_coeffs, Segments seg,
                           const std::vector<Resonance> &starting_estimates, Resonance *formants,
                           Resonance *resonances = nullptr, int32_t *res_count = nullptr, double *lpc_coeffs = nullptr,
-                          int32_t *status = nullptr) {
+                          int32_t *status = nullptr, double resample_ratio = 1.0) {
     if (f.window != nullptr) throw Error(VBX_E_INVALID, "find_formants applies its own periodic Hanning (lib.rs:65-70): pass rectangular frames");
+    if (resample_ratio != 1.0) {   // lib.rs:57-61 (sample-crate arithmetic: parity unpinned), then the same chain on the dense batch
+        const size_t m = vbx_resampled_len(f.frame_len, resample_ratio);
+        DeviceVec<double> dense(c, f.n_frames * m);
+        c.check(vbx_resample_linear_f64(c.get(), f.x, f.n_frames, f.frame_len, f.stride, resample_ratio, dense.data()));
+        c.check(vbx_find_formants_f64(c.get(), dense.data(), f.n_frames, m, m, sample_rate, n_coeffs, seg.h_seg_start,
+                                      seg.n, starting_estimates.data(), starting_estimates.size(), formants, resonances,
+                                      res_count, lpc_coeffs, status));
+        c.sync();
+        return;
+    }
     c.check(vbx_find_formants_f64(c.get(), f.x, f.n_frames, f.frame_len, f.stride, sample_rate, n_coeffs, seg.h_seg_start,
                                   seg.n, starting_estimates.data(), starting_estimates.size(), formants, resonances,
                                   res_count, lpc_coeffs, status));

@@ -92,6 +92,8 @@ def load_library():
         "vbx_find_formants_f64": (C.c_int, [vp, vp, sz, sz, sz, dbl, sz, vp, sz, vp, sz, vp, vp, vp, vp, vp]),
         "vbx_mfcc_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, dbl, dbl, dbl, vp, vp]),
         "vbx_dct_f64": (C.c_int, [vp, vp, sz, sz, vp]),
+        "vbx_resampled_len": (sz, [sz, dbl]),
+        "vbx_resample_linear_f64": (C.c_int, [vp, vp, sz, sz, sz, dbl, vp]),
         "vbx_pcm16_to_f64": (C.c_int, [vp, vp, sz, vp]),
         "vbx_rms_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, vp]),
         "vbx_preemphasis_f64": (C.c_int, [vp, vp, sz, sz, sz, dbl, vp]),
@@ -500,6 +502,14 @@ class VoxBox:
             self.sync()
             tmp.free()
         return o
+
+    def resample_linear(self, x, ratio, frame_len=None, stride=None, n_frames=None, out=None):
+        """find_formants' resample front end (src/lib.rs:57-61): dense [F, ceil(ratio*N)] batch."""
+        ptr, F, N, S, tmp = self._frames(x, frame_len, stride, n_frames)
+        m = int(self.L.vbx_resampled_len(N, ratio))
+        o = out if out is not None else self.empty((F, m))
+        self._check(self.L.vbx_resample_linear_f64(self.ctx, ptr, F, N, S, ratio, _ptr(o)))
+        return self._finish(o, out, tmp)
 
     def rms(self, x, frame_len=None, stride=None, n_frames=None, window=None):
         ptr, F, N, S, tmp = self._frames(x, frame_len, stride, n_frames)
