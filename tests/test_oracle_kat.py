@@ -283,3 +283,18 @@ def test_against_praat(oracle, golden_dir):
     assert st == 0 and np.all(np.isfinite(est))
     nz = res[res[:, 0] != 0.0, 0]
     assert np.all(np.diff(nz) >= 0)
+
+
+def test_resample_front_end_restatement(oracle):
+    """src/lib.rs:42,57-61 through the restated sample 0.10 Linear + Converter.  The reference has no
+    test on this branch (parity unpinned); these are the defining properties of the restatement."""
+    x = np.arange(20.0)
+    assert oracle.resampled_len(20, 0.25) == 5 and oracle.resampled_len(2878, 0.5) == 1439
+    assert list(oracle.resample_linear(x, 0.25)) == [0.0, 4.0, 8.0, 12.0, 16.0]           # whole steps: samples
+    assert list(oracle.resample_linear(x, 0.5)[:4]) == [0.0, 2.0, 4.0, 6.0]
+    up = oracle.resample_linear(x[:5], 2.0)                                               # up-sampling: lerp, then
+    assert list(up[:9]) == [0.0, 0.5, 1.0, 1.5, 2.0, 2.5, 3.0, 3.5, 4.0] and up[9] == 2.0  # equilibrium past the end
+    assert np.array_equal(oracle.resample_linear(x, 1.0), x)
+    st, f = oracle.find_formants_ratio(np.sin(0.3 * np.arange(1200)) + 0.01 * np.cos(np.arange(1200.0)), 10000.0,
+                                       10000.0 / 48000.0, 8, np.array([[320.0, 1.0], [1440.0, 1.0]]))
+    assert st == 0 and np.all(np.isfinite(f))
