@@ -439,6 +439,23 @@ def test_pitch_full_candidate_list(vb, oracle, audio):
     assert _check_pitch(vb, oracle, x, SR, 0.2, 75.0, 600.0, 64) == 0
 
 
+@pytest.mark.parametrize("thr", [0.0, 0.2, 0.6, 0.999, 5.0])
+def test_pitch_topk_is_the_prefix_of_the_full_list(vb, oracle, audio, pkg, thr):
+    """The refine kernel skips candidates that provably cannot reach the first kmax entries (DESIGN.md
+    "exact top-k pruning").  What is returned must be, bit for bit, the prefix of the unpruned list
+    (a list that never fills, kmax >= count, disables the bound), and count/status must not change."""
+    F = pkg.frame_count(audio.size, N48, H48)
+    x = _frames(audio, N48, H48, list(range(0, F, 7))) * oracle.window("hanning", N48)
+    full, cnt_full, st_full = vb.pitch(x, SR, thr, 75.0, 600.0, kmax=64)
+    assert cnt_full.min() < 64 < cnt_full.max()       # both unpruned and pruned frames in the 64-deep run
+    for kmax in (1, 2, 3, 8):
+        cand, cnt, st = vb.pitch(x, SR, thr, 75.0, 600.0, kmax=kmax)
+        assert np.array_equal(cnt, cnt_full) and np.array_equal(st, st_full)
+        assert np.array_equal(cand, full[:, :kmax]), kmax
+    # and the prefix agrees with the oracle's sorted Vec
+    assert _check_pitch(vb, oracle, x[::5], SR, thr, 75.0, 600.0, 1) == 0
+
+
 @pytest.mark.parametrize("n", [64, 100, 256, 513, 2048])
 def test_pitch_other_frame_lengths(vb, oracle, audio, n):
     x = _frames(audio, n, 211, range(0, 40, 3)) * oracle.window("hanning", n)

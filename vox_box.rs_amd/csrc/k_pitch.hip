@@ -395,6 +395,20 @@ __global__ __launch_bounds__(64) void pitch_refine_kernel(
     // a slow refinement never idles the other groups.  Finished candidates enter the lane-resident
     // list ordered by (strength desc, candidate index asc) == the reference's stable sort (:453).
     int li = 0;                                     // candidate index of the list entry held by this lane
+    // maxima.push(Pitch::new(0, threshold)) (:452) carries the largest index; it enters the list first so
+    // that the pruning bound below is armed from the start
+    { lf = 0.0; ls = threshold; li = ncand; kept = 1; }
+    // The group that would refine the tallest peak goes first: its strength usually becomes the bar that
+    // prunes everything else after one evaluation.
+    int first = 0;
+    {
+        double bv = -1.0e300; int bi = 0x7fffffff;
+        for (int i = lane; i < ncand; i += 64) { const double yv = ys[cand_list[i]]; if (yv > bv) { bv = yv; bi = i; } }
+        const double gm = wave_max(bv);
+        int pick = (bv == gm) ? bi : 0x7fffffff;
+        for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(pick, o, 64); pick = (other < pick) ? other : pick; }
+        first = (pick == 0x7fffffff) ? 0 : pick;
+    }
     int ci = -1, it = 0, next = 0;
     bool special = false;
     double ba = 0., bb = 0., v = 0., w = 0., x = 0., fv = 0., fw = 0., fx = 0., xmid = 0., ymid = 0.;
@@ -402,12 +416,13 @@ __global__ __launch_bounds__(64) void pitch_refine_kernel(
                                          : (PG == 32) ? 0x0000000100000001ull : (PG == 4) ? 0x1111111111111111ull : 1ull;
     for (;;) {
 #pragma clang fp contract(off)   // the scalar Brent arithmetic stays bit-identical to the unfused CPU arithmetic
-        {   // hand out candidates to idle groups, in group order
+        {   // hand out candidates to idle groups, in group order: sequence number q -> candidate index
             const bool idle = ci < 0;
             const unsigned long long im = __ballot(idle) & LEADERS;
             const int rank = __popcll(im & ((1ull << (gid * PG)) - 1ull));
             if (idle && next + rank < ncand) {
-                ci = next + rank;
+                const int q = next + rank;
+                ci = (q == 0) ? first : ((q - 1 < first) ? q - 1 : q);
                 double freq, nn;
                 cand_from_peak(ys, cand_list[ci], sample_rate, offset, freq, nn);
                 it = 0; special = false; xmid = 0.; ymid = 0.;
@@ -421,9 +436,16 @@ __global__ __launch_bounds__(64) void pitch_refine_kernel(
         }
         if (!__any(ci >= 0)) break;
 
+        // Pruning bar: the caller asked for the first kmax entries of the sorted list.  brent_maximize only
+        // ever replaces fx by a value <= fx (:162), so a candidate's final strength is <= min(f(v0), 1) where
+        // v0 is its first abscissa (the "> 1 -> 1/s" reflection of :446 keeps strengths <= 1).  If that is
+        // strictly below the kmax-th best strength already in the list, the candidate cannot be among the
+        // entries returned and its refinement is skipped.  The returned entries are exactly the reference's.
+        const double bar = (kept == kmax) ? readlane_f64(ls, kmax - 1) : -1.0e300;
+
         const double golden = 1. - 0.6180339887498948482045868343656381177203091798057628621;
         const double sqrt_epsilon = 1.4901161193847656e-08, eps = 2.220446049250313e-16, tol = 1e-10;
-        bool finished = false, need = false;
+        bool finished = false, need = false, pruned = false;
         double t = 0.;
         if (ci >= 0) {
             if (special) finished = true;
@@ -452,8 +474,11 @@ __global__ __launch_bounds__(64) void pitch_refine_kernel(
         }
         const double ft = sinc_interp<PG>(ys, nvalid, ylen, offset, nx, t, 1200, need, st);
         if (need) {
-            if (it == 0) { x = v; w = v; fv = ft; fx = ft; fw = ft; it = 1; }
-            else {
+            if (it == 0) {
+                x = v; w = v; fv = ft; fx = ft; fw = ft; it = 1;
+                const double ub = (ft <= 1.) ? ft : 1.;          // NaN -> 1: never pruned
+                if (ub < bar) { finished = true; pruned = true; }
+            } else {
                 if (ft <= fx) {
                     if (t < x) bb = x; else ba = x;
                     v = w; w = x; x = t;
@@ -472,8 +497,8 @@ __global__ __launch_bounds__(64) void pitch_refine_kernel(
             }
         }
         // finished candidates -> sorted list
-        unsigned long long fm = __ballot(finished) & LEADERS;
-        if (fm) {
+        if (__any(finished)) {
+            unsigned long long fm = __ballot(finished && !pruned) & LEADERS;
             double xm = xmid + (double)offset;                                // :445
             double ym = ymid;
             if (ym > 1.) ym = 1. / ym;                                        // :446
@@ -494,15 +519,7 @@ __global__ __launch_bounds__(64) void pitch_refine_kernel(
             if (finished) ci = -1;
         }
     }
-    int total_cand = ncand;
-    {   // maxima.push(Pitch::new(0, threshold)), :452
-        const int pos = __popcll(__ballot(lane < kept && ls >= threshold));   // it carries the largest index
-        const double pf = from_prev_lane(lf), ps = from_prev_lane(ls);
-        if (lane > pos) { lf = pf; ls = ps; }
-        if (lane == pos) { lf = 0.0; ls = threshold; }
-        kept = (kept + 1 < kmax) ? kept + 1 : kmax;
-        total_cand++;
-    }
+    const int total_cand = ncand + 1;
     st = __any(st & 4) ? 4 : 0;                     // a panic in any group is a panic of the frame
     if (total_cand > 1 && (any_nan || threshold != threshold)) st |= 8;   // partial_cmp().unwrap() panics (Q10)
     int code = 0;
