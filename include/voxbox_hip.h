@@ -102,6 +102,10 @@ int vbx_timer_end(vbx_ctx *ctx, float *h_ms);
 int vbx_profile_enable(vbx_ctx *ctx, int on);
 int vbx_profile_reset(vbx_ctx *ctx);
 int vbx_profile_get(vbx_ctx *ctx, const char *kernel_name, double *h_total_ms, long *h_launches);
+/* Work the pitch refine kernel executed while profiling was enabled (since the last
+ * vbx_profile_reset): h_out4 = { frames, candidates found, sinc evaluations, sinc terms }.
+ * Feeds bench.py's FP64 roofline with the work actually done, not the reference's. */
+int vbx_profile_pitch_work(vbx_ctx *ctx, uint64_t *h_out4);
 /* names of profiled kernels, '\n'-separated, into h_buf */
 int vbx_profile_names(vbx_ctx *ctx, char *h_buf, size_t cap);
 

@@ -456,6 +456,24 @@ def test_pitch_topk_is_the_prefix_of_the_full_list(vb, oracle, audio, pkg, thr):
     assert _check_pitch(vb, oracle, x[::5], SR, thr, 75.0, 600.0, 1) == 0
 
 
+def test_pitch_work_counters(vb, oracle, audio, pkg):
+    """vbx_profile_pitch_work reports the work the refine kernel executed (bench.py's FP64 roofline uses it)."""
+    F = pkg.frame_count(audio.size, N48, H48)
+    x = _frames(audio, N48, H48, list(range(0, F, 11))) * oracle.window("hanning", N48)
+    work = {}
+    vb.profile(True)
+    try:
+        for kmax in (1, 64):
+            vb.profile_reset()
+            _, cnt, st = vb.pitch(x, SR, 0.2, 75.0, 600.0, kmax=kmax)
+            work[kmax] = vb.profile_pitch_work()
+            assert work[kmax][0] == x.shape[0] and work[kmax][1] == int(np.sum(cnt[st == 0] - 1))
+    finally:
+        vb.profile(False)
+    assert work[1][2] < work[64][2] and work[1][3] < work[64][3]       # pruning skips evaluations ...
+    assert work[1][2] >= work[1][1]                                    # ... but every candidate gets at least one
+
+
 @pytest.mark.parametrize("n", [64, 100, 256, 513, 2048])
 def test_pitch_other_frame_lengths(vb, oracle, audio, n):
     x = _frames(audio, n, 211, range(0, 40, 3)) * oracle.window("hanning", n)
@@ -488,7 +506,11 @@ def test_mfcc_not_nan(vb):
 
 
 @pytest.mark.parametrize("n,k,lo,hi,sr", [(1200, 13, 100.0, 8000.0, 48000.0), (256, 26, 133.0, 6855.0, 22050.0),
-                                          (512, 13, 100.0, 8000.0, 22050.0), (1024, 20, 0.0, 4000.0, 16000.0)])
+                                          (512, 13, 100.0, 8000.0, 22050.0), (1024, 20, 0.0, 4000.0, 16000.0),
+                                          (509, 13, 100.0, 8000.0, 22050.0),      # prime length: Goertzel kernel
+                                          (1155, 13, 50.0, 11000.0, 22050.0),     # odd factors (3*5*7*11)
+                                          (1000, 40, 0.0, 8000.0, 16000.0),       # every bin up to n/2 needed
+                                          (2400, 13, 100.0, 8000.0, 96000.0), (94, 5, 300.0, 3000.0, 8000.0)])
 def test_mfcc(vb, oracle, audio, n, k, lo, hi, sr):
     x = _frames(audio, n, 977, range(0, 60, 4)) * oracle.window("hanning", n) * 40.0
     m, st = vb.mfcc(x, k, (lo, hi), sr)
@@ -496,6 +518,23 @@ def test_mfcc(vb, oracle, audio, n, k, lo, hi, sr):
         es, em = oracle.mfcc(x[f], k, lo, hi, sr)
         assert st[f] == es
         assert np.all(rel_close(m[f], em, 1e-6)), (f, np.max(np.abs(m[f] - em)))
+
+
+def test_mfcc_goertzel_fallback_matches_two_stage(pkg, oracle, audio, monkeypatch):
+    """Composite lengths take the two-stage DFT kernel; VBX_MFCC_GOERTZEL=1 forces the Goertzel kernel that
+    prime lengths use.  Both must agree with each other far inside the oracle tolerance."""
+    x = _frames(audio, N48, 977, range(0, 60, 4)) * oracle.window("hanning", N48) * 40.0
+    monkeypatch.setenv("VBX_MFCC_GOERTZEL", "1")
+    vg = pkg.VoxBox(0)
+    monkeypatch.delenv("VBX_MFCC_GOERTZEL")
+    vd = pkg.VoxBox(0)
+    try:
+        mg, sg = vg.mfcc(x, 13, (100.0, 8000.0), SR)
+        md, sd = vd.mfcc(x, 13, (100.0, 8000.0), SR)
+    finally:
+        vg.close(); vd.close()
+    assert np.array_equal(sg, sd) and not np.array_equal(mg, md)      # two different kernels ran
+    assert np.all(rel_close(mg, md, 1e-9))
 
 
 def test_mfcc_bins_beyond_spectrum_is_panic_status(vb, oracle):

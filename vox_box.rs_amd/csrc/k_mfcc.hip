@@ -19,6 +19,28 @@ namespace vbx {
 constexpr int MFCC_BPL = 4;                 // bins per lane and pass
 constexpr int MFCC_PASS = 64 * MFCC_BPL;    // bins per pass over the frame
 
+// mel energies (:421-437) and dct (:391-397) of one frame from its |X|^2 / |X| rows (one wavefront)
+__device__ __forceinline__ void mfcc_tail(const double *mag2, const double *mag, double *en, const int32_t *bins,
+                                          const double *dct_table, int num_coeffs, int b_lo, int lane,
+                                          double *out_row) {
+    // lane w <-> filter w, sequential sums in the reference's order
+    if (lane < num_coeffs) {
+        const int w0 = bins[lane], w1 = bins[lane + 1], w2 = bins[lane + 2];
+        const int up = w1 - w0, down = w2 - w1;
+        double up_sum = 0.0, down_sum = 0.0;
+        for (int i = 0; i < up; i++) up_sum = up_sum + fabs(mag2[w0 + i - b_lo]) * ((double)i / (double)up);
+        for (int i = 0; i < down; i++) down_sum = down_sum + fabs(mag[w1 + i - b_lo]) * ((double)i / (double)down);
+        const double lg = log10(up_sum + down_sum);
+        en[lane] = (lg != lg || lg < 1.0e-10) ? 1.0e-10 : lg;   // f64::max(1e-10): NaN yields the other operand
+    }
+    wave_sync();
+    if (lane < num_coeffs) {                              // dct (:391-397)
+        double acc = 0.0;
+        for (int j = 0; j < num_coeffs; j++) acc = acc + en[j] * dct_table[lane * num_coeffs + j];
+        out_row[lane] = 2.0 * acc;
+    }
+}
+
 // LDS per wave: mag2[nb] | mag[nb] | en[64]
 template <int W>
 __global__ __launch_bounds__(64 * W) void mfcc_kernel(
@@ -71,21 +93,115 @@ __global__ __launch_bounds__(64 * W) void mfcc_kernel(
     }
     wave_sync();       // mag2/mag are produced and consumed inside this wavefront
 
-    // mel energies (:421-437): lane w <-> filter w, sequential sums in the reference's order
-    if (lane < num_coeffs) {
-        const int w0 = bins[lane], w1 = bins[lane + 1], w2 = bins[lane + 2];
-        const int up = w1 - w0, down = w2 - w1;
-        double up_sum = 0.0, down_sum = 0.0;
-        for (int i = 0; i < up; i++) up_sum = up_sum + fabs(mag2[w0 + i - b_lo]) * ((double)i / (double)up);
-        for (int i = 0; i < down; i++) down_sum = down_sum + fabs(mag[w1 + i - b_lo]) * ((double)i / (double)down);
-        const double lg = log10(up_sum + down_sum);
-        en[lane] = (lg != lg || lg < 1.0e-10) ? 1.0e-10 : lg;   // f64::max(1e-10): NaN yields the other operand
-    }
-    wave_sync();
-    if (lane < num_coeffs) {                              // dct (:391-397)
-        double acc = 0.0;
-        for (int j = 0; j < num_coeffs; j++) acc = acc + en[j] * dct_table[lane * num_coeffs + j];
-        out[f * (long)num_coeffs + lane] = 2.0 * acc;
+    mfcc_tail(mag2, mag, en, bins, dct_table, num_coeffs, b_lo, lane, out + f * (long)num_coeffs);
+}
+
+// ------------------------------------------------------------------------------------------
+// Two-stage DFT of the needed bins (frame_len = n1 * n2).  With n = n2*i1 + i2 and k = k1 + n1*k2:
+//   A[i2][k1] = sum_i1 x[n2*i1 + i2] * W_n1^(i1*k1)            stage 1: one real [n2 x n1]*[n1 x n1] product
+//   X[k]      = sum_i2 A[i2][k mod n1] * W_n^(i2*k)             stage 2: n2 complex MACs per needed bin
+// which is n*n1 + 4*nb*n2 real MACs per frame instead of Goertzel's 3*n*nb.  The input is real, so stage 1
+// computes the cos columns k1 = 0..n1/2 and the sin columns k1 = 1..(n1-1)/2 only (n1 real columns, padded to
+// NC); the other half follows from A[i2][n1-k1] = conj A[i2][k1].  One wavefront per frame: each lane owns a
+// TM x 4 register tile of A (x broadcast from LDS, table rows as ds_read_b128), then one needed bin per pass in
+// stage 2 (twiddles W_n^j from a host-built table through L1).  Tables are rounded from long double.
+// LDS: per block the stage-1 table C[n1][NC]; per wave xs[max(n, 2 nb)] (reused for |X|^2, |X|) | A[n2][NC] | en[64].
+// ------------------------------------------------------------------------------------------
+template <int TM>
+__global__ void mfcc_dft2_kernel(
+    const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
+    const double *__restrict__ ctab /* [n1][NC] */, const double *__restrict__ twid /* [n][2] cos, sin */,
+    int n1, int n2, int NC, int xs_len, const int32_t *__restrict__ bins, const double *__restrict__ dct_table,
+    int num_coeffs, int nb, double *__restrict__ out) {
+    extern __shared__ double smem[];
+    const int wave = threadIdx.x >> 6, lane = lane_id(), W = blockDim.x >> 6;
+    double *ct = smem;                                                   // shared by the block
+    const size_t per_wave = (size_t)xs_len + (size_t)n2 * NC + 64;
+    double *xs = smem + (size_t)n1 * NC + (size_t)wave * per_wave, *A = xs + xs_len, *en = A + (size_t)n2 * NC;
+    for (int i = threadIdx.x; i < n1 * NC; i += blockDim.x) ct[i] = ctab[i];
+    __syncthreads();
+
+    const int b_lo = bins[0];
+    const int H = n1 >> 1, ncos = H + 1;
+    const int nct = NC >> 2;                                             // column tiles of 4
+    const int nrt = (n2 + TM - 1) / TM;                                  // row tiles of TM
+    const int ntiles = nrt * nct;
+    for (long f = (long)blockIdx.x * W + wave; f < n_frames; f += (long)gridDim.x * W) {
+        const double *xf = x + f * stride;
+        for (int i = lane; i < n; i += 64) xs[i] = (window != nullptr) ? xf[i] * window[i] : xf[i];
+        wave_sync();
+        // stage 1
+        for (int t = lane; t < ((ntiles + 63) & ~63); t += 64) {
+            const bool live = t < ntiles;
+            const int rt = live ? t / nct : 0, ctile = live ? t % nct : 0;
+            int roff[TM];
+#pragma unroll
+            for (int i = 0; i < TM; i++) { const int r = rt * TM + i; roff[i] = (r < n2) ? r : n2 - 1; }
+            double acc[TM][4];
+#pragma unroll
+            for (int i = 0; i < TM; i++) { acc[i][0] = 0.; acc[i][1] = 0.; acc[i][2] = 0.; acc[i][3] = 0.; }
+            const double *cp = ct + 4 * ctile;
+            const double *xp = xs;
+#pragma unroll 2
+            for (int i1 = 0; i1 < n1; i1++) {
+                const double2 c01 = *reinterpret_cast<const double2 *>(cp), c23 = *reinterpret_cast<const double2 *>(cp + 2);
+#pragma unroll
+                for (int i = 0; i < TM; i++) {
+                    const double xv = xp[roff[i]];
+                    acc[i][0] = fma(xv, c01.x, acc[i][0]);
+                    acc[i][1] = fma(xv, c01.y, acc[i][1]);
+                    acc[i][2] = fma(xv, c23.x, acc[i][2]);
+                    acc[i][3] = fma(xv, c23.y, acc[i][3]);
+                }
+                cp += NC; xp += n2;
+            }
+            if (live) {
+#pragma unroll
+                for (int i = 0; i < TM; i++) {
+                    const int r = rt * TM + i;
+                    if (r < n2) {
+                        double *ap = A + (size_t)r * NC + 4 * ctile;
+                        *reinterpret_cast<double2 *>(ap) = make_double2(acc[i][0], acc[i][1]);
+                        *reinterpret_cast<double2 *>(ap + 2) = make_double2(acc[i][2], acc[i][3]);
+                    }
+                }
+            }
+        }
+        wave_sync();
+        // stage 2: the frame's samples are dead, their space takes |X|^2 and |X|
+        double *mag2 = xs, *mag = xs + nb;
+        for (int p0 = 0; p0 < nb; p0 += 64) {
+            const int bi = p0 + lane;
+            const bool ok = bi < nb;
+            const int k = b_lo + (ok ? bi : 0);
+            const int k1 = k % n1;
+            const int cc = (k1 <= H) ? k1 : n1 - k1;                     // column of Re A
+            const bool has_im = cc >= 1 && 2 * cc != n1;
+            const int sc = has_im ? ncos + cc - 1 : 0;                   // column of -Im A[.][cc]
+            const double sgn = (k1 <= H) ? -1.0 : 1.0;
+            double re = 0., im = 0.;
+            int idx = 0;
+            const double *ap = A;
+#pragma unroll 2
+            for (int i2 = 0; i2 < n2; i2++) {
+                const double2 w = *reinterpret_cast<const double2 *>(twid + 2 * (size_t)idx);   // cos, sin of 2 pi idx / n
+                const double ar = ap[cc];
+                const double as = ap[sc];
+                const double ai = has_im ? sgn * as : 0.0;
+                re = fma(ar, w.x, re); re = fma(ai, w.y, re);            // (ar + i ai)(cos - i sin)
+                im = fma(ai, w.x, im); im = fma(-ar, w.y, im);
+                idx += k; idx -= (idx >= n) ? n : 0;
+                ap += NC;
+            }
+            if (ok) {
+                const double m2 = fma(re, re, im * im);                  // norm_sqr (:426)
+                mag2[bi] = m2;
+                mag[bi] = sqrt(m2);                                      // norm (:432)
+            }
+        }
+        wave_sync();
+        mfcc_tail(mag2, mag, en, bins, dct_table, num_coeffs, b_lo, lane, out + f * (long)num_coeffs);
+        wave_sync();                                                     // xs / en are rewritten by the next frame
     }
 }
 
@@ -115,6 +231,66 @@ void launch_mfcc(hipStream_t s, const double *x, long F, int n, long stride, con
         hipLaunchKernelGGL((mfcc_kernel<1>), dim3((unsigned)F), dim3(64), mfcc_lds(nb, 1), s,
                            x, F, n, stride, window, kappa_sigma, bins_dev, dct_table, num_coeffs, nb, out);
     }
+}
+
+// ---- two-stage plan: geometry shared by the host (table builder in vbx_api.hip) and the launcher ----
+size_t mfcc_dft2_lds(const mfcc_plan_t &pl, int nb, int n, int waves) {
+    const size_t xs_len = (size_t)((n > 2 * nb) ? n : 2 * nb);
+    return ((size_t)pl.n1 * pl.nc + (size_t)waves * (xs_len + (size_t)pl.n2 * pl.nc + 64)) * sizeof(double);
+}
+
+// Picks n1*n2 = n minimising n*n1 + 8*nb*n2 (stage 2 is the less efficient loop) and the row tile TM that
+// fills the lanes best; ok = false when n has no useful factorisation (the Goertzel kernel then runs).
+mfcc_plan_t mfcc_plan(int n, int nb) {
+    mfcc_plan_t best{};
+    best.ok = false;
+    double best_cost = 0.5 * 3.0 * (double)n * (double)nb;     // must at least halve Goertzel's work
+    for (int n1 = 2; n1 <= n / 2; n1++) {
+        if (n % n1) continue;
+        const int n2 = n / n1;
+        if (n1 > 128 || n2 > 256) continue;
+        const int nc = (n1 + 3) & ~3, nct = nc / 4;
+        int tm_best = 0; double tile_cost = 0.0;
+        for (int tm : {2, 3, 4, 5, 6, 8}) {
+            const int tiles = ((n2 + tm - 1) / tm) * nct;
+            const double c = (double)((tiles + 63) / 64) * 64.0 * (double)n1 * (4.0 * tm + 0.75 * (tm + 2));
+            if (tm_best == 0 || c < tile_cost) { tm_best = tm; tile_cost = c; }
+        }
+        const double cost = tile_cost + 8.0 * (double)(((nb + 63) / 64) * 64) * (double)n2;
+        mfcc_plan_t pl{true, n1, n2, nc, tm_best};
+        if (mfcc_dft2_lds(pl, nb, n, 1) > 160 * 1024) continue;
+        if (cost < best_cost) { best_cost = cost; best = pl; }
+    }
+    return best;
+}
+
+template <int TM>
+static void launch_dft2_tm(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
+                           const mfcc_plan_t &pl, const double *ctab, const double *twid, const int32_t *bins_dev,
+                           const double *dct_table, int num_coeffs, double *out, int nb, int cu_count) {
+    // waves per block: the most wavefronts per CU the LDS allows (the table is shared by the block)
+    int best_w = 1, best_res = 0;
+    for (int w = 1; w <= 8; w++) {
+        const size_t b = mfcc_dft2_lds(pl, nb, n, w);
+        if (b > 160 * 1024) break;
+        const int res = (int)((160 * 1024) / b) * w;
+        if (res > best_res || (res == best_res && w <= 4)) { best_res = res; best_w = w; }
+    }
+    const int xs_len = (n > 2 * nb) ? n : 2 * nb;
+    long blocks = (F + best_w - 1) / best_w;
+    const long cap = (long)(cu_count > 0 ? cu_count : 256) * 16;       // grid-stride: the table is loaded once per block
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((mfcc_dft2_kernel<TM>), dim3((unsigned)blocks), dim3(64 * best_w), mfcc_dft2_lds(pl, nb, n, best_w), s,
+                       x, F, n, stride, window, ctab, twid, pl.n1, pl.n2, pl.nc, xs_len, bins_dev, dct_table,
+                       num_coeffs, nb, out);
+}
+
+void launch_mfcc_dft2(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
+                      const mfcc_plan_t &pl, const double *ctab, const double *twid, const int32_t *bins_dev,
+                      const double *dct_table, int num_coeffs, double *out, int nb, int cu_count) {
+#define VBX_DFT2(TM) case TM: launch_dft2_tm<TM>(s, x, F, n, stride, window, pl, ctab, twid, bins_dev, dct_table, num_coeffs, out, nb, cu_count); break;
+    switch (pl.tm) { VBX_DFT2(2) VBX_DFT2(3) VBX_DFT2(4) VBX_DFT2(5) VBX_DFT2(6) VBX_DFT2(8) default: break; }
+#undef VBX_DFT2
 }
 
 void launch_dct_rows(hipStream_t s, const double *in, long rows, int n, const double *dct_table, double *out) {

@@ -174,7 +174,8 @@ __device__ __forceinline__ double sinc_terms_fast(const double *y, int ibase_l, 
 // after self_lag.resize(2N, 0).  Must be called from converged code.
 template <int G>
 __device__ __forceinline__ double sinc_interp(const double *y, int nvalid, int ylen, int offset, int nx,
-                                              double x, int max_depth, bool active, int &st) {
+                                              double x, int max_depth, bool active, int &st,
+                                              unsigned *terms = nullptr) {
     bool summed = false, fast = false;
     double special = 0.0, phil = 0.5, phir = 0.5;
     int nl = 0, nr = 1;
@@ -210,6 +211,7 @@ __device__ __forceinline__ double sinc_interp(const double *y, int nvalid, int y
         }
     }
     double acc = 0.0;
+    if (terms != nullptr && summed) *terms += 2u * (unsigned)(max_depth + 1);
     if (summed) {
         if (fast) acc = sinc_terms_fast<G>(y, offset + nr, offset + nl, phil, phir, max_depth);
         else acc = sinc_terms_general<G>(y, nvalid, ylen, offset, nl, nr, phil, phir, max_depth);
@@ -340,7 +342,8 @@ __device__ __forceinline__ void cand_from_peak(const double *ys, int kk, double 
 __global__ __launch_bounds__(64) void pitch_refine_kernel(
     const double *__restrict__ r_in, const double *__restrict__ lag_window, long n_frames, int n,
     double sample_rate, double threshold, double fmin, double fmax,
-    int kmax, pitch_t *__restrict__ out_cand, int32_t *__restrict__ out_count, int32_t *__restrict__ status) {
+    int kmax, pitch_t *__restrict__ out_cand, int32_t *__restrict__ out_count, int32_t *__restrict__ status,
+    unsigned long long *__restrict__ work) {
     extern __shared__ double ys[];                  // [n + Y_PAD] doubles, then the candidate list (ints)
     const long f = blockIdx.x;
     if (f >= n_frames) return;
@@ -410,6 +413,7 @@ __global__ __launch_bounds__(64) void pitch_refine_kernel(
         first = (pick == 0x7fffffff) ? 0 : pick;
     }
     int ci = -1, it = 0, next = 0;
+    unsigned nterms = 0, nevals = 0;                // work actually executed (group leaders' counts are summed)
     bool special = false;
     double ba = 0., bb = 0., v = 0., w = 0., x = 0., fv = 0., fw = 0., fx = 0., xmid = 0., ymid = 0.;
     constexpr unsigned long long LEADERS = (PG == 16) ? 0x0001000100010001ull : (PG == 8) ? 0x0101010101010101ull
@@ -472,12 +476,15 @@ __global__ __launch_bounds__(64) void pitch_refine_kernel(
                 }
             }
         }
-        const double ft = sinc_interp<PG>(ys, nvalid, ylen, offset, nx, t, 1200, need, st);
+        const double ft = sinc_interp<PG>(ys, nvalid, ylen, offset, nx, t, 1200, need, st, &nterms);
+        nevals += need ? 1u : 0u;
         if (need) {
             if (it == 0) {
                 x = v; w = v; fv = ft; fx = ft; fw = ft; it = 1;
                 const double ub = (ft <= 1.) ? ft : 1.;          // NaN -> 1: never pruned
-                if (ub < bar) { finished = true; pruned = true; }
+                // ba >= -offset: every abscissa of the bracket has its left neighbour at index >= 0, so none of
+                // the skipped evaluations could have been an out-of-bounds panic of the reference
+                if (ub < bar && ba >= (double)(-offset)) { finished = true; pruned = true; }
             } else {
                 if (ft <= fx) {
                     if (t < x) bb = x; else ba = x;
@@ -535,6 +542,16 @@ __global__ __launch_bounds__(64) void pitch_refine_kernel(
         if (out_count != nullptr) out_count[f] = (code == 0) ? total_cand : 0;
         if (status != nullptr) status[f] = code;
     }
+    if (work != nullptr) {                          // profiling only: frames, candidates, sinc evaluations, sinc terms
+        const bool leader = (lane & (PG - 1)) == 0;
+        unsigned long long te = leader ? nterms : 0u, ev = leader ? nevals : 0u;
+        for (int o = 32; o > 0; o >>= 1) { te += __shfl_xor(te, o, 64); ev += __shfl_xor(ev, o, 64); }
+        if (lane == 0) {
+            unsigned long long *w = work + 4 * (f & (PITCH_WORK_SLOTS - 1));
+            atomicAdd(w + 0, 1ull); atomicAdd(w + 1, (unsigned long long)ncand);
+            atomicAdd(w + 2, ev); atomicAdd(w + 3, te);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -580,14 +597,16 @@ long pitch_chunk_frames(int n, long n_frames) {
 
 void launch_pitch(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                   const double *lag_window, double sample_rate, double threshold, double fmin, double fmax,
-                  int kmax, pitch_t *out_cand, int32_t *out_count, int32_t *status, double *lag_ws, long chunk) {
+                  int kmax, pitch_t *out_cand, int32_t *out_count, int32_t *status, double *lag_ws, long chunk,
+                  unsigned long long *work) {
     for (long f0 = 0; f0 < F; f0 += chunk) {
         const long fc = (F - f0 < chunk) ? (F - f0) : chunk;
         hipLaunchKernelGGL(pitch_lag_kernel, dim3((unsigned)fc), dim3(64), pitch_lds_bytes(n), s,
                            x + f0 * stride, fc, n, stride, window, lag_ws);
         hipLaunchKernelGGL(pitch_refine_kernel, dim3((unsigned)fc), dim3(64), refine_lds_bytes(n), s,
                            lag_ws, lag_window, fc, n, sample_rate, threshold, fmin, fmax, kmax,
-                           out_cand + f0 * (long)kmax, out_count ? out_count + f0 : nullptr, status ? status + f0 : nullptr);
+                           out_cand + f0 * (long)kmax, out_count ? out_count + f0 : nullptr, status ? status + f0 : nullptr,
+                           work);
     }
 }
 

@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -43,6 +44,7 @@ struct vbx_ctx {
     std::map<std::pair<int, size_t>, double *> windows;   // (kind, n)
     std::map<std::tuple<size_t, int, int>, double *> goertzel;   // (n, b_lo, nb) -> [nb][2] kappa, sigma
     std::map<size_t, double *> dct_tables;                // K -> [K][K]
+    std::map<std::pair<size_t, int>, std::pair<double *, double *>> dft2_tabs;   // (n, n1) -> (stage-1 table, twiddles)
     std::map<std::tuple<size_t, size_t, double, double, double>, int32_t *> bins_cache;
     std::map<std::pair<size_t, double>, std::pair<int32_t *, double *>> resample_tabs;   // (n, ratio) -> (index, fraction)
     // timing
@@ -50,6 +52,8 @@ struct vbx_ctx {
     bool prof = false;
     std::vector<ProfRec> recs;
     std::map<std::string, std::pair<double, long>> prof_acc;
+    bool mfcc_force_goertzel = false;                     // test hook (VBX_MFCC_GOERTZEL=1): keep the fallback covered
+    unsigned long long *pitch_work = nullptr;             // [PITCH_WORK_SLOTS][4], counted while profiling
     std::mutex mu;
 };
 
@@ -174,6 +178,36 @@ int get_goertzel_dev(vbx_ctx *ctx, size_t n, int b_lo, int nb, const double **ou
     return VBX_SUCCESS;
 }
 
+// tables of the two-stage MFCC DFT (k_mfcc.hip): ctab[i1][c] = cos / sin columns of the n1-point DFT,
+// twid[j] = (cos, sin)(2 pi j / n); evaluated in long double and rounded once
+int get_dft2_dev(vbx_ctx *ctx, size_t n, const mfcc_plan_t &pl, const double **ctab, const double **twid) {
+    auto key = std::make_pair(n, pl.n1);
+    auto it = ctx->dft2_tabs.find(key);
+    if (it == ctx->dft2_tabs.end()) {
+        const long double two_pi = 6.283185307179586476925286766559005768L;
+        const int n1 = pl.n1, nc = pl.nc, ncos = n1 / 2 + 1;
+        std::vector<double> hc((size_t)n1 * nc, 0.0), ht(2 * n);
+        for (int i1 = 0; i1 < n1; i1++)
+            for (int c = 0; c < n1; c++) {
+                const int k1 = (c < ncos) ? c : c - ncos + 1;
+                const long double ang = two_pi * (long double)((long)i1 * k1 % n1) / (long double)n1;
+                hc[(size_t)i1 * nc + c] = (double)((c < ncos) ? cosl(ang) : sinl(ang));
+            }
+        for (size_t j = 0; j < n; j++) {
+            const long double ang = two_pi * (long double)j / (long double)n;
+            ht[2 * j] = (double)cosl(ang); ht[2 * j + 1] = (double)sinl(ang);
+        }
+        double *dc = nullptr, *dt = nullptr;
+        VBX_HIP(ctx, hipMalloc((void **)&dc, hc.size() * sizeof(double)));
+        VBX_HIP(ctx, hipMalloc((void **)&dt, ht.size() * sizeof(double)));
+        VBX_HIP(ctx, hipMemcpy(dc, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice));
+        VBX_HIP(ctx, hipMemcpy(dt, ht.data(), ht.size() * sizeof(double), hipMemcpyHostToDevice));
+        it = ctx->dft2_tabs.emplace(key, std::make_pair(dc, dt)).first;
+    }
+    *ctab = it->second.first; *twid = it->second.second;
+    return VBX_SUCCESS;
+}
+
 int get_dct_dev(vbx_ctx *ctx, size_t k, const double **out) {
     auto it = ctx->dct_tables.find(k);
     if (it == ctx->dct_tables.end()) {
@@ -278,6 +312,7 @@ int vbx_ctx_create(vbx_ctx **out, int device, void *hip_stream) {
     ctx->device = device;
     ctx->arch = prop.gcnArchName;
     ctx->cu_count = prop.multiProcessorCount;
+    { const char *e = std::getenv("VBX_MFCC_GOERTZEL"); ctx->mfcc_force_goertzel = e && e[0] == '1'; }
     if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->owns_stream = false; }
     else {
         e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -295,9 +330,11 @@ void vbx_ctx_destroy(vbx_ctx *ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < vbx_ctx::WS_N; i++) if (ctx->ws[i]) hipFree(ctx->ws[i]);
+    if (ctx->pitch_work) hipFree(ctx->pitch_work);
     for (auto &kv : ctx->windows) hipFree(kv.second);
     for (auto &kv : ctx->goertzel) hipFree(kv.second);
     for (auto &kv : ctx->dct_tables) hipFree(kv.second);
+    for (auto &kv : ctx->dft2_tabs) { hipFree(kv.second.first); hipFree(kv.second.second); }
     for (auto &kv : ctx->bins_cache) hipFree(kv.second);
     for (auto &kv : ctx->resample_tabs) { hipFree(kv.second.first); hipFree(kv.second.second); }
     for (auto &r : ctx->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -391,7 +428,19 @@ int vbx_profile_reset(vbx_ctx *ctx) {
     VBX_REQUIRE(ctx, ctx != nullptr, "null context");
     int rc = prof_flush(ctx);
     ctx->prof_acc.clear();
+    if (ctx->pitch_work)
+        VBX_HIP(ctx, hipMemsetAsync(ctx->pitch_work, 0, PITCH_WORK_SLOTS * 4 * sizeof(unsigned long long), ctx->stream));
     return rc;
+}
+int vbx_profile_pitch_work(vbx_ctx *ctx, uint64_t *h_out4) {
+    VBX_REQUIRE(ctx, ctx && h_out4, "null argument");
+    for (int i = 0; i < 4; i++) h_out4[i] = 0;
+    if (!ctx->pitch_work) return VBX_SUCCESS;
+    unsigned long long h[PITCH_WORK_SLOTS * 4];
+    VBX_HIP(ctx, hipMemcpyAsync(h, ctx->pitch_work, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    VBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int s = 0; s < PITCH_WORK_SLOTS; s++) for (int i = 0; i < 4; i++) h_out4[i] += h[4 * s + i];
+    return VBX_SUCCESS;
 }
 int vbx_profile_get(vbx_ctx *ctx, const char *kernel_name, double *h_total_ms, long *h_launches) {
     VBX_REQUIRE(ctx, ctx && kernel_name, "null argument");
@@ -500,10 +549,16 @@ int vbx_pitch_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_l
     void *lag_ws = nullptr;
     rc = ws_get(ctx, vbx_ctx::WS_LAG, (size_t)chunk * frame_len * sizeof(double), &lag_ws);
     if (rc != VBX_SUCCESS) return rc;
+    if (ctx->prof && !ctx->pitch_work) {
+        const size_t wb = PITCH_WORK_SLOTS * 4 * sizeof(unsigned long long);
+        VBX_HIP(ctx, hipMalloc((void **)&ctx->pitch_work, wb));
+        VBX_HIP(ctx, hipMemsetAsync(ctx->pitch_work, 0, wb, ctx->stream));
+    }
     {
         Prof p(ctx, "pitch");
         launch_pitch(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, lagw, sample_rate, threshold,
-                     fmin, fmax, (int)kmax, (pitch_t *)out_cand, out_count, status, (double *)lag_ws, chunk);
+                     fmin, fmax, (int)kmax, (pitch_t *)out_cand, out_count, status, (double *)lag_ws, chunk,
+                     ctx->prof ? ctx->pitch_work : nullptr);
     }
     return check_launch(ctx, __func__);
 }
@@ -689,12 +744,21 @@ int vbx_mfcc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_le
         return VBX_SUCCESS;
     }
     const int nb = hb.back() - hb.front();
-    VBX_REQUIRE(ctx, mfcc_fits((int)frame_len, nb), "frame / bin range does not fit the LDS");
-    const double *tw = nullptr, *dct = nullptr;
-    rc = get_goertzel_dev(ctx, frame_len, hb.front(), nb, &tw); if (rc != VBX_SUCCESS) return rc;
+    const double *dct = nullptr;
     rc = get_dct_dev(ctx, num_coeffs, &dct); if (rc != VBX_SUCCESS) return rc;
     if (status) VBX_HIP(ctx, hipMemsetAsync(status, 0, n_frames * sizeof(int32_t), ctx->stream));
-    {
+    // composite frame lengths: two-stage DFT of the needed bins; otherwise (prime-ish lengths) Goertzel
+    const mfcc_plan_t pl = (nb > 0 && !ctx->mfcc_force_goertzel) ? mfcc_plan((int)frame_len, nb) : mfcc_plan_t{false, 0, 0, 0, 0};
+    if (pl.ok) {
+        const double *ctab = nullptr, *twid = nullptr;
+        rc = get_dft2_dev(ctx, frame_len, pl, &ctab, &twid); if (rc != VBX_SUCCESS) return rc;
+        Prof p(ctx, "mfcc");
+        launch_mfcc_dft2(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, pl, ctab, twid, d_bins,
+                         dct, (int)num_coeffs, out, nb, ctx->cu_count);
+    } else {
+        VBX_REQUIRE(ctx, mfcc_fits((int)frame_len, nb), "frame / bin range does not fit the LDS");
+        const double *tw = nullptr;
+        rc = get_goertzel_dev(ctx, frame_len, hb.front(), nb, &tw); if (rc != VBX_SUCCESS) return rc;
         Prof p(ctx, "mfcc");
         launch_mfcc(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, tw, d_bins, dct, (int)num_coeffs, out, status, nb);
     }

@@ -46,10 +46,13 @@ void launch_tracker(hipStream_t s, const res_t *res, long F, int n_res, const in
 // k_pitch.hip
 size_t pitch_lds_bytes(int n);
 long pitch_chunk_frames(int n, long n_frames);
+// profiling counters of the refine kernel: [PITCH_WORK_SLOTS][4] = frames, candidates, sinc evaluations, sinc terms
+constexpr int PITCH_WORK_SLOTS = 64;
 void launch_pitch(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                   const double *lag_window, double sample_rate, double threshold, double fmin, double fmax,
                   int kmax, pitch_t *out_cand, int32_t *out_count, int32_t *status,
-                  double *lag_ws /* [chunk][n] scratch */, long chunk);
+                  double *lag_ws /* [chunk][n] scratch */, long chunk,
+                  unsigned long long *work);
 void launch_sinc_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *xs, long m,
                         long depth, double *out, int32_t *status);
 void launch_extremum_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *ix, long m,
@@ -57,6 +60,11 @@ void launch_extremum_points(hipStream_t s, const double *y, int ylen, long offse
 
 // k_mfcc.hip
 bool mfcc_fits(int n, int nb);
+struct mfcc_plan_t { bool ok; int n1, n2, nc, tm; };     // two-stage DFT geometry: n = n1*n2, nc = padded stage-1 columns
+mfcc_plan_t mfcc_plan(int n, int nb);
+void launch_mfcc_dft2(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
+                      const mfcc_plan_t &pl, const double *ctab /* [n1][nc] */, const double *twid /* [n][2] */,
+                      const int32_t *bins_dev, const double *dct_table, int num_coeffs, double *out, int nb, int cu_count);
 void launch_mfcc(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                  const double *kappa_sigma /* [nb][2] Goertzel-Reinsch constants */, const int32_t *bins /* K+2 */, const double *dct_table /* [K][K] */,
                  int num_coeffs, double *out, int32_t *status, int nb /* bins[K+1]-bins[0] */);

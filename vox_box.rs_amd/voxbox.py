@@ -71,6 +71,7 @@ def load_library():
         "vbx_profile_reset": (C.c_int, [vp]),
         "vbx_profile_get": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
         "vbx_profile_names": (C.c_int, [vp, C.c_char_p, sz]),
+        "vbx_profile_pitch_work": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         "vbx_window_table_f64": (C.c_int, [i32, sz, vp]),
         "vbx_frame_count": (sz, [sz, sz, sz]),
         "vbx_hz_to_mel": (dbl, [dbl]),
@@ -250,6 +251,12 @@ class VoxBox:
 
     def profile_reset(self):
         self._check(self.L.vbx_profile_reset(self.ctx))
+
+    def profile_pitch_work(self):
+        """(frames, candidates, sinc evaluations, sinc terms) the pitch refine kernel executed while profiling."""
+        w = (C.c_uint64 * 4)()
+        self._check(self.L.vbx_profile_pitch_work(self.ctx, w))
+        return tuple(int(v) for v in w)
 
     def profile_report(self):
         buf = C.create_string_buffer(4096)
