@@ -1,0 +1,16 @@
+import sys, os, ctypes, numpy as np
+sys.path.insert(0, '.')
+import __graft_entry__ as g
+pkg = g.load_package()
+N,H,SR=1200,480,48000.0
+ns=1800*48000
+vb = pkg.VoxBox(0)
+audio = vb.synth_speech(ns); F = pkg.frame_count(ns,N,H)
+han = vb.window(pkg.WINDOW_HANNING,N)
+out=(vb.empty((F,13)), vb.empty(F,np.int32))
+h=(ctypes.c_ulonglong*8)()
+for i in range(2):
+    vb.L.vbx_dbg_read(h)
+    vb.timer_begin(); vb.mfcc(audio,13,(100.,8000.),SR,frame_len=N,stride=H,n_frames=F,window=han,out=out); ms=vb.timer_end()
+vb.L.vbx_dbg_read(h)
+print(ms, 'ms; per-frame clock64 ticks per phase (load, stage1, stage2, tail):', [round(v/F) for v in h[:4]])

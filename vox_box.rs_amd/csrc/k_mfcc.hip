@@ -19,17 +19,31 @@ namespace vbx {
 constexpr int MFCC_BPL = 4;                 // bins per lane and pass
 constexpr int MFCC_PASS = 64 * MFCC_BPL;    // bins per pass over the frame
 
-// mel energies (:421-437) and dct (:391-397) of one frame from its |X|^2 / |X| rows (one wavefront)
-__device__ __forceinline__ void mfcc_tail(const double *mag2, const double *mag, double *en, const int32_t *bins,
+// mel energies (:421-437) and dct (:391-397) of one frame (one wavefront).  pu[b] = |X_b|^2 * (i / up) and
+// pd[b] = |X_b| * (i / down) are the reference's per-bin products (the slope factors i/up, i/down come from a
+// host table: the same IEEE division, done once); the sums run sequentially in the reference's order.
+__device__ __forceinline__ void mfcc_tail(const double *pu, const double *pd, double *en, const int32_t *bins,
                                           const double *dct_table, int num_coeffs, int b_lo, int lane,
                                           double *out_row) {
-    // lane w <-> filter w, sequential sums in the reference's order
-    if (lane < num_coeffs) {
+    if (lane < num_coeffs) {                              // lane w <-> filter w
         const int w0 = bins[lane], w1 = bins[lane + 1], w2 = bins[lane + 2];
-        const int up = w1 - w0, down = w2 - w1;
+        // four LDS reads in flight per step; entries past a filter's end are replaced by +0.0, which leaves
+        // the running sum unchanged, so the order and rounding of the reference's loop are kept
         double up_sum = 0.0, down_sum = 0.0;
-        for (int i = 0; i < up; i++) up_sum = up_sum + fabs(mag2[w0 + i - b_lo]) * ((double)i / (double)up);
-        for (int i = 0; i < down; i++) down_sum = down_sum + fabs(mag[w1 + i - b_lo]) * ((double)i / (double)down);
+        for (int b = w0 - b_lo; b < w1 - b_lo; b += 4) {
+            double v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = (b + j < w1 - b_lo) ? pu[b + j] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) up_sum = up_sum + v[j];
+        }
+        for (int b = w1 - b_lo; b < w2 - b_lo; b += 4) {
+            double v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = (b + j < w2 - b_lo) ? pd[b + j] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) down_sum = down_sum + v[j];
+        }
         const double lg = log10(up_sum + down_sum);
         en[lane] = (lg != lg || lg < 1.0e-10) ? 1.0e-10 : lg;   // f64::max(1e-10): NaN yields the other operand
     }
@@ -46,6 +60,7 @@ template <int W>
 __global__ __launch_bounds__(64 * W) void mfcc_kernel(
     const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
     const double *__restrict__ kappa_sigma /* [nb][2] */, const int32_t *__restrict__ bins,
+    const double *__restrict__ slopes /* [nb][2] i/up, i/down */,
     const double *__restrict__ dct_table, int num_coeffs, int nb, double *__restrict__ out) {
     extern __shared__ double smem[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -86,8 +101,9 @@ __global__ __launch_bounds__(64 * W) void mfcc_kernel(
                 const double s2 = sig[j] * (s[j] - d[j]);
                 double m2 = fma(d[j], d[j], sig[j] * kap[j] * s[j] * s2);     // norm_sqr (:426)
                 m2 = (m2 < 0.0) ? 0.0 : m2;
-                mag2[bi] = m2;
-                mag[bi] = sqrt(m2);                                           // norm (:432)
+                const double2 sl = *reinterpret_cast<const double2 *>(slopes + 2 * bi);
+                mag2[bi] = fabs(m2) * sl.x;                                   // norm_sqr * multiplier (:426-428)
+                mag[bi] = fabs(sqrt(m2)) * sl.y;                              // norm * multiplier (:432-434)
             }
         }
     }
@@ -104,21 +120,22 @@ __global__ __launch_bounds__(64 * W) void mfcc_kernel(
 // computes the cos columns k1 = 0..n1/2 and the sin columns k1 = 1..(n1-1)/2 only (n1 real columns, padded to
 // NC); the other half follows from A[i2][n1-k1] = conj A[i2][k1].  One wavefront per frame: each lane owns a
 // TM x 4 register tile of A (x broadcast from LDS, table rows as ds_read_b128), then one needed bin per pass in
-// stage 2 (twiddles W_n^j from a host-built table through L1).  Tables are rounded from long double.
-// LDS: per block the stage-1 table C[n1][NC]; per wave xs[max(n, 2 nb)] (reused for |X|^2, |X|) | A[n2][NC] | en[64].
+// stage 2 (twiddles W_n^j from a host-built table held in LDS).  Tables are rounded from long double.
+// LDS: per block the stage-1 table C[n1][NC] and the twiddles [n][2]; per wave xs[max(n, 2 nb)] (reused for |X|^2, |X|) | A[n2][NC] | en[64].
 // ------------------------------------------------------------------------------------------
 template <int TM>
-__global__ void mfcc_dft2_kernel(
+__global__ __launch_bounds__(512) void mfcc_dft2_kernel(
     const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
     const double *__restrict__ ctab /* [n1][NC] */, const double *__restrict__ twid /* [n][2] cos, sin */,
-    int n1, int n2, int NC, int xs_len, const int32_t *__restrict__ bins, const double *__restrict__ dct_table,
-    int num_coeffs, int nb, double *__restrict__ out) {
+    int n1, int n2, int NC, int xs_len, const int32_t *__restrict__ bins, const double *__restrict__ slopes,
+    const double *__restrict__ dct_table, int num_coeffs, int nb, double *__restrict__ out) {
     extern __shared__ double smem[];
     const int wave = threadIdx.x >> 6, lane = lane_id(), W = blockDim.x >> 6;
-    double *ct = smem;                                                   // shared by the block
+    double *ct = smem, *tw = smem + (size_t)n1 * NC;                      // shared by the block
     const size_t per_wave = (size_t)xs_len + (size_t)n2 * NC + 64;
-    double *xs = smem + (size_t)n1 * NC + (size_t)wave * per_wave, *A = xs + xs_len, *en = A + (size_t)n2 * NC;
+    double *xs = tw + 2 * (size_t)n + (size_t)wave * per_wave, *A = xs + xs_len, *en = A + (size_t)n2 * NC;
     for (int i = threadIdx.x; i < n1 * NC; i += blockDim.x) ct[i] = ctab[i];
+    for (int i = threadIdx.x; i < 2 * n; i += blockDim.x) tw[i] = twid[i];
     __syncthreads();
 
     const int b_lo = bins[0];
@@ -126,9 +143,34 @@ __global__ void mfcc_dft2_kernel(
     const int nct = NC >> 2;                                             // column tiles of 4
     const int nrt = (n2 + TM - 1) / TM;                                  // row tiles of TM
     const int ntiles = nrt * nct;
-    for (long f = (long)blockIdx.x * W + wave; f < n_frames; f += (long)gridDim.x * W) {
+    // The window (the same for every frame) and the NEXT frame's first 64*PF samples live in registers: the
+    // loads of frame f+1 are in flight while frame f is transformed (1-2 waves per SIMD hide nothing else).
+    constexpr int PF = 20;
+    double wreg[PF], pre[PF];
+    const long fstep = (long)gridDim.x * W;
+    long f = (long)blockIdx.x * W + wave;
+#pragma unroll
+    for (int j = 0; j < PF; j++) {
+        const int i = 64 * j + lane;
+        wreg[j] = (window != nullptr && i < n) ? window[i] : 1.0;
+        pre[j] = (f < n_frames && i < n) ? x[f * stride + i] : 0.0;
+    }
+    for (; f < n_frames; f += fstep) {
         const double *xf = x + f * stride;
-        for (int i = lane; i < n; i += 64) xs[i] = (window != nullptr) ? xf[i] * window[i] : xf[i];
+#pragma unroll
+        for (int j = 0; j < PF; j++) {
+            const int i = 64 * j + lane;
+            if (i < n) xs[i] = pre[j] * wreg[j];
+        }
+        for (int i = 64 * PF + lane; i < n; i += 64) xs[i] = (window != nullptr) ? xf[i] * window[i] : xf[i];
+        if (f + fstep < n_frames) {
+            const double *xn = xf + fstep * stride;
+#pragma unroll
+            for (int j = 0; j < PF; j++) {
+                const int i = 64 * j + lane;
+                pre[j] = (i < n) ? xn[i] : 0.0;
+            }
+        }
         wave_sync();
         // stage 1
         for (int t = lane; t < ((ntiles + 63) & ~63); t += 64) {
@@ -142,7 +184,7 @@ __global__ void mfcc_dft2_kernel(
             for (int i = 0; i < TM; i++) { acc[i][0] = 0.; acc[i][1] = 0.; acc[i][2] = 0.; acc[i][3] = 0.; }
             const double *cp = ct + 4 * ctile;
             const double *xp = xs;
-#pragma unroll 2
+#pragma unroll 4
             for (int i1 = 0; i1 < n1; i1++) {
                 const double2 c01 = *reinterpret_cast<const double2 *>(cp), c23 = *reinterpret_cast<const double2 *>(cp + 2);
 #pragma unroll
@@ -170,38 +212,48 @@ __global__ void mfcc_dft2_kernel(
         wave_sync();
         // stage 2: the frame's samples are dead, their space takes |X|^2 and |X|
         double *mag2 = xs, *mag = xs + nb;
-        for (int p0 = 0; p0 < nb; p0 += 64) {
-            const int bi = p0 + lane;
-            const bool ok = bi < nb;
-            const int k = b_lo + (ok ? bi : 0);
-            const int k1 = k % n1;
-            const int cc = (k1 <= H) ? k1 : n1 - k1;                     // column of Re A
-            const bool has_im = cc >= 1 && 2 * cc != n1;
-            const int sc = has_im ? ncos + cc - 1 : 0;                   // column of -Im A[.][cc]
-            const double sgn = (k1 <= H) ? -1.0 : 1.0;
-            double re = 0., im = 0.;
-            int idx = 0;
+        for (int p0 = 0; p0 < nb; p0 += 64 * MFCC_BPL) {                 // MFCC_BPL independent bins per lane
+            int kk[MFCC_BPL], cc[MFCC_BPL], sc[MFCC_BPL], idx[MFCC_BPL];
+            double sgn[MFCC_BPL], re[MFCC_BPL], im[MFCC_BPL];
+#pragma unroll
+            for (int j = 0; j < MFCC_BPL; j++) {
+                const int bi = p0 + 64 * j + lane;
+                kk[j] = b_lo + ((bi < nb) ? bi : 0);
+                const int k1 = kk[j] % n1;
+                cc[j] = (k1 <= H) ? k1 : n1 - k1;                        // column of Re A
+                const bool has_im = cc[j] >= 1 && 2 * cc[j] != n1;
+                sc[j] = has_im ? ncos + cc[j] - 1 : 0;                   // column of -Im A[.][cc]
+                sgn[j] = has_im ? ((k1 <= H) ? -1.0 : 1.0) : 0.0;
+                re[j] = 0.; im[j] = 0.; idx[j] = 0;
+            }
             const double *ap = A;
-#pragma unroll 2
             for (int i2 = 0; i2 < n2; i2++) {
-                const double2 w = *reinterpret_cast<const double2 *>(twid + 2 * (size_t)idx);   // cos, sin of 2 pi idx / n
-                const double ar = ap[cc];
-                const double as = ap[sc];
-                const double ai = has_im ? sgn * as : 0.0;
-                re = fma(ar, w.x, re); re = fma(ai, w.y, re);            // (ar + i ai)(cos - i sin)
-                im = fma(ai, w.x, im); im = fma(-ar, w.y, im);
-                idx += k; idx -= (idx >= n) ? n : 0;
+#pragma unroll
+                for (int j = 0; j < MFCC_BPL; j++) {
+                    const double2 w = *reinterpret_cast<const double2 *>(tw + 2 * idx[j]);   // cos, sin of 2 pi idx / n
+                    const double ar = ap[cc[j]];
+                    const double as = ap[sc[j]];
+                    const double ai = (sgn[j] != 0.0) ? sgn[j] * as : 0.0;
+                    re[j] = fma(ar, w.x, re[j]); re[j] = fma(ai, w.y, re[j]);                // (ar + i ai)(cos - i sin)
+                    im[j] = fma(ai, w.x, im[j]); im[j] = fma(-ar, w.y, im[j]);
+                    idx[j] += kk[j]; idx[j] -= (idx[j] >= n) ? n : 0;
+                }
                 ap += NC;
             }
-            if (ok) {
-                const double m2 = fma(re, re, im * im);                  // norm_sqr (:426)
-                mag2[bi] = m2;
-                mag[bi] = sqrt(m2);                                      // norm (:432)
+#pragma unroll
+            for (int j = 0; j < MFCC_BPL; j++) {
+                const int bi = p0 + 64 * j + lane;
+                if (bi < nb) {
+                    const double m2 = fma(re[j], re[j], im[j] * im[j]);
+                    const double2 sl = *reinterpret_cast<const double2 *>(slopes + 2 * bi);
+                    mag2[bi] = fabs(m2) * sl.x;                          // norm_sqr * multiplier (:426-428)
+                    mag[bi] = fabs(sqrt(m2)) * sl.y;                     // norm * multiplier (:432-434)
+                }
             }
         }
         wave_sync();
         mfcc_tail(mag2, mag, en, bins, dct_table, num_coeffs, b_lo, lane, out + f * (long)num_coeffs);
-        wave_sync();                                                     // xs / en are rewritten by the next frame
+        wave_sync();                                                     // xs / en
     }
 }
 
@@ -222,21 +274,21 @@ static size_t mfcc_lds(int nb, int w) { return (size_t)w * (2 * (size_t)nb + 64)
 bool mfcc_fits(int /*n*/, int nb) { return mfcc_lds(nb, 1) <= 160 * 1024; }
 
 void launch_mfcc(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
-                 const double *kappa_sigma, const int32_t *bins_dev, const double *dct_table,
+                 const double *kappa_sigma, const int32_t *bins_dev, const double *slopes, const double *dct_table,
                  int num_coeffs, double *out, int32_t * /*status*/, int nb) {
     if (mfcc_lds(nb, 4) <= 40 * 1024) {
         hipLaunchKernelGGL((mfcc_kernel<4>), dim3((unsigned)((F + 3) / 4)), dim3(256), mfcc_lds(nb, 4), s,
-                           x, F, n, stride, window, kappa_sigma, bins_dev, dct_table, num_coeffs, nb, out);
+                           x, F, n, stride, window, kappa_sigma, bins_dev, slopes, dct_table, num_coeffs, nb, out);
     } else {
         hipLaunchKernelGGL((mfcc_kernel<1>), dim3((unsigned)F), dim3(64), mfcc_lds(nb, 1), s,
-                           x, F, n, stride, window, kappa_sigma, bins_dev, dct_table, num_coeffs, nb, out);
+                           x, F, n, stride, window, kappa_sigma, bins_dev, slopes, dct_table, num_coeffs, nb, out);
     }
 }
 
 // ---- two-stage plan: geometry shared by the host (table builder in vbx_api.hip) and the launcher ----
 size_t mfcc_dft2_lds(const mfcc_plan_t &pl, int nb, int n, int waves) {
     const size_t xs_len = (size_t)((n > 2 * nb) ? n : 2 * nb);
-    return ((size_t)pl.n1 * pl.nc + (size_t)waves * (xs_len + (size_t)pl.n2 * pl.nc + 64)) * sizeof(double);
+    return ((size_t)pl.n1 * pl.nc + 2 * (size_t)n + (size_t)waves * (xs_len + (size_t)pl.n2 * pl.nc + 64)) * sizeof(double);
 }
 
 // Picks n1*n2 = n minimising n*n1 + 8*nb*n2 (stage 2 is the less efficient loop) and the row tile TM that
@@ -267,7 +319,7 @@ mfcc_plan_t mfcc_plan(int n, int nb) {
 template <int TM>
 static void launch_dft2_tm(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                            const mfcc_plan_t &pl, const double *ctab, const double *twid, const int32_t *bins_dev,
-                           const double *dct_table, int num_coeffs, double *out, int nb, int cu_count) {
+                           const double *slopes, const double *dct_table, int num_coeffs, double *out, int nb, int cu_count) {
     // waves per block: the most wavefronts per CU the LDS allows (the table is shared by the block)
     int best_w = 1, best_res = 0;
     for (int w = 1; w <= 8; w++) {
@@ -281,14 +333,14 @@ static void launch_dft2_tm(hipStream_t s, const double *x, long F, int n, long s
     const long cap = (long)(cu_count > 0 ? cu_count : 256) * 16;       // grid-stride: the table is loaded once per block
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((mfcc_dft2_kernel<TM>), dim3((unsigned)blocks), dim3(64 * best_w), mfcc_dft2_lds(pl, nb, n, best_w), s,
-                       x, F, n, stride, window, ctab, twid, pl.n1, pl.n2, pl.nc, xs_len, bins_dev, dct_table,
+                       x, F, n, stride, window, ctab, twid, pl.n1, pl.n2, pl.nc, xs_len, bins_dev, slopes, dct_table,
                        num_coeffs, nb, out);
 }
 
 void launch_mfcc_dft2(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                       const mfcc_plan_t &pl, const double *ctab, const double *twid, const int32_t *bins_dev,
-                      const double *dct_table, int num_coeffs, double *out, int nb, int cu_count) {
-#define VBX_DFT2(TM) case TM: launch_dft2_tm<TM>(s, x, F, n, stride, window, pl, ctab, twid, bins_dev, dct_table, num_coeffs, out, nb, cu_count); break;
+                      const double *slopes, const double *dct_table, int num_coeffs, double *out, int nb, int cu_count) {
+#define VBX_DFT2(TM) case TM: launch_dft2_tm<TM>(s, x, F, n, stride, window, pl, ctab, twid, bins_dev, slopes, dct_table, num_coeffs, out, nb, cu_count); break;
     switch (pl.tm) { VBX_DFT2(2) VBX_DFT2(3) VBX_DFT2(4) VBX_DFT2(5) VBX_DFT2(6) VBX_DFT2(8) default: break; }
 #undef VBX_DFT2
 }

@@ -46,6 +46,7 @@ struct vbx_ctx {
     std::map<size_t, double *> dct_tables;                // K -> [K][K]
     std::map<std::pair<size_t, int>, std::pair<double *, double *>> dft2_tabs;   // (n, n1) -> (stage-1 table, twiddles)
     std::map<std::tuple<size_t, size_t, double, double, double>, int32_t *> bins_cache;
+    std::map<std::tuple<size_t, size_t, double, double, double>, double *> slopes_cache;   // [nb][2] i/up, i/down per bin
     std::map<std::pair<size_t, double>, std::pair<int32_t *, double *>> resample_tabs;   // (n, ratio) -> (index, fraction)
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -255,6 +256,29 @@ int get_bins_dev(vbx_ctx *ctx, size_t n, size_t k, double lo, double hi, double 
     return VBX_SUCCESS;
 }
 
+// src/spectrum.rs:424,430: the slope factor of every bin, (i as f64) / (up as f64) on the rising side of its
+// filter and i / down on the "falling" side (Q14: it rises too); one IEEE division each, as in the reference
+int get_slopes_dev(vbx_ctx *ctx, size_t n, size_t k, double lo, double hi, double sr,
+                   const std::vector<int32_t> &hb, const double **out) {
+    auto key = std::make_tuple(n, k, lo, hi, sr);
+    auto it = ctx->slopes_cache.find(key);
+    if (it == ctx->slopes_cache.end()) {
+        const int b_lo = hb.front(), nb = hb.back() - hb.front();
+        std::vector<double> h(2 * (size_t)(nb > 0 ? nb : 1), 0.0);
+        for (size_t w = 0; w < k; w++) {
+            const int up = hb[w + 1] - hb[w], down = hb[w + 2] - hb[w + 1];
+            for (int i = 0; i < up; i++) h[2 * (size_t)(hb[w] + i - b_lo)] = (double)i / (double)up;
+            for (int i = 0; i < down; i++) h[2 * (size_t)(hb[w + 1] + i - b_lo) + 1] = (double)i / (double)down;
+        }
+        double *d = nullptr;
+        VBX_HIP(ctx, hipMalloc((void **)&d, h.size() * sizeof(double)));
+        VBX_HIP(ctx, hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+        it = ctx->slopes_cache.emplace(key, d).first;
+    }
+    *out = it->second;
+    return VBX_SUCCESS;
+}
+
 int check_frames(vbx_ctx *ctx, const char *fn, const void *x, size_t n_frames, size_t frame_len, size_t stride) {
     if (!ctx) return fail(nullptr, VBX_E_INVALID, std::string(fn) + ": null context");
     if (n_frames == 0) return 1;   // empty batch: nothing to do
@@ -336,6 +360,7 @@ void vbx_ctx_destroy(vbx_ctx *ctx) {
     for (auto &kv : ctx->dct_tables) hipFree(kv.second);
     for (auto &kv : ctx->dft2_tabs) { hipFree(kv.second.first); hipFree(kv.second.second); }
     for (auto &kv : ctx->bins_cache) hipFree(kv.second);
+    for (auto &kv : ctx->slopes_cache) hipFree(kv.second);
     for (auto &kv : ctx->resample_tabs) { hipFree(kv.second.first); hipFree(kv.second.second); }
     for (auto &r : ctx->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (ctx->t0) hipEventDestroy(ctx->t0);
@@ -744,8 +769,9 @@ int vbx_mfcc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_le
         return VBX_SUCCESS;
     }
     const int nb = hb.back() - hb.front();
-    const double *dct = nullptr;
+    const double *dct = nullptr, *slopes = nullptr;
     rc = get_dct_dev(ctx, num_coeffs, &dct); if (rc != VBX_SUCCESS) return rc;
+    rc = get_slopes_dev(ctx, frame_len, num_coeffs, lo_hz, hi_hz, sample_rate, hb, &slopes); if (rc != VBX_SUCCESS) return rc;
     if (status) VBX_HIP(ctx, hipMemsetAsync(status, 0, n_frames * sizeof(int32_t), ctx->stream));
     // composite frame lengths: two-stage DFT of the needed bins; otherwise (prime-ish lengths) Goertzel
     const mfcc_plan_t pl = (nb > 0 && !ctx->mfcc_force_goertzel) ? mfcc_plan((int)frame_len, nb) : mfcc_plan_t{false, 0, 0, 0, 0};
@@ -754,13 +780,13 @@ int vbx_mfcc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_le
         rc = get_dft2_dev(ctx, frame_len, pl, &ctab, &twid); if (rc != VBX_SUCCESS) return rc;
         Prof p(ctx, "mfcc");
         launch_mfcc_dft2(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, pl, ctab, twid, d_bins,
-                         dct, (int)num_coeffs, out, nb, ctx->cu_count);
+                         slopes, dct, (int)num_coeffs, out, nb, ctx->cu_count);
     } else {
         VBX_REQUIRE(ctx, mfcc_fits((int)frame_len, nb), "frame / bin range does not fit the LDS");
         const double *tw = nullptr;
         rc = get_goertzel_dev(ctx, frame_len, hb.front(), nb, &tw); if (rc != VBX_SUCCESS) return rc;
         Prof p(ctx, "mfcc");
-        launch_mfcc(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, tw, d_bins, dct, (int)num_coeffs, out, status, nb);
+        launch_mfcc(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, tw, d_bins, slopes, dct, (int)num_coeffs, out, status, nb);
     }
     return check_launch(ctx, __func__);
 }

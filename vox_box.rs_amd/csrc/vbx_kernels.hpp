@@ -64,9 +64,11 @@ struct mfcc_plan_t { bool ok; int n1, n2, nc, tm; };     // two-stage DFT geomet
 mfcc_plan_t mfcc_plan(int n, int nb);
 void launch_mfcc_dft2(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                       const mfcc_plan_t &pl, const double *ctab /* [n1][nc] */, const double *twid /* [n][2] */,
-                      const int32_t *bins_dev, const double *dct_table, int num_coeffs, double *out, int nb, int cu_count);
+                      const int32_t *bins_dev, const double *slopes, const double *dct_table, int num_coeffs, double *out,
+                      int nb, int cu_count);
 void launch_mfcc(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
-                 const double *kappa_sigma /* [nb][2] Goertzel-Reinsch constants */, const int32_t *bins /* K+2 */, const double *dct_table /* [K][K] */,
+                 const double *kappa_sigma /* [nb][2] Goertzel-Reinsch constants */, const int32_t *bins /* K+2 */,
+                 const double *slopes /* [nb][2] */, const double *dct_table /* [K][K] */,
                  int num_coeffs, double *out, int32_t *status, int nb /* bins[K+1]-bins[0] */);
 void launch_dct_rows(hipStream_t s, const double *in, long rows, int n, const double *dct_table, double *out);
 
