@@ -21,7 +21,7 @@ def terms(y, offset, nx, x):
     aR = np.pi * (phir + n); iR = np.minimum(offset + nl + n, len(y) - 1)
     tR = y[iR] * np.sin(aR) / aR * (0.5 + 0.5 * np.cos(aR / (phir + D)))
     cR = np.abs(np.sin(aR) / aR * (0.5 + 0.5 * np.cos(aR / (phir + D))))
-    return tL, tR, np.abs(y[iL]), np.abs(y[iR]), cL, cR
+    return tL, tR, np.abs(y[iL]), np.abs(y[iR]), cL, cR, iL, iR
 tot = {}; ncand_tot = 0; exact_pruned = 0
 for t in range(0, 1000, 25):
     x = audio[t * H:t * H + N] * w
@@ -37,19 +37,23 @@ for t in range(0, 1000, 25):
             if not (75. < freq < 600.): continue
             nn = SR / freq - offset
             v0 = (nn - 1) + golden * 2
-            tL, tR, aL, aR, cL, cR = terms(y, offset, nx, v0)
+            tL, tR, aL, aR, cL, cR, iL, iR = terms(y, offset, nx, v0); ay = np.abs(y); cs = np.concatenate([[0], np.cumsum(ay)])
             fv = tL.sum() + tR.sum(); ub = min(fv, 1.0)
             ncand_tot += 1
             if ub < bar: exact_pruned += 1
-            for D in (16, 32, 64, 128, 256):
+            for D in (8, 12, 16):
+              for B in (1, 4, 16):
                 part = tL[:D].sum() + tR[:D].sum()
-                # tail bound in geometric ranges: sum|y| * max coefficient in range
                 tail = 0.0; lo = D
+                def rs(i0, i1):
+                    i0 = (i0 // B) * B; i1 = ((i1 // B) + 1) * B - 1
+                    i0 = max(i0, 0); i1 = min(i1, len(ay) - 1)
+                    return cs[i1 + 1] - cs[i0] if i1 >= i0 else 0.0
                 while lo < len(tL):
                     hi = min(2 * lo, len(tL))
-                    tail += aL[lo:hi].sum() * cL[lo:hi].max() + aR[lo:hi].sum() * cR[lo:hi].max()
+                    tail += rs(iL[hi - 1], iL[lo]) * cL[lo] + rs(iR[lo], iR[hi - 1]) * cR[lo]
                     lo = hi
-                tot.setdefault(D, [0, 0.0]); tot[D][1] += tail
-                if min(part + tail, 1.0) < bar: tot[D][0] += 1
+                tot.setdefault((D, B), [0, 0.0]); tot[(D, B)][1] += tail
+                if min(part + tail, 1.0) < bar: tot[(D, B)][0] += 1
 print("candidates", ncand_tot, "pruned by exact first eval", exact_pruned)
 for D, (c, tl) in sorted(tot.items()): print("D", D, "pruned", c, "mean tail bound", tl / ncand_tot)

@@ -470,8 +470,8 @@ def test_pitch_work_counters(vb, oracle, audio, pkg):
             assert work[kmax][0] == x.shape[0] and work[kmax][1] == int(np.sum(cnt[st == 0] - 1))
     finally:
         vb.profile(False)
-    assert work[1][2] < work[64][2] and work[1][3] < work[64][3]       # pruning skips evaluations ...
-    assert work[1][2] >= work[1][1]                                    # ... but every candidate gets at least one
+    assert 0 < work[1][2] < work[64][2] and 0 < work[1][3] < work[64][3]     # pruning skips evaluations
+    assert work[64][2] >= work[64][1]                                  # unpruned: every candidate is evaluated
 
 
 @pytest.mark.parametrize("n", [64, 100, 256, 513, 2048])

@@ -226,7 +226,9 @@ __device__ __forceinline__ double sinc_interp(const double *y, int nvalid, int y
 template <int G>
 __device__ __forceinline__ void improve_extremum_sinc(const double *y, int nvalid, int ylen, int offset, int nx,
                                                       double ixmid, int depth, bool active,
-                                                      double &xmid, double &ymid, int &st) {
+                                                      double &xmid, double &ymid, int &st,
+                                                      unsigned *terms = nullptr, unsigned *evals = nullptr,
+                                                      double bar = -__builtin_inf(), bool *pruned = nullptr) {
 #pragma clang fp contract(off)   // keep the scalar iteration bit-identical to the unfused CPU arithmetic
     const double golden = 1. - 0.6180339887498948482045868343656381177203091798057628621;
     const double sqrt_epsilon = 1.4901161193847656e-08;   // sqrt(f64::EPSILON)
@@ -244,9 +246,15 @@ __device__ __forceinline__ void improve_extremum_sinc(const double *y, int nvali
     }
     double a = ixmid - 1., b = ixmid + 1.;
     double v = a + golden * (b - a);
-    double fv = sinc_interp<G>(y, nvalid, ylen, offset, nx, v, depth, run, st);
+    double fv = sinc_interp<G>(y, nvalid, ylen, offset, nx, v, depth, run, st, terms);
+    if (evals != nullptr && run) *evals += 1u;
     double x = v, w = v, fx = fv, fw = fv;
     bool done = !run;
+    if (pruned != nullptr) {     // exact top-k pruning (pitch_refine_kernel): f(v0) already caps the final strength
+        const double ub = (fv <= 1.) ? fv : 1.;
+        *pruned = run && ub < bar && a >= (double)(-offset);
+        done = done || *pruned;
+    }
     for (int it = 1; it <= 60; it++) {
         const double range = b - a;
         const double middle_range = (a + b) * 0.5;
@@ -265,7 +273,8 @@ __device__ __forceinline__ void improve_extremum_sinc(const double *y, int nvali
         }
         if (fabs(new_step) < tol_act) new_step = (new_step > 0.) ? tol_act : -tol_act;
         const double t = x + new_step;
-        const double ft = sinc_interp<G>(y, nvalid, ylen, offset, nx, t, depth, !done, st);
+        const double ft = sinc_interp<G>(y, nvalid, ylen, offset, nx, t, depth, !done, st, terms);
+        if (evals != nullptr && !done) *evals += 1u;
         if (!done) {
             if (ft <= fx) {
                 if (t < x) b = x; else a = x;
@@ -339,16 +348,96 @@ __device__ __forceinline__ void cand_from_peak(const double *ys, int kk, double 
     nn = sample_rate / freq - (double)offset;                         // :432, :443
 }
 
+constexpr int BOUND_HEAD = 8;                   // nearest terms per side evaluated by the first-evaluation bound
+
+// sum of |y_i| over i in [i0, i1], rounded outward to blocks of 4 (p16[j] = sum_{i < 4 j} |y_i|, j <= nblk)
+__device__ __forceinline__ double abs_range_bound(const double *p16, int nblk, int i0, int i1) {
+    i0 = (i0 < 0) ? 0 : i0;
+    const int last = 4 * nblk - 1;
+    i1 = (i1 > last) ? last : i1;
+    if (i1 < i0) return 0.0;
+    return p16[(i1 >> 2) + 1] - p16[i0 >> 2];
+}
+
+// Upper bound of f(v0), the FIRST value brent_maximize (src/periodic.rs:103-188) takes on the bracket
+// [nn-1, nn+1]: v0 = a + golden*(b-a).  Every later accepted value is <= f(v0), so this bounds the candidate's
+// final strength from above.  One lane per candidate: the 2*BOUND_HEAD terms nearest to v0 are summed, the rest
+// is bounded by  sum |y_i| * c(n)  with  c(n) = |sin(pi ph)| * taper(n) / (pi (ph + n)),  decreasing in n, taken
+// at the start of geometrically growing ranges.  +inf (= "refine it") for everything that is not the plain
+// clamp-free sum, and for NaN/inf data.
+__device__ __forceinline__ double first_eval_bound(const double *ys, const double *p16, int nblk, int nvalid, int ylen,
+                                                   int offset, int nx, double nn, int depth) {
+    const double INF = __builtin_inf();
+    if (nn == 0. || nn >= (double)nx || !(nn - 1. < nn + 1.)) return INF;
+    double v0;
+    {
+#pragma clang fp contract(off)
+        const double golden = 1. - 0.6180339887498948482045868343656381177203091798057628621;
+        const double ba = nn - 1., bb = nn + 1.;
+        if (!(ba >= (double)(-offset))) return INF;
+        v0 = ba + golden * (bb - ba);
+    }
+    if (nx < 1 || v0 > (double)nx || v0 < 0.0) return INF;
+    const double fl = floor(v0);
+    const int nl = (int)fl, nr = nl + 1;
+    const double phil = v0 - (double)nl, phir = 1.0 - phil;
+    if (fabs(v0 - (double)nl) < 1.0e-10 || fabs(v0 - (double)nr) < 1.0e-10) return INF;
+    int D = depth;
+    if ((offset + nr) < D) D = ((offset + nr) < 0) ? 0 : (offset + nr);            // :46-52
+    if ((offset + nl + D) >= nx) D = nx - offset + nl - 1;                          // :55-57
+    if (D < 0 || offset + nr >= ylen || D > offset + nr || offset + nl < 0 || offset + nl + D >= ylen) return INF;
+    const double s0 = sin_poly(M_PI * fmin(phil, phir)) * 0.31830988618379067154;   // |sin(pi ph)| / pi >= 0
+    const double hl = M_PI * rcp_nr1(phil + (double)D), hr = M_PI * rcp_nr1(phir + (double)D);
+    double head = 0.0;
+    const int nh = (BOUND_HEAD < D + 1) ? BOUND_HEAD : D + 1;
+    for (int m = 0; m < nh; m++) {
+        const double pl = phil + (double)m, pr = phir + (double)m;
+        const double tl = y_at(ys, nvalid, offset + nr - m) * rcp_nr1(pl) * fma(0.5, cos_0_pi(hl * pl), 0.5);
+        const double tr = y_at(ys, nvalid, offset + nl + m) * rcp_nr1(pr) * fma(0.5, cos_0_pi(hr * pr), 0.5);
+        const double t = tl + tr;
+        head += (m & 1) ? -t : t;
+    }
+    head *= s0;
+    double tail = 0.0;
+    for (int lo = nh; lo <= D; lo *= 2) {
+        const int hi = (2 * lo < D + 1) ? 2 * lo : D + 1;                            // terms [lo, hi)
+        const double pl = phil + (double)lo, pr = phir + (double)lo;
+        const double cl = rcp_nr1(pl) * fma(0.5, cos_0_pi(hl * pl), 0.5);
+        const double cr = rcp_nr1(pr) * fma(0.5, cos_0_pi(hr * pr), 0.5);
+        tail = fma(cl, abs_range_bound(p16, nblk, offset + nr - (hi - 1), offset + nr - lo), tail);
+        tail = fma(cr, abs_range_bound(p16, nblk, offset + nl + lo, offset + nl + hi - 1), tail);
+    }
+    tail *= s0;
+    const double ub = head + tail * (1.0 + 1.0e-9) + (1.0e-9 + 1.0e-11 * p16[nblk]);   // rounding of either sum is far below this
+    return (ub != ub) ? INF : ub;
+}
+
+// index of the largest key >= bar among keys[0, ncand) (lowest index on ties), or -1; the winner is retired
+__device__ __forceinline__ int pick_best(double *keys, int ncand, double bar, int lane) {
+    double bv = -__builtin_inf(); int bi = 0x7fffffff;
+    for (int i = lane; i < ncand; i += 64) { const double v = keys[i]; if (v > bv) { bv = v; bi = i; } }
+    const double gm = wave_max(bv);
+    int pick = (bv == gm) ? bi : 0x7fffffff;
+    for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(pick, o, 64); pick = (other < pick) ? other : pick; }
+    if (pick == 0x7fffffff || !(gm >= bar)) return -1;
+    if (lane == 0) keys[pick] = -__builtin_inf();
+    wave_sync();
+    return pick;
+}
+
 __global__ __launch_bounds__(64) void pitch_refine_kernel(
     const double *__restrict__ r_in, const double *__restrict__ lag_window, long n_frames, int n,
     double sample_rate, double threshold, double fmin, double fmax,
     int kmax, pitch_t *__restrict__ out_cand, int32_t *__restrict__ out_count, int32_t *__restrict__ status,
     unsigned long long *__restrict__ work) {
-    extern __shared__ double ys[];                  // [n + Y_PAD] doubles, then the candidate list (ints)
+    extern __shared__ double ys[];                  // y[n + Y_PAD] | p16[nblk + 1 (+pad)] | keys[n/4 + 8] | candidate list (ints)
     const long f = blockIdx.x;
     if (f >= n_frames) return;
     const int lane = lane_id();
-    int *cand_list = reinterpret_cast<int *>(ys + n + Y_PAD);
+    const int nblk = (n + 3) >> 2;                   // blocks of 4 lags for the |y| prefix sums
+    double *p16 = ys + n + Y_PAD;
+    double *keys = p16 + ((nblk + 2) & ~1);
+    int *cand_list = reinterpret_cast<int *>(keys + (n / 4 + 8));
     const double *ri = r_in + f * (long)n;
     double amax = -1.0;                             // max_amplitude over ALL lags (Q2; NaN never wins)
     for (int i = lane; i < n + Y_PAD; i += 64) {
@@ -387,32 +476,95 @@ __global__ __launch_bounds__(64) void pitch_refine_kernel(
     }
     __syncthreads();
 
+    // a') first-evaluation bounds.  p16: prefix sums of |y| over blocks of 4; keys[c]: upper bound of candidate c's strength
+    {
+        // lane l owns the consecutive blocks [l*per, (l+1)*per): local sums, one scan over the lanes, prefix written back
+        const int per = (nblk + 63) >> 6;
+        double tot = 0.0;
+        for (int q = 0; q < per; q++) {
+            const int j = lane * per + q;
+            if (j < nblk) { const double *yp = ys + 4 * j; tot += (fabs(yp[0]) + fabs(yp[1])) + (fabs(yp[2]) + fabs(yp[3])); }   // entries past n are zero
+        }
+        double incl = tot;                                   // inclusive scan over the lanes
+        for (int o = 1; o < 64; o <<= 1) { const double up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+        double run = incl - tot;
+        if (lane == 0) p16[0] = 0.0;
+        for (int q = 0; q < per; q++) {
+            const int j = lane * per + q;
+            if (j < nblk) {
+                const double *yp = ys + 4 * j;
+                run += (fabs(yp[0]) + fabs(yp[1])) + (fabs(yp[2]) + fabs(yp[3]));
+                p16[j + 1] = run;
+            }
+        }
+        wave_sync();
+        for (int c = lane; c < ncand; c += 64) {
+            double freq, nn;
+            cand_from_peak(ys, cand_list[c], sample_rate, offset, freq, nn);
+            const double ub = first_eval_bound(ys, p16, nblk, nvalid, ylen, offset, nx, nn, 1200);
+            keys[c] = (ub <= 1.) ? ub : ((ub != ub) ? __builtin_inf() : ((ub == __builtin_inf()) ? ub : 1.));
+        }
+        wave_sync();
+    }
+
     int st = 0;
     int kept = 0;
     double lf = 0.0, ls = 0.0;                      // lane j holds sorted candidate j
     bool any_nan = false;
     const int gid = lane / PG;
-
-    // b) + c): the 64/PG lane groups run improve_extremum (src/periodic.rs:192-229, brent_maximize
-    // :103-188) on one candidate each and take the NEXT candidate as soon as theirs has converged, so
-    // a slow refinement never idles the other groups.  Finished candidates enter the lane-resident
-    // list ordered by (strength desc, candidate index asc) == the reference's stable sort (:453).
     int li = 0;                                     // candidate index of the list entry held by this lane
     // maxima.push(Pitch::new(0, threshold)) (:452) carries the largest index; it enters the list first so
-    // that the pruning bound below is armed from the start
+    // that the pruning bar below is armed from the start
     { lf = 0.0; ls = threshold; li = ncand; kept = 1; }
-    // The group that would refine the tallest peak goes first: its strength usually becomes the bar that
-    // prunes everything else after one evaluation.
-    int first = 0;
+
+    // Exact top-k pruning.  The caller asked for the first kmax entries of the sorted list.  brent_maximize only
+    // ever replaces fx by a value <= fx (:162), so a candidate's final strength is <= min(f(v0), 1): v0 is its
+    // first abscissa and the "> 1 -> 1/s" reflection of :446 keeps strengths <= 1.  A candidate whose bound
+    // (keys[], or the exact f(v0) once evaluated) is strictly below the kmax-th best strength already in the
+    // list cannot be among the entries returned, and is skipped.  Candidates are taken best-bound-first, so the
+    // bar rises as early as possible; when the best remaining bound is below the bar, all the rest is too.
+    // A list that never fills (kmax >= count) keeps bar = -inf: everything is refined.
+#define VBX_BAR() ((kept == kmax) ? readlane_f64(ls, kmax - 1) : -__builtin_inf())
+    auto insert = [&](double f_g, double s_g, int c_g) {
+        if (s_g != s_g) any_nan = true;
+        const int pos = __popcll(__ballot(lane < kept && (ls > s_g || (ls == s_g && li < c_g))));
+        const double pf = from_prev_lane(lf), ps = from_prev_lane(ls);
+        const int pi = __builtin_amdgcn_update_dpp(0, li, DPP_WAVE_SHR1, 0xf, 0xf, true);
+        if (lane > pos) { lf = pf; ls = ps; li = pi; }
+        if (lane == pos) { lf = f_g; ls = s_g; li = c_g; }
+        kept = (kept + 1 < kmax) ? kept + 1 : kmax;
+    };
+    unsigned cterms = 0, cevals = 0;                // work of the 64-lane refinement (uniform)
+    bool exhausted = false;
+
+    // b) the candidate with the best bound: all 64 lanes on its sinc sums (improve_extremum, :192-229).  In a
+    // voiced frame its strength becomes the bar that retires every other candidate without an evaluation.
     {
-        double bv = -1.0e300; int bi = 0x7fffffff;
-        for (int i = lane; i < ncand; i += 64) { const double yv = ys[cand_list[i]]; if (yv > bv) { bv = yv; bi = i; } }
-        const double gm = wave_max(bv);
-        int pick = (bv == gm) ? bi : 0x7fffffff;
-        for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(pick, o, 64); pick = (other < pick) ? other : pick; }
-        first = (pick == 0x7fffffff) ? 0 : pick;
+        const int c0 = pick_best(keys, ncand, VBX_BAR(), lane);
+        if (c0 < 0) exhausted = true;
+        else {
+            double freq, nn, xmid, ymid;
+            cand_from_peak(ys, cand_list[c0], sample_rate, offset, freq, nn);
+            bool dropped = false;
+            improve_extremum_sinc<64>(ys, nvalid, ylen, offset, nx, nn, 1200, true, xmid, ymid, st, &cterms, &cevals,
+                                      VBX_BAR(), &dropped);
+            double xm, ym;
+            {
+#pragma clang fp contract(off)
+                xm = xmid + (double)offset;                                   // :445
+                ym = ymid;
+                if (ym > 1.) ym = 1. / ym;                                    // :446
+                xm = sample_rate / xm;                                        // :447
+            }
+            if (!dropped) insert(xm, ym, c0);
+        }
     }
-    int ci = -1, it = 0, next = 0;
+
+    // c) the others, PG lanes per candidate, 64/PG at a time: every lane of a group runs the reference's Brent
+    // iteration on identical values and takes the next-best candidate as soon as its own has converged.
+    // Finished candidates enter the lane-resident list ordered by (strength desc, candidate index asc) == the
+    // reference's stable sort (:453).
+    int ci = -1, it = 0;
     unsigned nterms = 0, nevals = 0;                // work actually executed (group leaders' counts are summed)
     bool special = false;
     double ba = 0., bb = 0., v = 0., w = 0., x = 0., fv = 0., fw = 0., fx = 0., xmid = 0., ymid = 0.;
@@ -420,32 +572,27 @@ __global__ __launch_bounds__(64) void pitch_refine_kernel(
                                          : (PG == 32) ? 0x0000000100000001ull : (PG == 4) ? 0x1111111111111111ull : 1ull;
     for (;;) {
 #pragma clang fp contract(off)   // the scalar Brent arithmetic stays bit-identical to the unfused CPU arithmetic
-        {   // hand out candidates to idle groups, in group order: sequence number q -> candidate index
-            const bool idle = ci < 0;
-            const unsigned long long im = __ballot(idle) & LEADERS;
-            const int rank = __popcll(im & ((1ull << (gid * PG)) - 1ull));
-            if (idle && next + rank < ncand) {
-                const int q = next + rank;
-                ci = (q == 0) ? first : ((q - 1 < first) ? q - 1 : q);
-                double freq, nn;
-                cand_from_peak(ys, cand_list[ci], sample_rate, offset, freq, nn);
-                it = 0; special = false; xmid = 0.; ymid = 0.;
-                if (nn == 0.) { special = true; xmid = 0.; ymid = ys[0]; }                              // :193
-                else if (nn >= (double)nx) { special = true; xmid = (double)nx; ymid = y_at(ys, nvalid, nx - 1); }   // :194
-                else if (!(nn - 1. < nn + 1.)) { special = true; st |= 4; }                             // assert!(a < b), :113
-                ba = nn - 1.; bb = nn + 1.;
+        {   // hand the best remaining candidates to the idle groups, in group order
+            unsigned long long im = __ballot(ci < 0) & LEADERS;
+            while (im != 0ull && !exhausted) {
+                const int c = pick_best(keys, ncand, VBX_BAR(), lane);
+                if (c < 0) { exhausted = true; break; }
+                const int g = __builtin_ctzll(im) / PG;
+                im &= im - 1ull;
+                if (gid == g) {
+                    ci = c;
+                    double freq, nn;
+                    cand_from_peak(ys, cand_list[ci], sample_rate, offset, freq, nn);
+                    it = 0; special = false; xmid = 0.; ymid = 0.;
+                    if (nn == 0.) { special = true; xmid = 0.; ymid = ys[0]; }                              // :193
+                    else if (nn >= (double)nx) { special = true; xmid = (double)nx; ymid = y_at(ys, nvalid, nx - 1); }   // :194
+                    else if (!(nn - 1. < nn + 1.)) { special = true; st |= 4; }                             // assert!(a < b), :113
+                    ba = nn - 1.; bb = nn + 1.;
+                }
             }
-            const int handed = __popcll(im);
-            next = (next + handed < ncand) ? next + handed : ncand;
         }
         if (!__any(ci >= 0)) break;
-
-        // Pruning bar: the caller asked for the first kmax entries of the sorted list.  brent_maximize only
-        // ever replaces fx by a value <= fx (:162), so a candidate's final strength is <= min(f(v0), 1) where
-        // v0 is its first abscissa (the "> 1 -> 1/s" reflection of :446 keeps strengths <= 1).  If that is
-        // strictly below the kmax-th best strength already in the list, the candidate cannot be among the
-        // entries returned and its refinement is skipped.  The returned entries are exactly the reference's.
-        const double bar = (kept == kmax) ? readlane_f64(ls, kmax - 1) : -1.0e300;
+        const double bar = VBX_BAR();
 
         const double golden = 1. - 0.6180339887498948482045868343656381177203091798057628621;
         const double sqrt_epsilon = 1.4901161193847656e-08, eps = 2.220446049250313e-16, tol = 1e-10;
@@ -513,19 +660,12 @@ __global__ __launch_bounds__(64) void pitch_refine_kernel(
             while (fm) {
                 const int ld = __builtin_ctzll(fm);
                 fm &= fm - 1;
-                const double f_g = readlane_f64(cf, ld), s_g = readlane_f64(cs, ld);
-                const int c_g = __builtin_amdgcn_readlane(ci, ld);
-                if (s_g != s_g) any_nan = true;
-                const int pos = __popcll(__ballot(lane < kept && (ls > s_g || (ls == s_g && li < c_g))));
-                const double pf = from_prev_lane(lf), ps = from_prev_lane(ls);
-                const int pi = __builtin_amdgcn_update_dpp(0, li, DPP_WAVE_SHR1, 0xf, 0xf, true);
-                if (lane > pos) { lf = pf; ls = ps; li = pi; }
-                if (lane == pos) { lf = f_g; ls = s_g; li = c_g; }
-                kept = (kept + 1 < kmax) ? kept + 1 : kmax;
+                insert(readlane_f64(cf, ld), readlane_f64(cs, ld), __builtin_amdgcn_readlane(ci, ld));
             }
             if (finished) ci = -1;
         }
     }
+#undef VBX_BAR
     const int total_cand = ncand + 1;
     st = __any(st & 4) ? 4 : 0;                     // a panic in any group is a panic of the frame
     if (total_cand > 1 && (any_nan || threshold != threshold)) st |= 8;   // partial_cmp().unwrap() panics (Q10)
@@ -549,7 +689,7 @@ __global__ __launch_bounds__(64) void pitch_refine_kernel(
         if (lane == 0) {
             unsigned long long *w = work + 4 * (f & (PITCH_WORK_SLOTS - 1));
             atomicAdd(w + 0, 1ull); atomicAdd(w + 1, (unsigned long long)ncand);
-            atomicAdd(w + 2, ev); atomicAdd(w + 3, te);
+            atomicAdd(w + 2, ev + cevals); atomicAdd(w + 3, te + cterms);
         }
     }
 }
@@ -586,7 +726,10 @@ __global__ __launch_bounds__(64) void extremum_points_kernel(const double *__res
 }
 
 size_t pitch_lds_bytes(int n) { return (size_t)(n + autocorr_pad(n)) * sizeof(double); }
-static size_t refine_lds_bytes(int n) { return (size_t)(n + Y_PAD) * sizeof(double) + (size_t)(n / 4 + 8) * sizeof(int); }
+static size_t refine_lds_bytes(int n) {
+    const int nblk = (n + 3) >> 2;
+    return (size_t)(n + Y_PAD + ((nblk + 2) & ~1) + (n / 4 + 8)) * sizeof(double) + (size_t)(n / 4 + 8) * sizeof(int);
+}
 
 // frames per chunk of the lag-curve scratch (about 2.5 GB of HBM, at least 4096 frames)
 long pitch_chunk_frames(int n, long n_frames) {
