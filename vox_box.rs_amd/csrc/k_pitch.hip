@@ -308,19 +308,21 @@ __global__ __launch_bounds__(64) void pitch_lag_kernel(
     const long f = blockIdx.x;
     if (f >= n_frames) return;
     const int lane = lane_id();
-    double *xs = smem;                              // [n + pad] windowed samples, zero padded
+    double *zs = smem;                              // padded image of the windowed frame (vbx_autocorr.hpp)
     const double *xf = x + f * stride;
-    const int total = n + autocorr_pad(n);
-    for (int i = lane; i < total; i += 64) {
-        double v = 0.0;
-        if (i < n) { v = xf[i]; if (window != nullptr) v *= window[i]; }
-        xs[i] = v;
+    const int total = ac_mf_lds_doubles(n);
+    for (int p = lane; p < total; p += 64) zs[p] = 0.0;
+    wave_sync();
+    for (int i = lane; i < n; i += 64) {
+        double v = xf[i];
+        if (window != nullptr) v *= window[i];
+        zs[ac_mf_phys(i)] = v;
     }
-    __syncthreads();
-    const double x0 = xs[0];
+    wave_sync();
+    const double x0 = zs[ac_mf_phys(0)];
     double *ro = r_out + f * (long)n;
-    autocorr_tiles(xs, n, n, [&](int lag, double s) {          // self.autocorrelate(self.len()), :403
-        ro[lag] = (s - x0 * xs[lag]) + x0;
+    autocorr_mfma(zs, n, n, [&](int lag, double s) {           // self.autocorrelate(self.len()), :403
+        ro[lag] = (s - x0 * zs[ac_mf_phys(lag)]) + x0;
     });
 }
 
@@ -725,7 +727,7 @@ __global__ __launch_bounds__(64) void extremum_points_kernel(const double *__res
     }
 }
 
-size_t pitch_lds_bytes(int n) { return (size_t)(n + autocorr_pad(n)) * sizeof(double); }
+size_t pitch_lds_bytes(int n) { return (size_t)ac_mf_lds_doubles(n) * sizeof(double); }
 static size_t refine_lds_bytes(int n) {
     const int nblk = (n + 3) >> 2;
     return (size_t)(n + Y_PAD + ((nblk + 2) & ~1) + (n / 4 + 8)) * sizeof(double) + (size_t)(n / 4 + 8) * sizeof(int);
