@@ -296,46 +296,18 @@ __device__ __forceinline__ void improve_extremum_sinc(const double *y, int nvali
 }
 
 // ------------------------------------------------------------------------------------------
-// pitch, kernel 1: frame -> raw autocorrelation r = self.autocorrelate(self.len()) (src/periodic.rs:403)
-// One wavefront per frame, frame staged in LDS (the only LDS user: 12 waves/CU), lag tiles
-// (vbx_autocorr.hpp); each lane stores its lags straight to a chunk-sized scratch in HBM.  Kernel 2
-// normalises while it loads the row:  y[i] = (r[i] / max|r|) / w_lag[i]  (:404-408).
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void pitch_lag_kernel(
-    const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
-    double *__restrict__ r_out) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const long f = blockIdx.x;
-    if (f >= n_frames) return;
-    const int lane = lane_id();
-    double *zs = smem;                              // padded image of the windowed frame (vbx_autocorr.hpp)
-    const double *xf = x + f * stride;
-    const int total = ac_mf_lds_doubles(n);
-    for (int p = lane; p < total; p += 64) zs[p] = 0.0;
-    wave_sync();
-    for (int i = lane; i < n; i += 64) {
-        double v = xf[i];
-        if (window != nullptr) v *= window[i];
-        zs[ac_mf_phys(i)] = v;
-    }
-    wave_sync();
-    const double x0 = zs[ac_mf_phys(0)];
-    double *ro = r_out + f * (long)n;
-    autocorr_mfma(zs, n, n, [&](int lag, double s) {           // self.autocorrelate(self.len()), :403
-        ro[lag] = (s - x0 * zs[ac_mf_phys(lag)]) + x0;
-    });
-}
-
-// ------------------------------------------------------------------------------------------
-// pitch, kernel 2: lag curve -> candidates (src/periodic.rs:411-455)
-// One wavefront per frame; y row in LDS (zero padded, standing for resize(2N, 0)).
+// Pitched::pitch, one wavefront per frame, one kernel (src/periodic.rs:396-455):
+//  1) the windowed frame is staged in LDS as the padded image of vbx_autocorr.hpp and
+//     r = self.autocorrelate(self.len()) (:403) runs on the FP64 matrix cores;
+//  2) y[i] = (r[i] / max|r|) / w_lag[i] (:404-408) replaces the image in LDS (zero padded, standing for
+//     resize(2N, 0), :411);
 //  a) peak scan, lane-parallel: strict local maxima of y[0..N/2) (Q4), the "parabolic" lag (Q5) and
 //     the frequency filter (:439); survivors are compacted in index order into an LDS list.
 //     The sinc(30) strength of :433 is dead in the reference (overwritten at :448 for every
 //     candidate that passes the filter, dropped otherwise) and is not evaluated.
-//  b) refinement in rounds of 64/PG candidates, PG lanes each (improve_extremum_sinc).
-//  c) results inserted in candidate order into a lane-resident list kept sorted by descending
-//     strength == the reference's stable sort (:453); the unvoiced candidate goes in last (:452).
+//  b, c) refinement (improve_extremum_sinc) and the sorted candidate list, see below.
+// Phase 1 keeps the matrix pipe busy and phases a-c the vector ALU; the wavefronts resident on a SIMD are in
+// different phases of different frames, so both pipes work at the same time.
 // ------------------------------------------------------------------------------------------
 constexpr int Y_PAD = 64;
 constexpr int PG = 16;                          // lanes per candidate
@@ -427,31 +399,72 @@ __device__ __forceinline__ int pick_best(double *keys, int ncand, double bar, in
     return pick;
 }
 
-__global__ __launch_bounds__(64) void pitch_refine_kernel(
-    const double *__restrict__ r_in, const double *__restrict__ lag_window, long n_frames, int n,
-    double sample_rate, double threshold, double fmin, double fmax,
+// ALIAS: a single autocorrelation pass (n <= AC_MF_NT * 256): the lag values wait in registers while y takes the
+// image's place in LDS.  Otherwise y has its own region.
+template <bool ALIAS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void pitch_kernel(
+    const double *__restrict__ frames, long n_frames, int n, long stride, const double *__restrict__ window,
+    const double *__restrict__ lag_window, double sample_rate, double threshold, double fmin, double fmax,
     int kmax, pitch_t *__restrict__ out_cand, int32_t *__restrict__ out_count, int32_t *__restrict__ status,
     unsigned long long *__restrict__ work) {
-    extern __shared__ double ys[];                  // y[n + Y_PAD] | p16[nblk + 1 (+pad)] | keys[n/4 + 8] | candidate list (ints)
+    extern __shared__ __attribute__((aligned(16))) double smem[];
     const long f = blockIdx.x;
     if (f >= n_frames) return;
     const int lane = lane_id();
+    double *zs = smem;                              // padded image of the windowed frame (vbx_autocorr.hpp)
+    // y[n + Y_PAD] | p16[nblk + 1 (+pad)] | keys[n/4 + 8] | candidate list (ints)
+    double *ys = ALIAS ? smem : smem + ((ac_mf_lds_doubles(n) + 1) & ~1);
     const int nblk = (n + 3) >> 2;                   // blocks of 4 lags for the |y| prefix sums
     double *p16 = ys + n + Y_PAD;
     double *keys = p16 + ((nblk + 2) & ~1);
     int *cand_list = reinterpret_cast<int *>(keys + (n / 4 + 8));
-    const double *ri = r_in + f * (long)n;
-    double amax = -1.0;                             // max_amplitude over ALL lags (Q2; NaN never wins)
-    for (int i = lane; i < n + Y_PAD; i += 64) {
-        const double r = (i < n) ? ri[i] : 0.0;
-        ys[i] = r;
-        const double a = fabs(r);
-        amax = (a > amax) ? a : amax;
+    {
+        const double *xf = frames + f * stride;
+        const int total = ac_mf_lds_doubles(n);
+        for (int p = lane; p < total; p += 64) zs[p] = 0.0;
+        wave_sync();
+        for (int i = lane; i < n; i += 64) {
+            double v = xf[i];
+            if (window != nullptr) v *= window[i];
+            zs[ac_mf_phys(i)] = v;
+        }
+        wave_sync();
     }
-    amax = wave_max(amax);
-    const double scale = 1.0 / amax;                // normalize (:404), then / lag window (:406-408)
-    for (int i = lane; i < n; i += 64) ys[i] = (ys[i] * scale) / lag_window[i];
-    __syncthreads();
+    const double x0 = zs[ac_mf_phys(0)];
+    double amax = -1.0;                             // max_amplitude over ALL lags (Q2; NaN never wins)
+    if (ALIAS) {
+        double rv[AC_MF_NT * 4];
+        autocorr_mfma(zs, n, n, [&](int slot, int lag, double s) {          // self.autocorrelate(self.len()), :403
+            const double r = (lag < n) ? (s - x0 * zs[ac_mf_phys(lag)]) + x0 : 0.0;
+            rv[slot] = r;
+            const double a = fabs(r);
+            amax = (lag < n && a > amax) ? a : amax;
+        });
+        wave_sync();                                // every lane is done with the image
+        amax = wave_max(amax);
+        const double scale = 1.0 / amax;            // normalize (:404), then / lag window (:406-408)
+#pragma unroll
+        for (int slot = 0; slot < AC_MF_NT * 4; slot++) {
+            const int lag = (slot >> 2) * AC_MF_TILE + 64 * (slot & 3) + lane;
+            if (lag < n) ys[lag] = (rv[slot] * scale) / lag_window[lag];
+        }
+        ys[n + lane] = 0.0;                         // Y_PAD == 64
+    } else {
+        autocorr_mfma(zs, n, n, [&](int, int lag, double s) {
+            if (lag < n) {
+                const double r = (s - x0 * zs[ac_mf_phys(lag)]) + x0;
+                ys[lag] = r;
+                const double a = fabs(r);
+                amax = (a > amax) ? a : amax;
+            }
+        });
+        wave_sync();
+        amax = wave_max(amax);
+        const double scale = 1.0 / amax;
+        for (int i = lane; i < n; i += 64) ys[i] = (ys[i] * scale) / lag_window[i];
+        ys[n + lane] = 0.0;
+    }
+    wave_sync();
 
     const int b = (int)floor(0.5 * (double)n);      // brent_ixmax, :414
     const int offset = -b - 1;                      // :429
@@ -476,7 +489,7 @@ __global__ __launch_bounds__(64) void pitch_refine_kernel(
         if (pass) cand_list[ncand + __popcll(mask & ((1ull << lane) - 1ull))] = k;
         ncand += __popcll(mask);
     }
-    __syncthreads();
+    wave_sync();
 
     // a') first-evaluation bounds.  p16: prefix sums of |y| over blocks of 4; keys[c]: upper bound of candidate c's strength
     {
@@ -727,32 +740,25 @@ __global__ __launch_bounds__(64) void extremum_points_kernel(const double *__res
     }
 }
 
-size_t pitch_lds_bytes(int n) { return (size_t)ac_mf_lds_doubles(n) * sizeof(double); }
-static size_t refine_lds_bytes(int n) {
+size_t pitch_lds_bytes(int n) {
     const int nblk = (n + 3) >> 2;
-    return (size_t)(n + Y_PAD + ((nblk + 2) & ~1) + (n / 4 + 8)) * sizeof(double) + (size_t)(n / 4 + 8) * sizeof(int);
-}
-
-// frames per chunk of the lag-curve scratch (about 2.5 GB of HBM, at least 4096 frames)
-long pitch_chunk_frames(int n, long n_frames) {
-    long c = (long)(2.5e9 / (8.0 * (double)n));
-    if (c < 4096) c = 4096;
-    return c < n_frames ? c : n_frames;
+    const size_t refine = (size_t)(n + Y_PAD + ((nblk + 2) & ~1) + (n / 4 + 8)) * sizeof(double) + (size_t)(n / 4 + 8) * sizeof(int);
+    const size_t image = (size_t)((ac_mf_lds_doubles(n) + 1) & ~1) * sizeof(double);
+    if (n <= AC_MF_NT * AC_MF_TILE) return image > refine ? image : refine;
+    return image + refine;
 }
 
 void launch_pitch(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                   const double *lag_window, double sample_rate, double threshold, double fmin, double fmax,
-                  int kmax, pitch_t *out_cand, int32_t *out_count, int32_t *status, double *lag_ws, long chunk,
-                  unsigned long long *work) {
-    for (long f0 = 0; f0 < F; f0 += chunk) {
-        const long fc = (F - f0 < chunk) ? (F - f0) : chunk;
-        hipLaunchKernelGGL(pitch_lag_kernel, dim3((unsigned)fc), dim3(64), pitch_lds_bytes(n), s,
-                           x + f0 * stride, fc, n, stride, window, lag_ws);
-        hipLaunchKernelGGL(pitch_refine_kernel, dim3((unsigned)fc), dim3(64), refine_lds_bytes(n), s,
-                           lag_ws, lag_window, fc, n, sample_rate, threshold, fmin, fmax, kmax,
-                           out_cand + f0 * (long)kmax, out_count ? out_count + f0 : nullptr, status ? status + f0 : nullptr,
-                           work);
-    }
+                  int kmax, pitch_t *out_cand, int32_t *out_count, int32_t *status, unsigned long long *work) {
+    if (n <= AC_MF_NT * AC_MF_TILE)
+        hipLaunchKernelGGL((pitch_kernel<true>), dim3((unsigned)F), dim3(64), pitch_lds_bytes(n), s,
+                           x, F, n, stride, window, lag_window, sample_rate, threshold, fmin, fmax, kmax,
+                           out_cand, out_count, status, work);
+    else
+        hipLaunchKernelGGL((pitch_kernel<false>), dim3((unsigned)F), dim3(64), pitch_lds_bytes(n), s,
+                           x, F, n, stride, window, lag_window, sample_rate, threshold, fmin, fmax, kmax,
+                           out_cand, out_count, status, work);
 }
 
 void launch_sinc_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *xs, long m,

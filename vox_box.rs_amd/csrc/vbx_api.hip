@@ -570,10 +570,6 @@ int vbx_pitch_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_l
     const double *lagw = nullptr;
     rc = get_window_dev(ctx, VBX_WINDOW_HANNING_LAG, frame_len, &lagw);
     if (rc != VBX_SUCCESS) return rc;
-    const long chunk = pitch_chunk_frames((int)frame_len, (long)n_frames);
-    void *lag_ws = nullptr;
-    rc = ws_get(ctx, vbx_ctx::WS_LAG, (size_t)chunk * frame_len * sizeof(double), &lag_ws);
-    if (rc != VBX_SUCCESS) return rc;
     if (ctx->prof && !ctx->pitch_work) {
         const size_t wb = PITCH_WORK_SLOTS * 4 * sizeof(unsigned long long);
         VBX_HIP(ctx, hipMalloc((void **)&ctx->pitch_work, wb));
@@ -582,7 +578,7 @@ int vbx_pitch_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_l
     {
         Prof p(ctx, "pitch");
         launch_pitch(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, lagw, sample_rate, threshold,
-                     fmin, fmax, (int)kmax, (pitch_t *)out_cand, out_count, status, (double *)lag_ws, chunk,
+                     fmin, fmax, (int)kmax, (pitch_t *)out_cand, out_count, status,
                      ctx->prof ? ctx->pitch_work : nullptr);
     }
     return check_launch(ctx, __func__);

@@ -117,8 +117,9 @@ __device__ __forceinline__ int ac_mf_segment(const double *(&pa)[4], const doubl
     return a;
 }
 
-// zs: LDS image described above.  Calls emit(lag, S_lag) for every lag in [0, n_lags), 64 consecutive lags per call
-// group (lane l of a call group owns lag base + l).
+// zs: LDS image described above.  Calls emit(slot, lag, S_lag) for the AC_MF_NT*4 accumulator registers of every
+// pass: slot = 4 t + r is a compile-time index (results can be kept in a register array), lag = l0 + 256 t + 64 r +
+// lane may be >= n_lags (the caller guards).
 template <typename Emit>
 __device__ __forceinline__ void autocorr_mfma(const double *zs, int n, int n_lags, Emit emit) {
     const int lane = lane_id();
@@ -148,8 +149,7 @@ __device__ __forceinline__ void autocorr_mfma(const double *zs, int n, int n_lag
         for (int t = 0; t < AC_MF_NT; t++) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int lag = l0 + t * AC_MF_TILE + 64 * r + lane;
-                if (lag < n_lags) emit(lag, acc[t][r]);
+                emit(4 * t + r, l0 + t * AC_MF_TILE + 64 * r + lane, acc[t][r]);
             }
         }
     }

@@ -45,14 +45,11 @@ void launch_tracker(hipStream_t s, const res_t *res, long F, int n_res, const in
 
 // k_pitch.hip
 size_t pitch_lds_bytes(int n);
-long pitch_chunk_frames(int n, long n_frames);
 // profiling counters of the refine kernel: [PITCH_WORK_SLOTS][4] = frames, candidates, sinc evaluations, sinc terms
 constexpr int PITCH_WORK_SLOTS = 64;
 void launch_pitch(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                   const double *lag_window, double sample_rate, double threshold, double fmin, double fmax,
-                  int kmax, pitch_t *out_cand, int32_t *out_count, int32_t *status,
-                  double *lag_ws /* [chunk][n] scratch */, long chunk,
-                  unsigned long long *work);
+                  int kmax, pitch_t *out_cand, int32_t *out_count, int32_t *status, unsigned long long *work);
 void launch_sinc_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *xs, long m,
                         long depth, double *out, int32_t *status);
 void launch_extremum_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *ix, long m,
