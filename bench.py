@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--hours", type=float, default=12.5, help="hours of 48 kHz audio PER GPU (pipeline / config3)")
     ap.add_argument("--frames", type=int, default=1_000_000, help="dense frames per GPU (config2 / config4)")
     ap.add_argument("--workload", default="pipeline", choices=["pipeline", "config2", "config3", "config4", "frontend"])
+    ap.add_argument("--kmax", type=int, default=1, help="pitch candidates kept per frame (1 = PitchExtractor output; "
+                    "64 = the reference's full sorted list, which disables the exact top-k pruning)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
@@ -231,7 +233,7 @@ def main():
     seg = np.arange(0, F, SEG_FRAMES, dtype=np.int64)
 
     # outputs (torch owns the device memory; the C ABI gets raw pointers)
-    o_cand = torch.empty((F, 1, 2), dtype=f64, device=dev)
+    o_cand = torch.empty((F, args.kmax, 2), dtype=f64, device=dev)
     o_cnt = torch.empty(F, dtype=torch.int32, device=dev)
     o_pst = torch.empty(F, dtype=torch.int32, device=dev)
     o_r = torch.empty((F, P + 1), dtype=f64, device=dev)
@@ -255,12 +257,12 @@ def main():
             side.mfcc(audio, 13, (100.0, 8000.0), SR, frame_len=frame_len, stride=stride, n_frames=F, window=win,
                       out=(o_mfcc, o_mst))
         if wl in ("pipeline", "config3"):
-            vb.pitch(audio, SR, 0.2, 75.0, 600.0, kmax=1, frame_len=frame_len, stride=stride, n_frames=F, window=win,
+            vb.pitch(audio, SR, 0.2, 75.0, 600.0, kmax=args.kmax, frame_len=frame_len, stride=stride, n_frames=F, window=win,
                      out=(o_cand, o_cnt, o_pst))
         if wl == "pipeline":
             tstream.wait_stream(sstream)            # join before anything consumes the records
         if world > 1:   # per-frame records to rank 0 over RCCL/xGMI (no other collective on the path)
-            rec = torch.cat([o_cand.view(F, 2), o_form.view(F, 8), o_mfcc, o_a], dim=1)
+            rec = torch.cat([o_cand[:, 0, :], o_form.view(F, 8), o_mfcc, o_a], dim=1)
             shard.gather_records(rec, counts, dst=0)
 
     def fence():
@@ -303,7 +305,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "frames_per_gpu": F, "frame_len": frame_len, "hop": stride,
-                       "lpc_order": P, "mfcc": 13, "parallelism": f"frame-range split x{world}, RCCL gather to rank 0"},
+                       "lpc_order": P, "mfcc": 13, "pitch_kmax": args.kmax, "parallelism": f"frame-range split x{world}, RCCL gather to rank 0"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_frame": bytes_per_frame, "ms_avg": dom_ms},
