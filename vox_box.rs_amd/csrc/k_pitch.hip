@@ -4,15 +4,14 @@
 //            :192-229 (improve_extremum), :362-375 (local_maxima), :396-455 (pitch),
 //            src/waves.rs:44-75 (max_amplitude / normalize).  Quirks Q1-Q10 reproduced.
 //
-// Two kernels, one wavefront per frame each: (1) the windowed frame is staged in LDS and the
-// all-lag autocorrelation runs as lag tiles (vbx_autocorr.hpp), giving the normalised /
-// lag-window-divided curve y; (2) y sits in LDS, the candidate peaks are compacted in index
-// order, and they are refined PG lanes per candidate, 64/PG candidates at a time: every lane of
-// a group runs the reference's Brent iteration on identical values (group sums are made
-// bit-identical across the group), while each sinc evaluation -- the dominant cost,
-// 2*(depth+1) terms -- is spread over the group's lanes and reduced with DPP.  The path is
-// FP64-VALU bound (hundreds of flop per byte); HBM traffic is the 3.8 KB of new samples per
-// frame plus the 19 KB round trip of y between the kernels.
+// One kernel, one wavefront per frame: (1) the windowed frame is staged in LDS and the all-lag autocorrelation
+// runs on the FP64 matrix cores (vbx_autocorr.hpp), giving the normalised / lag-window-divided curve y, which
+// replaces the frame in LDS; (2) the candidate peaks are compacted in index order, bounded from above (one lane
+// per candidate) and refined best-bound-first, one candidate at a time: every lane runs the reference's Brent
+// iteration on identical values (wave sums are bit-identical in all lanes), while each sinc evaluation -- the
+// dominant cost, 2*(depth+1) terms -- is spread over the 64 lanes and reduced with DPP.  Candidates that provably
+// cannot reach the returned top-kmax are skipped (exact).  The path is FP64 bound (hundreds of flop per byte);
+// HBM traffic is the frame's samples in and 16 bytes per kept candidate out.
 #include "vbx_autocorr.hpp"
 #include "vbx_kernels.hpp"
 
@@ -310,8 +309,8 @@ __device__ __forceinline__ void improve_extremum_sinc(const double *y, int nvali
 // different phases of different frames, so both pipes work at the same time.
 // ------------------------------------------------------------------------------------------
 constexpr int Y_PAD = 64;
-constexpr int PG = 16;                          // lanes per candidate
-constexpr int PNG = 64 / PG;                    // candidates per round
+constexpr int PG = 16;                          // lanes per query point (sinc_points / extremum_points kernels)
+constexpr int PNG = 64 / PG;                    // points per wavefront
 
 __device__ __forceinline__ void cand_from_peak(const double *ys, int kk, double sample_rate, int offset,
                                                double &freq, double &nn) {
@@ -526,7 +525,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     int kept = 0;
     double lf = 0.0, ls = 0.0;                      // lane j holds sorted candidate j
     bool any_nan = false;
-    const int gid = lane / PG;
     int li = 0;                                     // candidate index of the list entry held by this lane
     // maxima.push(Pitch::new(0, threshold)) (:452) carries the largest index; it enters the list first so
     // that the pruning bar below is armed from the start
@@ -549,140 +547,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         if (lane == pos) { lf = f_g; ls = s_g; li = c_g; }
         kept = (kept + 1 < kmax) ? kept + 1 : kmax;
     };
-    unsigned cterms = 0, cevals = 0;                // work of the 64-lane refinement (uniform)
-    bool exhausted = false;
+    unsigned cterms = 0, cevals = 0;                // sinc terms / evaluations executed (uniform)
 
-    // b) the candidate with the best bound: all 64 lanes on its sinc sums (improve_extremum, :192-229).  In a
-    // voiced frame its strength becomes the bar that retires every other candidate without an evaluation.
-    {
-        const int c0 = pick_best(keys, ncand, VBX_BAR(), lane);
-        if (c0 < 0) exhausted = true;
-        else {
-            double freq, nn, xmid, ymid;
-            cand_from_peak(ys, cand_list[c0], sample_rate, offset, freq, nn);
-            bool dropped = false;
-            improve_extremum_sinc<64>(ys, nvalid, ylen, offset, nx, nn, 1200, true, xmid, ymid, st, &cterms, &cevals,
-                                      VBX_BAR(), &dropped);
-            double xm, ym;
-            {
-#pragma clang fp contract(off)
-                xm = xmid + (double)offset;                                   // :445
-                ym = ymid;
-                if (ym > 1.) ym = 1. / ym;                                    // :446
-                xm = sample_rate / xm;                                        // :447
-            }
-            if (!dropped) insert(xm, ym, c0);
-        }
-    }
-
-    // c) the others, PG lanes per candidate, 64/PG at a time: every lane of a group runs the reference's Brent
-    // iteration on identical values and takes the next-best candidate as soon as its own has converged.
-    // Finished candidates enter the lane-resident list ordered by (strength desc, candidate index asc) == the
-    // reference's stable sort (:453).
-    int ci = -1, it = 0;
-    unsigned nterms = 0, nevals = 0;                // work actually executed (group leaders' counts are summed)
-    bool special = false;
-    double ba = 0., bb = 0., v = 0., w = 0., x = 0., fv = 0., fw = 0., fx = 0., xmid = 0., ymid = 0.;
-    constexpr unsigned long long LEADERS = (PG == 16) ? 0x0001000100010001ull : (PG == 8) ? 0x0101010101010101ull
-                                         : (PG == 32) ? 0x0000000100000001ull : (PG == 4) ? 0x1111111111111111ull : 1ull;
+    // b, c) refinement, best bound first, one candidate at a time with all 64 lanes on its sinc sums
+    // (improve_extremum, :192-229): every lane runs the reference's Brent iteration on identical values (the wave
+    // sums are bit-identical in all lanes).  In a voiced frame the first strength becomes the bar that retires every
+    // other candidate without an evaluation.  Finished candidates enter the lane-resident list ordered by
+    // (strength desc, candidate index asc) == the reference's stable sort (:453).  One path for every candidate,
+    // whatever kmax is: a candidate's result never depends on which others are refined.
     for (;;) {
-#pragma clang fp contract(off)   // the scalar Brent arithmetic stays bit-identical to the unfused CPU arithmetic
-        {   // hand the best remaining candidates to the idle groups, in group order
-            unsigned long long im = __ballot(ci < 0) & LEADERS;
-            while (im != 0ull && !exhausted) {
-                const int c = pick_best(keys, ncand, VBX_BAR(), lane);
-                if (c < 0) { exhausted = true; break; }
-                const int g = __builtin_ctzll(im) / PG;
-                im &= im - 1ull;
-                if (gid == g) {
-                    ci = c;
-                    double freq, nn;
-                    cand_from_peak(ys, cand_list[ci], sample_rate, offset, freq, nn);
-                    it = 0; special = false; xmid = 0.; ymid = 0.;
-                    if (nn == 0.) { special = true; xmid = 0.; ymid = ys[0]; }                              // :193
-                    else if (nn >= (double)nx) { special = true; xmid = (double)nx; ymid = y_at(ys, nvalid, nx - 1); }   // :194
-                    else if (!(nn - 1. < nn + 1.)) { special = true; st |= 4; }                             // assert!(a < b), :113
-                    ba = nn - 1.; bb = nn + 1.;
-                }
-            }
-        }
-        if (!__any(ci >= 0)) break;
         const double bar = VBX_BAR();
-
-        const double golden = 1. - 0.6180339887498948482045868343656381177203091798057628621;
-        const double sqrt_epsilon = 1.4901161193847656e-08, eps = 2.220446049250313e-16, tol = 1e-10;
-        bool finished = false, need = false, pruned = false;
-        double t = 0.;
-        if (ci >= 0) {
-            if (special) finished = true;
-            else if (it == 0) { v = ba + golden * (bb - ba); t = v; need = true; }
-            else {
-                const double range = bb - ba;
-                const double middle_range = (ba + bb) * 0.5;
-                const double tol_act = sqrt_epsilon * fabs(x) + tol / 3.;
-                if (it > 60 || fabs(x - middle_range) + range * 0.5 <= 2. * tol_act) { finished = true; xmid = x; ymid = fx; }
-                else {
-                    double new_step = (x < middle_range) ? golden * (bb - x) : golden * (ba - x);
-                    if (fabs(x - w) >= tol_act) {
-                        const double tt = (x - w) * (fx - fv);
-                        double q = (x - v) * (fx - fw);
-                        double pp = (x - v) * q - (x - w) * tt;
-                        q = 2. * q - tt;
-                        if (q > 0.) pp = -pp; else q = -q;
-                        if (fabs(pp) < fabs(new_step * q) && pp > q * (ba - x + 2. * tol_act) && pp < q * (bb - x - 2. * tol_act))
-                            new_step = pp / q;
-                    }
-                    if (fabs(new_step) < tol_act) new_step = (new_step > 0.) ? tol_act : -tol_act;
-                    t = x + new_step;
-                    need = true;
-                }
-            }
+        const int c = pick_best(keys, ncand, bar, lane);
+        if (c < 0) break;
+        double freq, nn, xmid, ymid;
+        cand_from_peak(ys, cand_list[c], sample_rate, offset, freq, nn);
+        bool dropped = false;
+        improve_extremum_sinc<64>(ys, nvalid, ylen, offset, nx, nn, 1200, true, xmid, ymid, st, &cterms, &cevals, bar, &dropped);
+        if (dropped) continue;
+        double xm, ym;
+        {
+#pragma clang fp contract(off)
+            xm = xmid + (double)offset;                                   // :445
+            ym = ymid;
+            if (ym > 1.) ym = 1. / ym;                                    // :446
+            xm = sample_rate / xm;                                        // :447
         }
-        const double ft = sinc_interp<PG>(ys, nvalid, ylen, offset, nx, t, 1200, need, st, &nterms);
-        nevals += need ? 1u : 0u;
-        if (need) {
-            if (it == 0) {
-                x = v; w = v; fv = ft; fx = ft; fw = ft; it = 1;
-                const double ub = (ft <= 1.) ? ft : 1.;          // NaN -> 1: never pruned
-                // ba >= -offset: every abscissa of the bracket has its left neighbour at index >= 0, so none of
-                // the skipped evaluations could have been an out-of-bounds panic of the reference
-                if (ub < bar && ba >= (double)(-offset)) { finished = true; pruned = true; }
-            } else {
-                if (ft <= fx) {
-                    if (t < x) bb = x; else ba = x;
-                    v = w; w = x; x = t;
-                    fv = fw; fw = fx; fx = ft;
-                } else {
-                    if (t < x) ba = t; else bb = t;
-                    if (ft <= fw || fabs(w - x) < eps) {
-                        v = w; w = t;
-                        fv = fw; fw = ft;
-                    } else if (ft <= fv || fabs(v - x) < eps || fabs(v - w) < eps) {
-                        v = t;
-                        fv = ft;
-                    }
-                }
-                it++;
-            }
-        }
-        // finished candidates -> sorted list
-        if (__any(finished)) {
-            unsigned long long fm = __ballot(finished && !pruned) & LEADERS;
-            double xm = xmid + (double)offset;                                // :445
-            double ym = ymid;
-            if (ym > 1.) ym = 1. / ym;                                        // :446
-            const double cf = sample_rate / xm, cs = ym;                      // :447-448
-            while (fm) {
-                const int ld = __builtin_ctzll(fm);
-                fm &= fm - 1;
-                insert(readlane_f64(cf, ld), readlane_f64(cs, ld), __builtin_amdgcn_readlane(ci, ld));
-            }
-            if (finished) ci = -1;
-        }
+        insert(xm, ym, c);
     }
 #undef VBX_BAR
     const int total_cand = ncand + 1;
-    st = __any(st & 4) ? 4 : 0;                     // a panic in any group is a panic of the frame
+    st = __any(st & 4) ? 4 : 0;
     if (total_cand > 1 && (any_nan || threshold != threshold)) st |= 8;   // partial_cmp().unwrap() panics (Q10)
     int code = 0;
     if (st & 4) code = 4; else if (st & 8) code = 3;
@@ -697,15 +591,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         if (out_count != nullptr) out_count[f] = (code == 0) ? total_cand : 0;
         if (status != nullptr) status[f] = code;
     }
-    if (work != nullptr) {                          // profiling only: frames, candidates, sinc evaluations, sinc terms
-        const bool leader = (lane & (PG - 1)) == 0;
-        unsigned long long te = leader ? nterms : 0u, ev = leader ? nevals : 0u;
-        for (int o = 32; o > 0; o >>= 1) { te += __shfl_xor(te, o, 64); ev += __shfl_xor(ev, o, 64); }
-        if (lane == 0) {
-            unsigned long long *w = work + 4 * (f & (PITCH_WORK_SLOTS - 1));
-            atomicAdd(w + 0, 1ull); atomicAdd(w + 1, (unsigned long long)ncand);
-            atomicAdd(w + 2, ev + cevals); atomicAdd(w + 3, te + cterms);
-        }
+    if (work != nullptr && lane == 0) {             // profiling only: frames, candidates, sinc evaluations, sinc terms
+        unsigned long long *w = work + 4 * (f & (PITCH_WORK_SLOTS - 1));
+        atomicAdd(w + 0, 1ull); atomicAdd(w + 1, (unsigned long long)ncand);
+        atomicAdd(w + 2, (unsigned long long)cevals); atomicAdd(w + 3, (unsigned long long)cterms);
     }
 }
 
