@@ -474,10 +474,41 @@ def test_pitch_work_counters(vb, oracle, audio, pkg):
     assert work[64][2] >= work[64][1]                                  # unpruned: every candidate is evaluated
 
 
-@pytest.mark.parametrize("n", [64, 100, 256, 513, 2048])
+@pytest.mark.parametrize("n", [64, 100, 256, 513, 1280, 1281, 2048, 4096])   # 1280 / 1281: one / two autocorrelation passes
 def test_pitch_other_frame_lengths(vb, oracle, audio, n):
-    x = _frames(audio, n, 211, range(0, 40, 3)) * oracle.window("hanning", n)
+    x = _frames(audio, n, 211, range(0, 40, 3 if n <= 2048 else 8)) * oracle.window("hanning", n)
     assert _check_pitch(vb, oracle, x, SR, 0.45, 60.0, 2000.0, 8) == 0
+
+
+@pytest.mark.parametrize("n", [4, 5, 6, 8, 13, 16, 31])
+def test_pitch_tiny_frames(vb, oracle, audio, n):
+    """Frames of a few samples: the depth clips, the x > nx / x < 0 branches and the panics of the reference's
+    index arithmetic all live here; status, count and values must follow the oracle."""
+    x = _frames(audio, n, 7, range(0, 200, 5))
+    cand, cnt, st = vb.pitch(x, SR, 0.1, 1000.0, 30000.0, kmax=8)
+    for f in range(x.shape[0]):
+        es, ec, en = oracle.pitch(x[f], SR, 0.1, 1000.0, 30000.0)
+        assert st[f] == es and cnt[f] == (en if es == 0 else 0), (n, f, st[f], es, cnt[f], en)
+        if es == 0:
+            k = min(8, en)
+            assert np.all(np.abs(cand[f, :k, 0] - ec[:k, 0]) <= 1e-4 * np.abs(ec[:k, 0]) + 1e-12), (n, f)
+            assert np.all(np.abs(cand[f, :k, 1] - ec[:k, 1]) <= 1e-4), (n, f)
+
+
+def test_pitch_nonfinite_input(vb, oracle, audio):
+    """NaN / inf samples: the reference's sort panics on NaN strengths (status 3) -- pruning must not hide that."""
+    x = _frames(audio, N48, H48, [5, 40, 150, 260]) * oracle.window("hanning", N48)
+    x[1, 100] = np.nan
+    x[2, 7] = np.inf
+    x[3, :] = 0.0
+    for kmax in (1, 8):
+        cand, cnt, st = vb.pitch(x, SR, 0.2, 75.0, 600.0, kmax=kmax)
+        for f in range(x.shape[0]):
+            es, ec, en = oracle.pitch(x[f], SR, 0.2, 75.0, 600.0)
+            assert st[f] == es and cnt[f] == (en if es == 0 else 0), (kmax, f, st[f], es, cnt[f], en)
+    cand, cnt, st = vb.pitch(x[:1], SR, float("nan"), 75.0, 600.0, kmax=1)       # NaN threshold: unwrap() panics
+    es, ec, en = oracle.pitch(x[0], SR, float("nan"), 75.0, 600.0)
+    assert st[0] == es
 
 
 def test_pitch_edge_frames(vb, oracle):
