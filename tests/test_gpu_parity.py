@@ -70,7 +70,8 @@ def test_synth_matches_host_statement(vb, pkg, audio):
 # ---- autocorrelate / normalize / lpc --------------------------------------------------------
 
 @pytest.mark.parametrize("n,lags", [(512, 13), (512, 1), (16, 16), (100, 7), (1200, 13), (1200, 1200),
-                                    (333, 333), (2048, 17), (4096, 40), (640, 321), (64, 64), (5, 5)])
+                                    (333, 333), (2048, 17), (4096, 40), (640, 321), (64, 64), (5, 5),
+                                    (1300, 1290), (4096, 4096), (1280, 257)])     # several matrix-core passes / partial tiles
 def test_autocorrelate(vb, oracle, n, lags):
     rng = np.random.default_rng(n * 1000 + lags)
     x = rng.uniform(-1, 1, (9, n))          # rectangular frames: x[0] != 0 exercises the Q1 seed

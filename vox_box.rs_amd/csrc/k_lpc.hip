@@ -167,7 +167,8 @@ __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// All-lag path (n_lags up to frame_len): frame staged in LDS, lag tiles (vbx_autocorr.hpp).
+// Many-lag path (n_lags up to frame_len): frame staged in LDS as the padded image of vbx_autocorr.hpp, lags on the
+// FP64 matrix cores, 256 per tile; only the tiles that hold requested lags are computed.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void autocorr_tiles_kernel(
     const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
@@ -177,17 +178,20 @@ __global__ __launch_bounds__(64) void autocorr_tiles_kernel(
     if (f >= n_frames) return;
     const int lane = lane_id();
     const double *xf = x + f * stride;
-    const int total = n + autocorr_pad(n);
-    for (int i = lane; i < total; i += 64) {
-        double v = 0.0;
-        if (i < n) { v = xf[i]; if (window != nullptr) v *= window[i]; }
-        smem[i] = v;
+    double *zs = smem;
+    const int total = ac_mf_lds_doubles(n);
+    for (int p = lane; p < total; p += 64) zs[p] = 0.0;
+    wave_sync();
+    for (int i = lane; i < n; i += 64) {
+        double v = xf[i];
+        if (window != nullptr) v *= window[i];
+        zs[ac_mf_phys(i)] = v;
     }
-    __syncthreads();
-    const double x0 = smem[0];
+    wave_sync();
+    const double x0 = zs[ac_mf_phys(0)];
     double *o = out + f * (long)n_lags;
-    autocorr_tiles(smem, n, n_lags, [&](int lag, double s) {
-        o[lag] = (s - x0 * smem[lag]) + x0;
+    autocorr_mfma(zs, n, n_lags, [&](int, int lag, double s) {
+        if (lag < n_lags) o[lag] = (s - x0 * zs[ac_mf_phys(lag < n ? lag : n)]) + x0;   // lags >= n: empty sum, r = x0
     });
 }
 
@@ -274,7 +278,7 @@ void launch_autocorr_fewlags(hipStream_t s, const double *x, long F, int n, long
 
 void launch_autocorr_tiles(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                            int n_lags, double *out) {
-    const size_t lds = (size_t)(n + autocorr_pad(n)) * sizeof(double);
+    const size_t lds = (size_t)ac_mf_lds_doubles(n) * sizeof(double);
     hipLaunchKernelGGL(autocorr_tiles_kernel, dim3((unsigned)F), dim3(64), lds, s, x, F, n, stride, window, n_lags, out);
 }
 
