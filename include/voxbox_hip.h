@@ -157,7 +157,10 @@ int vbx_improve_extremum_f64(vbx_ctx *ctx, const double *y, size_t ylen, long of
  * (src/periodic.rs:356-358,396-455; local_peak/global_peak are unused by the reference).
  * out_cand: [F, kmax] candidates, stable-sorted by descending strength exactly as the
  * reference's Vec (entries past count are zero); out_count[F] = full candidate count
- * (may exceed kmax).  PitchExtractor (src/periodic.rs:337-353) output = out_cand[f*kmax + 0]. */
+ * (may exceed kmax).  PitchExtractor (src/periodic.rs:337-353) output = out_cand[f*kmax + 0].
+ * Only the kmax entries that are returned are guaranteed to have been refined: a candidate whose strength
+ * is provably below the kmax-th best is skipped (exact -- the returned entries, the count and the status
+ * are the reference's; DESIGN.md "exact top-k pruning").  kmax = 1 is the fast path. */
 int vbx_pitch_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
                   const double *window, double sample_rate, double threshold, double fmin, double fmax,
                   size_t kmax, vbx_pitch *out_cand, int32_t *out_count, int32_t *status);
