@@ -552,21 +552,26 @@ def test_mfcc(vb, oracle, audio, n, k, lo, hi, sr):
         assert np.all(rel_close(m[f], em, 1e-6)), (f, np.max(np.abs(m[f] - em)))
 
 
-def test_mfcc_goertzel_fallback_matches_two_stage(pkg, oracle, audio, monkeypatch):
-    """Composite lengths take the two-stage DFT kernel; VBX_MFCC_GOERTZEL=1 forces the Goertzel kernel that
-    prime lengths use.  Both must agree with each other far inside the oracle tolerance."""
+def test_mfcc_three_kernels_agree(pkg, oracle, audio, monkeypatch):
+    """N = 1200 takes the matrix-core kernel; VBX_MFCC_DFT2=1 forces the vector two-stage kernel (lengths whose
+    factorisation does not fit the MFMA tiles) and VBX_MFCC_GOERTZEL=1 the Goertzel kernel (prime lengths).  The
+    three must agree with each other far inside the oracle tolerance, and differ in the last bits (three kernels ran)."""
     x = _frames(audio, N48, 977, range(0, 60, 4)) * oracle.window("hanning", N48) * 40.0
-    monkeypatch.setenv("VBX_MFCC_GOERTZEL", "1")
-    vg = pkg.VoxBox(0)
-    monkeypatch.delenv("VBX_MFCC_GOERTZEL")
-    vd = pkg.VoxBox(0)
-    try:
-        mg, sg = vg.mfcc(x, 13, (100.0, 8000.0), SR)
-        md, sd = vd.mfcc(x, 13, (100.0, 8000.0), SR)
-    finally:
-        vg.close(); vd.close()
-    assert np.array_equal(sg, sd) and not np.array_equal(mg, md)      # two different kernels ran
-    assert np.all(rel_close(mg, md, 1e-9))
+    res = {}
+    for name, var in (("mfma", None), ("dft2", "VBX_MFCC_DFT2"), ("goertzel", "VBX_MFCC_GOERTZEL")):
+        if var:
+            monkeypatch.setenv(var, "1")
+        v = pkg.VoxBox(0)
+        if var:
+            monkeypatch.delenv(var)
+        try:
+            res[name] = v.mfcc(x, 13, (100.0, 8000.0), SR)
+        finally:
+            v.close()
+    for a in ("dft2", "goertzel"):
+        assert np.array_equal(res["mfma"][1], res[a][1]) and not np.array_equal(res["mfma"][0], res[a][0])
+        assert np.all(rel_close(res["mfma"][0], res[a][0], 1e-9)), a
+    assert not np.array_equal(res["dft2"][0], res["goertzel"][0])
 
 
 def test_mfcc_bins_beyond_spectrum_is_panic_status(vb, oracle):

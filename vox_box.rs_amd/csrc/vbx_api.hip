@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <array>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -45,6 +46,7 @@ struct vbx_ctx {
     std::map<std::tuple<size_t, int, int>, double *> goertzel;   // (n, b_lo, nb) -> [nb][2] kappa, sigma
     std::map<size_t, double *> dct_tables;                // K -> [K][K]
     std::map<std::pair<size_t, int>, std::pair<double *, double *>> dft2_tabs;   // (n, n1) -> (stage-1 table, twiddles)
+    std::map<std::tuple<size_t, int, int>, std::array<double *, 4>> mfma_tabs;   // (n, n1, k2) -> ctab, twd, twm, wm
     std::map<std::tuple<size_t, size_t, double, double, double>, int32_t *> bins_cache;
     std::map<std::tuple<size_t, size_t, double, double, double>, double *> slopes_cache;   // [nb][2] i/up, i/down per bin
     std::map<std::pair<size_t, double>, std::pair<int32_t *, double *>> resample_tabs;   // (n, ratio) -> (index, fraction)
@@ -53,7 +55,8 @@ struct vbx_ctx {
     bool prof = false;
     std::vector<ProfRec> recs;
     std::map<std::string, std::pair<double, long>> prof_acc;
-    bool mfcc_force_goertzel = false;                     // test hook (VBX_MFCC_GOERTZEL=1): keep the fallback covered
+    bool mfcc_force_goertzel = false;                     // test hooks: VBX_MFCC_GOERTZEL=1 / VBX_MFCC_DFT2=1 keep the
+    bool mfcc_force_dft2 = false;                         //   fallback kernels covered on lengths the MFMA kernel takes
     unsigned long long *pitch_work = nullptr;             // [PITCH_WORK_SLOTS][4], counted while profiling
     std::mutex mu;
 };
@@ -209,6 +212,66 @@ int get_dft2_dev(vbx_ctx *ctx, size_t n, const mfcc_plan_t &pl, const double **c
     return VBX_SUCCESS;
 }
 
+// tables of the matrix-core MFCC kernel (k_mfcc_mfma.hip), evaluated in long double and rounded once
+int get_mfcc_mfma_dev(vbx_ctx *ctx, size_t n, const mfcc_mplan_t &pl, const double **ctab, const double **twd,
+                      const double **twm, const double **wm) {
+    auto key = std::make_tuple(n, pl.n1, pl.k2);
+    auto it = ctx->mfma_tabs.find(key);
+    if (it == ctx->mfma_tabs.end()) {
+        const long double two_pi = 6.283185307179586476925286766559005768L;
+        const int n1 = pl.n1, n2 = pl.n2, n1p = (n1 + 3) & ~3, nc = 32 * pl.ntd, mt = pl.mt;
+        std::vector<double> hc((size_t)n1p * nc, 0.0);
+        for (int i1 = 0; i1 < n1; i1++)
+            for (int c = 0; c < nc; c++) {
+                const bool is_sin = c >= 16 * pl.ntd;
+                const int k1 = is_sin ? c - 16 * pl.ntd : c;
+                if (k1 >= n1) continue;
+                const long double ang = two_pi * (long double)((long)i1 * k1 % n1) / (long double)n1;
+                hc[(size_t)i1 * nc + c] = (double)(is_sin ? sinl(ang) : cosl(ang));
+            }
+        auto twiddle = [&](int i2, int k1, double *dst) {
+            if (i2 >= n2 || k1 < 0 || k1 >= n1) { dst[0] = 0.0; dst[1] = 0.0; return; }
+            const long double ang = two_pi * (long double)((long)i2 * k1 % (long)n) / (long double)n;
+            dst[0] = (double)cosl(ang); dst[1] = (double)sinl(ang);
+        };
+        std::vector<double> hd((size_t)mt * pl.ntd * 4 * 128 + 2, 0.0), hm((size_t)mt * pl.ntm * 4 * 128 + 2, 0.0);
+        for (int m = 0; m < mt; m++)
+            for (int r = 0; r < 4; r++)
+                for (int l = 0; l < 64; l++) {
+                    const int i2 = 16 * m + 4 * r + (l >> 4), col = l & 15;
+                    for (int t = 0; t < pl.ntd; t++)
+                        twiddle(i2, 16 * t + col, &hd[((size_t)((m * pl.ntd + t) * 4 + r) * 64 + l) * 2]);
+                    for (int t = 0; t < pl.ntm; t++) {
+                        const int kp = 16 * (t == 0 ? pl.src0 : pl.src1) + col;
+                        twiddle(i2, (kp >= 1) ? n1 - kp : -1, &hm[((size_t)((m * pl.ntm + t) * 4 + r) * 64 + l) * 2]);
+                    }
+                }
+        // stage-2 A operand: Wm[2 k2 + p][kk], kk = Re rows i2 (0 .. 16 mt) then Im rows; lane l of K-step s holds
+        // Wm[l & 15][4 s + (l >> 4)]
+        std::vector<double> hw((size_t)8 * mt * 64, 0.0);
+        for (int s = 0; s < 8 * mt; s++)
+            for (int l = 0; l < 64; l++) {
+                const int rowm = l & 15, kk = 4 * s + (l >> 4);
+                const bool im_half = kk >= 16 * mt;
+                const int i2 = im_half ? kk - 16 * mt : kk, k2 = rowm >> 1, p = rowm & 1;
+                if (i2 >= n2 || k2 >= pl.k2) continue;
+                const long double ang = two_pi * (long double)((long)i2 * k2 % n2) / (long double)n2;
+                const long double c = cosl(ang), sn = sinl(ang);
+                // (Bre + i Bim)(c - i sn): Re = Bre c + Bim sn, Im = Bim c - Bre sn
+                hw[(size_t)s * 64 + l] = (double)(p == 0 ? (im_half ? sn : c) : (im_half ? c : -sn));
+            }
+        std::array<double *, 4> d{nullptr, nullptr, nullptr, nullptr};
+        const std::vector<double> *src[4] = {&hc, &hd, &hm, &hw};
+        for (int i = 0; i < 4; i++) {
+            VBX_HIP(ctx, hipMalloc((void **)&d[i], src[i]->size() * sizeof(double)));
+            VBX_HIP(ctx, hipMemcpy(d[i], src[i]->data(), src[i]->size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        it = ctx->mfma_tabs.emplace(key, d).first;
+    }
+    *ctab = it->second[0]; *twd = it->second[1]; *twm = it->second[2]; *wm = it->second[3];
+    return VBX_SUCCESS;
+}
+
 int get_dct_dev(vbx_ctx *ctx, size_t k, const double **out) {
     auto it = ctx->dct_tables.find(k);
     if (it == ctx->dct_tables.end()) {
@@ -337,6 +400,7 @@ int vbx_ctx_create(vbx_ctx **out, int device, void *hip_stream) {
     ctx->arch = prop.gcnArchName;
     ctx->cu_count = prop.multiProcessorCount;
     { const char *e = std::getenv("VBX_MFCC_GOERTZEL"); ctx->mfcc_force_goertzel = e && e[0] == '1'; }
+    { const char *e = std::getenv("VBX_MFCC_DFT2"); ctx->mfcc_force_dft2 = e && e[0] == '1'; }
     if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->owns_stream = false; }
     else {
         e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -359,6 +423,7 @@ void vbx_ctx_destroy(vbx_ctx *ctx) {
     for (auto &kv : ctx->goertzel) hipFree(kv.second);
     for (auto &kv : ctx->dct_tables) hipFree(kv.second);
     for (auto &kv : ctx->dft2_tabs) { hipFree(kv.second.first); hipFree(kv.second.second); }
+    for (auto &kv : ctx->mfma_tabs) for (double *q : kv.second) hipFree(q);
     for (auto &kv : ctx->bins_cache) hipFree(kv.second);
     for (auto &kv : ctx->slopes_cache) hipFree(kv.second);
     for (auto &kv : ctx->resample_tabs) { hipFree(kv.second.first); hipFree(kv.second.second); }
@@ -769,9 +834,18 @@ int vbx_mfcc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_le
     rc = get_dct_dev(ctx, num_coeffs, &dct); if (rc != VBX_SUCCESS) return rc;
     rc = get_slopes_dev(ctx, frame_len, num_coeffs, lo_hz, hi_hz, sample_rate, hb, &slopes); if (rc != VBX_SUCCESS) return rc;
     if (status) VBX_HIP(ctx, hipMemsetAsync(status, 0, n_frames * sizeof(int32_t), ctx->stream));
-    // composite frame lengths: two-stage DFT of the needed bins; otherwise (prime-ish lengths) Goertzel
-    const mfcc_plan_t pl = (nb > 0 && !ctx->mfcc_force_goertzel) ? mfcc_plan((int)frame_len, nb) : mfcc_plan_t{false, 0, 0, 0, 0};
-    if (pl.ok) {
+    // composite frame lengths: two-stage DFT of the needed bins, on the matrix cores when the factorisation fits
+    // the MFMA kernel's tiles, else on the vector ALU; otherwise (prime-ish lengths) Goertzel
+    const bool composite_ok = nb > 0 && !ctx->mfcc_force_goertzel;
+    const mfcc_mplan_t mp = (composite_ok && !ctx->mfcc_force_dft2) ? mfcc_mfma_plan((int)frame_len, hb.front(), nb) : mfcc_mplan_t{};
+    const mfcc_plan_t pl = (composite_ok && !mp.ok) ? mfcc_plan((int)frame_len, nb) : mfcc_plan_t{false, 0, 0, 0, 0};
+    if (mp.ok) {
+        const double *ctab = nullptr, *twd = nullptr, *twm = nullptr, *wm = nullptr;
+        rc = get_mfcc_mfma_dev(ctx, frame_len, mp, &ctab, &twd, &twm, &wm); if (rc != VBX_SUCCESS) return rc;
+        Prof p(ctx, "mfcc");
+        launch_mfcc_mfma(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, mp, ctab, twd, twm, wm, d_bins,
+                         slopes, dct, (int)num_coeffs, out, nb, ctx->cu_count);
+    } else if (pl.ok) {
         const double *ctab = nullptr, *twid = nullptr;
         rc = get_dft2_dev(ctx, frame_len, pl, &ctab, &twid); if (rc != VBX_SUCCESS) return rc;
         Prof p(ctx, "mfcc");

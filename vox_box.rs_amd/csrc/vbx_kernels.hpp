@@ -63,6 +63,13 @@ void launch_mfcc_dft2(hipStream_t s, const double *x, long F, int n, long stride
                       const mfcc_plan_t &pl, const double *ctab /* [n1][nc] */, const double *twid /* [n][2] */,
                       const int32_t *bins_dev, const double *slopes, const double *dct_table, int num_coeffs, double *out,
                       int nb, int cu_count);
+// k_mfcc_mfma.hip: both DFT stages on the matrix cores
+struct mfcc_mplan_t { bool ok; int n1, n2, k2, mt, ntd, ntm, src0, src1; };
+mfcc_mplan_t mfcc_mfma_plan(int n, int b_lo, int nb);
+void launch_mfcc_mfma(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
+                      const mfcc_mplan_t &pl, const double *ctab, const double *twd, const double *twm, const double *wm,
+                      const int32_t *bins_dev, const double *slopes, const double *dct_table, int num_coeffs, double *out,
+                      int nb, int cu_count);
 void launch_mfcc(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                  const double *kappa_sigma /* [nb][2] Goertzel-Reinsch constants */, const int32_t *bins /* K+2 */,
                  const double *slopes /* [nb][2] */, const double *dct_table /* [K][K] */,
