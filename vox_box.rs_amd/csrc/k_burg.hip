@@ -5,7 +5,8 @@
 //   b2[j] <- b2[j+1] - a*b1[j+1]
 // needs ONE neighbour-lane fetch per order (DPP wave_shl) instead of a pass through memory.
 // Per order: two group reductions (num, denum; DPP, bit-identical inside the group), the
-// coefficient recursion (tiny, LDS-resident, group leader), one fused update sweep.
+// coefficient recursion with coefficient t in lane t of the group (the reversed operand aa[i-2-t] by one
+// lane permute: no LDS, no serial loop), one fused update sweep.
 // The shrinking valid range [0, N-i) is kept by zeroing exactly the element that drops out.
 // Short frames use small groups so that the per-order overhead is shared by several frames.
 #include "vbx_device.hpp"
@@ -18,9 +19,7 @@ __global__ __launch_bounds__(64) void burg_kernel(
     const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
     int p, double *__restrict__ out, int32_t *__restrict__ status) {
     constexpr int NG = 64 / G;
-    constexpr int CS = VBX_MAX_LPC_ORDER_K + 2;
-    __shared__ double aa[NG][CS];
-    __shared__ double co[NG][CS];
+    static_assert(G >= VBX_MAX_LPC_ORDER_K || G == 16, "one coefficient per lane of the group");
     const int lane = lane_id();
     const int gid = lane / G, lig = lane % G;
     const long f = (long)blockIdx.x * NG + gid;
@@ -50,6 +49,8 @@ __global__ __launch_bounds__(64) void burg_kernel(
     }
 
     int st = 0;
+    double aa = 0.0, co = 0.0;                       // lane t of the group: aa[t], coeffs[t]  (src/spectrum.rs:116-139)
+    const int gbase = lane - lig;
     for (int i = 1; i <= p; i++) {
         double num = 0.0, den = 0.0;
 #pragma unroll
@@ -62,14 +63,15 @@ __global__ __launch_bounds__(64) void burg_kernel(
         den = group_sum<G>(den);
         if (st == 0 && den <= 0.0) st = 1;           // Err(LPC), src/spectrum.rs:123-125 (NaN falls through)
         const double c = 2.0 * num / den;
-        wave_sync();
-        if (lig == 0) {
-            co[gid][i - 1] = c;
-            for (int j = 1; j < i; j++) co[gid][j - 1] = aa[gid][j - 1] - c * aa[gid][i - j - 1];
+        {   // coeffs[i-1] = c;  coeffs[j-1] = aa[j-1] - c * aa[i-j-1], j = 1..i-1   (t = j-1 <-> lane t)
+            int srcl = i - 2 - lig;
+            srcl = (srcl < 0) ? 0 : srcl;
+            const double rev = __shfl(aa, gbase + srcl, 64);
+            if (lig < i - 1) co = aa - c * rev;
+            else if (lig == i - 1) co = c;
         }
-        wave_sync();
         if (i < p) {
-            if (lig == 0) for (int j = 1; j <= i; j++) aa[gid][j - 1] = co[gid][j - 1];
+            if (lig < i) aa = co;                    // aa[j-1] = coeffs[j-1], j = 1..i
             const double a = c;                      // aa[i-1] == coeffs[i-1]
             const double f1 = from_next_lane(b1[0]), f2 = from_next_lane(b2[0]);
             const double nb1 = last_lane ? 0.0 : f1;
@@ -92,9 +94,8 @@ __global__ __launch_bounds__(64) void burg_kernel(
             }
         }
     }
-    wave_sync();
     if (have) {
-        for (int j = lig; j < p; j += G) out[f * (long)p + j] = (st == 0) ? co[gid][j] * -1.0 : 0.0;   // :142-144
+        if (lig < p) out[f * (long)p + lig] = (st == 0) ? co * -1.0 : 0.0;   // :142-144
         if (status != nullptr && lig == 0) status[f] = st;
     }
 }
@@ -103,15 +104,19 @@ bool burg_supported(int n, int p) {
     return n >= 2 && n <= 64 * 64 && p >= 1 && p <= VBX_MAX_LPC_ORDER_K;
 }
 
+// orders above 16 need more than 16 lanes per frame (one coefficient per lane)
+static bool burg_small_groups_ok(int p) { return p <= 16; }
+
 void launch_burg(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                  int p, double *out, int32_t *status) {
     dim3 b(64);
 #define VBX_BURG(GG, E)                                                                                   \
     hipLaunchKernelGGL((burg_kernel<GG, E>), dim3((unsigned)((F + (64 / GG) - 1) / (64 / GG))), b, 0, s, \
                        x, F, n, stride, window, p, out, status)
-    if (n <= 16 * 8) VBX_BURG(16, 8);
-    else if (n <= 16 * 16) VBX_BURG(16, 16);
-    else if (n <= 16 * 32) VBX_BURG(16, 32);
+    const bool g16 = burg_small_groups_ok(p);
+    if (g16 && n <= 16 * 8) VBX_BURG(16, 8);
+    else if (g16 && n <= 16 * 16) VBX_BURG(16, 16);
+    else if (g16 && n <= 16 * 32) VBX_BURG(16, 32);
     else if (n <= 32 * 32) VBX_BURG(32, 32);
     else if (n <= 64 * 20) VBX_BURG(64, 20);
     else if (n <= 64 * 32) VBX_BURG(64, 32);
