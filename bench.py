@@ -245,21 +245,26 @@ def main():
     ff = {"formants": o_form, "res": None, "count": None, "coeffs": None, "status": o_fst}
     counts = [F] * world
 
+    arrange = os.environ.get("VBX_BENCH_ARRANGE", "two")     # stream arrangement of the pipeline workload (experiments)
+
     def step():
-        side = vb2 if wl == "pipeline" else vb
-        if wl == "pipeline":
+        side = vb2 if (wl == "pipeline" and arrange != "one") else vb
+        if wl == "pipeline" and arrange != "one":
             sstream.wait_stream(tstream)            # the side stream starts after whatever produced the inputs
         if wl in ("pipeline", "config4"):
             side.find_formants(audio, SR, P, est0, seg_start=seg, frame_len=frame_len, stride=stride, n_frames=F, out=ff)
         if wl in ("pipeline", "config2"):
             side.autocorr_lpc(audio, P, frame_len=frame_len, stride=stride, n_frames=F, window=win, out=(o_r, o_a))
-        if wl == "pipeline":
+        if wl == "pipeline" and arrange != "mfcc_main":
             side.mfcc(audio, 13, (100.0, 8000.0), SR, frame_len=frame_len, stride=stride, n_frames=F, window=win,
                       out=(o_mfcc, o_mst))
         if wl in ("pipeline", "config3"):
             vb.pitch(audio, SR, 0.2, 75.0, 600.0, kmax=args.kmax, frame_len=frame_len, stride=stride, n_frames=F, window=win,
                      out=(o_cand, o_cnt, o_pst))
-        if wl == "pipeline":
+        if wl == "pipeline" and arrange == "mfcc_main":
+            vb.mfcc(audio, 13, (100.0, 8000.0), SR, frame_len=frame_len, stride=stride, n_frames=F, window=win,
+                    out=(o_mfcc, o_mst))
+        if wl == "pipeline" and arrange != "one":
             tstream.wait_stream(sstream)            # join before anything consumes the records
         if world > 1:   # per-frame records to rank 0 over RCCL/xGMI (no other collective on the path)
             rec = torch.cat([o_cand[:, 0, :], o_form.view(F, 8), o_mfcc, o_a], dim=1)

@@ -1,0 +1,15 @@
+import sys, ctypes, numpy as np
+sys.path.insert(0, '.')
+import __graft_entry__ as g
+pkg = g.load_package(); vb = pkg.VoxBox(0)
+N,H,SR=1200,480,48000.0
+ns=1800*48000
+audio = vb.synth_speech(ns); F = pkg.frame_count(ns,N,H)
+han = vb.window(pkg.WINDOW_HANNING,N)
+out=(vb.empty((F,1,2)), vb.empty(F,np.int32), vb.empty(F,np.int32))
+h=(ctypes.c_ulonglong*8)()
+for i in range(2):
+    vb.L.vbx_dbg_read(h)
+    vb.timer_begin(); vb.pitch(audio,SR,0.2,75.,600.,kmax=1,frame_len=N,stride=H,n_frames=F,window=han,out=out); ms=vb.timer_end()
+vb.L.vbx_dbg_read(h)
+print(ms, 'ms; clock64 ticks per frame: load, mfma, normalize, peaks, prefix+bounds, refine:', [round(v/F) for v in h[:6]])

@@ -418,14 +418,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     double *keys = p16 + ((nblk + 2) & ~1);
     int *cand_list = reinterpret_cast<int *>(keys + (n / 4 + 8));
     {
+        // all of the frame's loads are issued before the first LDS store (nothing else hides their latency here);
+        // only the zero margins of the image are cleared, the pad double inside each 16 samples is never read
         const double *xf = frames + f * stride;
-        const int total = ac_mf_lds_doubles(n);
-        for (int p = lane; p < total; p += 64) zs[p] = 0.0;
-        wave_sync();
-        for (int i = lane; i < n; i += 64) {
-            double v = xf[i];
-            if (window != nullptr) v *= window[i];
-            zs[ac_mf_phys(i)] = v;
+        constexpr int NB = 8;
+        for (int p = lane; p < ac_mf_phys(0); p += 64) zs[p] = 0.0;
+        for (int p = ac_mf_phys(n) + lane; p < ac_mf_lds_doubles(n); p += 64) zs[p] = 0.0;
+        for (int i0 = 0; i0 < n; i0 += 64 * NB) {
+            double xv[NB], wv[NB];
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                const int i = i0 + 64 * j + lane;
+                xv[j] = (i < n) ? xf[i] : 0.0;
+                wv[j] = (window != nullptr && i < n) ? window[i] : 1.0;
+            }
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                const int i = i0 + 64 * j + lane;
+                if (i < n) zs[ac_mf_phys(i)] = (window != nullptr) ? xv[j] * wv[j] : xv[j];
+            }
         }
         wave_sync();
     }
