@@ -195,6 +195,13 @@ int vbx_find_roots_c64(vbx_ctx *ctx, vbx_complex *polys, size_t n_polys, size_t 
 int vbx_laguerre_c64(vbx_ctx *ctx, const vbx_complex *polys, size_t n_polys, size_t len,
                      vbx_complex start, vbx_complex *out);
 
+/* The f32 instantiation of Polynomial (Complex<f32>, exercised by the reference's own tests at
+ * src/polynomial.rs:336-386): same algorithms in single precision.  polys: [F, len] of {float re, im}. */
+typedef struct { float re, im; } vbx_complex32;
+int vbx_find_roots_c32(vbx_ctx *ctx, vbx_complex32 *polys, size_t n_polys, size_t len, int32_t *status);
+int vbx_laguerre_c32(vbx_ctx *ctx, const vbx_complex32 *polys, size_t n_polys, size_t len,
+                     vbx_complex32 start, vbx_complex32 *out);
+
 /* ------------------------------------------------------------------ spectrum.rs: resonances, tracker */
 
 /* ToResonance::to_resonance(sample_rate) per row of roots (src/spectrum.rs:165-210): roots with
@@ -265,6 +272,13 @@ int vbx_preemphasis_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t f
 size_t vbx_resampled_len(size_t frame_len, double resample_ratio);
 int vbx_resample_linear_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
                             double resample_ratio, double *out);
+
+/* VecDeque input (`impl Autocorrelate<T> for VecDeque<T>`, src/periodic.rs:291-304 -- the streaming form of the
+ * trait): logical sample i of the deque is ring[(head + i) % capacity].  Copies the Windower view over the deque
+ * (frame t = logical samples [t*stride, t*stride + frame_len)) into the dense batch out[F, frame_len], which every
+ * entry point above accepts with stride = frame_len.  Requires (n_frames-1)*stride + frame_len <= capacity. */
+int vbx_ring_frames_f64(vbx_ctx *ctx, const double *ring, size_t capacity, size_t head, size_t n_frames,
+                        size_t frame_len, size_t stride, double *out);
 
 /* ------------------------------------------------------------------ bench utility */
 

@@ -17,7 +17,7 @@ MAX_RESONANCES = 32
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("vbx_oracle.c", "vbx_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("vbx_oracle.c", "vbx_oracle_f32.c", "vbx_oracle.h")]
     if force or not os.path.exists(_SO) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_SO) for s in src
     ):
@@ -184,6 +184,34 @@ def find_roots(p):
 def find_roots_mut(p):
     p = _c128(p).copy()
     st = lib().vbxo_find_roots_mut(_p(p), C.c_size_t(p.size))
+    return st, p
+
+
+class _C32(C.Structure):
+    _fields_ = [("re", C.c_float), ("im", C.c_float)]
+
+
+def laguerre_f32(p, start):
+    """Complex<f32> instantiation (src/polynomial.rs:336-386)."""
+    p = np.ascontiguousarray(p, dtype=np.complex64)
+    L = lib()
+    L.vbxo_laguerre_f32.restype = _C32
+    L.vbxo_laguerre_f32.argtypes = [C.c_void_p, C.c_size_t, _C32]
+    z = L.vbxo_laguerre_f32(_p(p), p.size, _C32(start.real, start.imag))
+    return np.complex64(complex(z.re, z.im))
+
+
+def find_roots_f32(p):
+    p = np.ascontiguousarray(p, dtype=np.complex64)
+    roots = np.zeros(p.size, dtype=np.complex64)
+    n = C.c_size_t()
+    st = lib().vbxo_find_roots_f32(_p(p), C.c_size_t(p.size), _p(roots), C.byref(n))
+    return st, roots[:n.value].copy()
+
+
+def find_roots_mut_f32(p):
+    p = np.ascontiguousarray(p, dtype=np.complex64).copy()
+    st = lib().vbxo_find_roots_mut_f32(_p(p), C.c_size_t(p.size))
     return st, p
 
 

@@ -82,6 +82,12 @@ int vbxo_find_roots_mut(vbxo_c64 *p, size_t len);                               
 /* find_roots (:79-89): copies, solves, pops trailing zeros. returns status; *n_roots out */
 int vbxo_find_roots(const vbxo_c64 *p, size_t len, vbxo_c64 *roots, size_t *n_roots);
 
+/* ---- polynomial.rs, Complex<f32> instantiation (vbx_oracle_f32.c; reference tests :336-386) ---- */
+typedef struct { float re, im; } vbxo_c32;
+vbxo_c32 vbxo_laguerre_f32(const vbxo_c32 *p, size_t len, vbxo_c32 start);
+int vbxo_find_roots_mut_f32(vbxo_c32 *p, size_t len);
+int vbxo_find_roots_f32(const vbxo_c32 *p, size_t len, vbxo_c32 *roots, size_t *n_roots);
+
 /* ---- spectrum.rs: resonances, tracker ---- */
 int vbxo_resonance_from_root(vbxo_c64 root, double sample_rate, vbxo_resonance_t *out); /* :165-193, 1 = Some */
 size_t vbxo_to_resonance(const vbxo_c64 *roots, size_t n, double sample_rate, vbxo_resonance_t *out); /* :199-210 */

@@ -98,3 +98,24 @@ def test_find_formants_with_resample_ratio(vb, oracle, pkg):
         assert st == out["status"][t]
         bad += 0 if np.all(np.abs(out["formants"][t] - est) <= 1e-4 * np.abs(est)) else 1
     assert bad == 0
+
+
+@pytest.mark.gpu
+def test_ring_buffer_view_autocorrelate(vb, oracle):
+    """`impl Autocorrelate for VecDeque` (src/periodic.rs:291-304): the deque's logical order, wrapped around the
+    end of its ring, through vbx_ring_frames_f64 + vbx_autocorrelate_f64 == the oracle on the linearised deque."""
+    rng = np.random.default_rng(5)
+    cap, head, n, hop, F = 4096, 3000, 512, 160, 12          # frames cross the wrap point
+    ring = rng.uniform(-1, 1, cap)
+    logical = np.concatenate([ring[head:], ring[:head]])
+    d = vb.ring_frames(ring, head, F, n, hop)
+    dense = d.numpy()
+    for t in range(F):
+        assert np.array_equal(dense[t], logical[t * hop:t * hop + n])
+    got = vb.autocorrelate(d, 13, frame_len=n, stride=n, n_frames=F)
+    d.free()
+    for t in range(F):
+        exp = oracle.autocorrelate(logical[t * hop:t * hop + n], 13)
+        assert np.all(rel_close(got[t], exp)), t
+    with pytest.raises(Exception):
+        vb.ring_frames(ring, head, 30, n, hop)               # 29*160 + 512 > 4096: longer than the deque can be

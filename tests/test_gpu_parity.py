@@ -188,6 +188,47 @@ def test_roots_kats(vb, oracle):
     assert cnt[0] == 1 and abs(res[0, 0, 0] - 4045.196) < 1.0
 
 
+def test_roots_f32_kats(vb, oracle):
+    """src/polynomial.rs:336-386, the Complex<f32> instantiation through the GPU path."""
+    r, st = vb.find_roots_f32(np.array([[1.0, -2.5, 2.0]]))
+    assert st[0] == 0 and r.dtype == np.complex64
+    exp = [np.complex64(complex(0.625, -0.33071891388307)), np.complex64(complex(0.625, 0.33071891388307))]
+    for a, b in zip(r[0, :2], exp):
+        assert abs(float(a.real) - float(b.real)) < 1e-12 and abs(float(a.imag) - float(b.imag)) < 1e-12
+    r, st = vb.find_roots_f32(np.array([[1.0, 2.5, -2.0, -3.0]]))
+    for a, b in zip(r[0, :3], [-1.1409835232292, -0.35308705904629, 0.82740391560878]):
+        assert abs(float(a.real) - np.float32(b)) < 1e-6 and abs(float(a.imag)) < 1e-6
+    lpc = [1.0, -0.99640256, 0.25383306, -0.25471634, 0.5084799, -0.0685858, -0.35042483, 0.07676613, -0.12874511,
+           0.11829436, 0.023972526]
+    z = vb.laguerre_f32(np.array([lpc]), complex(-64.0, -64.0))[0]
+    assert np.isfinite(z.real) and np.isfinite(z.imag)
+    zo = oracle.laguerre_f32(lpc, complex(-64.0, -64.0))
+    assert abs(complex(z) - complex(zo)) <= 1e-4 * abs(complex(zo))
+    r, st = vb.find_roots_f32(np.array([[1.0, 0.0, 0.0]]))
+    assert st[0] == 2
+
+
+def test_find_roots_f32_random(vb, oracle):
+    """Random real-coefficient f32 polynomials against the f32 oracle: same root SET within single-precision
+    conditioning (discovery order can differ when two Laguerre limits are rounding-close)."""
+    rng = np.random.default_rng(12)
+    P = rng.uniform(-1.0, 1.0, (64, 9)).astype(np.float32)
+    P[:, -1] = 1.0
+    r, st = vb.find_roots_f32(P.astype(np.complex64))
+    for f in range(P.shape[0]):
+        es, er = oracle.find_roots_f32(P[f].astype(np.complex64))
+        assert st[f] == es
+        if es != 0:
+            continue
+        g = np.sort_complex(r[f, :er.size].astype(np.complex128))
+        e = np.sort_complex(er.astype(np.complex128))
+        # residual check (conditioning-independent): every GPU root is a root of the polynomial to f32 accuracy
+        pv = np.polyval(P[f, ::-1].astype(np.float64), r[f, :er.size].astype(np.complex128))
+        scale = np.polyval(np.abs(P[f, ::-1]).astype(np.float64), np.abs(r[f, :er.size]).astype(np.float64))
+        assert np.all(np.abs(pv) <= 2e-4 * scale), (f, np.abs(pv) / scale)
+        assert g.size == e.size
+
+
 def test_find_roots_random(vb, oracle):
     rng = np.random.default_rng(11)
     for deg in (3, 5, 8, 12, 13, 20):

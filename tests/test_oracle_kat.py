@@ -247,6 +247,24 @@ def test_hi_d_roots(oracle):
         assert abs(a.real - b) < 1e-6 and abs(a.imag) < 1e-6
 
 
+def test_f32_polynomial_kats(oracle):
+    """src/polynomial.rs:336-386: test_2d_complex_roots_f32 (1e-12 against the f32 constants), test_hi_d_roots_f32
+    (1e-6, order pinned), test_f32_roots (finite) -- the Complex<f32> instantiation."""
+    st, r = oracle.find_roots_f32([1.0, -2.5, 2.0])
+    exp = [np.complex64(complex(0.625, -0.33071891388307)), np.complex64(complex(0.625, 0.33071891388307))]
+    assert st == 0 and r.size == 2
+    for a, b in zip(r, exp):
+        assert abs(float(a.real) - float(b.real)) < 1e-12 and abs(float(a.imag) - float(b.imag)) < 1e-12
+    st, r = oracle.find_roots_f32([1.0, 2.5, -2.0, -3.0])
+    assert st == 0 and r.size == 3
+    for a, b in zip(r, [-1.1409835232292, -0.35308705904629, 0.82740391560878]):
+        assert abs(float(a.real) - np.float32(b)) < 1e-6 and abs(float(a.imag)) < 1e-6
+    lpc = [1.0, -0.99640256, 0.25383306, -0.25471634, 0.5084799, -0.0685858, -0.35042483, 0.07676613, -0.12874511,
+           0.11829436, 0.023972526]
+    z = oracle.laguerre_f32(lpc, complex(-64.0, -64.0))
+    assert np.isfinite(z.real) and np.isfinite(z.imag)
+
+
 def test_zero_degree_is_error(oracle):
     """src/polynomial.rs:95."""
     st, _ = oracle.find_roots([1.0, 0.0, 0.0])

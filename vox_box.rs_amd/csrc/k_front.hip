@@ -108,6 +108,23 @@ __global__ void resample_kernel(const double *__restrict__ x, long n_frames, int
     }
 }
 
+// VecDeque view (src/periodic.rs:291-304): logical sample i of the deque is ring[(head + i) % capacity].
+// Frame t of the Windower view over the deque, copied into a dense [F, N] batch (coalesced on the write side).
+__global__ void ring_frames_kernel(const double *__restrict__ ring, long capacity, long head, long n_frames, int n,
+                                   long stride, double *__restrict__ out) {
+    const long total = n_frames * (long)n;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long t = e / n, i = e - t * n;
+        out[e] = ring[(head + t * stride + i) % capacity];
+    }
+}
+
+void launch_ring_frames(hipStream_t s, const double *ring, long capacity, long head, long F, int n, long stride, double *out) {
+    long blocks = (F * (long)n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(ring_frames_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ring, capacity, head, F, n, stride, out);
+}
+
 void launch_resample(hipStream_t s, const double *x, long F, int n, long stride, const int32_t *tab_idx,
                      const double *tab_frac, int m, double *out) {
     long blocks = (F * (long)m + 255) / 256;

@@ -16,49 +16,54 @@ namespace vbx {
 
 constexpr int ROOTS_BLOCK = 64;
 
-struct lds_poly {
-    c64 *base;   // element j of this lane at base[j * ROOTS_BLOCK]
-    __device__ __forceinline__ c64 get(int j) const { return base[j * ROOTS_BLOCK]; }
-    __device__ __forceinline__ void set(int j, c64 v) const { base[j * ROOTS_BLOCK] = v; }
+template <typename T>
+struct lds_poly_t {
+    cx<T> *base;   // element j of this lane at base[j * ROOTS_BLOCK]
+    __device__ __forceinline__ cx<T> get(int j) const { return base[j * ROOTS_BLOCK]; }
+    __device__ __forceinline__ void set(int j, cx<T> v) const { base[j * ROOTS_BLOCK] = v; }
 };
+using lds_poly = lds_poly_t<double>;
 
 // src/polynomial.rs:26-32
-__device__ __forceinline__ int poly_degree(const lds_poly &p, int len) {
+template <typename T>
+__device__ __forceinline__ int poly_degree(const lds_poly_t<T> &p, int len) {
     int d = 0;
     for (int j = 0; j < len; j++) if (!ciszero(p.get(j))) d = j;
     return d;
 }
-__device__ __forceinline__ int poly_off_low(const lds_poly &p, int len) {
+template <typename T>
+__device__ __forceinline__ int poly_off_low(const lds_poly_t<T> &p, int len) {
     int d = -1;
     for (int j = len - 1; j >= 0; j--) if (!ciszero(p.get(j))) d = j;
     return d < 0 ? 0 : d;
 }
 
 // src/polynomial.rs:34-72.  n = len - 1 stays fixed across deflations (Q11).
-__device__ __forceinline__ c64 laguerre(const lds_poly &p, int len, c64 start) {
+template <typename T>
+__device__ __forceinline__ cx<T> laguerre(const lds_poly_t<T> &p, int len, cx<T> start) {
     const int n = len - 1;
-    const double dn = (double)n, dnn1 = (double)(n - 1) * (double)n;
-    c64 z = start;
+    const T dn = (T)n, dnn1 = (T)(n - 1) * (T)n;
+    cx<T> z = start;
     bool done = false;
     for (int it = 0; it < 20; it++) {
-        c64 a0 = p.get(n), a1 = cmk(0.0, 0.0), a2 = cmk(0.0, 0.0);
+        cx<T> a0 = p.get(n), a1 = cmk<T>(T(0), T(0)), a2 = cmk<T>(T(0), T(0));
         for (int j = n - 1; j >= 0; j--) {
             a2 = cmad(a2, z, a1);
             a1 = cmad(a1, z, a0);
             a0 = cmad(a0, z, p.get(j));
         }
         // |p(z)| <= 1e-16  (compared on squared norms)
-        const double n0 = a0.re * a0.re + a0.im * a0.im;
-        if (!done && n0 <= 1.0e-32) done = true;
+        const T n0 = a0.re * a0.re + a0.im * a0.im;
+        if (!done && n0 <= T(1.0e-32)) done = true;
         if (__all(done)) break;
-        const c64 ca = cdiv(cneg(a1), a0);
-        const c64 ca2 = cmul(ca, ca);
-        const c64 cb = csub(ca2, cdiv(cmk(2.0 * a2.re, 2.0 * a2.im), a0));
-        const c64 c1 = csqrt(csub(cmk(dnn1 * cb.re, dnn1 * cb.im), ca2));
-        const c64 cc1 = cadd(ca, c1), cc2 = csub(ca, c1);
-        const double m1 = cc1.re * cc1.re + cc1.im * cc1.im, m2 = cc2.re * cc2.re + cc2.im * cc2.im;
-        const c64 den = (m1 > m2) ? cc1 : cc2;
-        const c64 cc = cdiv(cmk(dn, 0.0), den);
+        const cx<T> ca = cdiv(cneg(a1), a0);
+        const cx<T> ca2 = cmul(ca, ca);
+        const cx<T> cb = csub(ca2, cdiv(cmk<T>(T(2) * a2.re, T(2) * a2.im), a0));
+        const cx<T> c1 = csqrt(csub(cmk<T>(dnn1 * cb.re, dnn1 * cb.im), ca2));
+        const cx<T> cc1 = cadd(ca, c1), cc2 = csub(ca, c1);
+        const T m1 = cc1.re * cc1.re + cc1.im * cc1.im, m2 = cc2.re * cc2.re + cc2.im * cc2.im;
+        const cx<T> den = (m1 > m2) ? cc1 : cc2;
+        const cx<T> cc = cdiv(cmk<T>(dn, T(0)), den);
         if (!done) z = cadd(z, cc);
     }
     return z;
@@ -66,8 +71,8 @@ __device__ __forceinline__ c64 laguerre(const lds_poly &p, int len, c64 start) {
 
 // src/polynomial.rs:92-152 (+ div_polynomial_mut :155-195 inlined as in-place synthetic division).
 // co: polynomial in / scratch; emit(index, root) receives the roots in discovery order.
-template <typename Emit>
-__device__ __forceinline__ int find_roots_emit(const lds_poly &co, int len, Emit emit) {
+template <typename T, typename Emit>
+__device__ __forceinline__ int find_roots_emit(const lds_poly_t<T> &co, int len, Emit emit) {
     const int coeff_high = poly_degree(co, len);
     if (coeff_high < 1) return 2;                       // Err(Polynomial), :95
     const int coeff_low = poly_off_low(co, len);
@@ -76,26 +81,26 @@ __device__ __forceinline__ int find_roots_emit(const lds_poly &co, int len, Emit
     const int clen = coeff_high + 1;
     int zi = 0;
     for (int k = m; k >= 3; k--) {                      // (3..m+1).rev()
-        const c64 z = laguerre(co, clen, cmk(-2.0, -2.0));
+        const cx<T> z = laguerre(co, clen, cmk<T>(T(-2), T(-2)));
         emit(zi++, z);
         if (ciszero(z)) return 2;                       // div by zero -> Err, :123,:192
         // divide by (x - z): other = -z; q[i] = c[i+1] - q[i+1]*other
         const int ns = poly_degree(co, clen);
-        c64 t = co.get(ns);
+        cx<T> t = co.get(ns);
         for (int i = ns - 1; i >= 0; i--) {
-            const c64 old = co.get(i);
+            const cx<T> old = co.get(i);
             co.set(i, t);
             t = cmad(t, z, old);                        // old - t*(-z)
         }
-        co.set(ns, cmk(0.0, 0.0));
+        co.set(ns, cmk<T>(T(0), T(0)));
         m -= 1;
     }
     if (m == 2) {                                       // :131-139
-        const c64 c0 = co.get(0), c1 = co.get(1), c2 = co.get(2);
-        const c64 a2 = cadd(c2, c2);
-        const c64 four_ac = cmul(cmk(4.0 * c2.re, 4.0 * c2.im), c0);
-        const c64 d = csqrt(csub(cmul(c1, c1), four_ac));
-        const c64 xx = cneg(c1);
+        const cx<T> c0 = co.get(0), c1 = co.get(1), c2 = co.get(2);
+        const cx<T> a2 = cadd(c2, c2);
+        const cx<T> four_ac = cmul(cmk<T>(T(4) * c2.re, T(4) * c2.im), c0);
+        const cx<T> d = csqrt(csub(cmul(c1, c1), four_ac));
+        const cx<T> xx = cneg(c1);
         emit(zi, cdiv(cadd(xx, d), a2));
         emit(zi + 1, cdiv(csub(xx, d), a2));
         zi += 2;
@@ -107,9 +112,10 @@ __device__ __forceinline__ int find_roots_emit(const lds_poly &co, int len, Emit
 }
 
 // roots into an LDS array (len entries, zero filled past the roots)
-__device__ __forceinline__ int find_roots_lane(const lds_poly &co, const lds_poly &zr, int len) {
-    for (int j = 0; j < len; j++) zr.set(j, cmk(0.0, 0.0));
-    return find_roots_emit(co, len, [&](int i, c64 z) { zr.set(i, z); });
+template <typename T>
+__device__ __forceinline__ int find_roots_lane(const lds_poly_t<T> &co, const lds_poly_t<T> &zr, int len) {
+    for (int j = 0; j < len; j++) zr.set(j, cmk<T>(T(0), T(0)));
+    return find_roots_emit(co, len, [&](int i, cx<T> z) { zr.set(i, z); });
 }
 
 // src/spectrum.rs:166-192
@@ -133,34 +139,39 @@ __device__ __forceinline__ bool resonance_from_root(c64 root, double sample_rate
 
 // ---- kernels ---------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(ROOTS_BLOCK) void find_roots_kernel(cplx_t *__restrict__ polys, long n_polys, int len,
+// T = double: Complex<f64>; T = float: the f32 instantiation.  CT is the matching {re, im} pair of the ABI.
+template <typename T, typename CT>
+__global__ __launch_bounds__(ROOTS_BLOCK) void find_roots_kernel(CT *__restrict__ polys, long n_polys, int len,
                                                                  int32_t *__restrict__ status) {
-    extern __shared__ c64 lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    cx<T> *lds = reinterpret_cast<cx<T> *>(lds_raw);
     const long f = (long)blockIdx.x * ROOTS_BLOCK + threadIdx.x;
     const bool active = f < n_polys;
-    lds_poly co{lds + threadIdx.x}, zr{lds + (size_t)len * ROOTS_BLOCK + threadIdx.x};
+    lds_poly_t<T> co{lds + threadIdx.x}, zr{lds + (size_t)len * ROOTS_BLOCK + threadIdx.x};
     const long fr = active ? f : n_polys - 1;           // idle lanes shadow the last polynomial
-    cplx_t *pp = polys + fr * (long)len;
-    for (int j = 0; j < len; j++) co.set(j, cmk(pp[j].re, pp[j].im));
+    CT *pp = polys + fr * (long)len;
+    for (int j = 0; j < len; j++) co.set(j, cmk<T>(pp[j].re, pp[j].im));
     const int st = find_roots_lane(co, zr, len);
     if (active) {
         if (st == 0) {
-            for (int j = 0; j < len; j++) { const c64 v = zr.get(j); pp[j].re = v.re; pp[j].im = v.im; }
+            for (int j = 0; j < len; j++) { const cx<T> v = zr.get(j); pp[j].re = v.re; pp[j].im = v.im; }
         }
         if (status != nullptr) status[f] = st;
     }
 }
 
-__global__ __launch_bounds__(ROOTS_BLOCK) void laguerre_kernel(const cplx_t *__restrict__ polys, long n_polys, int len,
-                                                               cplx_t start, cplx_t *__restrict__ out) {
-    extern __shared__ c64 lds[];
+template <typename T, typename CT>
+__global__ __launch_bounds__(ROOTS_BLOCK) void laguerre_kernel(const CT *__restrict__ polys, long n_polys, int len,
+                                                               CT start, CT *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    cx<T> *lds = reinterpret_cast<cx<T> *>(lds_raw);
     const long f = (long)blockIdx.x * ROOTS_BLOCK + threadIdx.x;
     const bool active = f < n_polys;
-    lds_poly co{lds + threadIdx.x};
+    lds_poly_t<T> co{lds + threadIdx.x};
     const long fr = active ? f : n_polys - 1;
-    const cplx_t *pp = polys + fr * (long)len;
-    for (int j = 0; j < len; j++) co.set(j, cmk(pp[j].re, pp[j].im));
-    const c64 z = laguerre(co, len, cmk(start.re, start.im));
+    const CT *pp = polys + fr * (long)len;
+    for (int j = 0; j < len; j++) co.set(j, cmk<T>(pp[j].re, pp[j].im));
+    const cx<T> z = laguerre(co, len, cmk<T>(start.re, start.im));
     if (active) { out[f].re = z.re; out[f].im = z.im; }
 }
 
@@ -199,7 +210,8 @@ __global__ void to_resonance_kernel(const cplx_t *__restrict__ roots, long n_row
 __global__ __launch_bounds__(ROOTS_BLOCK) void formant_resonances_kernel(
     const double *__restrict__ coeffs, long n_frames, int p, double sample_rate,
     res_t *__restrict__ out_res, int32_t *__restrict__ out_count, int32_t *__restrict__ status) {
-    extern __shared__ c64 lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    c64 *lds = reinterpret_cast<c64 *>(lds_raw);
     const long f = (long)blockIdx.x * ROOTS_BLOCK + threadIdx.x;
     const bool active = f < n_frames;
     const int len = p + 1;
@@ -236,13 +248,25 @@ __global__ __launch_bounds__(ROOTS_BLOCK) void formant_resonances_kernel(
 
 void launch_find_roots(hipStream_t s, cplx_t *polys, long F, int len, int32_t *status) {
     const size_t lds = (size_t)2 * len * ROOTS_BLOCK * sizeof(c64);
-    hipLaunchKernelGGL(find_roots_kernel, dim3((unsigned)((F + ROOTS_BLOCK - 1) / ROOTS_BLOCK)), dim3(ROOTS_BLOCK), lds, s,
+    hipLaunchKernelGGL((find_roots_kernel<double, cplx_t>), dim3((unsigned)((F + ROOTS_BLOCK - 1) / ROOTS_BLOCK)), dim3(ROOTS_BLOCK), lds, s,
                        polys, F, len, status);
 }
 
 void launch_laguerre(hipStream_t s, const cplx_t *polys, long F, int len, cplx_t start, cplx_t *out) {
     const size_t lds = (size_t)len * ROOTS_BLOCK * sizeof(c64);
-    hipLaunchKernelGGL(laguerre_kernel, dim3((unsigned)((F + ROOTS_BLOCK - 1) / ROOTS_BLOCK)), dim3(ROOTS_BLOCK), lds, s,
+    hipLaunchKernelGGL((laguerre_kernel<double, cplx_t>), dim3((unsigned)((F + ROOTS_BLOCK - 1) / ROOTS_BLOCK)), dim3(ROOTS_BLOCK), lds, s,
+                       polys, F, len, start, out);
+}
+
+void launch_find_roots_f32(hipStream_t s, cplx32_t *polys, long F, int len, int32_t *status) {
+    const size_t lds = (size_t)2 * len * ROOTS_BLOCK * sizeof(c32);
+    hipLaunchKernelGGL((find_roots_kernel<float, cplx32_t>), dim3((unsigned)((F + ROOTS_BLOCK - 1) / ROOTS_BLOCK)), dim3(ROOTS_BLOCK), lds, s,
+                       polys, F, len, status);
+}
+
+void launch_laguerre_f32(hipStream_t s, const cplx32_t *polys, long F, int len, cplx32_t start, cplx32_t *out) {
+    const size_t lds = (size_t)len * ROOTS_BLOCK * sizeof(c32);
+    hipLaunchKernelGGL((laguerre_kernel<float, cplx32_t>), dim3((unsigned)((F + ROOTS_BLOCK - 1) / ROOTS_BLOCK)), dim3(ROOTS_BLOCK), lds, s,
                        polys, F, len, start, out);
 }
 

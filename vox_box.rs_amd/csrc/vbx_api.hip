@@ -732,6 +732,29 @@ int vbx_laguerre_c64(vbx_ctx *ctx, const vbx_complex *polys, size_t n_polys, siz
     return check_launch(ctx, __func__);
 }
 
+int vbx_find_roots_c32(vbx_ctx *ctx, vbx_complex32 *polys, size_t n_polys, size_t len, int32_t *status) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    if (n_polys == 0) return VBX_SUCCESS;
+    VBX_REQUIRE(ctx, polys != nullptr, "null polynomials");
+    VBX_REQUIRE(ctx, len >= 1 && len <= 2 * VBX_MAX_LPC_ORDER + 4, "len must be in [1, 64]");
+    VBX_REQUIRE(ctx, n_polys <= 0x7fffffffull, "too many polynomials");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    { Prof p(ctx, "find_roots_f32"); launch_find_roots_f32(ctx->stream, (cplx32_t *)polys, (long)n_polys, (int)len, status); }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_laguerre_c32(vbx_ctx *ctx, const vbx_complex32 *polys, size_t n_polys, size_t len,
+                     vbx_complex32 start, vbx_complex32 *out) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    if (n_polys == 0) return VBX_SUCCESS;
+    VBX_REQUIRE(ctx, polys && out, "null argument");
+    VBX_REQUIRE(ctx, len >= 2 && len <= 2 * VBX_MAX_LPC_ORDER + 4, "len must be in [2, 64]");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    cplx32_t s; s.re = start.re; s.im = start.im;
+    { Prof p(ctx, "laguerre_f32"); launch_laguerre_f32(ctx->stream, (const cplx32_t *)polys, (long)n_polys, (int)len, s, (cplx32_t *)out); }
+    return check_launch(ctx, __func__);
+}
+
 // ---- spectrum.rs: resonances, tracker -----------------------------------------------------
 
 int vbx_to_resonance_c64(vbx_ctx *ctx, const vbx_complex *roots, size_t n_rows, size_t n_roots,
@@ -901,6 +924,19 @@ int vbx_preemphasis_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t f
     VBX_REQUIRE(ctx, out != x || stride == frame_len, "in-place filtering needs a dense batch (stride == frame_len)");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     { Prof p(ctx, "preemphasis"); launch_preemphasis(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, 2.0 * M_PI * factor, out); }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_ring_frames_f64(vbx_ctx *ctx, const double *ring, size_t capacity, size_t head, size_t n_frames,
+                        size_t frame_len, size_t stride, double *out) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    if (n_frames == 0) return VBX_SUCCESS;
+    VBX_REQUIRE(ctx, ring && out, "null argument");
+    VBX_REQUIRE(ctx, capacity >= 1 && head < capacity, "head must lie inside the ring");
+    VBX_REQUIRE(ctx, frame_len >= 1 && frame_len <= VBX_MAX_FRAME_LEN && stride >= 1, "bad frame geometry");
+    VBX_REQUIRE(ctx, (n_frames - 1) * stride + frame_len <= capacity, "the view is longer than the deque can be");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    { Prof p(ctx, "ring_frames"); launch_ring_frames(ctx->stream, ring, (long)capacity, (long)head, (long)n_frames, (int)frame_len, (long)stride, out); }
     return check_launch(ctx, __func__);
 }
 

@@ -105,39 +105,43 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // ---- complex arithmetic (num-complex 0.2 formulas; FMA contraction allowed) -------
+// Generic over the scalar: Complex<f64> on the hot path, Complex<f32> for the f32 instantiation of Polynomial
+// (src/polynomial.rs:336-386).
 
-struct c64 { double re, im; };
+template <typename T> struct cx { T re, im; };
+using c64 = cx<double>;
+using c32 = cx<float>;
 
-__device__ __forceinline__ c64 cmk(double re, double im) { c64 z; z.re = re; z.im = im; return z; }
-__device__ __forceinline__ c64 cadd(c64 a, c64 b) { return cmk(a.re + b.re, a.im + b.im); }
-__device__ __forceinline__ c64 csub(c64 a, c64 b) { return cmk(a.re - b.re, a.im - b.im); }
-__device__ __forceinline__ c64 cneg(c64 a) { return cmk(-a.re, -a.im); }
-__device__ __forceinline__ c64 cmul(c64 a, c64 b) {
-    return cmk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re);
+template <typename T> __device__ __forceinline__ cx<T> cmk(T re, T im) { cx<T> z; z.re = re; z.im = im; return z; }
+template <typename T> __device__ __forceinline__ cx<T> cadd(cx<T> a, cx<T> b) { return cmk<T>(a.re + b.re, a.im + b.im); }
+template <typename T> __device__ __forceinline__ cx<T> csub(cx<T> a, cx<T> b) { return cmk<T>(a.re - b.re, a.im - b.im); }
+template <typename T> __device__ __forceinline__ cx<T> cneg(cx<T> a) { return cmk<T>(-a.re, -a.im); }
+template <typename T> __device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> b) {
+    return cmk<T>(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re);
 }
 // a*b + c
-__device__ __forceinline__ c64 cmad(c64 a, c64 b, c64 c) {
-    return cmk(fma(a.re, b.re, fma(-a.im, b.im, c.re)), fma(a.re, b.im, fma(a.im, b.re, c.im)));
+template <typename T> __device__ __forceinline__ cx<T> cmad(cx<T> a, cx<T> b, cx<T> c) {
+    return cmk<T>(fma(a.re, b.re, fma(-a.im, b.im, c.re)), fma(a.re, b.im, fma(a.im, b.re, c.im)));
 }
-__device__ __forceinline__ c64 cdiv(c64 a, c64 b) {
-    double ns = b.re * b.re + b.im * b.im;
-    double inv = 1.0 / ns;
-    double re = a.re * b.re + a.im * b.im;
-    double im = a.im * b.re - a.re * b.im;
-    return cmk(re * inv, im * inv);
+template <typename T> __device__ __forceinline__ cx<T> cdiv(cx<T> a, cx<T> b) {
+    T ns = b.re * b.re + b.im * b.im;
+    T inv = T(1) / ns;
+    T re = a.re * b.re + a.im * b.im;
+    T im = a.im * b.re - a.re * b.im;
+    return cmk<T>(re * inv, im * inv);
 }
-__device__ __forceinline__ double cnorm(c64 a) { return hypot(a.re, a.im); }
-__device__ __forceinline__ bool ciszero(c64 a) { return a.re == 0.0 && a.im == 0.0; }
+template <typename T> __device__ __forceinline__ T cnorm(cx<T> a) { return hypot(a.re, a.im); }
+template <typename T> __device__ __forceinline__ bool ciszero(cx<T> a) { return a.re == T(0) && a.im == T(0); }
 // principal square root, algebraic form (equals the polar form of num-complex up to rounding)
-__device__ __forceinline__ c64 csqrt(c64 z) {
-    double r = hypot(z.re, z.im);
-    if (r == 0.0) return cmk(0.0, z.im);
-    if (z.re >= 0.0) {
-        double t = sqrt(0.5 * (r + z.re));
-        return cmk(t, z.im / (2.0 * t));
+template <typename T> __device__ __forceinline__ cx<T> csqrt(cx<T> z) {
+    T r = hypot(z.re, z.im);
+    if (r == T(0)) return cmk<T>(T(0), z.im);
+    if (z.re >= T(0)) {
+        T t = sqrt(T(0.5) * (r + z.re));
+        return cmk<T>(t, z.im / (T(2) * t));
     }
-    double t = sqrt(0.5 * (r - z.re));
-    return cmk(fabs(z.im) / (2.0 * t), copysign(t, z.im));
+    T t = sqrt(T(0.5) * (r - z.re));
+    return cmk<T>(fabs(z.im) / (T(2) * t), copysign(t, z.im));
 }
 
 }  // namespace vbx

@@ -14,6 +14,7 @@ namespace vbx {
 struct res_t { double frequency, bandwidth; };
 struct pitch_t { double frequency, strength; };
 struct cplx_t { double re, im; };
+struct cplx32_t { float re, im; };
 
 // k_lpc.hip
 bool fewlags_supported(int n, int n_lags, bool want_lpc);
@@ -32,6 +33,8 @@ void launch_burg(hipStream_t s, const double *x, long F, int n, long stride, con
 // k_roots.hip
 void launch_find_roots(hipStream_t s, cplx_t *polys, long F, int len, int32_t *status);
 void launch_laguerre(hipStream_t s, const cplx_t *polys, long F, int len, cplx_t start, cplx_t *out);
+void launch_find_roots_f32(hipStream_t s, cplx32_t *polys, long F, int len, int32_t *status);
+void launch_laguerre_f32(hipStream_t s, const cplx32_t *polys, long F, int len, cplx32_t start, cplx32_t *out);
 void launch_to_resonance(hipStream_t s, const cplx_t *roots, long F, int n_roots, double sample_rate,
                          int strict_im, res_t *out, int out_stride, int32_t *out_count, const int32_t *status);
 // Burg coefficients [F,p] -> reversed complex polynomial -> roots -> resonances [F,32] (find_formants core)
@@ -79,6 +82,7 @@ void launch_dct_rows(hipStream_t s, const double *in, long rows, int n, const do
 // k_front.hip
 void launch_resample(hipStream_t s, const double *x, long F, int n, long stride, const int32_t *tab_idx,
                      const double *tab_frac, int m, double *out);
+void launch_ring_frames(hipStream_t s, const double *ring, long capacity, long head, long F, int n, long stride, double *out);
 void launch_pcm16(hipStream_t s, const int16_t *pcm, size_t n, double denom, double *out);
 void launch_rms(hipStream_t s, const double *x, long F, int n, long stride, const double *window, double *out);
 void launch_preemphasis(hipStream_t s, const double *x, long F, int n, long stride, double c, double *out);

@@ -27,6 +27,10 @@ class VoxBoxError(RuntimeError):
     pass
 
 
+class _Complex32(C.Structure):
+    _fields_ = [("re", C.c_float), ("im", C.c_float)]
+
+
 class _Complex(C.Structure):
     _fields_ = [("re", C.c_double), ("im", C.c_double)]
 
@@ -88,6 +92,9 @@ def load_library():
         "vbx_lpc_burg_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, vp, vp]),
         "vbx_find_roots_c64": (C.c_int, [vp, vp, sz, sz, vp]),
         "vbx_laguerre_c64": (C.c_int, [vp, vp, sz, sz, _Complex, vp]),
+        "vbx_ring_frames_f64": (C.c_int, [vp, vp, sz, sz, sz, sz, sz, vp]),
+        "vbx_find_roots_c32": (C.c_int, [vp, vp, sz, sz, vp]),
+        "vbx_laguerre_c32": (C.c_int, [vp, vp, sz, sz, _Complex32, vp]),
         "vbx_to_resonance_c64": (C.c_int, [vp, vp, sz, sz, dbl, vp, vp]),
         "vbx_estimate_formants_f64": (C.c_int, [vp, vp, sz, sz, vp, sz, vp, sz, vp, vp]),
         "vbx_find_formants_f64": (C.c_int, [vp, vp, sz, sz, sz, dbl, sz, vp, sz, vp, sz, vp, vp, vp, vp, vp]),
@@ -404,6 +411,35 @@ class VoxBox:
         d = self.to_device(p)
         o = self.empty(p.shape[0], np.complex128)
         self._check(self.L.vbx_laguerre_c64(self.ctx, d.ptr, p.shape[0], p.shape[1], _Complex(start.real, start.imag), o.ptr))
+        res = o.numpy()
+        d.free(); o.free()
+        return res
+
+    def ring_frames(self, ring, head, n_frames, frame_len, stride):
+        """VecDeque view -> dense [F, frame_len] DeviceArray (src/periodic.rs:291-304)."""
+        r = ring if isinstance(ring, DeviceArray) else self.to_device(np.ascontiguousarray(ring, dtype=np.float64))
+        cap = int(np.prod(r.shape))
+        out = self.empty((n_frames, frame_len))
+        self._check(self.L.vbx_ring_frames_f64(self.ctx, r.ptr, cap, head, n_frames, frame_len, stride, out.ptr))
+        if r is not ring:
+            self.sync(); r.free()
+        return out
+
+    def find_roots_f32(self, polys):
+        """The Complex<f32> instantiation of find_roots (src/polynomial.rs:336-386): polys [F, len] complex64."""
+        p = np.ascontiguousarray(polys, dtype=np.complex64)
+        d = self.to_device(p)
+        st = self.empty(p.shape[0], np.int32)
+        self._check(self.L.vbx_find_roots_c32(self.ctx, d.ptr, p.shape[0], p.shape[1], st.ptr))
+        res = (d.numpy(), st.numpy())
+        d.free(); st.free()
+        return res
+
+    def laguerre_f32(self, polys, start):
+        p = np.ascontiguousarray(polys, dtype=np.complex64)
+        d = self.to_device(p)
+        o = self.empty(p.shape[0], np.complex64)
+        self._check(self.L.vbx_laguerre_c32(self.ctx, d.ptr, p.shape[0], p.shape[1], _Complex32(start.real, start.imag), o.ptr))
         res = o.numpy()
         d.free(); o.free()
         return res
