@@ -195,6 +195,15 @@ int vbx_find_roots_c64(vbx_ctx *ctx, vbx_complex *polys, size_t n_polys, size_t 
 int vbx_laguerre_c64(vbx_ctx *ctx, const vbx_complex *polys, size_t n_polys, size_t len,
                      vbx_complex start, vbx_complex *out);
 
+/* Polynomial::div_polynomial_mut (src/polynomial.rs:155-195) on F polynomials: polys[f] / (x + others[f]);
+ * the quotient is left in polys, rem: [F, len] receives the remainder exactly as the reference leaves it.
+ * status: VBX_FRAME_ERR_POLYNOMIAL where others[f] == 0 ("Tried to divide by zero"). */
+int vbx_div_polynomial_c64(vbx_ctx *ctx, vbx_complex *polys, const vbx_complex *others, size_t n_polys, size_t len,
+                           vbx_complex *rem, int32_t *status);
+/* Polynomial::degree / off_low (src/polynomial.rs:26-32) of one HOST polynomial (trivial scans, no device work) */
+size_t vbx_degree_c64(const vbx_complex *h_poly, size_t len);
+size_t vbx_off_low_c64(const vbx_complex *h_poly, size_t len);
+
 /* The f32 instantiation of Polynomial (Complex<f32>, exercised by the reference's own tests at
  * src/polynomial.rs:336-386): same algorithms in single precision.  polys: [F, len] of {float re, im}. */
 typedef struct { float re, im; } vbx_complex32;

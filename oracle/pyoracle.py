@@ -187,6 +187,16 @@ def find_roots_mut(p):
     return st, p
 
 
+def div_polynomial(p, other):
+    """div_polynomial_mut (src/polynomial.rs:155-195): returns (status, quotient-in-self, rem)."""
+    p = _c128(p).copy()
+    rem = np.zeros_like(p)
+    L = lib()
+    L.vbxo_div_polynomial_mut.argtypes = [C.c_void_p, C.c_size_t, _C64, C.c_void_p]
+    st = L.vbxo_div_polynomial_mut(_p(p), p.size, _C64(other.real, other.imag), _p(rem))
+    return st, p, rem
+
+
 class _C32(C.Structure):
     _fields_ = [("re", C.c_float), ("im", C.c_float)]
 

@@ -509,6 +509,10 @@ static int div_polynomial_mut(vbxo_c64 *self, size_t len, vbxo_c64 other, vbxo_c
     for (size_t k = 0; k < cnt; k++) self[vbxo_degree(self, len)] = c_new(0, 0);
     return VBXO_OK;
 }
+/* the public trait method (polynomial.rs:155): quotient of self / (x + other) left in self, remainder in rem */
+int vbxo_div_polynomial_mut(vbxo_c64 *self, size_t len, vbxo_c64 other, vbxo_c64 *rem) {
+    return div_polynomial_mut(self, len, other, rem);
+}
 
 /* polynomial.rs:92-152.  The caller's work slice is restated as zeroed scratch
  * (as in find_roots :80 and tests/lib.rs:34,67). */

@@ -79,6 +79,7 @@ size_t vbxo_degree(const vbxo_c64 *p, size_t len);                              
 size_t vbxo_off_low(const vbxo_c64 *p, size_t len);                                /* :30-32 */
 vbxo_c64 vbxo_laguerre(const vbxo_c64 *p, size_t len, vbxo_c64 start);             /* :34-72 */
 int vbxo_find_roots_mut(vbxo_c64 *p, size_t len);                                  /* :92-152 */
+int vbxo_div_polynomial_mut(vbxo_c64 *p, size_t len, vbxo_c64 other, vbxo_c64 *rem); /* :155-195 */
 /* find_roots (:79-89): copies, solves, pops trailing zeros. returns status; *n_roots out */
 int vbxo_find_roots(const vbxo_c64 *p, size_t len, vbxo_c64 *roots, size_t *n_roots);
 

@@ -66,6 +66,13 @@ def test_mel_scalars(pkg, oracle):
     assert lib.vbx_find_formants_complex_work_size(10) == 74                           # src/lib.rs:34-36
 
 
+def test_polynomial_host_helpers(pkg, oracle):
+    """src/polynomial.rs:269-279 test_degree / test_off_low through the library's host helpers."""
+    assert pkg.poly_degree([3.0, 2.0, 4.0, 0.0, 0.0]) == 2 == oracle.degree([3.0, 2.0, 4.0, 0.0, 0.0])
+    assert pkg.poly_off_low([0.0, 0.0, 3.0, 2.0, 4.0]) == 2 == oracle.off_low([0.0, 0.0, 3.0, 2.0, 4.0])
+    assert pkg.poly_degree([0.0, 0.0]) == 0 and pkg.poly_off_low([0.0, 0.0]) == 0
+
+
 def test_host_synth_is_deterministic(pkg):
     import __graft_entry__ as g
     synth = __import__("importlib").import_module(g.PKG_NAME + ".synth")

@@ -188,6 +188,26 @@ def test_roots_kats(vb, oracle):
     assert cnt[0] == 1 and abs(res[0, 0, 0] - 4045.196) < 1.0
 
 
+def test_div_polynomial(vb, oracle):
+    """Polynomial::div_polynomial_mut (src/polynomial.rs:155-195): quotient, remainder and the Err on a zero divisor
+    against the oracle's literal restatement (the reference's own test is commented out, :216-267)."""
+    rng = np.random.default_rng(21)
+    P = (rng.uniform(-1, 1, (40, 8)) + 1j * rng.uniform(-1, 1, (40, 8)))
+    P[5, 5:] = 0.0                                     # lower degree than the slice
+    P[6, :] = 0.0; P[6, 0] = 2.0                       # degree 0
+    O = rng.uniform(-2, 2, 40) + 1j * rng.uniform(-2, 2, 40)
+    O[7] = 0.0                                         # "Tried to divide by zero"
+    q, r, st = vb.div_polynomial(P, O)
+    for f in range(P.shape[0]):
+        es, eq, er = oracle.div_polynomial(P[f], complex(O[f]))
+        assert st[f] == es, f
+        assert np.allclose(q[f], eq, rtol=1e-12, atol=1e-13) and np.allclose(r[f], er, rtol=1e-12, atol=1e-13), f
+    assert st[7] == 2
+    # (x - 1)(x + 2) = x^2 + x - 2 divided by (x + 2): quotient x - 1, remainder 0
+    q, r, st = vb.div_polynomial(np.array([[-2.0, 1.0, 1.0]]), np.array([2.0]))
+    assert st[0] == 0 and np.allclose(q[0], [-1.0, 1.0, 0.0]) and np.allclose(r[0], 0.0)
+
+
 def test_roots_f32_kats(vb, oracle):
     """src/polynomial.rs:336-386, the Complex<f32> instantiation through the GPU path."""
     r, st = vb.find_roots_f32(np.array([[1.0, -2.5, 2.0]]))

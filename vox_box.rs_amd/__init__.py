@@ -12,7 +12,7 @@ The directory name contains a dot, so import it through ``__graft_entry__.load_p
 """
 from .voxbox import (  # noqa: F401
     VoxBox, VoxBoxError, DeviceArray, LIB_PATH, load_library, exported_symbols,
-    window_table, frame_count, hz_to_mel, mel_to_hz,
+    window_table, frame_count, hz_to_mel, mel_to_hz, poly_degree, poly_off_low,
     WINDOW_HANNING, WINDOW_HANNING_LAG, WINDOW_HANNING_PERIODIC, WINDOW_RECTANGLE,
     MALE_FORMANT_ESTIMATES, FEMALE_FORMANT_ESTIMATES,
     FRAME_OK, FRAME_ERR_LPC, FRAME_ERR_POLYNOMIAL, FRAME_ERR_NAN, FRAME_ERR_PANIC,

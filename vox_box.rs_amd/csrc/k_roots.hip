@@ -175,6 +175,41 @@ __global__ __launch_bounds__(ROOTS_BLOCK) void laguerre_kernel(const CT *__restr
     if (active) { out[f].re = z.re; out[f].im = z.im; }
 }
 
+// Polynomial::div_polynomial_mut (src/polynomial.rs:155-195): self / (x + other), quotient left in self, the
+// remainder bookkeeping of the reference reproduced literally (degree() re-evaluated after every zeroing).
+// One lane per polynomial, straight on global memory (a helper of find_roots in the reference; not a hot path).
+__global__ void div_polynomial_kernel(cplx_t *__restrict__ polys, const cplx_t *__restrict__ others, long n_polys, int len,
+                                      cplx_t *__restrict__ rem, int32_t *__restrict__ status) {
+    const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_polys) return;
+    cplx_t *p = polys + f * (long)len, *r = rem + f * (long)len;
+    const cplx_t o = others[f];
+    auto degree = [&](const cplx_t *q) { int d = 0; for (int j = 0; j < len; j++) if (!(q[j].re == 0.0 && q[j].im == 0.0)) d = j; return d; };
+    for (int i = 0; i < len; i++) r[i] = p[i];
+    int st = 0;
+    if (o.re == 0.0 && o.im == 0.0) st = 2;                                        // Err(Polynomial), :192
+    else {
+        const int ns = degree(p);
+        for (int i = ns - 1; i >= 0; i--) {                                           // (0..(ns - ds + 1)).rev(), ds = 1
+            p[i] = r[1 + i];
+            cplx_t t;                                                                 // rem[i] - self[i] * other
+            t.re = r[i].re - (p[i].re * o.re - p[i].im * o.im);
+            t.im = r[i].im - (p[i].re * o.im + p[i].im * o.re);
+            r[i] = t;
+        }
+        for (int k = 1; k < ns + 1; k++) { const int d = degree(r); r[d].re = 0.0; r[d].im = 0.0; }   // :174-176
+        const int l = degree(p);
+        const int cnt = (l + 1) - ns;                                                 // (l + 1) - ns - ds + 1
+        if (cnt < 0) st = 4;                                                          // usize underflow panics
+        for (int k = 0; k < cnt; k++) { const int d = degree(p); p[d].re = 0.0; p[d].im = 0.0; }
+    }
+    if (status != nullptr) status[f] = st;
+}
+
+void launch_div_polynomial(hipStream_t s, cplx_t *polys, const cplx_t *others, long F, int len, cplx_t *rem, int32_t *status) {
+    hipLaunchKernelGGL(div_polynomial_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, s, polys, others, F, len, rem, status);
+}
+
 // insertion of one resonance into a frequency-sorted row (stable: equal keys keep arrival order)
 __device__ __forceinline__ void res_insert_sorted(res_t *row, int count, res_t v) {
     int j = count;

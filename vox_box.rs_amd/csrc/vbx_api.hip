@@ -732,6 +732,29 @@ int vbx_laguerre_c64(vbx_ctx *ctx, const vbx_complex *polys, size_t n_polys, siz
     return check_launch(ctx, __func__);
 }
 
+int vbx_div_polynomial_c64(vbx_ctx *ctx, vbx_complex *polys, const vbx_complex *others, size_t n_polys, size_t len,
+                           vbx_complex *rem, int32_t *status) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    if (n_polys == 0) return VBX_SUCCESS;
+    VBX_REQUIRE(ctx, polys && others && rem, "null argument");
+    VBX_REQUIRE(ctx, len >= 1 && len <= 2 * VBX_MAX_LPC_ORDER + 4, "len must be in [1, 64]");
+    VBX_REQUIRE(ctx, n_polys <= 0x7fffffffull, "too many polynomials");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    { Prof p(ctx, "div_polynomial"); launch_div_polynomial(ctx->stream, (cplx_t *)polys, (const cplx_t *)others, (long)n_polys, (int)len, (cplx_t *)rem, status); }
+    return check_launch(ctx, __func__);
+}
+
+size_t vbx_degree_c64(const vbx_complex *h_poly, size_t len) {          // src/polynomial.rs:26-28
+    if (!h_poly) return 0;
+    for (size_t i = len; i-- > 0;) if (!(h_poly[i].re == 0.0 && h_poly[i].im == 0.0)) return i;
+    return 0;
+}
+size_t vbx_off_low_c64(const vbx_complex *h_poly, size_t len) {         // src/polynomial.rs:30-32
+    if (!h_poly) return 0;
+    for (size_t i = 0; i < len; i++) if (!(h_poly[i].re == 0.0 && h_poly[i].im == 0.0)) return i;
+    return 0;
+}
+
 int vbx_find_roots_c32(vbx_ctx *ctx, vbx_complex32 *polys, size_t n_polys, size_t len, int32_t *status) {
     VBX_REQUIRE(ctx, ctx != nullptr, "null context");
     if (n_polys == 0) return VBX_SUCCESS;

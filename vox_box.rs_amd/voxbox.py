@@ -92,6 +92,9 @@ def load_library():
         "vbx_lpc_burg_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, vp, vp]),
         "vbx_find_roots_c64": (C.c_int, [vp, vp, sz, sz, vp]),
         "vbx_laguerre_c64": (C.c_int, [vp, vp, sz, sz, _Complex, vp]),
+        "vbx_div_polynomial_c64": (C.c_int, [vp, vp, vp, sz, sz, vp, vp]),
+        "vbx_degree_c64": (sz, [vp, sz]),
+        "vbx_off_low_c64": (sz, [vp, sz]),
         "vbx_ring_frames_f64": (C.c_int, [vp, vp, sz, sz, sz, sz, sz, vp]),
         "vbx_find_roots_c32": (C.c_int, [vp, vp, sz, sz, vp]),
         "vbx_laguerre_c32": (C.c_int, [vp, vp, sz, sz, _Complex32, vp]),
@@ -117,6 +120,18 @@ def load_library():
 
 
 # ---- host-only helpers (no GPU needed) --------------------------------------------------
+
+def poly_degree(poly):
+    """Polynomial::degree (src/polynomial.rs:26-28) of one host polynomial."""
+    p = np.ascontiguousarray(poly, dtype=np.complex128)
+    return int(load_library().vbx_degree_c64(p.ctypes.data, p.size))
+
+
+def poly_off_low(poly):
+    """Polynomial::off_low (src/polynomial.rs:30-32)."""
+    p = np.ascontiguousarray(poly, dtype=np.complex128)
+    return int(load_library().vbx_off_low_c64(p.ctypes.data, p.size))
+
 
 def window_table(kind, n):
     out = np.empty(n, dtype=np.float64)
@@ -413,6 +428,18 @@ class VoxBox:
         self._check(self.L.vbx_laguerre_c64(self.ctx, d.ptr, p.shape[0], p.shape[1], _Complex(start.real, start.imag), o.ptr))
         res = o.numpy()
         d.free(); o.free()
+        return res
+
+    def div_polynomial(self, polys, others):
+        """div_polynomial_mut (src/polynomial.rs:155-195) per row: returns (quotient rows, remainder rows, status)."""
+        p = np.ascontiguousarray(polys, dtype=np.complex128)
+        o = np.ascontiguousarray(others, dtype=np.complex128)
+        d, do = self.to_device(p), self.to_device(o)
+        rem, st = self.empty(p.shape, np.complex128), self.empty(p.shape[0], np.int32)
+        self._check(self.L.vbx_div_polynomial_c64(self.ctx, d.ptr, do.ptr, p.shape[0], p.shape[1], rem.ptr, st.ptr))
+        res = (d.numpy(), rem.numpy(), st.numpy())
+        for b in (d, do, rem, st):
+            b.free()
         return res
 
     def ring_frames(self, ring, head, n_frames, frame_len, stride):
