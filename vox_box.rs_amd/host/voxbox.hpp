@@ -120,6 +120,13 @@ struct Autocorrelate {   // periodic.rs:265-274
         autocorrelate_mut(c, f, n_coeffs, out.data());
         return out;
     }
+    // impl Autocorrelate for VecDeque (periodic.rs:291-304): the Windower view over a ring buffer as a dense batch
+    static DeviceVec<double> ring_frames(Context &c, const double *ring, size_t capacity, size_t head, size_t n_frames,
+                                         size_t frame_len, size_t stride) {
+        DeviceVec<double> out(c, n_frames * frame_len);
+        c.check(vbx_ring_frames_f64(c.get(), ring, capacity, head, n_frames, frame_len, stride, out.data()));
+        return out;
+    }
 };
 
 struct RMS {             // waves.rs:10-23
@@ -180,6 +187,21 @@ struct Polynomial {      // polynomial.rs:10-21
         c.check(vbx_laguerre_c64(c.get(), polys, n_polys, len, start, out));
     }
     static size_t find_roots_work_size(size_t len) { return len * 6 + 4; }   // polynomial.rs:75-77 (unused: the library owns its scratch)
+    // self / (x + other): quotient left in polys, remainder in rem (polynomial.rs:155-195)
+    static void div_polynomial_mut(Context &c, Complex *polys, const Complex *others, size_t n_polys, size_t len,
+                                   Complex *rem, int32_t *status) {
+        c.check(vbx_div_polynomial_c64(c.get(), polys, others, n_polys, len, rem, status));
+    }
+    static size_t degree(const Complex *h_poly, size_t len) { return vbx_degree_c64(h_poly, len); }     // polynomial.rs:26
+    static size_t off_low(const Complex *h_poly, size_t len) { return vbx_off_low_c64(h_poly, len); }   // polynomial.rs:30
+    // the Complex<f32> instantiation (polynomial.rs:336-386)
+    static void find_roots_mut(Context &c, vbx_complex32 *polys, size_t n_polys, size_t len, int32_t *status) {
+        c.check(vbx_find_roots_c32(c.get(), polys, n_polys, len, status));
+    }
+    static void laguerre(Context &c, const vbx_complex32 *polys, size_t n_polys, size_t len, vbx_complex32 start,
+                         vbx_complex32 *out) {
+        c.check(vbx_laguerre_c32(c.get(), polys, n_polys, len, start, out));
+    }
 };
 
 struct ToResonance {     // spectrum.rs:195-210
