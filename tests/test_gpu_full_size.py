@@ -73,6 +73,19 @@ def test_pipeline_one_hour_strided(vb, oracle, pkg):
     dense = np.stack([ah[t * H:t * H + N] for t in idx])
     c2, k2, s2 = vb.pitch(dense, SR, 0.2, 75.0, 600.0, kmax=2, window=han)
     assert np.array_equal(c2, C[idx]) and np.array_equal(k2, K[idx])
+    # exact top-k pruning at scale: the entries returned for kmax = 1, 2 are, bit for bit, the head of the list
+    # returned for kmax = 64 (which refines everything in frames of up to 64 candidates) -- all 359,998 frames
+    c1, k1, s1 = vb.empty((F, 1, 2)), vb.empty(F, np.int32), vb.empty(F, np.int32)
+    vb.pitch(audio, SR, 0.2, 75.0, 600.0, kmax=1, frame_len=N, stride=H, n_frames=F, window=han, out=(c1, k1, s1))
+    c64, k64, s64 = vb.empty((F, 64, 2)), vb.empty(F, np.int32), vb.empty(F, np.int32)
+    vb.pitch(audio, SR, 0.2, 75.0, 600.0, kmax=64, frame_len=N, stride=H, n_frames=F, window=han, out=(c64, k64, s64))
+    C64 = c64.numpy()
+    assert np.array_equal(k1.numpy(), K) and np.array_equal(k64.numpy(), K)
+    assert np.array_equal(c1.numpy()[:, 0], C64[:, 0]) and np.array_equal(C, C64[:, :2])
+    full = K <= 64                                                          # frames whose whole list fits
+    assert full.sum() > 0.7 * F and np.all(np.diff(C64[full][:, :8, 1], axis=1) <= 0.0)
+    for d in (c1, k1, s1, c64, k64, s64):
+        d.free()
     # spot checks against the oracle inside the big batch (top candidate, BASELINE tolerance)
     wh = oracle.window("hanning", N)
     bad = 0
