@@ -482,24 +482,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const int ylen = 2 * n;                         // :411
     const int nvalid = n + Y_PAD;
 
-    // a) peaks -> filtered candidate list
-    int ncand = 0;
+    // a) peaks -> filtered candidate list.  Two passes so that the two divisions of the frequency filter run once per
+    // 64 PEAKS, not once per 64 lags: first every strict local maximum is compacted (index order), then the filter.
+    int npeak = 0;
     for (int base = 0; base < b; base += 64) {
         const int k = base + lane;
-        bool pass = false;
+        bool peak = false;
         if (k >= 1 && k + 1 < b) {                  // windows(3) over self_lag[0..b] (Q4)
             const double c = ys[k];
-            if ((ys[k - 1] < c) && (ys[k + 1] < c)) {
-                double freq, nn;
-                cand_from_peak(ys, k, sample_rate, offset, freq, nn);
-                pass = (freq == 0.0) || (freq > fmin && freq < fmax);         // :439
-            }
+            peak = (ys[k - 1] < c) && (ys[k + 1] < c);
         }
+        const unsigned long long mask = __ballot(peak);
+        if (peak) cand_list[npeak + __popcll(mask & ((1ull << lane) - 1ull))] = k;
+        npeak += __popcll(mask);
+    }
+    wave_sync();
+    int ncand = 0;
+    for (int base = 0; base < npeak; base += 64) {  // in place: the write position never passes the read position
+        const int i = base + lane;
+        bool pass = false;
+        int k = 0;
+        if (i < npeak) {
+            k = cand_list[i];
+            double freq, nn;
+            cand_from_peak(ys, k, sample_rate, offset, freq, nn);
+            pass = (freq == 0.0) || (freq > fmin && freq < fmax);             // :439
+        }
+        wave_sync();                                // all reads of this pass before its writes
         const unsigned long long mask = __ballot(pass);
         if (pass) cand_list[ncand + __popcll(mask & ((1ull << lane) - 1ull))] = k;
         ncand += __popcll(mask);
+        wave_sync();
     }
-    wave_sync();
 
     // a') first-evaluation bounds.  p16: prefix sums of |y| over blocks of 4; keys[c]: upper bound of candidate c's strength
     {
