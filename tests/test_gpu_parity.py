@@ -146,7 +146,8 @@ def test_lpc_praat_kat(vb, oracle):
     assert st[0] == 0 and np.all(np.abs(co[0] - exp) < 1e-10)
 
 
-@pytest.mark.parametrize("n,p", [(512, 12), (1200, 12), (1024, 10), (100, 5), (2049, 13), (4096, 8), (30, 4), (513, 30)])
+@pytest.mark.parametrize("n,p", [(512, 12), (1200, 12), (1024, 10), (100, 5), (2049, 13), (4096, 8), (30, 4), (513, 30),
+                                 (64, 20), (128, 16), (200, 17), (2000, 30), (1025, 1), (40, 30)])   # every lane-group shape
 def test_lpc_praat(vb, oracle, n, p):
     rng = np.random.default_rng(n * 31 + p)
     t = np.arange(n)
@@ -372,7 +373,7 @@ def test_find_formants_wav_fixture(vb, oracle, golden_dir):
         assert np.all(np.abs(out["formants"][t] - est) <= 1e-4 * np.abs(est))
 
 
-@pytest.mark.parametrize("n,hop,p", [(N48, H48, 12), (512, 480, 12), (1024, 512, 10)])
+@pytest.mark.parametrize("n,hop,p", [(N48, H48, 12), (512, 480, 12), (1024, 512, 10), (1024, 512, 16), (400, 160, 8)])
 def test_find_formants_synthetic(vb, oracle, audio, pkg, n, hop, p):
     F = min(pkg.frame_count(audio.size, n, hop), 420)
     est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
