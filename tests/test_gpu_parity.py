@@ -558,6 +558,37 @@ def test_pitch_tiny_frames(vb, oracle, audio, n):
             assert np.all(np.abs(cand[f, :k, 1] - ec[:k, 1]) <= 1e-4), (n, f)
 
 
+def test_pitch_odd_signals(vb, oracle):
+    """Noise, pure and clipped tones, square waves, chirps, impulses, DC, 1e-150 and 1e120 amplitudes: status and
+    candidate count exact, top candidate within BASELINE tolerance, and the kmax = 1, 3 outputs bit-identical to
+    the head of the kmax = 64 list."""
+    N, rng = 1200, np.random.default_rng(123)
+    t = np.arange(N) / SR
+    w = oracle.window("hanning", N)
+    gens = [lambda: rng.standard_normal(N),
+            lambda: np.sin(2 * np.pi * rng.uniform(60, 700) * t + rng.uniform(0, 6)),
+            lambda: np.sign(np.sin(2 * np.pi * rng.uniform(80, 400) * t)),
+            lambda: np.sin(2 * np.pi * (100 + 3000 * t) * t),
+            lambda: np.bincount(rng.integers(0, N, 5), minlength=N).astype(np.float64),
+            lambda: 0.5 + 0.01 * rng.standard_normal(N),
+            lambda: 1e-150 * np.sin(2 * np.pi * 200 * t),
+            lambda: 1e120 * np.sin(2 * np.pi * 150 * t),
+            lambda: np.sin(2 * np.pi * 120 * t) * (1 + 0.5 * np.sin(2 * np.pi * 7 * t)) + 0.2 * rng.standard_normal(N),
+            lambda: np.clip(3 * np.sin(2 * np.pi * rng.uniform(75, 600) * t), -1, 1)]
+    X = np.array([gens[i % len(gens)]() * w for i in range(200)])
+    res = {k: vb.pitch(X, SR, 0.2, 75.0, 600.0, kmax=k) for k in (1, 3, 64)}
+    for k in (1, 3):
+        assert np.array_equal(res[k][1], res[64][1]) and np.array_equal(res[k][2], res[64][2])
+        assert np.array_equal(res[k][0], res[64][0][:, :k]), k
+    for f in range(X.shape[0]):
+        es, ec, en = oracle.pitch(X[f], SR, 0.2, 75.0, 600.0)
+        assert res[1][2][f] == es and res[1][1][f] == (en if es == 0 else 0), f
+        if es == 0:
+            tie = en > 1 and abs(ec[0, 1] - ec[1, 1]) < 1e-3
+            ok = abs(res[1][0][f, 0, 0] - ec[0, 0]) <= 1e-4 * abs(ec[0, 0]) and abs(res[1][0][f, 0, 1] - ec[0, 1]) <= 1e-4
+            assert ok or tie, f
+
+
 def test_pitch_nonfinite_input(vb, oracle, audio):
     """NaN / inf samples: the reference's sort panics on NaN strengths (status 3) -- pruning must not hide that."""
     x = _frames(audio, N48, H48, [5, 40, 150, 260]) * oracle.window("hanning", N48)
