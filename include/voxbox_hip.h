@@ -21,8 +21,11 @@
  *    `window` (device, frame_len doubles, or NULL) is multiplied onto the
  *    samples on load: the batched form of window::Windower::hanning, whose
  *    frames the reference's traits receive already windowed.
- *  - all arithmetic is f64 ("Sample = f64" instantiation of the traits).
+ *  - all arithmetic is f64 ("Sample = f64" instantiation of the traits); the only f32 entry points are the
+ *    Complex<f32> Polynomial ones (vbx_*_c32).
  *  - calls are asynchronous on the context's HIP stream; vbx_sync() waits.
+ *  - a context (stream, cached tables, scratch) is not internally synchronised: one host thread per context at
+ *    a time.  Contexts are independent of each other and cheap; use one per thread / stream.
  *  - return value: 0 ok, <0 API misuse / runtime failure (vbx_last_error()).
  *    Per-frame conditions that make the reference return Err or panic are
  *    reported in an int32 status[F] array (codes below) so one bad frame never
