@@ -35,6 +35,7 @@ SEG_FRAMES = 1000                 # tracker state resets every 10 s utterance
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6           # FP64 vector peak
 FLOPS_PER_SINC_TERM = 13.0        # reference formula per term: sin, cos, 2 div, 9 mul/add (each counted once)
+METRIC = "frames/sec (pitch+LPC+formants), 48 kHz 25 ms/10 ms hop, 1\u21928 MI355X"   # BASELINE.json "metric", verbatim
 REC = 2 + 8 + 13 + 13             # per-frame record: pitch(f,s) + 4 formants(f,bw) + 13 MFCC + 13 LPC  (288 B)
 
 
@@ -306,7 +307,7 @@ def main():
             bytes_per_frame = stride * 8 + 2 * 13 * 8
         ach = F * bytes_per_frame / (dom_ms * 1e-3) / 1e9
         out = {
-            "metric": "frames/sec (pitch+LPC+formants), 48 kHz 25 ms/10 ms hop" if wl == "pipeline" else f"frames/sec ({wl})",
+            "metric": METRIC if wl == "pipeline" else f"frames/sec ({wl})",
             "value": total / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
