@@ -25,10 +25,14 @@ __device__ __forceinline__ bool slot_greater(const slot_t &a, const slot_t &b) {
     return false;
 }
 
-// One estimate_formants step.  The row has n_res entries of which the first `cnt` are read from
-// memory; the rest are the zero padding the reference passes along (src/lib.rs:55,114).
+constexpr int TRK_PF = 8;                 // leading row entries prefetched into registers one frame ahead
+
+// One estimate_formants step.  The row has n_res entries of which the first `cnt` are real (the first TRK_PF of
+// them arrive in registers, `pre`, the rest are read from memory); the others are the zero padding the reference
+// passes along (src/lib.rs:55,114).
 __device__ __forceinline__ void estimate_formants_step(double (&ef)[NS], double (&eb)[NS], int n_est,
-                                                       const res_t *__restrict__ row, int n_res, int cnt) {
+                                                       const res_t (&pre)[TRK_PF], const res_t *__restrict__ row,
+                                                       int n_res, int cnt) {
     slot_t s[NS];
 #pragma unroll
     for (int i = 0; i < NS; i++) { s[i].some = false; s[i].f = 0.0; s[i].bw = 0.0; }
@@ -37,11 +41,22 @@ __device__ __forceinline__ void estimate_formants_step(double (&ef)[NS], double 
     // the row serves all estimates.  Entries >= cnt are zeros: the first of them may win, the rest tie.
     {
         double bf[NS], bb[NS], bd[NS];
-        const res_t r0 = (cnt > 0) ? row[0] : res_t{0.0, 0.0};
+        const res_t r0 = (cnt > 0) ? pre[0] : res_t{0.0, 0.0};
 #pragma unroll
         for (int e = 0; e < NS; e++) { bf[e] = r0.frequency; bb[e] = r0.bandwidth; bd[e] = fabs(r0.frequency - ef[e]); }
         const int lim = (cnt < n_res) ? cnt + 1 : n_res;      // real entries + one representative zero
-        for (int i = 1; i < lim; i++) {
+#pragma unroll
+        for (int i = 1; i < TRK_PF; i++) {                    // register-resident entries: static indices
+            if (i < lim) {
+                const res_t it = (i < cnt) ? pre[i] : res_t{0.0, 0.0};
+#pragma unroll
+                for (int e = 0; e < NS; e++) {
+                    const double d = fabs(it.frequency - ef[e]);
+                    if (d < bd[e]) { bf[e] = it.frequency; bb[e] = it.bandwidth; bd[e] = d; }
+                }
+            }
+        }
+        for (int i = TRK_PF; i < lim; i++) {                  // long rows (orders above 14): from memory
             const res_t it = (i < cnt) ? row[i] : res_t{0.0, 0.0};
 #pragma unroll
             for (int e = 0; e < NS; e++) {
@@ -83,7 +98,7 @@ __device__ __forceinline__ void estimate_formants_step(double (&ef)[NS], double 
 #pragma unroll
         for (int j = 0; j < NS; j++) {
             if (j < n_res) {
-                const res_t pk = (j < cnt) ? row[j] : res_t{0.0, 0.0};
+                const res_t pk = (j < cnt) ? pre[j] : res_t{0.0, 0.0};         // NS <= TRK_PF
                 bool contained = false;
 #pragma unroll
                 for (int q = 0; q < NS; q++) contained = contained || (s[q].some && same_res(s[q].f, s[q].bw, pk.frequency, pk.bandwidth));
@@ -123,7 +138,7 @@ __device__ __forceinline__ void estimate_formants_step(double (&ef)[NS], double 
     }
 }
 
-__global__ void tracker_kernel(const res_t *__restrict__ res, long n_frames, int n_res,
+__global__ __launch_bounds__(64) void tracker_kernel(const res_t *__restrict__ res, long n_frames, int n_res,
                                const int32_t *__restrict__ res_count,
                                const int64_t *__restrict__ seg_start, long n_seg,
                                const res_t *__restrict__ est_init, int n_est,
@@ -138,15 +153,32 @@ __global__ void tracker_kernel(const res_t *__restrict__ res, long n_frames, int
         ef[e] = (e < n_est) ? est_init[e].frequency : 0.0;
         eb[e] = (e < n_est) ? est_init[e].bandwidth : 0.0;
     }
+    // The scan is a chain of dependent steps; frame f+1's status, count and leading row entries are requested
+    // before frame f is processed so that their latency is off the chain.
+    static_assert(NS <= TRK_PF, "step 4 reads its peaks from the prefetched entries");
+    res_t cur[TRK_PF];
+    int cur_cnt = 0;
+    bool cur_ok = false;
+    auto fetch = [&](long f, res_t (&dst)[TRK_PF], int &cnt, bool &ok) {
+        ok = (frame_status == nullptr) || frame_status[f] == 0;
+        cnt = (res_count != nullptr) ? res_count[f] : n_res;
+        const res_t *row = res + f * (long)n_res;
+#pragma unroll
+        for (int i = 0; i < TRK_PF; i++) dst[i] = (i < n_res) ? row[i] : res_t{0.0, 0.0};
+    };
+    if (f0 < f1) fetch(f0, cur, cur_cnt, cur_ok);
     for (long f = f0; f < f1; f++) {
-        const bool ok = (frame_status == nullptr) || frame_status[f] == 0;
-        if (ok) {
-            const int cnt = (res_count != nullptr) ? res_count[f] : n_res;
-            estimate_formants_step(ef, eb, n_est, res + f * (long)n_res, n_res, cnt);
-        }
+        res_t nxt[TRK_PF];
+        int nxt_cnt = 0;
+        bool nxt_ok = false;
+        if (f + 1 < f1) fetch(f + 1, nxt, nxt_cnt, nxt_ok);
+        if (cur_ok) estimate_formants_step(ef, eb, n_est, cur, res + f * (long)n_res, n_res, cur_cnt);
 #pragma unroll
         for (int e = 0; e < NS; e++)
             if (e < n_est) { res_t o; o.frequency = ef[e]; o.bandwidth = eb[e]; out[f * (long)n_est + e] = o; }
+#pragma unroll
+        for (int i = 0; i < TRK_PF; i++) cur[i] = nxt[i];
+        cur_cnt = nxt_cnt; cur_ok = nxt_ok;
     }
 }
 
