@@ -257,9 +257,12 @@ def main():
             side.find_formants(audio, SR, P, est0, seg_start=seg, frame_len=frame_len, stride=stride, n_frames=F, out=ff)
         if wl in ("pipeline", "config2"):
             side.autocorr_lpc(audio, P, frame_len=frame_len, stride=stride, n_frames=F, window=win, out=(o_r, o_a))
-        if wl == "pipeline" and arrange != "mfcc_main":
+        if wl == "pipeline" and arrange not in ("mfcc_main", "mfcc_first"):
             side.mfcc(audio, 13, (100.0, 8000.0), SR, frame_len=frame_len, stride=stride, n_frames=F, window=win,
                       out=(o_mfcc, o_mst))
+        if wl == "pipeline" and arrange == "mfcc_first":
+            vb.mfcc(audio, 13, (100.0, 8000.0), SR, frame_len=frame_len, stride=stride, n_frames=F, window=win,
+                    out=(o_mfcc, o_mst))
         if wl in ("pipeline", "config3"):
             vb.pitch(audio, SR, 0.2, 75.0, 600.0, kmax=args.kmax, frame_len=frame_len, stride=stride, n_frames=F, window=win,
                      out=(o_cand, o_cnt, o_pst))
