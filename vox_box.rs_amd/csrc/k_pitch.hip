@@ -311,6 +311,7 @@ __device__ __forceinline__ void improve_extremum_sinc(const double *y, int nvali
 constexpr int Y_PAD = 64;
 constexpr int PG = 16;                          // lanes per query point (sinc_points / extremum_points kernels)
 constexpr int PNG = 64 / PG;                    // points per wavefront
+constexpr int GROUP_PATH_MIN_CAND = 32;         // pitch frames with more candidates refine them 4 at a time, 16 lanes each
 
 __device__ __forceinline__ void cand_from_peak(const double *ys, int kk, double sample_rate, int offset,
                                                double &freq, double &nn) {
@@ -578,26 +579,135 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     // (improve_extremum, :192-229): every lane runs the reference's Brent iteration on identical values (the wave
     // sums are bit-identical in all lanes).  In a voiced frame the first strength becomes the bar that retires every
     // other candidate without an evaluation.  Finished candidates enter the lane-resident list ordered by
-    // (strength desc, candidate index asc) == the reference's stable sort (:453).  One path for every candidate,
-    // whatever kmax is: a candidate's result never depends on which others are refined.
-    for (;;) {
-        const double bar = VBX_BAR();
-        const int c = pick_best(keys, ncand, bar, lane);
-        if (c < 0) break;
-        double freq, nn, xmid, ymid;
-        cand_from_peak(ys, cand_list[c], sample_rate, offset, freq, nn);
-        bool dropped = false;
-        improve_extremum_sinc<64>(ys, nvalid, ylen, offset, nx, nn, 1200, true, xmid, ymid, st, &cterms, &cevals, bar, &dropped);
-        if (dropped) continue;
-        double xm, ym;
-        {
+    // (strength desc, candidate index asc) == the reference's stable sort (:453).
+    // Frames with many candidates (noise-like frames: short lags, little work per evaluation) use four groups of 16
+    // lanes instead, each refining one candidate and taking the next-best as soon as its own has converged.  Which of
+    // the two paths a frame takes depends on its candidate count only, never on kmax: a candidate's result does not
+    // depend on which others are refined, and the returned list is the same head of the same full list.
+    unsigned nterms = 0, nevals = 0;                // group path: work executed (group leaders' counts are summed)
+    if (ncand <= GROUP_PATH_MIN_CAND) {
+        for (;;) {
+            const double bar = VBX_BAR();
+            const int c = pick_best(keys, ncand, bar, lane);
+            if (c < 0) break;
+            double freq, nn, xmid, ymid;
+            cand_from_peak(ys, cand_list[c], sample_rate, offset, freq, nn);
+            bool dropped = false;
+            improve_extremum_sinc<64>(ys, nvalid, ylen, offset, nx, nn, 1200, true, xmid, ymid, st, &cterms, &cevals, bar, &dropped);
+            if (dropped) continue;
+            double xm, ym;
+            {
 #pragma clang fp contract(off)
-            xm = xmid + (double)offset;                                   // :445
-            ym = ymid;
-            if (ym > 1.) ym = 1. / ym;                                    // :446
-            xm = sample_rate / xm;                                        // :447
+                xm = xmid + (double)offset;                                   // :445
+                ym = ymid;
+                if (ym > 1.) ym = 1. / ym;                                    // :446
+                xm = sample_rate / xm;                                        // :447
+            }
+            insert(xm, ym, c);
         }
-        insert(xm, ym, c);
+    } else {
+        bool exhausted = false;
+        const int gid = lane / PG;
+        int ci = -1, it = 0;
+        bool special = false;
+        double ba = 0., bb = 0., v = 0., w = 0., x = 0., fv = 0., fw = 0., fx = 0., xmid = 0., ymid = 0.;
+        constexpr unsigned long long LEADERS = (PG == 16) ? 0x0001000100010001ull : (PG == 8) ? 0x0101010101010101ull
+                                             : (PG == 32) ? 0x0000000100000001ull : (PG == 4) ? 0x1111111111111111ull : 1ull;
+        for (;;) {
+#pragma clang fp contract(off)   // the scalar Brent arithmetic stays bit-identical to the unfused CPU arithmetic
+            {   // hand the best remaining candidates to the idle groups, in group order
+                unsigned long long im = __ballot(ci < 0) & LEADERS;
+                while (im != 0ull && !exhausted) {
+                    const int c = pick_best(keys, ncand, VBX_BAR(), lane);
+                    if (c < 0) { exhausted = true; break; }
+                    const int g = __builtin_ctzll(im) / PG;
+                    im &= im - 1ull;
+                    if (gid == g) {
+                        ci = c;
+                        double freq, nn;
+                        cand_from_peak(ys, cand_list[ci], sample_rate, offset, freq, nn);
+                        it = 0; special = false; xmid = 0.; ymid = 0.;
+                        if (nn == 0.) { special = true; xmid = 0.; ymid = ys[0]; }                              // :193
+                        else if (nn >= (double)nx) { special = true; xmid = (double)nx; ymid = y_at(ys, nvalid, nx - 1); }   // :194
+                        else if (!(nn - 1. < nn + 1.)) { special = true; st |= 4; }                             // assert!(a < b), :113
+                        ba = nn - 1.; bb = nn + 1.;
+                    }
+                }
+            }
+            if (!__any(ci >= 0)) break;
+            const double bar = VBX_BAR();
+
+            const double golden = 1. - 0.6180339887498948482045868343656381177203091798057628621;
+            const double sqrt_epsilon = 1.4901161193847656e-08, eps = 2.220446049250313e-16, tol = 1e-10;
+            bool finished = false, need = false, pruned = false;
+            double t = 0.;
+            if (ci >= 0) {
+                if (special) finished = true;
+                else if (it == 0) { v = ba + golden * (bb - ba); t = v; need = true; }
+                else {
+                    const double range = bb - ba;
+                    const double middle_range = (ba + bb) * 0.5;
+                    const double tol_act = sqrt_epsilon * fabs(x) + tol / 3.;
+                    if (it > 60 || fabs(x - middle_range) + range * 0.5 <= 2. * tol_act) { finished = true; xmid = x; ymid = fx; }
+                    else {
+                        double new_step = (x < middle_range) ? golden * (bb - x) : golden * (ba - x);
+                        if (fabs(x - w) >= tol_act) {
+                            const double tt = (x - w) * (fx - fv);
+                            double q = (x - v) * (fx - fw);
+                            double pp = (x - v) * q - (x - w) * tt;
+                            q = 2. * q - tt;
+                            if (q > 0.) pp = -pp; else q = -q;
+                            if (fabs(pp) < fabs(new_step * q) && pp > q * (ba - x + 2. * tol_act) && pp < q * (bb - x - 2. * tol_act))
+                                new_step = pp / q;
+                        }
+                        if (fabs(new_step) < tol_act) new_step = (new_step > 0.) ? tol_act : -tol_act;
+                        t = x + new_step;
+                        need = true;
+                    }
+                }
+            }
+            const double ft = sinc_interp<PG>(ys, nvalid, ylen, offset, nx, t, 1200, need, st, &nterms);
+            nevals += need ? 1u : 0u;
+            if (need) {
+                if (it == 0) {
+                    x = v; w = v; fv = ft; fx = ft; fw = ft; it = 1;
+                    const double ub = (ft <= 1.) ? ft : 1.;          // NaN -> 1: never pruned
+                    // ba >= -offset: every abscissa of the bracket has its left neighbour at index >= 0, so none of
+                    // the skipped evaluations could have been an out-of-bounds panic of the reference
+                    if (ub < bar && ba >= (double)(-offset)) { finished = true; pruned = true; }
+                } else {
+                    if (ft <= fx) {
+                        if (t < x) bb = x; else ba = x;
+                        v = w; w = x; x = t;
+                        fv = fw; fw = fx; fx = ft;
+                    } else {
+                        if (t < x) ba = t; else bb = t;
+                        if (ft <= fw || fabs(w - x) < eps) {
+                            v = w; w = t;
+                            fv = fw; fw = ft;
+                        } else if (ft <= fv || fabs(v - x) < eps || fabs(v - w) < eps) {
+                            v = t;
+                            fv = ft;
+                        }
+                    }
+                    it++;
+                }
+            }
+            // finished candidates -> sorted list
+            if (__any(finished)) {
+                unsigned long long fm = __ballot(finished && !pruned) & LEADERS;
+                double xm = xmid + (double)offset;                                // :445
+                double ym = ymid;
+                if (ym > 1.) ym = 1. / ym;                                        // :446
+                const double cf = sample_rate / xm, cs = ym;                      // :447-448
+                while (fm) {
+                    const int ld = __builtin_ctzll(fm);
+                    fm &= fm - 1;
+                    insert(readlane_f64(cf, ld), readlane_f64(cs, ld), __builtin_amdgcn_readlane(ci, ld));
+                }
+                if (finished) ci = -1;
+            }
+        }
     }
 #undef VBX_BAR
     const int total_cand = ncand + 1;
@@ -616,10 +726,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         if (out_count != nullptr) out_count[f] = (code == 0) ? total_cand : 0;
         if (status != nullptr) status[f] = code;
     }
-    if (work != nullptr && lane == 0) {             // profiling only: frames, candidates, sinc evaluations, sinc terms
-        unsigned long long *w = work + 4 * (f & (PITCH_WORK_SLOTS - 1));
-        atomicAdd(w + 0, 1ull); atomicAdd(w + 1, (unsigned long long)ncand);
-        atomicAdd(w + 2, (unsigned long long)cevals); atomicAdd(w + 3, (unsigned long long)cterms);
+    if (work != nullptr) {                          // profiling only: frames, candidates, sinc evaluations, sinc terms
+        const bool leader = (lane & (PG - 1)) == 0;
+        unsigned long long te = leader ? nterms : 0u, ev = leader ? nevals : 0u;
+        for (int o = 32; o > 0; o >>= 1) { te += __shfl_xor(te, o, 64); ev += __shfl_xor(ev, o, 64); }
+        if (lane == 0) {
+            unsigned long long *w = work + 4 * (f & (PITCH_WORK_SLOTS - 1));
+            atomicAdd(w + 0, 1ull); atomicAdd(w + 1, (unsigned long long)ncand);
+            atomicAdd(w + 2, ev + cevals); atomicAdd(w + 3, te + cterms);
+        }
     }
 }
 
