@@ -667,6 +667,35 @@ def test_mfcc_three_kernels_agree(pkg, oracle, audio, monkeypatch):
     assert not np.array_equal(res["dft2"][0], res["goertzel"][0])
 
 
+def test_mfcc_and_formants_odd_signals(vb, oracle):
+    """Noise, tones, impulses, DC, silence, extreme scales through MFCC (matrix-core kernel at N = 1200) and
+    find_formants: statuses exact (silence -> Err(LPC)), values within BASELINE tolerance of the oracle."""
+    N, rng = 1200, np.random.default_rng(77)
+    t = np.arange(N) / SR
+    gens = [lambda: rng.standard_normal(N), lambda: np.sin(2 * np.pi * rng.uniform(60, 7000) * t),
+            lambda: np.bincount(rng.integers(0, N, 5), minlength=N).astype(np.float64),
+            lambda: 0.5 + 0.01 * rng.standard_normal(N), lambda: np.zeros(N),
+            lambda: 1e-120 * rng.standard_normal(N), lambda: 1e100 * np.sin(2 * np.pi * 440 * t),
+            lambda: np.sign(np.sin(2 * np.pi * 150 * t)) + 0.1 * rng.standard_normal(N)]
+    X = np.array([gens[i % len(gens)]() for i in range(48)])
+    w = oracle.window("hanning", N)
+    m, ms = vb.mfcc(X * w, 13, (100.0, 8000.0), SR)
+    for f in range(X.shape[0]):
+        es, em = oracle.mfcc(X[f] * w, 13, 100.0, 8000.0, SR)
+        assert ms[f] == es
+        assert np.all(rel_close(m[f], em, 1e-6)), (f, np.max(np.abs(m[f] - em)))
+    est0 = np.array([[fq, 1.0] for fq in (320.0, 1440.0, 2760.0, 3200.0)])
+    out = vb.find_formants(X, SR, 12, est0, seg_start=np.arange(0, X.shape[0], 1), want=("formants", "status"))
+    broadband = {0, 3, 5, 7}                                 # pure tones / impulses / 1e100 tones give an order-12 Burg
+    for f in range(X.shape[0]):                              # polynomial with clustered roots: root positions are then
+        es, ef, _, _ = oracle.find_formants(X[f], SR, 12, est0)   # ill-conditioned (1 % moves under ANY rounding change)
+        assert out["status"][f] == es, (f, out["status"][f], es)  # every frame its own segment: no carried state
+        if es == 0:
+            assert np.all(np.isfinite(out["formants"][f]))
+            if f % len(gens) in broadband:
+                assert np.all(np.abs(out["formants"][f, :, 0] - ef[:, 0]) <= 1e-4 * np.abs(ef[:, 0]) + 1e-9), f
+
+
 def test_mfcc_bins_beyond_spectrum_is_panic_status(vb, oracle):
     x = np.ones((2, 64))
     m, st = vb.mfcc(x, 13, (100.0, 30000.0), 22050.0)      # mel points beyond the spectrum length
