@@ -308,7 +308,9 @@ __device__ __forceinline__ void improve_extremum_sinc(const double *y, int nvali
 // Phase 1 keeps the matrix pipe busy and phases a-c the vector ALU; the wavefronts resident on a SIMD are in
 // different phases of different frames, so both pipes work at the same time.
 // ------------------------------------------------------------------------------------------
-constexpr int Y_PAD = 64;
+constexpr int Y_PAD = 16;                       // zeros kept after y[n) (stand for the head of resize(2N, 0))
+constexpr int PB = 5;                           // lags per block of the |y| prefix sums
+typedef unsigned short cand_t;                  // candidate lags (< 2048)
 constexpr int PG = 16;                          // lanes per query point (sinc_points / extremum_points kernels)
 constexpr int PNG = 64 / PG;                    // points per wavefront
 constexpr int GROUP_PATH_MIN_CAND = 32;         // pitch frames with more candidates refine them 4 at a time, 16 lanes each
@@ -324,13 +326,13 @@ __device__ __forceinline__ void cand_from_peak(const double *ys, int kk, double 
 
 constexpr int BOUND_HEAD = 8;                   // nearest terms per side evaluated by the first-evaluation bound
 
-// sum of |y_i| over i in [i0, i1], rounded outward to blocks of 4 (p16[j] = sum_{i < 4 j} |y_i|, j <= nblk)
+// sum of |y_i| over i in [i0, i1], rounded outward to blocks of PB (p16[j] = sum_{i < PB j} |y_i|, j <= nblk)
 __device__ __forceinline__ double abs_range_bound(const double *p16, int nblk, int i0, int i1) {
     i0 = (i0 < 0) ? 0 : i0;
-    const int last = 4 * nblk - 1;
+    const int last = PB * nblk - 1;
     i1 = (i1 > last) ? last : i1;
     if (i1 < i0) return 0.0;
-    return p16[(i1 >> 2) + 1] - p16[i0 >> 2];
+    return p16[i1 / PB + 1] - p16[i0 / PB];
 }
 
 // Upper bound of f(v0), the FIRST value brent_maximize (src/periodic.rs:103-188) takes on the bracket
@@ -387,14 +389,14 @@ __device__ __forceinline__ double first_eval_bound(const double *ys, const doubl
 }
 
 // index of the largest key >= bar among keys[0, ncand) (lowest index on ties), or -1; the winner is retired
-__device__ __forceinline__ int pick_best(double *keys, int ncand, double bar, int lane) {
+__device__ __forceinline__ int pick_best(float *keys, int ncand, double bar, int lane) {
     double bv = -__builtin_inf(); int bi = 0x7fffffff;
-    for (int i = lane; i < ncand; i += 64) { const double v = keys[i]; if (v > bv) { bv = v; bi = i; } }
+    for (int i = lane; i < ncand; i += 64) { const double v = (double)keys[i]; if (v > bv) { bv = v; bi = i; } }
     const double gm = wave_max(bv);
     int pick = (bv == gm) ? bi : 0x7fffffff;
     for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(pick, o, 64); pick = (other < pick) ? other : pick; }
     if (pick == 0x7fffffff || !(gm >= bar)) return -1;
-    if (lane == 0) keys[pick] = -__builtin_inf();
+    if (lane == 0) keys[pick] = -__builtin_inff();
     wave_sync();
     return pick;
 }
@@ -412,12 +414,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     if (f >= n_frames) return;
     const int lane = lane_id();
     double *zs = smem;                              // padded image of the windowed frame (vbx_autocorr.hpp)
-    // y[n + Y_PAD] | p16[nblk + 1 (+pad)] | keys[n/4 + 8] | candidate list (ints)
+    // y[n + Y_PAD] | p16[nblk + 1 (+pad)] | keys[n/4 + 8] (float, rounded up) | candidate list (uint16)
     double *ys = ALIAS ? smem : smem + ((ac_mf_lds_doubles(n) + 1) & ~1);
-    const int nblk = (n + 3) >> 2;                   // blocks of 4 lags for the |y| prefix sums
+    const int nblk = (n + PB - 1) / PB;              // blocks of PB lags for the |y| prefix sums
     double *p16 = ys + n + Y_PAD;
-    double *keys = p16 + ((nblk + 2) & ~1);
-    int *cand_list = reinterpret_cast<int *>(keys + (n / 4 + 8));
+    float *keys = reinterpret_cast<float *>(p16 + ((nblk + 2) & ~1));
+    cand_t *cand_list = reinterpret_cast<cand_t *>(keys + (n / 4 + 8));
     {
         // all of the frame's loads are issued before the first LDS store (nothing else hides their latency here);
         // only the zero margins of the image are cleared, the pad double inside each 16 samples is never read
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             const int lag = (slot >> 2) * AC_MF_TILE + 64 * (slot & 3) + lane;
             if (lag < n) ys[lag] = (rv[slot] * scale) / lag_window[lag];
         }
-        ys[n + lane] = 0.0;                         // Y_PAD == 64
+        if (lane < Y_PAD) ys[n + lane] = 0.0;
     } else {
         autocorr_mfma(zs, n, n, [&](int, int lag, double s) {
             if (lag < n) {
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         amax = wave_max(amax);
         const double scale = 1.0 / amax;
         for (int i = lane; i < n; i += 64) ys[i] = (ys[i] * scale) / lag_window[i];
-        ys[n + lane] = 0.0;
+        if (lane < Y_PAD) ys[n + lane] = 0.0;
     }
     wave_sync();
 
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             peak = (ys[k - 1] < c) && (ys[k + 1] < c);
         }
         const unsigned long long mask = __ballot(peak);
-        if (peak) cand_list[npeak + __popcll(mask & ((1ull << lane) - 1ull))] = k;
+        if (peak) cand_list[npeak + __popcll(mask & ((1ull << lane) - 1ull))] = (cand_t)k;
         npeak += __popcll(mask);
     }
     wave_sync();
@@ -511,19 +513,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         }
         wave_sync();                                // all reads of this pass before its writes
         const unsigned long long mask = __ballot(pass);
-        if (pass) cand_list[ncand + __popcll(mask & ((1ull << lane) - 1ull))] = k;
+        if (pass) cand_list[ncand + __popcll(mask & ((1ull << lane) - 1ull))] = (cand_t)k;
         ncand += __popcll(mask);
         wave_sync();
     }
 
-    // a') first-evaluation bounds.  p16: prefix sums of |y| over blocks of 4; keys[c]: upper bound of candidate c's strength
+    // a') first-evaluation bounds.  p16: prefix sums of |y| over blocks of PB; keys[c]: upper bound of candidate c's
+    // strength, stored as a float rounded UP (still an upper bound; the whole frame then fits 12 wavefronts per CU)
     {
         // lane l owns the consecutive blocks [l*per, (l+1)*per): local sums, one scan over the lanes, prefix written back
         const int per = (nblk + 63) >> 6;
         double tot = 0.0;
         for (int q = 0; q < per; q++) {
             const int j = lane * per + q;
-            if (j < nblk) { const double *yp = ys + 4 * j; tot += (fabs(yp[0]) + fabs(yp[1])) + (fabs(yp[2]) + fabs(yp[3])); }   // entries past n are zero
+            if (j < nblk) { const double *yp = ys + PB * j; tot += ((fabs(yp[0]) + fabs(yp[1])) + (fabs(yp[2]) + fabs(yp[3]))) + fabs(yp[4]); }   // entries past n are zero
         }
         double incl = tot;                                   // inclusive scan over the lanes
         for (int o = 1; o < 64; o <<= 1) { const double up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
@@ -532,8 +535,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         for (int q = 0; q < per; q++) {
             const int j = lane * per + q;
             if (j < nblk) {
-                const double *yp = ys + 4 * j;
-                run += (fabs(yp[0]) + fabs(yp[1])) + (fabs(yp[2]) + fabs(yp[3]));
+                const double *yp = ys + PB * j;
+                run += ((fabs(yp[0]) + fabs(yp[1])) + (fabs(yp[2]) + fabs(yp[3]))) + fabs(yp[4]);
                 p16[j + 1] = run;
             }
         }
@@ -542,7 +545,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             double freq, nn;
             cand_from_peak(ys, cand_list[c], sample_rate, offset, freq, nn);
             const double ub = first_eval_bound(ys, p16, nblk, nvalid, ylen, offset, nx, nn, 1200);
-            keys[c] = (ub <= 1.) ? ub : ((ub != ub) ? __builtin_inf() : ((ub == __builtin_inf()) ? ub : 1.));
+            const double kb = (ub <= 1.) ? ub : ((ub != ub) ? __builtin_inf() : ((ub == __builtin_inf()) ? ub : 1.));
+            keys[c] = __double2float_ru(kb);
         }
         wave_sync();
     }
@@ -770,8 +774,8 @@ __global__ __launch_bounds__(64) void extremum_points_kernel(const double *__res
 }
 
 size_t pitch_lds_bytes(int n) {
-    const int nblk = (n + 3) >> 2;
-    const size_t refine = (size_t)(n + Y_PAD + ((nblk + 2) & ~1) + (n / 4 + 8)) * sizeof(double) + (size_t)(n / 4 + 8) * sizeof(int);
+    const int nblk = (n + PB - 1) / PB;
+    const size_t refine = (size_t)(n + Y_PAD + ((nblk + 2) & ~1)) * sizeof(double) + (size_t)(n / 4 + 8) * (sizeof(float) + sizeof(cand_t));
     const size_t image = (size_t)((ac_mf_lds_doubles(n) + 1) & ~1) * sizeof(double);
     if (n <= AC_MF_NT * AC_MF_TILE) return image > refine ? image : refine;
     return image + refine;
