@@ -1,26 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec of the vox_box hot path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the whole per-frame path over this rank's shard of a long synthetic
-48 kHz recording (25 ms window = 1200 samples, 10 ms hop = 480 samples): Boersma pitch
-candidates, autocorrelation + Levinson LPC(12), find_formants (Burg(12) -> Laguerre roots ->
-resonances -> formant tracker), MFCC(13); at N > 1 it ends with the RCCL gather of the
-fixed-size per-frame records to rank 0.  The audio is generated on the device before the
-timed region (inputs resident in HBM), frames are range-split over ranks (weak scaling:
---hours is per GPU; the default 12.5 h/GPU is BASELINE config 5's 100 h over 8 GPUs).
+N > 1: when no RANK is in the environment this process only LAUNCHES N fresh rank processes (before it makes any
+GPU call itself), relays rank 0's JSON line and exits with their status; under torch.distributed.run (RANK set)
+it is one of the ranks.  One process per GPU; torch.distributed (backend nccl = RCCL) carries the barrier and the
+max-over-ranks of the timing, the data path's only exchange -- the gather of per-frame records to rank 0 -- is the
+library's own grouped ncclSend/ncclRecv (vbx_gather_records_f64).
+
+A "step" is one pass of the whole per-frame path over this rank's shard of a long synthetic 48 kHz recording
+(25 ms window = 1200 samples, 10 ms hop = 480 samples): vbx_analyze_frames_f64 = Boersma pitch candidates,
+autocorrelation + Levinson LPC(12), find_formants (Burg(12) -> Laguerre roots -> resonances -> formant tracker),
+MFCC(13), written as one fixed-size record per frame; at N > 1 the step ends by queueing the gather of the records
+to rank 0 (it overlaps the next step's kernels; every gather is complete when the timed region ends).  The audio is
+generated on the device before the timed region (inputs resident in HBM); frames are range-split over ranks (weak
+scaling: --hours is per GPU; the default 12.5 h/GPU is BASELINE config 5's 100 h over 8 GPUs).
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline      dominant kernel against the roof that binds it: pitch -> FP64 matrix/vector peak (flops executed,
-                counted on the device); config2 / config4 / frontend -> HBM (algorithmic bytes)
+  roofline      the kernel with the largest measured time against the roof that binds it: pitch -> FP64 matrix/vector
+                peak; everything else -> HBM (algorithmic bytes).  `traffic` = measured HBM bytes per launch from the
+                PMC passes committed under profiles/ (profiles/pmc_traffic.json), scaled to this launch's frames.
   roofline_hbm  the pitch kernel against the HBM roof, as north_star asks (tiny by construction)
-  cpu_baseline  the CPU oracle (C restatement of the reference path) timed on host cores
-Other workloads (--workload config2|config3|config4) time a single BASELINE config.
+  cpu_baseline  the CPU oracle (C restatement of the reference path) timed natively (oracle/vbx_cpu_bench.c) on
+                1 core and on all host cores
+Other workloads (--workload config2|config3|config4|frontend) time a single BASELINE config.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,10 +43,21 @@ import __graft_entry__ as graft  # noqa: E402
 SR, N48, H48, P = 48000.0, 1200, 480, 12
 SEG_FRAMES = 1000                 # tracker state resets every 10 s utterance
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
-FP64_PEAK_TFLOPS = 78.6           # FP64 vector peak
+FP64_PEAK_TFLOPS = 78.6           # FP64 vector peak (= FP64 matrix peak on gfx950)
 FLOPS_PER_SINC_TERM = 13.0        # reference formula per term: sin, cos, 2 div, 9 mul/add (each counted once)
-METRIC = "frames/sec (pitch+LPC+formants), 48 kHz 25 ms/10 ms hop, 1\u21928 MI355X"   # BASELINE.json "metric", verbatim
-REC = 2 + 8 + 13 + 13             # per-frame record: pitch(f,s) + 4 formants(f,bw) + 13 MFCC + 13 LPC  (288 B)
+METRIC = "frames/sec (pitch+LPC+formants), 48 kHz 25 ms/10 ms hop, 1→8 MI355X"   # BASELINE.json "metric", verbatim
+
+# algorithmic HBM bytes per frame of each kernel, keyed by the profile name
+ALG_BYTES = {
+    "pitch": lambda n, hop, p: hop * 8 + 16,                      # new samples in, top candidate out
+    "analyze": lambda n, hop, p: hop * 8 + 16 + 13 * 8 + 13 * 8,  # fused: + MFCC + LPC rows out
+    "autocorr_lpc": lambda n, hop, p: hop * 8 + 2 * (p + 1) * 8,
+    "burg": lambda n, hop, p: hop * 8 + p * 8 + 4,
+    "formant_resonances": lambda n, hop, p: p * 8 + 4 + 32 * 16 + 4,
+    "tracker": lambda n, hop, p: 32 * 16 + 8 + 64,
+    "mfcc": lambda n, hop, p: hop * 8 + 13 * 8,
+    "pcm16": lambda n, hop, p: 10,
+}
 
 
 def parse():
@@ -48,81 +69,98 @@ def parse():
     ap.add_argument("--frames", type=int, default=1_000_000, help="dense frames per GPU (config2 / config4)")
     ap.add_argument("--workload", default="pipeline", choices=["pipeline", "config2", "config3", "config4", "frontend"])
     ap.add_argument("--kmax", type=int, default=1, help="pitch candidates kept per frame (1 = PitchExtractor output; "
-                    "64 = the reference's full sorted list, which disables the exact top-k pruning)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU baseline leg")
+                    "64 = the head of the reference's sorted list, which disables the exact top-k pruning)")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="wall budget of the CPU baseline leg (both legs together)")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
 
 
 # ------------------------------------------------------------------------------------------------
-# CPU baseline: the oracle (kind "port") on a bounded sample of the same workload, all host cores
+# N > 1 without a launcher: start the ranks ourselves (this process never touches the GPU)
+# ------------------------------------------------------------------------------------------------
+def launch_ranks(args):
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    # wait for all ranks; if one dies the others would sit in a rendezvous or a collective until its timeout,
+    # so its exit ends them too (these are exactly the children started above)
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    out0 = procs[0].stdout.read() if procs[0].stdout else ""
+    codes = [p.wait() for p in procs]
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write(f"bench.py: ranks failed (rank, exit code): {bad}\n")
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (kind "port") on a bounded sample of the same workload, natively threaded
 # ------------------------------------------------------------------------------------------------
 def cpu_baseline(workload, budget_s):
-    import threading
-    o = graft.load_oracle()
-    pkg = graft.load_package()
     import importlib
+    o = graft.load_oracle()
+    graft.load_package()
     synth = importlib.import_module(graft.PKG_NAME + ".synth")
-    cores = os.cpu_count() or 1
+    logical = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = logical
+    try:    # physical cores: distinct (package, core) pairs
+        pairs, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    pairs.add((phys, core))
+                phys = core = None
+        physical = len(pairs) or None
+    except OSError:
+        physical = None
     if workload in ("pipeline", "config3"):
-        audio = synth.synth_speech(10 * 48000 + N48, sample_offset=0)      # 10 s: 2 of 10 seconds unvoiced
-        w = o.window("hanning", N48)
-        n_avail = pkg.frame_count(audio.size, N48, H48)
-        order = [(i * 37) % n_avail for i in range(n_avail)] * 200          # spread over the 10 s, cycled
-        est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
-
-        def work(t):
-            fr = audio[t * H48:t * H48 + N48]
-            xw = fr * w
-            o.pitch(xw, SR, 0.2, 75.0, 600.0, cap=4)
-            if workload == "pipeline":
-                o.lpc(o.autocorrelate(xw, P + 1), P)
-                o.find_formants(fr, SR, P, est0)
-                o.mfcc(xw, 13, 100.0, 8000.0, SR, use_fft=True)
-        what = "frames spread over 10 s of the same synthetic audio (2 of 10 s unvoiced)"
+        frame_len, hop = N48, H48
+        audio = synth.synth_speech(10 * 48000 + N48, sample_offset=0)       # 10 s: 2 of 10 seconds unvoiced
+        what = "frames of the 48 kHz / 25 ms / 10 ms view of 10 s of the same synthetic audio (2 of 10 s unvoiced), scrambled order"
     else:
-        x = synth.synth_speech(4000 * 512, sample_offset=0).reshape(4000, 512)
-        w = o.window("hanning", 512)
-        order = list(range(4000)) * 5000
-        est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
-
-        def work(t):
-            if workload == "config2":
-                o.lpc(o.autocorrelate(x[t] * w, P + 1), P)
-            else:
-                o.find_formants(x[t], SR, P, est0)
-        what = "dense 512-sample frames of the same synthetic audio"
-    done = [0] * cores
-    stop_at = time.time() + budget_s
-    it = iter(order)
-    lock = threading.Lock()
-
-    def runner(k):
-        while time.time() < stop_at:
-            with lock:
-                t = next(it, None)
-            if t is None:
-                return
-            work(t)
-            done[k] += 1
-    t0 = time.time()
-    th = [threading.Thread(target=runner, args=(k,)) for k in range(cores)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.time() - t0
-    n = sum(done)
-    return {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} {what}, {dt:.1f} s wall, {cores} threads (C restatement of the reference CPU path; "
-                      "the Rust crate cannot be built here)"}
+        frame_len, hop = 512, 480
+        audio = synth.synth_speech(40 * 48000 + 512, sample_offset=0)
+        what = "512-sample frames (hop 480) of 40 s of the same synthetic audio, scrambled order"
+    leg = max(budget_s / 2.0, 1.0)
+    n1, t1 = o.cpu_bench(workload, audio, frame_len, hop, P, SR, 1, leg)
+    na, ta = o.cpu_bench(workload, audio, frame_len, hop, P, SR, usable, leg)
+    return {"value": na / ta, "unit": "frames/s", "cores": usable, "kind": "port",
+            "one_core": {"value": n1 / t1, "unit": "frames/s", "cores": 1, "frames": n1, "seconds": round(t1, 2)},
+            "logical_cpus": logical, "physical_cores": physical,
+            "sample": f"{na} {what}, {ta:.1f} s wall on {usable} native threads (and {n1} frames in {t1:.1f} s on 1 thread); "
+                      "oracle/vbx_cpu_bench.c: C restatement of the reference CPU path, pthreads over frames -- the Rust "
+                      "crate itself is single-threaded and cannot be built here"}
 
 
-def flop_model(workload):
+def flop_model():
     """Algorithmic FP64 flops per frame of the pitch path, counted by instrumenting the oracle on a
     10 s sample: 2 * autocorrelation MACs + 13 * sinc terms."""
-    o = graft.load_oracle()
     import importlib
+    o = graft.load_oracle()
     synth = importlib.import_module(graft.PKG_NAME + ".synth")
     audio = synth.synth_speech(10 * 48000 + N48, sample_offset=0)
     w = o.window("hanning", N48)
@@ -137,7 +175,21 @@ def flop_model(workload):
             "flops": (2.0 * c["autocorr_macs"] + FLOPS_PER_SINC_TERM * c["sinc_terms"]) / n}
 
 
-def bench_frontend(args, torch, dev, vb, vb2, pkg):
+def measured_traffic(kernel, frames):
+    """HBM bytes of one launch from the committed PMC passes (profiles/pmc_traffic.json: bytes per frame of each
+    kernel, FETCH_SIZE x2 per the guide's gfx950 correction + WRITE_SIZE, with the commit and the raw file)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            tab = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    e = tab.get(kernel)
+    if not e:
+        return None, None
+    return e["bytes_per_frame"] * frames, {k: e[k] for k in ("bytes_per_frame", "source", "commit") if k in e}
+
+
+def bench_frontend(args, torch, dev, vb, pkg):
     """PCM16 ingestion -> Windower view -> RMS and pre-emphasis per frame (HBM-bound)."""
     hours = min(args.hours, 2.0)
     n = int(hours * 3600 * 48000)
@@ -165,23 +217,24 @@ def bench_frontend(args, torch, dev, vb, vb2, pkg):
     prof = vb.profile_report(); vb.profile(False)
     k = {name: ms / max(c, 1) for name, (ms, c) in prof.items()}
     ach = n * 10 / (k["pcm16"] * 1e-3) / 1e9
+    traffic, tsrc = measured_traffic("pcm16", n)
     out = {"metric": "frames/sec (frontend: pcm16 ingestion + rms + preemphasis)", "value": F * args.steps / dt,
            "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"frontend, {hours:g} h 48 kHz int16 PCM -> f64, rms over {F} frames, preemphasis over {Fp}"},
            "roofline": {"bound": "hbm", "kernel": "pcm16", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_sample": 10, "ms_avg": k["pcm16"]},
+                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                        "algorithmic_bytes_per_sample": 10, "ms_avg": k["pcm16"]},
            "kernels_ms": {a: round(b, 3) for a, b in k.items()},
            "gbs": {"rms": F * (H48 * 8 + 8) / (k["rms"] * 1e-3) / 1e9,
                    "preemphasis": Fp * (H48 * 8 + N48 * 8) / (k["preemphasis"] * 1e-3) / 1e9}}
     print(json.dumps(out), flush=True)
-    vb2.close(); vb.close()
+    vb.close()
 
 
 # ------------------------------------------------------------------------------------------------
-def main():
-    args = parse()
+def run_rank(args):
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -190,34 +243,50 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("VBX_BENCH_DRY_RUN"):    # tests/test_shard_cpu.py: the launcher's plumbing without a GPU
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, local, os.environ.get("MASTER_PORT")))
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": seen, "gpus_arg": args.gpus}), flush=True)
+        dist.destroy_process_group()
+        return 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: the product has no CPU path")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     pkg = graft.load_package()
-    shard = pkg.shard
-    # one explicit HIP stream shared by torch (allocation, cat, RCCL) and the library's kernels
+    # one explicit HIP stream shared by torch (allocation) and the library's kernels; the library adds its own side
+    # stream (formant chain, MFCC beside the pitch kernel) and the communicator's transfer stream
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     vb = pkg.VoxBox(local, tstream.cuda_stream)
-    # second context/stream: the formant chain (Burg -> roots -> latency-bound tracker scan) and the
-    # small LPC / MFCC kernels run beside the FP64-bound pitch kernels instead of behind them
-    sstream = torch.cuda.Stream(device=dev)
-    vb2 = pkg.VoxBox(local, sstream.cuda_stream)
 
     wl = args.workload
     f64 = torch.float64
     if wl == "frontend":
-        return bench_frontend(args, torch, dev, vb, vb2, pkg)
+        return bench_frontend(args, torch, dev, vb, pkg)
+    comm = None
+    if world > 1:
+        # the library's own RCCL communicator for the record gather; the 128-byte id travels over torch.distributed
+        ids = [pkg.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0, device=dev)
+        comm = pkg.Comm(vb, ids[0], world, rank)
+
     est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
     if wl in ("pipeline", "config3"):
         total_frames_per_gpu = int(round(args.hours * 3600 * 100))            # 100 frames per second
         total_frames_per_gpu -= total_frames_per_gpu % SEG_FRAMES             # whole utterances per rank
         F = max(total_frames_per_gpu, SEG_FRAMES)
-        lo = rank * F                                                         # weak scaling: contiguous range split
-        s0, s1 = shard.sample_range(lo, lo + F, N48, H48)
+        # weak scaling: the recording is world * F frames long and splits by contiguous ranges at utterance boundaries
+        seg_all = np.arange(0, world * F, SEG_FRAMES, dtype=np.int64)
+        lo, hi = pkg.shard_range(world * F, world, rank, seg_all)
+        assert hi - lo == F
+        s0, s1 = pkg.shard_samples(lo, hi, N48, H48)                          # includes the 720-sample halo
         audio = torch.empty(s1 - s0, dtype=f64, device=dev)
         vb.synth_speech(s1 - s0, sample_offset=s0, sample_rate=SR, out=audio)
         frame_len, stride = N48, H48
@@ -233,68 +302,68 @@ def main():
         desc = ("batched autocorrelation + LPC order-12" if wl == "config2" else
                 "LPC(Burg)->Laguerre roots->formant track") + f", {F} x 512-sample f64 frames/GPU"
     seg = np.arange(0, F, SEG_FRAMES, dtype=np.int64)
-
-    # outputs (torch owns the device memory; the C ABI gets raw pointers)
-    o_cand = torch.empty((F, args.kmax, 2), dtype=f64, device=dev)
-    o_cnt = torch.empty(F, dtype=torch.int32, device=dev)
-    o_pst = torch.empty(F, dtype=torch.int32, device=dev)
-    o_r = torch.empty((F, P + 1), dtype=f64, device=dev)
-    o_a = torch.empty((F, P + 1), dtype=f64, device=dev)
-    o_form = torch.empty((F, 4, 2), dtype=f64, device=dev)
-    o_fst = torch.empty(F, dtype=torch.int32, device=dev)
-    o_mfcc = torch.empty((F, 13), dtype=f64, device=dev)
-    o_mst = torch.empty(F, dtype=torch.int32, device=dev)
-    ff = {"formants": o_form, "res": None, "count": None, "coeffs": None, "status": o_fst}
     counts = [F] * world
 
-    arrange = os.environ.get("VBX_BENCH_ARRANGE", "two")     # stream arrangement of the pipeline workload (experiments)
+    # outputs (torch owns the device memory; the C ABI gets raw pointers).  The pipeline writes one record per frame
+    # straight into the buffer the gather sends (rank 0: straight into the gathered array), double-buffered so that
+    # step i+1's kernels overlap step i's transfer.
+    if wl == "pipeline":
+        params = pkg.AnalysisParams.make(SR, pitch=(0.2, 75.0, 600.0), lpc_order=P, formant_order=P, est_init=est0,
+                                         mfcc=(13, 100.0, 8000.0))
+        REC = int(vb.L.vbx_record_doubles(params))
+        nbuf = 2 if world > 1 else 1
+        if rank == 0:
+            gathered = [torch.empty((world * F, REC), dtype=f64, device=dev) for _ in range(nbuf)]
+            rec = [g[:F] for g in gathered]                                   # rank 0 owns rows [0, F): written in place
+        else:
+            gathered = [None] * nbuf
+            rec = [torch.empty((F, REC), dtype=f64, device=dev) for _ in range(nbuf)]
+        st3 = torch.empty((3, F), dtype=torch.int32, device=dev)
+    else:
+        REC = 0
+        o_cand = torch.empty((F, args.kmax, 2), dtype=f64, device=dev)
+        o_cnt = torch.empty(F, dtype=torch.int32, device=dev)
+        o_pst = torch.empty(F, dtype=torch.int32, device=dev)
+        o_r = torch.empty((F, P + 1), dtype=f64, device=dev)
+        o_a = torch.empty((F, P + 1), dtype=f64, device=dev)
+        o_form = torch.empty((F, 4, 2), dtype=f64, device=dev)
+        o_fst = torch.empty(F, dtype=torch.int32, device=dev)
+        ff = {"formants": o_form, "res": None, "count": None, "coeffs": None, "status": o_fst}
 
-    def step():
-        side = vb2 if (wl == "pipeline" and arrange != "one") else vb
-        if wl == "pipeline" and arrange != "one":
-            sstream.wait_stream(tstream)            # the side stream starts after whatever produced the inputs
-        if wl in ("pipeline", "config4"):
-            side.find_formants(audio, SR, P, est0, seg_start=seg, frame_len=frame_len, stride=stride, n_frames=F, out=ff)
-        if wl in ("pipeline", "config2"):
-            side.autocorr_lpc(audio, P, frame_len=frame_len, stride=stride, n_frames=F, window=win, out=(o_r, o_a))
-        if wl == "pipeline" and arrange not in ("mfcc_main", "mfcc_first"):
-            side.mfcc(audio, 13, (100.0, 8000.0), SR, frame_len=frame_len, stride=stride, n_frames=F, window=win,
-                      out=(o_mfcc, o_mst))
-        if wl == "pipeline" and arrange == "mfcc_first":
-            vb.mfcc(audio, 13, (100.0, 8000.0), SR, frame_len=frame_len, stride=stride, n_frames=F, window=win,
-                    out=(o_mfcc, o_mst))
-        if wl in ("pipeline", "config3"):
+    def step(i):
+        if wl == "pipeline":
+            b = i % len(rec)
+            if comm is not None:
+                comm.wait(b)                                                  # device-side: buffer b's last transfer is done
+            vb.analyze_frames(audio, params, seg_start=seg, frame_len=frame_len, stride=stride, n_frames=F,
+                              out=rec[b], record_ld=REC, status=st3)
+            if comm is not None:   # per-frame records to rank 0 over RCCL/xGMI (no other collective on the path)
+                comm.gather_records(rec[b], counts, REC, 0, out=gathered[b], slot=b)
+        elif wl == "config4":
+            vb.find_formants(audio, SR, P, est0, seg_start=seg, frame_len=frame_len, stride=stride, n_frames=F, out=ff)
+        elif wl == "config2":
+            vb.autocorr_lpc(audio, P, frame_len=frame_len, stride=stride, n_frames=F, window=win, out=(o_r, o_a))
+        elif wl == "config3":
             vb.pitch(audio, SR, 0.2, 75.0, 600.0, kmax=args.kmax, frame_len=frame_len, stride=stride, n_frames=F, window=win,
                      out=(o_cand, o_cnt, o_pst))
-        if wl == "pipeline" and arrange == "mfcc_main":
-            vb.mfcc(audio, 13, (100.0, 8000.0), SR, frame_len=frame_len, stride=stride, n_frames=F, window=win,
-                    out=(o_mfcc, o_mst))
-        if wl == "pipeline" and arrange != "one":
-            tstream.wait_stream(sstream)            # join before anything consumes the records
-        if world > 1:   # per-frame records to rank 0 over RCCL/xGMI (no other collective on the path)
-            rec = torch.cat([o_cand[:, 0, :], o_form.view(F, 8), o_mfcc, o_a], dim=1)
-            shard.gather_records(rec, counts, dst=0)
 
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()                                              # every stream of the device, the transfers included
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     fence()
-    for c in (vb, vb2):
-        c.profile_reset()
-        c.profile(True)
+    vb.profile_reset()
+    vb.profile(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
     prof = dict(vb.profile_report())
-    prof.update(vb2.profile_report())
     vb.profile(False)
-    vb2.profile(False)
     if world > 1:
         tt = torch.tensor([dt], dtype=f64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -303,54 +372,65 @@ def main():
     if rank == 0:
         total = F * world * args.steps
         kernels = {k: {"ms_avg": ms / max(c, 1), "launches": c} for k, (ms, c) in prof.items()}
-        dom = {"pipeline": "pitch", "config3": "pitch", "config2": "autocorr_lpc", "config4": "burg"}[wl]
+        dom = max(kernels, key=lambda k: kernels[k]["ms_avg"] * kernels[k]["launches"])   # by measured time
         dom_ms = kernels[dom]["ms_avg"]
-        bytes_per_frame = {"pitch": 480 * 8 + 16, "autocorr_lpc": 512 * 8 + 2 * 13 * 8, "burg": 512 * 8 + 12 * 8 + 4}[dom]
-        if dom == "autocorr_lpc" and frame_len != 512:
-            bytes_per_frame = stride * 8 + 2 * 13 * 8
+        bytes_per_frame = ALG_BYTES.get(dom, lambda n, hop, p: hop * 8)(frame_len, stride, P)
         ach = F * bytes_per_frame / (dom_ms * 1e-3) / 1e9
+        traffic, tsrc = measured_traffic(dom if wl != "config2" else "autocorr_lpc_512", F)
         out = {
             "metric": METRIC if wl == "pipeline" else f"frames/sec ({wl})",
             "value": total / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "frames_per_gpu": F, "frame_len": frame_len, "hop": stride,
-                       "lpc_order": P, "mfcc": 13, "pitch_kmax": args.kmax, "parallelism": f"frame-range split x{world}, RCCL gather to rank 0"},
+                       "lpc_order": P, "mfcc": 13, "pitch_kmax": args.kmax if wl != "pipeline" else 1,
+                       "record_bytes": REC * 8,
+                       "parallelism": f"frame-range split x{world}, one process per GPU, RCCL gather of the records to rank 0"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_frame": bytes_per_frame, "ms_avg": dom_ms},
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                         "algorithmic_bytes_per_frame": bytes_per_frame, "ms_avg": dom_ms,
+                         "note": "dominant kernel = largest measured time; ms_avg from HIP events on the stream the kernel runs on"},
             "kernels_ms": {k: round(v["ms_avg"], 3) for k, v in kernels.items()},
         }
-        if dom == "pitch":
-            # FP64 roof with the work the kernels EXECUTED: the autocorrelation computes every lag (the oracle's
-            # MAC count is exact for it); the sinc terms are counted on the device by the refine kernel itself
-            # (exact top-k pruning skips most of the reference's refinements), not taken from the oracle
-            fm = flop_model(wl)
+        if dom in ("pitch", "analyze"):
+            # FP64 roof.  Two flop models, both stated: ALGORITHMIC = what the reference's algorithm does per frame for
+            # the parts this kernel replaces (2 * autocorrelation MACs, exact, + the sinc terms the kernel actually
+            # evaluated -- the exact top-k pruning skips most of the reference's refinements, and pruned work is not
+            # credited); EXECUTED = the arithmetic the kernel issues.
+            fm = flop_model()
             frames_w, cand_w, evals_w, terms_w = vb.profile_pitch_work()
             terms_pf = terms_w / max(frames_w, 1)
             flops_pf = 2.0 * fm["autocorr_macs"] + FLOPS_PER_SINC_TERM * terms_pf
             tf = F * flops_pf / (dom_ms * 1e-3) / 1e12
-            # The pitch kernel is FP64-compute bound (autocorrelation on the FP64 matrix cores, refinement on the
-            # vector ALU; both peak at 78.6 TFLOP/s on gfx950 and share the ALUs): that roof is the primary
-            # `roofline`; the HBM figure north_star asks for moves to `roofline_hbm`.
             out["roofline_hbm"] = out["roofline"]
-            out["roofline"] = {"bound": "mfma", "kernel": "pitch", "achieved": tf, "peak": FP64_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": None, "ms_avg": dom_ms,
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": tf, "peak": FP64_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
+                               "ms_avg": dom_ms,
                                "flops_per_frame": flops_pf, "autocorr_macs_per_frame": fm["autocorr_macs"],
                                "sinc_terms_per_frame": terms_pf, "sinc_evals_per_frame": evals_w / max(frames_w, 1),
                                "candidates_per_frame": cand_w / max(frames_w, 1),
                                "reference_sinc_terms_per_frame": fm["sinc_terms"],
-                               "model": "FP64 flops EXECUTED: 2*autocorr MACs (every lag, v_mfma_f64_16x16x4) + 13*sinc terms "
-                                        "(device counters); reference_sinc_terms = what the unpruned reference evaluates "
-                                        "(oracle counters); peak = FP64 matrix = FP64 vector peak of MI355X"}
+                               "model": "algorithmic FP64 flops: 2*autocorr MACs of the reference's all-lag autocorrelation "
+                                        "(oracle MAC counter) + 13*sinc terms the kernel evaluated (device counters; the "
+                                        "reference evaluates reference_sinc_terms); peak = FP64 matrix = FP64 vector peak"}
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    vb2.close()
+    if comm is not None:
+        comm.close()
     vb.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define VBX_ABI_VERSION 1
+#define VBX_ABI_VERSION 2
 
 /* API return codes */
 #define VBX_SUCCESS 0
@@ -291,6 +291,74 @@ int vbx_resample_linear_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size
  * entry point above accepts with stride = frame_len.  Requires (n_frames-1)*stride + frame_len <= capacity. */
 int vbx_ring_frames_f64(vbx_ctx *ctx, const double *ring, size_t capacity, size_t head, size_t n_frames,
                         size_t frame_len, size_t stride, double *out);
+
+/* ------------------------------------------------------------------ the user's frame loop, fused */
+
+/* What a user of the crate writes per frame (examples/pitch_detection.rs:23-30, tests/lib.rs:71-83,
+ * examples/formant_extraction/src/main.rs:72-88), as ONE call over F frames of the Windower view:
+ *   hanning frame -> pitch::<Hanning>(sr, threshold, _, _, fmin, fmax)[0]        (PitchExtractor output)
+ *   hanning frame -> autocorrelate(lpc_order + 1) -> lpc(lpc_order)              (raw, un-normalised autocorrelation)
+ *   rectangle frame -> find_formants(.., 1.0, .., formant_order, .., formants)   (state carried per segment)
+ *   hanning frame -> mfcc(mfcc_coeffs, (lo, hi), sr)
+ * Each part with order / count 0 is skipped.  The library is free to share work between the parts (one pass over
+ * the samples, one spectral transform feeding several of them); results obey the same tolerances as the
+ * separate entry points.  Output: one record of vbx_record_doubles(params) doubles per frame,
+ *   [ pitch.frequency, pitch.strength | formants[n_est] {frequency, bandwidth} | mfcc[mfcc_coeffs] | lpc[lpc_order + 1] ]
+ * at out_records + f * record_ld (record_ld even, >= the record size; 16-byte aligned base): the fixed-size
+ * per-frame record that the multi-GPU gather below moves.  status3 (optional): [3, F] = pitch / formant / mfcc
+ * status rows.  Asynchronous on the context's stream (a second, context-owned stream is used inside and joined). */
+typedef struct {
+    double sample_rate;
+    double pitch_threshold, pitch_fmin, pitch_fmax;
+    size_t lpc_order;
+    size_t formant_order;
+    size_t n_est;
+    vbx_resonance est_init[VBX_FORMANT_SLOTS];
+    size_t mfcc_coeffs;
+    double mfcc_lo_hz, mfcc_hi_hz;
+} vbx_analysis_params;
+size_t vbx_record_doubles(const vbx_analysis_params *h_params);
+int vbx_analyze_frames_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
+                           const vbx_analysis_params *h_params, const int64_t *h_seg_start, size_t n_segments,
+                           double *out_records, size_t record_ld, int32_t *status3);
+
+/* ------------------------------------------------------------------ multi-GPU: frame-range sharding */
+
+/* The reference has no distribution of any kind; frames are independent (the tracker per utterance), so a long
+ * recording shards by contiguous frame ranges, one process per GPU, and the only exchange is ONE gather of the
+ * fixed-size per-frame records to a destination rank: grouped ncclSend / ncclRecv (RCCL), each peer's payload
+ * crossing its own xGMI link.  No reduction, no all-to-all.
+ *
+ * vbx_shard_range: frames [*lo, *hi) of rank `rank` (first ranks take the remainder); with h_seg_start the cut is
+ * moved to the next utterance boundary so that no tracker segment straddles two ranks.
+ * vbx_shard_samples: the samples [*s0, *s1) those frames read, i.e. including the frame_len - hop halo. */
+int vbx_shard_range(size_t n_frames, int world, int rank, const int64_t *h_seg_start, size_t n_segments,
+                    size_t *lo, size_t *hi);
+int vbx_shard_samples(size_t lo, size_t hi, size_t frame_len, size_t hop, size_t *s0, size_t *s1);
+
+typedef struct vbx_comm vbx_comm;
+#define VBX_UNIQUE_ID_BYTES 128
+#define VBX_COMM_SLOTS 4
+/* ncclGetUniqueId on the root; the caller ships the 128 bytes to the other ranks (MPI, TCP store, file ...). */
+int vbx_comm_unique_id(void *h_id);
+/* One communicator per (context, process): rank `rank` of `world` on the context's device.  Collective call. */
+int vbx_comm_create(vbx_ctx *ctx, const void *h_id, int world, int rank, vbx_comm **out);
+void vbx_comm_destroy(vbx_comm *comm);
+/* Gathers per-frame records to rank dst: rank r contributes h_rows[r] rows of row_doubles doubles (`local`, device),
+ * which land in `out` (device, on dst only) at row offset h_rows[0] + .. + h_rows[r-1].  On dst, `local` may point
+ * into `out` at its own offset (kernels write their records in place: no copy).  The transfer is queued on the
+ * communicator's own stream behind the work already queued on the context's stream, so the context's next
+ * batch overlaps it; `slot` in [0, VBX_COMM_SLOTS) names the buffer being sent for vbx_comm_wait. */
+int vbx_gather_records_f64(vbx_ctx *ctx, vbx_comm *comm, const double *local, const int64_t *h_rows,
+                           size_t row_doubles, int dst, double *out, int slot);
+/* Makes the context's stream wait (on the device, not the host) until the gather that used `slot` has finished:
+ * call before overwriting that buffer. */
+int vbx_comm_wait(vbx_ctx *ctx, vbx_comm *comm, int slot);
+/* Host waits for every queued gather. */
+int vbx_comm_sync(vbx_comm *comm);
+/* Loopback self-test: a grouped ncclSend/ncclRecv of n doubles from this rank to itself on the communicator's
+ * stream, verified on the host.  Exercises the RCCL path on a single GPU.  Returns 0 when the data arrived intact. */
+int vbx_comm_selftest(vbx_ctx *ctx, vbx_comm *comm, size_t n_doubles);
 
 /* ------------------------------------------------------------------ bench utility */
 

@@ -17,7 +17,7 @@ MAX_RESONANCES = 32
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("vbx_oracle.c", "vbx_oracle_f32.c", "vbx_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("vbx_oracle.c", "vbx_oracle_f32.c", "vbx_cpu_bench.c", "vbx_oracle.h")]
     if force or not os.path.exists(_SO) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_SO) for s in src
     ):
@@ -326,3 +326,20 @@ def frames_view(audio, n, hop):
     audio = _f64(audio)
     f = (audio.size - n) // hop + 1 if audio.size >= n else 0
     return np.lib.stride_tricks.as_strided(audio, shape=(f, n), strides=(hop * 8, 8), writeable=False)
+
+
+def cpu_bench(workload, audio, frame_len, hop, order, sample_rate, n_threads, seconds, max_frames=0):
+    """vbx_cpu_bench.c: the oracle's frame loop on native threads.  workload: 'pipeline' | 'config2' | 'config3' |
+    'config4'.  Returns (frames_done, elapsed_seconds)."""
+    a = _f64(audio)
+    code = {"pipeline": 0, "config2": 1, "config3": 2, "config4": 3}[workload]
+    done, dt, cs = C.c_ulong(), C.c_double(), C.c_double()
+    fn = lib().vbxo_cpu_bench
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.c_int, C.c_double,
+                   C.c_ulong, C.POINTER(C.c_ulong), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    rc = fn(code, _p(a), a.size, frame_len, hop, order, sample_rate, n_threads, seconds, max_frames,
+            C.byref(done), C.byref(dt), C.byref(cs))
+    if rc != 0:
+        raise ValueError("vbxo_cpu_bench: bad argument")
+    return int(done.value), float(dt.value)

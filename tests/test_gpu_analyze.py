@@ -1,0 +1,123 @@
+"""vbx_analyze_frames_f64 (the user's whole frame loop as one call, writing per-frame records) and the RCCL record
+gather of the library, on a real MI355X.  The records are checked against the separate entry points (same
+tolerances as their own parity tests) and against the CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import rel_close
+
+pytestmark = pytest.mark.gpu
+
+SR, N, H, P = 48000.0, 1200, 480, 12
+
+
+@pytest.fixture(scope="module")
+def audio_d(vb):
+    d = vb.synth_speech(6 * 48000, sample_offset=2 * 48000)     # voiced glide + one unvoiced second
+    yield d
+    d.free()
+
+
+def _oracle_records(oracle, pkg, audio, F, seg):
+    w = oracle.window("hanning", N)
+    est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+    rec = np.zeros((F, 36))
+    st = np.zeros((3, F), dtype=np.int32)
+    est = est0.copy()
+    for t in range(F):
+        fr = audio[t * H:t * H + N]
+        xw = fr * w
+        s, c, _ = oracle.pitch(xw, SR, 0.2, 75.0, 600.0, cap=1)
+        st[0, t] = s
+        rec[t, 0:2] = c[0]
+        if t in seg:
+            est = est0.copy()
+        s, est, _, _ = oracle.find_formants(fr, SR, P, est)
+        st[1, t] = s
+        rec[t, 2:10] = est.reshape(-1)
+        s, m = oracle.mfcc(xw, 13, 100.0, 8000.0, SR)
+        st[2, t] = s
+        rec[t, 10:23] = m
+        rec[t, 23:36] = oracle.lpc(oracle.autocorrelate(xw, P + 1), P)
+    return rec, st
+
+
+def test_analyze_frames_matches_the_oracle_and_the_separate_entry_points(vb, pkg, oracle, audio_d):
+    audio = audio_d.numpy()
+    F = pkg.frame_count(audio.size, N, H)
+    seg = np.array([0, 150, 151, 400], dtype=np.int64)
+    params = pkg.AnalysisParams.make(SR)
+    assert params.columns() == {"pitch": (0, 2), "formants": (2, 8), "mfcc": (10, 13), "lpc": (23, 13)}
+    rec, st = vb.analyze_frames(audio_d, params, seg_start=seg, frame_len=N, stride=H, n_frames=F)
+    assert rec.shape == (F, 36) and st.shape == (3, F)
+    # the separate entry points on the same frames
+    han = vb.window(pkg.WINDOW_HANNING, N)
+    cand, cnt, pst = vb.pitch(audio_d, SR, 0.2, 75.0, 600.0, kmax=1, frame_len=N, stride=H, n_frames=F, window=han)
+    est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+    ff = vb.find_formants(audio_d, SR, P, est0, seg_start=seg, frame_len=N, stride=H, n_frames=F)
+    mf, mst = vb.mfcc(audio_d, 13, (100.0, 8000.0), SR, frame_len=N, stride=H, n_frames=F, window=han)
+    r, a = vb.autocorr_lpc(audio_d, P, frame_len=N, stride=H, n_frames=F, window=han)
+    assert np.array_equal(st[0], pst) and np.array_equal(st[1], ff["status"]) and np.array_equal(st[2], mst)
+    # pitch: same refinement code -> same top candidate up to the documented Brent sensitivity
+    assert np.all(np.abs(rec[:, 0] - cand[:, 0, 0]) <= 1e-4 * np.abs(cand[:, 0, 0]))
+    assert np.array_equal(rec[:, 2:10], ff["formants"].reshape(F, 8))        # same kernels, same stream order: bit-equal
+    assert np.all(rel_close(rec[:, 10:23], mf)) and np.all(rel_close(rec[:, 23:36], a))
+    # and the oracle on a subset (it takes ~10 ms per frame)
+    sub = 160
+    orec, ost = _oracle_records(oracle, pkg, audio, sub, set(seg.tolist()))
+    assert np.array_equal(st[:, :sub], ost)
+    voiced_equal = (orec[:, 0] == 0.0) == (rec[:sub, 0] == 0.0)
+    assert np.all(voiced_equal), "voiced / unvoiced decision differs"
+    assert np.all(np.abs(rec[:sub, 0] - orec[:, 0]) <= 1e-4 * np.abs(orec[:, 0]))
+    assert np.all(np.abs(rec[:sub, 1] - orec[:, 1]) <= 1e-4)
+    assert np.all(np.abs(rec[:sub, 2:10:2] - orec[:, 2:10:2]) <= 1e-4 * np.abs(orec[:, 2:10:2]))
+    for t in range(sub):
+        assert np.all(rel_close(rec[t, 10:23], orec[t, 10:23])), t
+        assert np.all(rel_close(rec[t, 23:36], orec[t, 23:36])), t
+
+
+def test_analyze_frames_parts_can_be_skipped_and_rows_can_be_padded(vb, pkg, audio_d):
+    F = 64
+    full = pkg.AnalysisParams.make(SR)
+    rec, _ = vb.analyze_frames(audio_d, full, frame_len=N, stride=H, n_frames=F)
+    only_pitch = pkg.AnalysisParams.make(SR, lpc_order=0, formant_order=0, mfcc=None)
+    assert int(vb.L.vbx_record_doubles(only_pitch)) == 2
+    r2, st2 = vb.analyze_frames(audio_d, only_pitch, frame_len=N, stride=H, n_frames=F)
+    assert r2.shape == (F, 2) and np.all(st2 == 0)
+    assert np.all(np.abs(r2[:, 0] - rec[:, 0]) <= 1e-4 * np.abs(rec[:, 0]))
+    no_mfcc = pkg.AnalysisParams.make(SR, mfcc=None)
+    assert no_mfcc.columns() == {"pitch": (0, 2), "formants": (2, 8), "lpc": (10, 13)}
+    r3, _ = vb.analyze_frames(audio_d, no_mfcc, frame_len=N, stride=H, n_frames=F, record_ld=40)
+    assert r3.shape == (F, 40)
+    assert np.array_equal(r3[:, 2:10], rec[:, 2:10]) and np.array_equal(r3[:, 10:23], rec[:, 23:36])
+    with pytest.raises(pkg.VoxBoxError):          # rows too short / odd
+        vb.analyze_frames(audio_d, full, frame_len=N, stride=H, n_frames=F, record_ld=35)
+    # empty batch
+    r0, _ = vb.analyze_frames(audio_d, full, frame_len=N, stride=H, n_frames=0)
+    assert r0.shape == (0, 36)
+
+
+def test_rccl_record_gather_single_rank(vb, pkg):
+    """The library's RCCL path on one GPU: communicator of world 1, loopback ncclSend/ncclRecv self-test, and the
+    gather entry point (own rows in place / copied, slots, device-side wait)."""
+    comm = pkg.Comm(vb, pkg.comm_unique_id(), 1, 0)
+    try:
+        comm.selftest(1 << 16)
+        rows, rec = 1000, 36
+        src = np.arange(rows * rec, dtype=np.float64).reshape(rows, rec)
+        d_src = vb.to_device(src)
+        d_out = vb.zeros((rows, rec))
+        comm.gather_records(d_src, [rows], rec, dst=0, out=d_out, slot=1)       # copy path
+        comm.wait(1)
+        comm.sync()
+        assert np.array_equal(d_out.numpy(), src)
+        comm.gather_records(d_out, [rows], rec, dst=0, out=d_out, slot=2)       # in place: nothing moves
+        comm.sync()
+        assert np.array_equal(d_out.numpy(), src)
+        with pytest.raises(pkg.VoxBoxError):
+            comm.gather_records(d_src, [rows], rec, dst=1, out=d_out, slot=0)   # dst outside the communicator
+        with pytest.raises(pkg.VoxBoxError):
+            comm.gather_records(d_src, [rows], rec, dst=0, out=d_out, slot=9)
+        d_src.free(); d_out.free()
+    finally:
+        comm.close()

@@ -127,3 +127,41 @@ def test_two_rank_gloo_gather_equals_single_process(tmp_path, pkg, oracle):
         _, est, _, _ = oracle.find_formants(fr, SR, P, est)
         exp = np.concatenate([c[0], est.reshape(-1), oracle.lpc(oracle.autocorrelate(fr * w, P + 1), P)])
         assert np.array_equal(got[t], exp), t
+
+
+def test_library_shard_helpers_match_the_python_ones(pkg):
+    """vbx_shard_range / vbx_shard_samples (what a C or Rust caller of the ABI uses) == shard.py."""
+    sh = pkg.shard
+    for n_frames in (0, 1, 7, 1000, 35999998):
+        for world in (1, 2, 3, 8):
+            assert [pkg.shard_range(n_frames, world, r) for r in range(world)] == \
+                   [sh.frame_range(r, world, n_frames) for r in range(world)]
+    for seg, n in ((np.arange(0, 10000, 1000), 10000), (np.array([0, 60, 131]), 197), (np.array([0]), 50),
+                   (np.arange(0, 36000000, 1000), 36000000)):
+        for world in (1, 2, 4, 8):
+            assert [pkg.shard_range(n, world, r, seg) for r in range(world)] == sh.segment_aligned_ranges(world, seg, n)
+    assert pkg.shard_samples(100, 200, N, H) == sh.sample_range(100, 200, N, H)
+    assert pkg.shard_samples(5, 5, N, H) == sh.sample_range(5, 5, N, H)
+
+
+def test_bench_gpus_n_launches_n_ranks_itself():
+    """`python bench.py --gpus 2` with no RANK in the environment starts 2 rank processes before touching the GPU,
+    relays rank 0's JSON line and returns their status (dry run: the ranks only rendezvous over gloo)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["VBX_BENCH_DRY_RUN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["dry_run"] and line["n_gpus"] == 2 and line["gpus_arg"] == 2
+    assert sorted(x[0] for x in line["ranks"]) == [0, 1] and sorted(x[1] for x in line["ranks"]) == [0, 1]
+    assert len({x[2] for x in line["ranks"]}) == 1
+    # a failing rank makes the launcher fail (no GPU here: the ranks refuse to run)
+    env.pop("VBX_BENCH_DRY_RUN")
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0

@@ -16,5 +16,6 @@ from .voxbox import (  # noqa: F401
     WINDOW_HANNING, WINDOW_HANNING_LAG, WINDOW_HANNING_PERIODIC, WINDOW_RECTANGLE,
     MALE_FORMANT_ESTIMATES, FEMALE_FORMANT_ESTIMATES,
     FRAME_OK, FRAME_ERR_LPC, FRAME_ERR_POLYNOMIAL, FRAME_ERR_NAN, FRAME_ERR_PANIC,
+    AnalysisParams, Comm, comm_unique_id, shard_range, shard_samples,
 )
 from . import shard  # noqa: F401

@@ -52,7 +52,7 @@ constexpr int AC_FPW = 16;   // frames per wavefront: short enough that the last
 template <int EPL, int NL>
 __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
     const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
-    int n_lags, int normalize, double *__restrict__ out_r, double *__restrict__ out_lpc) {
+    int n_lags, int normalize, double *__restrict__ out_r, double *__restrict__ out_lpc, long lpc_ld) {
     constexpr int FPW = AC_FPW;
     constexpr int TS = NL | 1;                       // odd row stride: conflict-free column reads
     __shared__ double T[64 * TS];                    // per-frame transpose buffer [lane][lag]
@@ -158,10 +158,10 @@ __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
 #pragma unroll
         for (int k = 0; k < NL; k++) R[lane * TS + k] = ac[k];
         wave_sync();
-        double *o = out_lpc + f0 * (long)NL;
+        double *o = out_lpc + f0 * lpc_ld;       // rows lpc_ld doubles apart (NL when dense)
         for (int idx = lane; idx < nf * NL; idx += 64) {
             const int fr = idx / NL, k = idx - fr * NL;
-            o[idx] = R[fr * TS + k];
+            o[fr * lpc_ld + k] = R[fr * TS + k];
         }
     }
 }
@@ -211,11 +211,11 @@ __global__ __launch_bounds__(64) void normalize_rows_kernel(double *__restrict__
 
 // LPC::lpc on autocorrelation rows: one thread per row (src/spectrum.rs:63-92).
 __global__ void levinson_rows_kernel(const double *__restrict__ r, long n_rows, long r_stride, int p,
-                                     double *__restrict__ out) {
+                                     double *__restrict__ out, long out_ld) {
     const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
     const double *rr = r + row * r_stride;
-    double *ac = out + row * (long)(p + 1);
+    double *ac = out + row * out_ld;
     double tmp[VBX_MAX_LPC_ORDER_K + 1];
     double err = rr[0];
     ac[0] = 1.0;
@@ -237,18 +237,18 @@ __global__ void levinson_rows_kernel(const double *__restrict__ r, long n_rows, 
 
 template <int EPL, int NL>
 static void launch_fewlags(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
-                           int n_lags, int normalize, double *out_r, double *out_lpc) {
+                           int n_lags, int normalize, double *out_r, double *out_lpc, long lpc_ld) {
     hipLaunchKernelGGL((autocorr_fewlags_kernel<EPL, NL>), dim3((unsigned)((F + AC_FPW - 1) / AC_FPW)), dim3(64), 0, s,
-                       x, F, n, stride, window, n_lags, normalize, out_r, out_lpc);
+                       x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
 }
 
 template <int NL>
 static bool dispatch_epl(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
-                         int n_lags, int normalize, double *out_r, double *out_lpc) {
-    if (n <= 64 * 8) launch_fewlags<8, NL>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc);
-    else if (n <= 64 * 16) launch_fewlags<16, NL>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc);
-    else if (n <= 64 * 20) launch_fewlags<20, NL>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc);
-    else if (n <= 64 * 32) launch_fewlags<32, NL>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc);
+                         int n_lags, int normalize, double *out_r, double *out_lpc, long lpc_ld) {
+    if (n <= 64 * 8) launch_fewlags<8, NL>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
+    else if (n <= 64 * 16) launch_fewlags<16, NL>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
+    else if (n <= 64 * 20) launch_fewlags<20, NL>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
+    else if (n <= 64 * 32) launch_fewlags<32, NL>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
     else return false;
     return true;
 }
@@ -261,19 +261,20 @@ bool fewlags_supported(int n, int n_lags, bool want_lpc) {
 }
 
 void launch_autocorr_fewlags(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
-                             int n_lags, int normalize, double *out_r, double *out_lpc) {
+                             int n_lags, int normalize, double *out_r, double *out_lpc, long lpc_ld) {
+    if (lpc_ld <= 0) lpc_ld = n_lags;
     if (out_lpc != nullptr) {
         switch (n_lags) {
-            case 9:  dispatch_epl<9>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc); break;
-            case 11: dispatch_epl<11>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc); break;
-            case 13: dispatch_epl<13>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc); break;
-            case 17: dispatch_epl<17>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc); break;
+            case 9:  dispatch_epl<9>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld); break;
+            case 11: dispatch_epl<11>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld); break;
+            case 13: dispatch_epl<13>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld); break;
+            case 17: dispatch_epl<17>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld); break;
         }
         return;
     }
-    if (n_lags <= 9) dispatch_epl<9>(s, x, F, n, stride, window, n_lags, normalize, out_r, nullptr);
-    else if (n_lags <= 13) dispatch_epl<13>(s, x, F, n, stride, window, n_lags, normalize, out_r, nullptr);
-    else dispatch_epl<17>(s, x, F, n, stride, window, n_lags, normalize, out_r, nullptr);
+    if (n_lags <= 9) dispatch_epl<9>(s, x, F, n, stride, window, n_lags, normalize, out_r, nullptr, lpc_ld);
+    else if (n_lags <= 13) dispatch_epl<13>(s, x, F, n, stride, window, n_lags, normalize, out_r, nullptr, lpc_ld);
+    else dispatch_epl<17>(s, x, F, n, stride, window, n_lags, normalize, out_r, nullptr, lpc_ld);
 }
 
 void launch_autocorr_tiles(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
@@ -286,9 +287,9 @@ void launch_normalize_rows(hipStream_t s, double *data, long rows, int n) {
     hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)rows), dim3(64), 0, s, data, rows, n);
 }
 
-void launch_levinson_rows(hipStream_t s, const double *r, long rows, long r_stride, int p, double *out) {
+void launch_levinson_rows(hipStream_t s, const double *r, long rows, long r_stride, int p, double *out, long out_ld) {
     const int bs = 64;
-    hipLaunchKernelGGL(levinson_rows_kernel, dim3((unsigned)((rows + bs - 1) / bs)), dim3(bs), 0, s, r, rows, r_stride, p, out);
+    hipLaunchKernelGGL(levinson_rows_kernel, dim3((unsigned)((rows + bs - 1) / bs)), dim3(bs), 0, s, r, rows, r_stride, p, out, out_ld);
 }
 
 }  // namespace vbx

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64 * W) void mfcc_kernel(
     const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
     const double *__restrict__ kappa_sigma /* [nb][2] */, const int32_t *__restrict__ bins,
     const double *__restrict__ slopes /* [nb][2] i/up, i/down */,
-    const double *__restrict__ dct_table, int num_coeffs, int nb, double *__restrict__ out) {
+    const double *__restrict__ dct_table, int num_coeffs, int nb, double *__restrict__ out, long out_ld, int32_t *__restrict__ status) {
     extern __shared__ double smem[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const long f = (long)blockIdx.x * W + wave;
@@ -109,7 +109,8 @@ __global__ __launch_bounds__(64 * W) void mfcc_kernel(
     }
     wave_sync();       // mag2/mag are produced and consumed inside this wavefront
 
-    mfcc_tail(mag2, mag, en, bins, dct_table, num_coeffs, b_lo, lane, out + f * (long)num_coeffs);
+    mfcc_tail(mag2, mag, en, bins, dct_table, num_coeffs, b_lo, lane, out + f * out_ld);
+        if (status != nullptr && lane == 0) status[f] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(512) void mfcc_dft2_kernel(
     const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
     const double *__restrict__ ctab /* [n1][NC] */, const double *__restrict__ twid /* [n][2] cos, sin */,
     int n1, int n2, int NC, int xs_len, const int32_t *__restrict__ bins, const double *__restrict__ slopes,
-    const double *__restrict__ dct_table, int num_coeffs, int nb, double *__restrict__ out) {
+    const double *__restrict__ dct_table, int num_coeffs, int nb, double *__restrict__ out, long out_ld, int32_t *__restrict__ status) {
     extern __shared__ double smem[];
     const int wave = threadIdx.x >> 6, lane = lane_id(), W = blockDim.x >> 6;
     double *ct = smem, *tw = smem + (size_t)n1 * NC;                      // shared by the block
@@ -252,7 +253,8 @@ __global__ __launch_bounds__(512) void mfcc_dft2_kernel(
             }
         }
         wave_sync();
-        mfcc_tail(mag2, mag, en, bins, dct_table, num_coeffs, b_lo, lane, out + f * (long)num_coeffs);
+        mfcc_tail(mag2, mag, en, bins, dct_table, num_coeffs, b_lo, lane, out + f * out_ld);
+        if (status != nullptr && lane == 0) status[f] = 0;
         wave_sync();                                                     // xs / en
     }
 }
@@ -275,13 +277,13 @@ bool mfcc_fits(int /*n*/, int nb) { return mfcc_lds(nb, 1) <= 160 * 1024; }
 
 void launch_mfcc(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                  const double *kappa_sigma, const int32_t *bins_dev, const double *slopes, const double *dct_table,
-                 int num_coeffs, double *out, int32_t * /*status*/, int nb) {
+                 int num_coeffs, double *out, long out_ld, int32_t *status, int nb) {
     if (mfcc_lds(nb, 4) <= 40 * 1024) {
         hipLaunchKernelGGL((mfcc_kernel<4>), dim3((unsigned)((F + 3) / 4)), dim3(256), mfcc_lds(nb, 4), s,
-                           x, F, n, stride, window, kappa_sigma, bins_dev, slopes, dct_table, num_coeffs, nb, out);
+                           x, F, n, stride, window, kappa_sigma, bins_dev, slopes, dct_table, num_coeffs, nb, out, out_ld, status);
     } else {
         hipLaunchKernelGGL((mfcc_kernel<1>), dim3((unsigned)F), dim3(64), mfcc_lds(nb, 1), s,
-                           x, F, n, stride, window, kappa_sigma, bins_dev, slopes, dct_table, num_coeffs, nb, out);
+                           x, F, n, stride, window, kappa_sigma, bins_dev, slopes, dct_table, num_coeffs, nb, out, out_ld, status);
     }
 }
 
@@ -319,7 +321,7 @@ mfcc_plan_t mfcc_plan(int n, int nb) {
 template <int TM>
 static void launch_dft2_tm(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                            const mfcc_plan_t &pl, const double *ctab, const double *twid, const int32_t *bins_dev,
-                           const double *slopes, const double *dct_table, int num_coeffs, double *out, int nb, int cu_count) {
+                           const double *slopes, const double *dct_table, int num_coeffs, double *out, long out_ld, int32_t *status, int nb, int cu_count) {
     // waves per block: the most wavefronts per CU the LDS allows (the table is shared by the block)
     int best_w = 1, best_res = 0;
     for (int w = 1; w <= 8; w++) {
@@ -334,15 +336,30 @@ static void launch_dft2_tm(hipStream_t s, const double *x, long F, int n, long s
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((mfcc_dft2_kernel<TM>), dim3((unsigned)blocks), dim3(64 * best_w), mfcc_dft2_lds(pl, nb, n, best_w), s,
                        x, F, n, stride, window, ctab, twid, pl.n1, pl.n2, pl.nc, xs_len, bins_dev, slopes, dct_table,
-                       num_coeffs, nb, out);
+                       num_coeffs, nb, out, out_ld, status);
 }
 
 void launch_mfcc_dft2(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                       const mfcc_plan_t &pl, const double *ctab, const double *twid, const int32_t *bins_dev,
-                      const double *slopes, const double *dct_table, int num_coeffs, double *out, int nb, int cu_count) {
-#define VBX_DFT2(TM) case TM: launch_dft2_tm<TM>(s, x, F, n, stride, window, pl, ctab, twid, bins_dev, slopes, dct_table, num_coeffs, out, nb, cu_count); break;
+                      const double *slopes, const double *dct_table, int num_coeffs, double *out, long out_ld, int32_t *status, int nb, int cu_count) {
+#define VBX_DFT2(TM) case TM: launch_dft2_tm<TM>(s, x, F, n, stride, window, pl, ctab, twid, bins_dev, slopes, dct_table, num_coeffs, out, out_ld, status, nb, cu_count); break;
     switch (pl.tm) { VBX_DFT2(2) VBX_DFT2(3) VBX_DFT2(4) VBX_DFT2(5) VBX_DFT2(6) VBX_DFT2(8) default: break; }
 #undef VBX_DFT2
+}
+
+// rows of a constant + a constant status (frames the reference panics on before looking at the data)
+__global__ void fill_rows_kernel(double *__restrict__ out, long n_rows, int n, long ld, double value,
+                                 int32_t *__restrict__ status, int32_t code) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * n) return;
+    const long row = i / n; const int k = (int)(i - row * n);
+    out[row * ld + k] = value;
+    if (k == 0 && status != nullptr) status[row] = code;
+}
+
+void launch_fill_rows(hipStream_t s, double *out, long rows, int n, long ld, double value, int32_t *status, int32_t code) {
+    const long total = rows * n;
+    hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, rows, n, ld, value, status, code);
 }
 
 void launch_dct_rows(hipStream_t s, const double *in, long rows, int n, const double *dct_table, double *out) {

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(512) void mfcc_mfma_kernel(
     const double *__restrict__ ctab_g, const double *__restrict__ twd_g, const double *__restrict__ twm_g,
     const double *__restrict__ wm_g /* [8*MT][64] */, int n1, int n2, int k2n, int mir_src0, int mir_src1,
     const int32_t *__restrict__ bins, const double *__restrict__ slopes, const double *__restrict__ dct_table,
-    int num_coeffs, int nb, double *__restrict__ out) {
+    int num_coeffs, int nb, double *__restrict__ out, long out_ld, int32_t *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NC = 32 * NTD;                         // stage-1 table columns: cos tiles, then sin tiles
     constexpr int N2P = 16 * MT;
@@ -187,7 +187,8 @@ __global__ __launch_bounds__(512) void mfcc_mfma_kernel(
             xim[bi] = fabs(sqrt(m2)) * sl.y;                                 // norm * multiplier (:432-434)
         }
         wave_sync();
-        mfcc_tail_m(xre, xim, en, bins, dct_table, num_coeffs, b_lo, lane, out + f * (long)num_coeffs);
+        mfcc_tail_m(xre, xim, en, bins, dct_table, num_coeffs, b_lo, lane, out + f * out_ld);
+        if (status != nullptr && lane == 0) status[f] = 0;
         wave_sync();
     }
 }
@@ -235,7 +236,7 @@ template <int MT, int NTD, int NTM>
 static void launch_mm(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                       const mfcc_mplan_t &pl, const double *ctab, const double *twd, const double *twm, const double *wm,
                       const int32_t *bins_dev, const double *slopes, const double *dct_table, int num_coeffs, double *out,
-                      int nb, int cu_count) {
+                      long out_ld, int32_t *status, int nb, int cu_count) {
     int w = 8;
     while (w > 1 && mfcc_mfma_lds(pl, nb, w) > 160 * 1024) w--;
     long blocks = (F + w - 1) / w;
@@ -243,15 +244,15 @@ static void launch_mm(hipStream_t s, const double *x, long F, int n, long stride
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((mfcc_mfma_kernel<MT, NTD, NTM>), dim3((unsigned)blocks), dim3(64 * w), mfcc_mfma_lds(pl, nb, w), s,
                        x, F, n, stride, window, ctab, twd, twm, wm, pl.n1, pl.n2, pl.k2, pl.src0, pl.src1, bins_dev, slopes,
-                       dct_table, num_coeffs, nb, out);
+                       dct_table, num_coeffs, nb, out, out_ld, status);
 }
 
 template <int MT>
 static void launch_mm_mt(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                          const mfcc_mplan_t &pl, const double *ctab, const double *twd, const double *twm, const double *wm,
                          const int32_t *bins_dev, const double *slopes, const double *dct_table, int num_coeffs, double *out,
-                         int nb, int cu_count) {
-#define VBX_MM(A, B) launch_mm<MT, A, B>(s, x, F, n, stride, window, pl, ctab, twd, twm, wm, bins_dev, slopes, dct_table, num_coeffs, out, nb, cu_count)
+                         long out_ld, int32_t *status, int nb, int cu_count) {
+#define VBX_MM(A, B) launch_mm<MT, A, B>(s, x, F, n, stride, window, pl, ctab, twd, twm, wm, bins_dev, slopes, dct_table, num_coeffs, out, out_ld, status, nb, cu_count)
     if (pl.ntd == 1 && pl.ntm == 0) VBX_MM(1, 0);
     else if (pl.ntd == 1 && pl.ntm == 1) VBX_MM(1, 1);
     else if (pl.ntd == 2 && pl.ntm == 0) VBX_MM(2, 0);
@@ -263,8 +264,8 @@ static void launch_mm_mt(hipStream_t s, const double *x, long F, int n, long str
 void launch_mfcc_mfma(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                       const mfcc_mplan_t &pl, const double *ctab, const double *twd, const double *twm, const double *wm,
                       const int32_t *bins_dev, const double *slopes, const double *dct_table, int num_coeffs, double *out,
-                      int nb, int cu_count) {
-#define VBX_MT(M) launch_mm_mt<M>(s, x, F, n, stride, window, pl, ctab, twd, twm, wm, bins_dev, slopes, dct_table, num_coeffs, out, nb, cu_count)
+                      long out_ld, int32_t *status, int nb, int cu_count) {
+#define VBX_MT(M) launch_mm_mt<M>(s, x, F, n, stride, window, pl, ctab, twd, twm, wm, bins_dev, slopes, dct_table, num_coeffs, out, out_ld, status, nb, cu_count)
     switch (pl.mt) { case 1: VBX_MT(1); break; case 2: VBX_MT(2); break; case 3: VBX_MT(3); break; default: VBX_MT(4); break; }
 #undef VBX_MT
 }

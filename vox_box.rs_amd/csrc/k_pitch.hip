@@ -407,7 +407,7 @@ template <bool ALIAS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void pitch_kernel(
     const double *__restrict__ frames, long n_frames, int n, long stride, const double *__restrict__ window,
     const double *__restrict__ lag_window, double sample_rate, double threshold, double fmin, double fmax,
-    int kmax, pitch_t *__restrict__ out_cand, int32_t *__restrict__ out_count, int32_t *__restrict__ status,
+    int kmax, double *__restrict__ out_cand, long cand_ld, int32_t *__restrict__ out_count, int32_t *__restrict__ status,
     unsigned long long *__restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const long f = blockIdx.x;
@@ -720,11 +720,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     int code = 0;
     if (st & 4) code = 4; else if (st & 8) code = 3;
     if (lane < kmax) {
-        pitch_t o;
         const bool valid = (code == 0) && lane < kept;
-        o.frequency = valid ? lf : 0.0;
-        o.strength = valid ? ls : 0.0;
-        out_cand[f * (long)kmax + lane] = o;
+        double2 o;
+        o.x = valid ? lf : 0.0;                     // Pitch { frequency, strength }
+        o.y = valid ? ls : 0.0;
+        *reinterpret_cast<double2 *>(out_cand + f * cand_ld + 2 * lane) = o;   // row f of a [F, cand_ld] array of doubles
     }
     if (lane == 0) {
         if (out_count != nullptr) out_count[f] = (code == 0) ? total_cand : 0;
@@ -783,15 +783,16 @@ size_t pitch_lds_bytes(int n) {
 
 void launch_pitch(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                   const double *lag_window, double sample_rate, double threshold, double fmin, double fmax,
-                  int kmax, pitch_t *out_cand, int32_t *out_count, int32_t *status, unsigned long long *work) {
+                  int kmax, pitch_t *out_cand, long cand_ld, int32_t *out_count, int32_t *status,
+                  unsigned long long *work) {
     if (n <= AC_MF_NT * AC_MF_TILE)
         hipLaunchKernelGGL((pitch_kernel<true>), dim3((unsigned)F), dim3(64), pitch_lds_bytes(n), s,
                            x, F, n, stride, window, lag_window, sample_rate, threshold, fmin, fmax, kmax,
-                           out_cand, out_count, status, work);
+                           reinterpret_cast<double *>(out_cand), cand_ld, out_count, status, work);
     else
         hipLaunchKernelGGL((pitch_kernel<false>), dim3((unsigned)F), dim3(64), pitch_lds_bytes(n), s,
                            x, F, n, stride, window, lag_window, sample_rate, threshold, fmin, fmax, kmax,
-                           out_cand, out_count, status, work);
+                           reinterpret_cast<double *>(out_cand), cand_ld, out_count, status, work);
 }
 
 void launch_sinc_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *xs, long m,

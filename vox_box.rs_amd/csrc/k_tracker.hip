@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(const res_t *__restrict__ r
                                const int32_t *__restrict__ res_count,
                                const int64_t *__restrict__ seg_start, long n_seg,
                                const res_t *__restrict__ est_init, int n_est,
-                               const int32_t *__restrict__ frame_status, res_t *__restrict__ out) {
+                               const int32_t *__restrict__ frame_status, double *__restrict__ out, long out_ld) {
     const long sg = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (sg >= n_seg) return;
     const long f0 = (seg_start != nullptr) ? seg_start[sg] : 0;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(const res_t *__restrict__ r
         if (cur_ok) estimate_formants_step(ef, eb, n_est, cur, res + f * (long)n_res, n_res, cur_cnt);
 #pragma unroll
         for (int e = 0; e < NS; e++)
-            if (e < n_est) { res_t o; o.frequency = ef[e]; o.bandwidth = eb[e]; out[f * (long)n_est + e] = o; }
+            if (e < n_est) { double2 o; o.x = ef[e]; o.y = eb[e]; *reinterpret_cast<double2 *>(out + f * out_ld + 2 * e) = o; }
 #pragma unroll
         for (int i = 0; i < TRK_PF; i++) cur[i] = nxt[i];
         cur_cnt = nxt_cnt; cur_ok = nxt_ok;
@@ -184,10 +184,11 @@ __global__ __launch_bounds__(64) void tracker_kernel(const res_t *__restrict__ r
 
 void launch_tracker(hipStream_t s, const res_t *res, long F, int n_res, const int32_t *res_count,
                     const int64_t *seg_start, long n_seg, const res_t *est_init, int n_est,
-                    const int32_t *frame_status, res_t *out) {
+                    const int32_t *frame_status, res_t *out, long out_ld) {
     const int bs = 64;
     hipLaunchKernelGGL(tracker_kernel, dim3((unsigned)((n_seg + bs - 1) / bs)), dim3(bs), 0, s,
-                       res, F, n_res, res_count, seg_start, n_seg, est_init, n_est, frame_status, out);
+                       res, F, n_res, res_count, seg_start, n_seg, est_init, n_est, frame_status,
+                       reinterpret_cast<double *>(out), out_ld);
 }
 
 }  // namespace vbx

@@ -25,7 +25,7 @@ namespace {
 
 thread_local std::string g_last_error;
 
-struct ProfRec { std::string name; hipEvent_t a, b; };
+struct ProfRec { std::string name; hipEvent_t a, b; hipStream_t stream; };
 
 }  // namespace
 
@@ -57,6 +57,15 @@ struct vbx_ctx {
     bool mfcc_force_goertzel = false;                     // test hooks: VBX_MFCC_GOERTZEL=1 / VBX_MFCC_DFT2=1 keep the
     bool mfcc_force_dft2 = false;                         //   fallback kernels covered on lengths the MFMA kernel takes
     unsigned long long *pitch_work = nullptr;             // [PITCH_WORK_SLOTS][4], counted while profiling
+    // second stream of vbx_analyze_frames_f64 (the formant chain runs beside the pitch kernel) + fork/join events
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // pinned staging of the small host arrays (segment starts, initial estimates): the caller's arrays may be
+    // freed on return, and an upload whose content has not changed since the last call is skipped
+    void *stage[2] = {nullptr, nullptr};
+    size_t stage_cap[2] = {0, 0};
+    std::vector<char> staged[2];                          // content now on the device
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};          // completion of the last staged copy
 };
 
 namespace {
@@ -84,12 +93,12 @@ int check_launch(vbx_ctx *ctx, const char *what) {
 }
 
 struct Prof {
-    vbx_ctx *ctx; const char *name; hipEvent_t a = nullptr, b = nullptr;
-    Prof(vbx_ctx *c, const char *n) : ctx(c), name(n) {
-        if (ctx->prof) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, ctx->stream); }
+    vbx_ctx *ctx; const char *name; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    Prof(vbx_ctx *c, const char *n, hipStream_t stream = nullptr) : ctx(c), name(n), st(stream ? stream : c->stream) {
+        if (ctx->prof) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, st); }
     }
     ~Prof() {
-        if (ctx->prof) { hipEventRecord(b, ctx->stream); ctx->recs.push_back({name, a, b}); }
+        if (ctx->prof) { hipEventRecord(b, st); ctx->recs.push_back({name, a, b, st}); }
     }
 };
 
@@ -98,6 +107,7 @@ int ws_get(vbx_ctx *ctx, int slot, size_t bytes, void **out) {
     if (ctx->ws_bytes[slot] < bytes) {
         if (ctx->ws[slot]) {
             VBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->side) VBX_HIP(ctx, hipStreamSynchronize(ctx->side));
             VBX_HIP(ctx, hipFree(ctx->ws[slot]));
             ctx->ws[slot] = nullptr; ctx->ws_bytes[slot] = 0;
         }
@@ -351,24 +361,49 @@ int check_frames(vbx_ctx *ctx, const char *fn, const void *x, size_t n_frames, s
     return VBX_SUCCESS;
 }
 
-int upload_segments(vbx_ctx *ctx, const int64_t *h_seg, size_t n_seg, size_t n_frames, const int64_t **d_seg, size_t *n_out) {
+// Small host array -> ctx-owned device buffer through pinned staging.  The caller's array may be freed on return
+// (the copy below reads the staging buffer, not the caller's memory), the host is not blocked behind queued work,
+// and identical content (the usual case: the same segments / estimates every call) is not uploaded again.
+int stage_upload(vbx_ctx *ctx, int which, int ws_slot, const void *h_src, size_t bytes, hipStream_t st, void **d_out) {
+    void *d = nullptr;
+    const bool grown = ctx->ws_bytes[ws_slot] < bytes;
+    int rc = ws_get(ctx, ws_slot, bytes, &d);
+    if (rc != VBX_SUCCESS) return rc;
+    *d_out = d;
+    std::vector<char> &have = ctx->staged[which];
+    if (!grown && have.size() == bytes && std::memcmp(have.data(), h_src, bytes) == 0) return VBX_SUCCESS;
+    if (!ctx->stage_ev[which]) VBX_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_ev[which], hipEventDisableTiming));
+    else VBX_HIP(ctx, hipEventSynchronize(ctx->stage_ev[which]));          // the previous copy has left the staging buffer
+    if (ctx->stage_cap[which] < bytes) {
+        if (ctx->stage[which]) VBX_HIP(ctx, hipHostFree(ctx->stage[which]));
+        ctx->stage[which] = nullptr; ctx->stage_cap[which] = 0;
+        VBX_HIP(ctx, hipHostMalloc(&ctx->stage[which], bytes + bytes / 2, hipHostMallocDefault));
+        ctx->stage_cap[which] = bytes + bytes / 2;
+    }
+    std::memcpy(ctx->stage[which], h_src, bytes);
+    // uploads of either stream are ordered behind everything queued on the main stream that may still read the old content
+    VBX_HIP(ctx, hipMemcpyAsync(d, ctx->stage[which], bytes, hipMemcpyHostToDevice, st));
+    VBX_HIP(ctx, hipEventRecord(ctx->stage_ev[which], st));
+    have.assign((const char *)h_src, (const char *)h_src + bytes);
+    return VBX_SUCCESS;
+}
+
+int upload_segments(vbx_ctx *ctx, hipStream_t st, const int64_t *h_seg, size_t n_seg, size_t n_frames, const int64_t **d_seg, size_t *n_out) {
     if (h_seg == nullptr || n_seg == 0) { *d_seg = nullptr; *n_out = 1; return VBX_SUCCESS; }
     if (h_seg[0] != 0) return fail(ctx, VBX_E_INVALID, "seg_start[0] must be 0");
     for (size_t i = 1; i < n_seg; i++)
         if (h_seg[i] < h_seg[i - 1] || (size_t)h_seg[i] > n_frames) return fail(ctx, VBX_E_INVALID, "seg_start must ascend within [0, n_frames]");
     void *d = nullptr;
-    int rc = ws_get(ctx, vbx_ctx::WS_SEG, n_seg * sizeof(int64_t), &d);
+    int rc = stage_upload(ctx, 0, vbx_ctx::WS_SEG, h_seg, n_seg * sizeof(int64_t), st, &d);
     if (rc != VBX_SUCCESS) return rc;
-    VBX_HIP(ctx, hipMemcpyAsync(d, h_seg, n_seg * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     *d_seg = (const int64_t *)d; *n_out = n_seg;
     return VBX_SUCCESS;
 }
 
-int upload_estimates(vbx_ctx *ctx, const vbx_resonance *h_est, size_t n_est, const res_t **d_est) {
+int upload_estimates(vbx_ctx *ctx, hipStream_t st, const vbx_resonance *h_est, size_t n_est, const res_t **d_est) {
     void *d = nullptr;
-    int rc = ws_get(ctx, vbx_ctx::WS_EST, n_est * sizeof(vbx_resonance), &d);
+    int rc = stage_upload(ctx, 1, vbx_ctx::WS_EST, h_est, n_est * sizeof(vbx_resonance), st, &d);
     if (rc != VBX_SUCCESS) return rc;
-    VBX_HIP(ctx, hipMemcpyAsync(d, h_est, n_est * sizeof(vbx_resonance), hipMemcpyHostToDevice, ctx->stream));
     *d_est = (const res_t *)d;
     return VBX_SUCCESS;
 }
@@ -377,6 +412,11 @@ int upload_estimates(vbx_ctx *ctx, const vbx_resonance *h_est, size_t n_est, con
 
 // =============================================================================================
 extern "C" {
+
+// hooks for vbx_comm.hip (the context is opaque outside this file)
+int vbx_internal_fail(vbx_ctx *ctx, int code, const char *msg) { return fail(ctx, code, msg ? msg : ""); }
+void *vbx_internal_stream(vbx_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int vbx_internal_device(vbx_ctx *ctx) { return ctx ? ctx->device : 0; }
 
 int vbx_abi_version(void) { return VBX_ABI_VERSION; }
 
@@ -426,6 +466,10 @@ void vbx_ctx_destroy(vbx_ctx *ctx) {
     for (auto &kv : ctx->slopes_cache) hipFree(kv.second);
     for (auto &kv : ctx->resample_tabs) { hipFree(kv.second.first); hipFree(kv.second.second); }
     for (auto &r : ctx->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+    for (int i = 0; i < 2; i++) { if (ctx->stage[i]) hipHostFree(ctx->stage[i]); if (ctx->stage_ev[i]) hipEventDestroy(ctx->stage_ev[i]); }
     if (ctx->t0) hipEventDestroy(ctx->t0);
     if (ctx->t1) hipEventDestroy(ctx->t1);
     if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
@@ -495,6 +539,7 @@ int vbx_timer_end(vbx_ctx *ctx, float *h_ms) {
 static int prof_flush(vbx_ctx *ctx) {
     if (ctx->recs.empty()) return VBX_SUCCESS;
     VBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->side) VBX_HIP(ctx, hipStreamSynchronize(ctx->side));
     for (auto &r : ctx->recs) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
@@ -620,31 +665,39 @@ int vbx_improve_extremum_f64(vbx_ctx *ctx, const double *y, size_t ylen, long of
     return check_launch(ctx, __func__);
 }
 
+static int run_pitch(vbx_ctx *ctx, hipStream_t st, const double *x, size_t n_frames, size_t frame_len, size_t stride,
+                     const double *window, double sample_rate, double threshold, double fmin, double fmax,
+                     size_t kmax, vbx_pitch *out_cand, size_t cand_ld, int32_t *out_count, int32_t *status) {
+    VBX_REQUIRE(ctx, out_cand != nullptr, "null output");
+    VBX_REQUIRE(ctx, kmax >= 1 && kmax <= VBX_MAX_PITCH_CANDIDATES, "kmax must be in [1, 64]");
+    VBX_REQUIRE(ctx, cand_ld >= 2 * kmax && cand_ld % 2 == 0, "candidate rows must be 16-byte aligned and hold kmax entries");
+    VBX_REQUIRE(ctx, frame_len >= 4, "frame_len must be >= 4");
+    VBX_REQUIRE(ctx, pitch_lds_bytes((int)frame_len) <= 160 * 1024, "frame does not fit the LDS");
+    const double *lagw = nullptr;
+    int rc = get_window_dev(ctx, VBX_WINDOW_HANNING_LAG, frame_len, &lagw);
+    if (rc != VBX_SUCCESS) return rc;
+    if (ctx->prof && !ctx->pitch_work) {
+        const size_t wb = PITCH_WORK_SLOTS * 4 * sizeof(unsigned long long);
+        VBX_HIP(ctx, hipMalloc((void **)&ctx->pitch_work, wb));
+        VBX_HIP(ctx, hipMemsetAsync(ctx->pitch_work, 0, wb, st));
+    }
+    {
+        Prof p(ctx, "pitch", st);
+        launch_pitch(st, x, (long)n_frames, (int)frame_len, (long)stride, window, lagw, sample_rate, threshold,
+                     fmin, fmax, (int)kmax, (pitch_t *)out_cand, (long)cand_ld, out_count, status,
+                     ctx->prof ? ctx->pitch_work : nullptr);
+    }
+    return check_launch(ctx, "vbx_pitch_f64");
+}
+
 int vbx_pitch_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
                   const double *window, double sample_rate, double threshold, double fmin, double fmax,
                   size_t kmax, vbx_pitch *out_cand, int32_t *out_count, int32_t *status) {
     int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
     if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
-    VBX_REQUIRE(ctx, out_cand != nullptr, "null output");
-    VBX_REQUIRE(ctx, kmax >= 1 && kmax <= VBX_MAX_PITCH_CANDIDATES, "kmax must be in [1, 64]");
-    VBX_REQUIRE(ctx, frame_len >= 4, "frame_len must be >= 4");
-    VBX_REQUIRE(ctx, pitch_lds_bytes((int)frame_len) <= 160 * 1024, "frame does not fit the LDS");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
-    const double *lagw = nullptr;
-    rc = get_window_dev(ctx, VBX_WINDOW_HANNING_LAG, frame_len, &lagw);
-    if (rc != VBX_SUCCESS) return rc;
-    if (ctx->prof && !ctx->pitch_work) {
-        const size_t wb = PITCH_WORK_SLOTS * 4 * sizeof(unsigned long long);
-        VBX_HIP(ctx, hipMalloc((void **)&ctx->pitch_work, wb));
-        VBX_HIP(ctx, hipMemsetAsync(ctx->pitch_work, 0, wb, ctx->stream));
-    }
-    {
-        Prof p(ctx, "pitch");
-        launch_pitch(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, lagw, sample_rate, threshold,
-                     fmin, fmax, (int)kmax, (pitch_t *)out_cand, out_count, status,
-                     ctx->prof ? ctx->pitch_work : nullptr);
-    }
-    return check_launch(ctx, __func__);
+    return run_pitch(ctx, ctx->stream, x, n_frames, frame_len, stride, window, sample_rate, threshold, fmin, fmax,
+                     kmax, out_cand, 2 * kmax, out_count, status);
 }
 
 // ---- spectrum.rs: LPC ---------------------------------------------------------------------
@@ -656,23 +709,22 @@ int vbx_lpc_f64(vbx_ctx *ctx, const double *r, size_t n_frames, size_t r_stride,
     VBX_REQUIRE(ctx, n_coeffs >= 1 && n_coeffs <= VBX_MAX_LPC_ORDER && r_stride >= n_coeffs + 1, "bad order / stride");
     VBX_REQUIRE(ctx, n_frames <= 0x7fffffffull, "too many rows");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
-    { Prof p(ctx, "levinson_rows"); launch_levinson_rows(ctx->stream, r, (long)n_frames, (long)r_stride, (int)n_coeffs, out); }
+    { Prof p(ctx, "levinson_rows"); launch_levinson_rows(ctx->stream, r, (long)n_frames, (long)r_stride, (int)n_coeffs, out, (long)n_coeffs + 1); }
     return check_launch(ctx, __func__);
 }
 
-int vbx_autocorr_lpc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
-                         size_t stride, const double *window, size_t n_coeffs, int normalize,
-                         double *out_r, double *out_lpc) {
-    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
-    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+static int run_autocorr_lpc(vbx_ctx *ctx, hipStream_t st, const double *x, size_t n_frames, size_t frame_len,
+                            size_t stride, const double *window, size_t n_coeffs, int normalize,
+                            double *out_r, double *out_lpc, size_t lpc_ld) {
     VBX_REQUIRE(ctx, out_r || out_lpc, "both outputs null");
     VBX_REQUIRE(ctx, n_coeffs >= 1 && n_coeffs <= VBX_MAX_LPC_ORDER && n_coeffs + 1 <= frame_len, "bad order");
-    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    VBX_REQUIRE(ctx, lpc_ld >= n_coeffs + 1, "LPC rows must hold n_coeffs + 1 entries");
     const int n_lags = (int)n_coeffs + 1;
+    int rc;
     if (fewlags_supported((int)frame_len, n_lags, out_lpc != nullptr)) {
-        Prof p(ctx, "autocorr_lpc");
-        launch_autocorr_fewlags(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, n_lags, normalize, out_r, out_lpc);
-        return check_launch(ctx, __func__);
+        Prof p(ctx, "autocorr_lpc", st);
+        launch_autocorr_fewlags(st, x, (long)n_frames, (int)frame_len, (long)stride, window, n_lags, normalize, out_r, out_lpc, (long)lpc_ld);
+        return check_launch(ctx, "vbx_autocorr_lpc_f64");
     }
     // general shapes: autocorrelate -> [normalize] -> Levinson as three launches
     double *r = out_r;
@@ -683,15 +735,24 @@ int vbx_autocorr_lpc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t 
         r = (double *)w;
     }
     if (fewlags_supported((int)frame_len, n_lags, false)) {
-        Prof p(ctx, "autocorr_fewlags");
-        launch_autocorr_fewlags(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, n_lags, 0, r, nullptr);
+        Prof p(ctx, "autocorr_fewlags", st);
+        launch_autocorr_fewlags(st, x, (long)n_frames, (int)frame_len, (long)stride, window, n_lags, 0, r, nullptr);
     } else {
-        Prof p(ctx, "autocorr_tiles");
-        launch_autocorr_tiles(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, n_lags, r);
+        Prof p(ctx, "autocorr_tiles", st);
+        launch_autocorr_tiles(st, x, (long)n_frames, (int)frame_len, (long)stride, window, n_lags, r);
     }
-    if (normalize) { Prof p(ctx, "normalize_rows"); launch_normalize_rows(ctx->stream, r, (long)n_frames, n_lags); }
-    if (out_lpc) { Prof p(ctx, "levinson_rows"); launch_levinson_rows(ctx->stream, r, (long)n_frames, n_lags, (int)n_coeffs, out_lpc); }
-    return check_launch(ctx, __func__);
+    if (normalize) { Prof p(ctx, "normalize_rows", st); launch_normalize_rows(st, r, (long)n_frames, n_lags); }
+    if (out_lpc) { Prof p(ctx, "levinson_rows", st); launch_levinson_rows(st, r, (long)n_frames, n_lags, (int)n_coeffs, out_lpc, (long)lpc_ld); }
+    return check_launch(ctx, "vbx_autocorr_lpc_f64");
+}
+
+int vbx_autocorr_lpc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
+                         size_t stride, const double *window, size_t n_coeffs, int normalize,
+                         double *out_r, double *out_lpc) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    return run_autocorr_lpc(ctx, ctx->stream, x, n_frames, frame_len, stride, window, n_coeffs, normalize, out_r, out_lpc, n_coeffs + 1);
 }
 
 int vbx_lpc_burg_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
@@ -803,31 +864,30 @@ int vbx_estimate_formants_f64(vbx_ctx *ctx, const vbx_resonance *res, size_t n_f
     VBX_REQUIRE(ctx, n_est >= 1 && n_est <= VBX_FORMANT_SLOTS, "n_est must be in [1, 6]");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t *d_seg = nullptr; size_t nseg = 1; const res_t *d_est = nullptr;
-    int rc = upload_segments(ctx, h_seg_start, n_segments, n_frames, &d_seg, &nseg);
+    int rc = upload_segments(ctx, ctx->stream, h_seg_start, n_segments, n_frames, &d_seg, &nseg);
     if (rc != VBX_SUCCESS) return rc;
-    rc = upload_estimates(ctx, h_est_init, n_est, &d_est);
+    rc = upload_estimates(ctx, ctx->stream, h_est_init, n_est, &d_est);
     if (rc != VBX_SUCCESS) return rc;
     {
         Prof p(ctx, "tracker");
         launch_tracker(ctx->stream, (const res_t *)res, (long)n_frames, (int)n_res, nullptr, d_seg, (long)nseg, d_est,
-                       (int)n_est, frame_status, (res_t *)out);
+                       (int)n_est, frame_status, (res_t *)out, 2 * (long)n_est);
     }
     return check_launch(ctx, __func__);
 }
 
-int vbx_find_formants_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
-                          size_t stride, double sample_rate, size_t n_coeffs,
-                          const int64_t *h_seg_start, size_t n_segments,
-                          const vbx_resonance *h_est_init, size_t n_est,
-                          vbx_resonance *out_formants, vbx_resonance *out_res, int32_t *out_res_count,
-                          double *out_coeffs, int32_t *status) {
-    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
-    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+static int run_find_formants(vbx_ctx *ctx, hipStream_t stm, const double *x, size_t n_frames, size_t frame_len,
+                             size_t stride, double sample_rate, size_t n_coeffs,
+                             const int64_t *h_seg_start, size_t n_segments,
+                             const vbx_resonance *h_est_init, size_t n_est,
+                             vbx_resonance *out_formants, size_t formants_ld, vbx_resonance *out_res, int32_t *out_res_count,
+                             double *out_coeffs, int32_t *status) {
     VBX_REQUIRE(ctx, h_est_init && out_formants, "null argument");
     VBX_REQUIRE(ctx, burg_supported((int)frame_len, (int)n_coeffs), "frame_len must be in [2, 4096], order in [1, 30]");
     VBX_REQUIRE(ctx, n_est >= 1 && n_est <= VBX_FORMANT_SLOTS, "n_est must be in [1, 6]");
-    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    VBX_REQUIRE(ctx, formants_ld >= 2 * n_est && formants_ld % 2 == 0, "formant rows must be 16-byte aligned and hold n_est entries");
     const long F = (long)n_frames; const int p = (int)n_coeffs;
+    int rc;
     void *w = nullptr;
     double *coeffs = out_coeffs;
     if (!coeffs) { rc = ws_get(ctx, vbx_ctx::WS_COEFFS, n_frames * n_coeffs * sizeof(double), &w); if (rc) return rc; coeffs = (double *)w; }
@@ -841,68 +901,84 @@ int vbx_find_formants_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t
     rc = get_window_dev(ctx, VBX_WINDOW_HANNING_PERIODIC, frame_len, &hann);   // src/lib.rs:65-70
     if (rc != VBX_SUCCESS) return rc;
     const int64_t *d_seg = nullptr; size_t nseg = 1; const res_t *d_est = nullptr;
-    rc = upload_segments(ctx, h_seg_start, n_segments, n_frames, &d_seg, &nseg);
+    rc = upload_segments(ctx, stm, h_seg_start, n_segments, n_frames, &d_seg, &nseg);
     if (rc != VBX_SUCCESS) return rc;
-    rc = upload_estimates(ctx, h_est_init, n_est, &d_est);
+    rc = upload_estimates(ctx, stm, h_est_init, n_est, &d_est);
     if (rc != VBX_SUCCESS) return rc;
-    { Prof pr(ctx, "burg"); launch_burg(ctx->stream, x, F, (int)frame_len, (long)stride, hann, p, coeffs, st); }                 // :75
-    { Prof pr(ctx, "formant_resonances"); launch_formant_resonances(ctx->stream, coeffs, F, p, sample_rate, res, cnt, st); }      // :80-110
-    { Prof pr(ctx, "tracker"); launch_tracker(ctx->stream, res, F, VBX_MAX_RESONANCES, cnt, d_seg, (long)nseg, d_est, (int)n_est, st, (res_t *)out_formants); }  // :114
-    return check_launch(ctx, __func__);
+    { Prof pr(ctx, "burg", stm); launch_burg(stm, x, F, (int)frame_len, (long)stride, hann, p, coeffs, st); }                 // :75
+    { Prof pr(ctx, "formant_resonances", stm); launch_formant_resonances(stm, coeffs, F, p, sample_rate, res, cnt, st); }      // :80-110
+    { Prof pr(ctx, "tracker", stm); launch_tracker(stm, res, F, VBX_MAX_RESONANCES, cnt, d_seg, (long)nseg, d_est, (int)n_est, st, (res_t *)out_formants, (long)formants_ld); }  // :114
+    return check_launch(ctx, "vbx_find_formants_f64");
+}
+
+int vbx_find_formants_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
+                          size_t stride, double sample_rate, size_t n_coeffs,
+                          const int64_t *h_seg_start, size_t n_segments,
+                          const vbx_resonance *h_est_init, size_t n_est,
+                          vbx_resonance *out_formants, vbx_resonance *out_res, int32_t *out_res_count,
+                          double *out_coeffs, int32_t *status) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    return run_find_formants(ctx, ctx->stream, x, n_frames, frame_len, stride, sample_rate, n_coeffs, h_seg_start, n_segments,
+                             h_est_init, n_est, out_formants, 2 * n_est, out_res, out_res_count, out_coeffs, status);
 }
 
 // ---- spectrum.rs: MFCC --------------------------------------------------------------------
 
-int vbx_mfcc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
-                 const double *window, size_t num_coeffs, double lo_hz, double hi_hz,
-                 double sample_rate, double *out, int32_t *status) {
-    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
-    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+static int run_mfcc(vbx_ctx *ctx, hipStream_t stm, const double *x, size_t n_frames, size_t frame_len, size_t stride,
+                    const double *window, size_t num_coeffs, double lo_hz, double hi_hz,
+                    double sample_rate, double *out, size_t out_ld, int32_t *status) {
     VBX_REQUIRE(ctx, out != nullptr, "null output");
     VBX_REQUIRE(ctx, num_coeffs >= 1 && num_coeffs <= 64, "num_coeffs must be in [1, 64]");
-    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    VBX_REQUIRE(ctx, out_ld >= num_coeffs, "output rows must hold num_coeffs entries");
     std::vector<int32_t> hb; bool bad = false; const int32_t *d_bins = nullptr;
-    rc = get_bins_dev(ctx, frame_len, num_coeffs, lo_hz, hi_hz, sample_rate, &d_bins, hb, bad);
+    int rc = get_bins_dev(ctx, frame_len, num_coeffs, lo_hz, hi_hz, sample_rate, &d_bins, hb, bad);
     if (rc != VBX_SUCCESS) return rc;
     if (bad) {   // the reference panics on every frame (bins do not depend on the data)
-        VBX_HIP(ctx, hipMemsetAsync(out, 0, n_frames * num_coeffs * sizeof(double), ctx->stream));
-        if (status) {
-            std::vector<int32_t> h(n_frames, VBX_FRAME_ERR_PANIC);
-            VBX_HIP(ctx, hipMemcpyAsync(status, h.data(), n_frames * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-            VBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        }
-        return VBX_SUCCESS;
+        { Prof p(ctx, "fill_rows", stm); launch_fill_rows(stm, out, (long)n_frames, (int)num_coeffs, (long)out_ld, 0.0, status, VBX_FRAME_ERR_PANIC); }
+        return check_launch(ctx, "vbx_mfcc_f64");
     }
     const int nb = hb.back() - hb.front();
     const double *dct = nullptr, *slopes = nullptr;
     rc = get_dct_dev(ctx, num_coeffs, &dct); if (rc != VBX_SUCCESS) return rc;
     rc = get_slopes_dev(ctx, frame_len, num_coeffs, lo_hz, hi_hz, sample_rate, hb, &slopes); if (rc != VBX_SUCCESS) return rc;
-    if (status) VBX_HIP(ctx, hipMemsetAsync(status, 0, n_frames * sizeof(int32_t), ctx->stream));
     // composite frame lengths: two-stage DFT of the needed bins, on the matrix cores when the factorisation fits
-    // the MFMA kernel's tiles, else on the vector ALU; otherwise (prime-ish lengths) Goertzel
+    // the MFMA kernel's tiles, else on the vector ALU; otherwise (prime-ish lengths) Goertzel.  Every kernel writes
+    // status 0 itself (no separate memset queued behind whatever the stream is running).
     const bool composite_ok = nb > 0 && !ctx->mfcc_force_goertzel;
     const mfcc_mplan_t mp = (composite_ok && !ctx->mfcc_force_dft2) ? mfcc_mfma_plan((int)frame_len, hb.front(), nb) : mfcc_mplan_t{};
     const mfcc_plan_t pl = (composite_ok && !mp.ok) ? mfcc_plan((int)frame_len, nb) : mfcc_plan_t{false, 0, 0, 0, 0};
     if (mp.ok) {
         const double *ctab = nullptr, *twd = nullptr, *twm = nullptr, *wm = nullptr;
         rc = get_mfcc_mfma_dev(ctx, frame_len, mp, &ctab, &twd, &twm, &wm); if (rc != VBX_SUCCESS) return rc;
-        Prof p(ctx, "mfcc");
-        launch_mfcc_mfma(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, mp, ctab, twd, twm, wm, d_bins,
-                         slopes, dct, (int)num_coeffs, out, nb, ctx->cu_count);
+        Prof p(ctx, "mfcc", stm);
+        launch_mfcc_mfma(stm, x, (long)n_frames, (int)frame_len, (long)stride, window, mp, ctab, twd, twm, wm, d_bins,
+                         slopes, dct, (int)num_coeffs, out, (long)out_ld, status, nb, ctx->cu_count);
     } else if (pl.ok) {
         const double *ctab = nullptr, *twid = nullptr;
         rc = get_dft2_dev(ctx, frame_len, pl, &ctab, &twid); if (rc != VBX_SUCCESS) return rc;
-        Prof p(ctx, "mfcc");
-        launch_mfcc_dft2(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, pl, ctab, twid, d_bins,
-                         slopes, dct, (int)num_coeffs, out, nb, ctx->cu_count);
+        Prof p(ctx, "mfcc", stm);
+        launch_mfcc_dft2(stm, x, (long)n_frames, (int)frame_len, (long)stride, window, pl, ctab, twid, d_bins,
+                         slopes, dct, (int)num_coeffs, out, (long)out_ld, status, nb, ctx->cu_count);
     } else {
         VBX_REQUIRE(ctx, mfcc_fits((int)frame_len, nb), "frame / bin range does not fit the LDS");
         const double *tw = nullptr;
         rc = get_goertzel_dev(ctx, frame_len, hb.front(), nb, &tw); if (rc != VBX_SUCCESS) return rc;
-        Prof p(ctx, "mfcc");
-        launch_mfcc(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, tw, d_bins, slopes, dct, (int)num_coeffs, out, status, nb);
+        Prof p(ctx, "mfcc", stm);
+        launch_mfcc(stm, x, (long)n_frames, (int)frame_len, (long)stride, window, tw, d_bins, slopes, dct, (int)num_coeffs, out, (long)out_ld, status, nb);
     }
-    return check_launch(ctx, __func__);
+    return check_launch(ctx, "vbx_mfcc_f64");
+}
+
+int vbx_mfcc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
+                 const double *window, size_t num_coeffs, double lo_hz, double hi_hz,
+                 double sample_rate, double *out, int32_t *status) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    return run_mfcc(ctx, ctx->stream, x, n_frames, frame_len, stride, window, num_coeffs, lo_hz, hi_hz, sample_rate,
+                    out, num_coeffs, status);
 }
 
 int vbx_dct_f64(vbx_ctx *ctx, const double *in, size_t n_rows, size_t n, double *out) {
@@ -999,6 +1075,80 @@ int vbx_resample_linear_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size
     }
     { Prof p(ctx, "resample"); launch_resample(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, it->second.first, it->second.second, (int)m, out); }
     return check_launch(ctx, __func__);
+}
+
+// ---- the user's frame loop, batched and fused ------------------------------------------------------------------
+
+static int ensure_side_stream(vbx_ctx *ctx) {
+    if (ctx->side) return VBX_SUCCESS;
+    VBX_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    VBX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    VBX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    return VBX_SUCCESS;
+}
+
+size_t vbx_record_doubles(const vbx_analysis_params *h_p) {
+    if (!h_p) return 0;
+    size_t n = 2;                                                   // Pitch { frequency, strength }
+    if (h_p->formant_order) n += 2 * h_p->n_est;                    // Resonance { frequency, bandwidth } x n_est
+    if (h_p->mfcc_coeffs) n += h_p->mfcc_coeffs;
+    if (h_p->lpc_order) n += h_p->lpc_order + 1;
+    return n;
+}
+
+int vbx_analyze_frames_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
+                           const vbx_analysis_params *h_p, const int64_t *h_seg_start, size_t n_segments,
+                           double *out_records, size_t record_ld, int32_t *status3) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_REQUIRE(ctx, h_p && out_records, "null argument");
+    const size_t rec = vbx_record_doubles(h_p);
+    VBX_REQUIRE(ctx, record_ld >= rec && record_ld % 2 == 0, "record_ld must be even and >= vbx_record_doubles(params)");
+    VBX_REQUIRE(ctx, ((uintptr_t)out_records & 15) == 0, "records must be 16-byte aligned");
+    VBX_REQUIRE(ctx, !h_p->formant_order || (h_p->n_est >= 1 && h_p->n_est <= VBX_FORMANT_SLOTS), "n_est must be in [1, 6]");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    rc = ensure_side_stream(ctx);
+    if (rc != VBX_SUCCESS) return rc;
+    const double *hann = nullptr;
+    rc = get_window_dev(ctx, VBX_WINDOW_HANNING, frame_len, &hann);        // Windower::hanning frames (examples/pitch_detection.rs:23)
+    if (rc != VBX_SUCCESS) return rc;
+    // record columns
+    const size_t c_form = 2, c_mfcc = c_form + (h_p->formant_order ? 2 * h_p->n_est : 0),
+                 c_lpc = c_mfcc + h_p->mfcc_coeffs;
+    int32_t *st_pitch = nullptr, *st_form = nullptr, *st_mfcc = nullptr;
+    if (status3) { st_pitch = status3; st_form = status3 + n_frames; st_mfcc = status3 + 2 * n_frames; }
+    // fork: the formant chain (Burg -> roots -> the latency-bound tracker scan) and the MFCC run on the side stream,
+    // beside the FP64-bound pitch kernel
+    VBX_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    VBX_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    if (h_p->formant_order) {
+        vbx_resonance est[VBX_FORMANT_SLOTS];
+        for (size_t e = 0; e < h_p->n_est; e++) est[e] = h_p->est_init[e];
+        rc = run_find_formants(ctx, ctx->side, x, n_frames, frame_len, stride, h_p->sample_rate, h_p->formant_order,
+                               h_seg_start, n_segments, est, h_p->n_est, (vbx_resonance *)(out_records + c_form), record_ld,
+                               nullptr, nullptr, nullptr, st_form);
+        if (rc != VBX_SUCCESS) return rc;
+    } else if (st_form) {
+        VBX_HIP(ctx, hipMemsetAsync(st_form, 0, n_frames * sizeof(int32_t), ctx->side));
+    }
+    if (h_p->lpc_order) {
+        rc = run_autocorr_lpc(ctx, ctx->side, x, n_frames, frame_len, stride, hann, h_p->lpc_order, 0, nullptr,
+                              out_records + c_lpc, record_ld);
+        if (rc != VBX_SUCCESS) return rc;
+    }
+    if (h_p->mfcc_coeffs) {
+        rc = run_mfcc(ctx, ctx->side, x, n_frames, frame_len, stride, hann, h_p->mfcc_coeffs, h_p->mfcc_lo_hz, h_p->mfcc_hi_hz,
+                      h_p->sample_rate, out_records + c_mfcc, record_ld, st_mfcc);
+        if (rc != VBX_SUCCESS) return rc;
+    } else if (st_mfcc) {
+        VBX_HIP(ctx, hipMemsetAsync(st_mfcc, 0, n_frames * sizeof(int32_t), ctx->side));
+    }
+    VBX_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+    rc = run_pitch(ctx, ctx->stream, x, n_frames, frame_len, stride, hann, h_p->sample_rate, h_p->pitch_threshold,
+                   h_p->pitch_fmin, h_p->pitch_fmax, 1, (vbx_pitch *)out_records, record_ld, nullptr, st_pitch);
+    if (rc != VBX_SUCCESS) return rc;
+    VBX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));       // join: the records are complete on ctx's stream
+    return VBX_SUCCESS;
 }
 
 // ---- bench utility ------------------------------------------------------------------------

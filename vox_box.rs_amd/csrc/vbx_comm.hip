@@ -1,0 +1,202 @@
+// vbx_comm.hip -- frame-range sharding and the one collective of the path: the gather of per-frame records to a
+// destination rank, RCCL directly from C++.  The reference has no distribution at all; this is the
+// MI355X-side design: one process per GPU, contiguous frame ranges, and a single grouped ncclSend/ncclRecv set in
+// which every peer's payload crosses its own direct xGMI link to the destination (no ring, no reduction).
+#include "../../include/voxbox_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+// shared with vbx_api.hip
+extern "C" int vbx_internal_fail(vbx_ctx *ctx, int code, const char *msg);
+extern "C" void *vbx_internal_stream(vbx_ctx *ctx);
+extern "C" int vbx_internal_device(vbx_ctx *ctx);
+
+struct vbx_comm {
+    ncclComm_t nccl = nullptr;
+    int world = 1, rank = 0, device = 0;
+    hipStream_t stream = nullptr;                    // transfers run here, beside the context's kernels
+    hipEvent_t ready = nullptr;                      // "the records are written" (recorded on the context's stream)
+    hipEvent_t done[VBX_COMM_SLOTS] = {nullptr};     // "the gather that used slot s has finished"
+    bool used[VBX_COMM_SLOTS] = {false};
+};
+
+namespace {
+
+int fail(vbx_ctx *ctx, int code, const std::string &msg) { return vbx_internal_fail(ctx, code, msg.c_str()); }
+
+#define VBXC_HIP(ctx, expr)                                                                        \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(ctx, VBX_E_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define VBXC_NCCL(ctx, expr)                                                                       \
+    do {                                                                                           \
+        ncclResult_t r_ = (expr);                                                                  \
+        if (r_ != ncclSuccess) return fail(ctx, VBX_E_RUNTIME, std::string(#expr) + ": " + ncclGetErrorString(r_)); \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int vbx_shard_range(size_t n_frames, int world, int rank, const int64_t *h_seg_start, size_t n_segments,
+                    size_t *lo, size_t *hi) {
+    if (!lo || !hi || world < 1 || rank < 0 || rank >= world) return fail(nullptr, VBX_E_INVALID, "vbx_shard_range: bad argument");
+    auto even_hi = [&](int r) {                      // end of rank r under the plain even split
+        const size_t base = n_frames / (size_t)world, rem = n_frames % (size_t)world;
+        return (size_t)(r + 1) * base + ((size_t)(r + 1) < rem ? (size_t)(r + 1) : rem);
+    };
+    auto cut = [&](int r) -> size_t {                // end of rank r, moved up to an utterance boundary
+        if (r < 0) return 0;
+        if (r >= world - 1) return n_frames;
+        const size_t target = even_hi(r);
+        if (!h_seg_start || n_segments == 0) return target;
+        for (size_t i = 0; i < n_segments; i++)      // first boundary >= target
+            if ((size_t)h_seg_start[i] >= target) return (size_t)h_seg_start[i] < n_frames ? (size_t)h_seg_start[i] : n_frames;
+        return n_frames;
+    };
+    size_t a = cut(rank - 1), b = cut(rank);
+    // cuts are monotone in r because targets are
+    if (b < a) b = a;
+    *lo = a; *hi = b;
+    return VBX_SUCCESS;
+}
+
+int vbx_shard_samples(size_t lo, size_t hi, size_t frame_len, size_t hop, size_t *s0, size_t *s1) {
+    if (!s0 || !s1 || frame_len < 1 || hop < 1) return fail(nullptr, VBX_E_INVALID, "vbx_shard_samples: bad argument");
+    *s0 = lo * hop;
+    *s1 = (hi <= lo) ? lo * hop : (hi - 1) * hop + frame_len;     // includes the frame_len - hop halo
+    return VBX_SUCCESS;
+}
+
+int vbx_comm_unique_id(void *h_id) {
+    if (!h_id) return fail(nullptr, VBX_E_INVALID, "vbx_comm_unique_id: null argument");
+    static_assert(sizeof(ncclUniqueId) == VBX_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    VBXC_NCCL(nullptr, ncclGetUniqueId(&id));
+    std::memcpy(h_id, &id, sizeof id);
+    return VBX_SUCCESS;
+}
+
+int vbx_comm_create(vbx_ctx *ctx, const void *h_id, int world, int rank, vbx_comm **out) {
+    if (!ctx || !h_id || !out || world < 1 || rank < 0 || rank >= world)
+        return fail(ctx, VBX_E_INVALID, "vbx_comm_create: bad argument");
+    *out = nullptr;
+    const int dev = vbx_internal_device(ctx);
+    VBXC_HIP(ctx, hipSetDevice(dev));
+    vbx_comm *c = new vbx_comm();
+    c->world = world; c->rank = rank; c->device = dev;
+    ncclUniqueId id;
+    std::memcpy(&id, h_id, sizeof id);
+    ncclResult_t r = ncclCommInitRank(&c->nccl, world, id, rank);
+    if (r != ncclSuccess) { delete c; return fail(ctx, VBX_E_RUNTIME, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ready, hipEventDisableTiming);
+    for (int s = 0; s < VBX_COMM_SLOTS && e == hipSuccess; s++) e = hipEventCreateWithFlags(&c->done[s], hipEventDisableTiming);
+    if (e != hipSuccess) { vbx_comm_destroy(c); return fail(ctx, VBX_E_RUNTIME, std::string("vbx_comm_create: ") + hipGetErrorString(e)); }
+    *out = c;
+    return VBX_SUCCESS;
+}
+
+void vbx_comm_destroy(vbx_comm *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->nccl) ncclCommDestroy(c->nccl);
+    if (c->ready) hipEventDestroy(c->ready);
+    for (int s = 0; s < VBX_COMM_SLOTS; s++) if (c->done[s]) hipEventDestroy(c->done[s]);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int vbx_gather_records_f64(vbx_ctx *ctx, vbx_comm *c, const double *local, const int64_t *h_rows,
+                           size_t row_doubles, int dst, double *out, int slot) {
+    if (!ctx || !c || !h_rows) return fail(ctx, VBX_E_INVALID, "vbx_gather_records_f64: null argument");
+    if (dst < 0 || dst >= c->world || slot < 0 || slot >= VBX_COMM_SLOTS || row_doubles < 1)
+        return fail(ctx, VBX_E_INVALID, "vbx_gather_records_f64: bad dst / slot / row size");
+    for (int r = 0; r < c->world; r++) if (h_rows[r] < 0) return fail(ctx, VBX_E_INVALID, "vbx_gather_records_f64: negative row count");
+    const size_t mine = (size_t)h_rows[c->rank];
+    if (mine > 0 && !local) return fail(ctx, VBX_E_INVALID, "vbx_gather_records_f64: null local records");
+    if (c->rank == dst && !out) return fail(ctx, VBX_E_INVALID, "vbx_gather_records_f64: null output on the destination rank");
+    VBXC_HIP(ctx, hipSetDevice(c->device));
+    hipStream_t main = (hipStream_t)vbx_internal_stream(ctx);
+    // the transfer starts when everything queued on the context's stream so far (the kernels writing `local`) is done
+    VBXC_HIP(ctx, hipEventRecord(c->ready, main));
+    VBXC_HIP(ctx, hipStreamWaitEvent(c->stream, c->ready, 0));
+    if (c->rank == dst) {
+        size_t off = 0;
+        for (int r = 0; r < dst; r++) off += (size_t)h_rows[r];
+        double *own = out + off * row_doubles;
+        if (mine > 0 && own != local)
+            VBXC_HIP(ctx, hipMemcpyAsync(own, local, mine * row_doubles * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (c->world > 1) {
+        // one group: every peer -> dst transfer is posted together and runs concurrently, each over the direct
+        // xGMI link between that peer and dst
+        VBXC_NCCL(ctx, ncclGroupStart());
+        ncclResult_t res = ncclSuccess;
+        if (c->rank == dst) {
+            size_t off = 0;
+            for (int r = 0; r < c->world && res == ncclSuccess; r++) {
+                const size_t rows = (size_t)h_rows[r];
+                if (r != dst && rows > 0)
+                    res = ncclRecv(out + off * row_doubles, rows * row_doubles, ncclDouble, r, c->nccl, c->stream);
+                off += rows;
+            }
+        } else if (mine > 0) {
+            res = ncclSend(local, mine * row_doubles, ncclDouble, dst, c->nccl, c->stream);
+        }
+        ncclResult_t end = ncclGroupEnd();
+        if (res != ncclSuccess) return fail(ctx, VBX_E_RUNTIME, std::string("ncclSend/ncclRecv: ") + ncclGetErrorString(res));
+        if (end != ncclSuccess) return fail(ctx, VBX_E_RUNTIME, std::string("ncclGroupEnd: ") + ncclGetErrorString(end));
+    }
+    VBXC_HIP(ctx, hipEventRecord(c->done[slot], c->stream));
+    c->used[slot] = true;
+    return VBX_SUCCESS;
+}
+
+int vbx_comm_wait(vbx_ctx *ctx, vbx_comm *c, int slot) {
+    if (!ctx || !c || slot < 0 || slot >= VBX_COMM_SLOTS) return fail(ctx, VBX_E_INVALID, "vbx_comm_wait: bad argument");
+    if (!c->used[slot]) return VBX_SUCCESS;
+    VBXC_HIP(ctx, hipStreamWaitEvent((hipStream_t)vbx_internal_stream(ctx), c->done[slot], 0));
+    return VBX_SUCCESS;
+}
+
+int vbx_comm_sync(vbx_comm *c) {
+    if (!c) return fail(nullptr, VBX_E_INVALID, "vbx_comm_sync: null communicator");
+    VBXC_HIP(nullptr, hipSetDevice(c->device));
+    VBXC_HIP(nullptr, hipStreamSynchronize(c->stream));
+    return VBX_SUCCESS;
+}
+
+int vbx_comm_selftest(vbx_ctx *ctx, vbx_comm *c, size_t n) {
+    if (!ctx || !c || n < 1) return fail(ctx, VBX_E_INVALID, "vbx_comm_selftest: bad argument");
+    VBXC_HIP(ctx, hipSetDevice(c->device));
+    std::vector<double> h(n), back(n, 0.0);
+    for (size_t i = 0; i < n; i++) h[i] = (double)(c->rank + 1) * 1.0e6 + (double)i * 0.25;
+    double *a = nullptr, *b = nullptr;
+    VBXC_HIP(ctx, hipMalloc((void **)&a, n * sizeof(double)));
+    VBXC_HIP(ctx, hipMalloc((void **)&b, n * sizeof(double)));
+    VBXC_HIP(ctx, hipMemcpy(a, h.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    VBXC_HIP(ctx, hipMemset(b, 0, n * sizeof(double)));
+    ncclResult_t r1 = ncclGroupStart();
+    ncclResult_t r2 = ncclSend(a, n, ncclDouble, c->rank, c->nccl, c->stream);
+    ncclResult_t r3 = ncclRecv(b, n, ncclDouble, c->rank, c->nccl, c->stream);
+    ncclResult_t r4 = ncclGroupEnd();
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(back.data(), b, n * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(a); hipFree(b);
+    for (ncclResult_t r : {r1, r2, r3, r4})
+        if (r != ncclSuccess) return fail(ctx, VBX_E_RUNTIME, std::string("vbx_comm_selftest: ") + ncclGetErrorString(r));
+    if (e != hipSuccess) return fail(ctx, VBX_E_RUNTIME, std::string("vbx_comm_selftest: ") + hipGetErrorString(e));
+    if (std::memcmp(h.data(), back.data(), n * sizeof(double)) != 0)
+        return fail(ctx, VBX_E_RUNTIME, "vbx_comm_selftest: loopback data mismatch");
+    return VBX_SUCCESS;
+}
+
+}  // extern "C"

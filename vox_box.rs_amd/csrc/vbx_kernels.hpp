@@ -19,11 +19,11 @@ struct cplx32_t { float re, im; };
 // k_lpc.hip
 bool fewlags_supported(int n, int n_lags, bool want_lpc);
 void launch_autocorr_fewlags(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
-                             int n_lags, int normalize, double *out_r, double *out_lpc);
+                             int n_lags, int normalize, double *out_r, double *out_lpc, long lpc_ld = 0 /* 0: n_lags */);
 void launch_autocorr_tiles(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                            int n_lags, double *out);
 void launch_normalize_rows(hipStream_t s, double *data, long rows, int n);
-void launch_levinson_rows(hipStream_t s, const double *r, long rows, long r_stride, int p, double *out);
+void launch_levinson_rows(hipStream_t s, const double *r, long rows, long r_stride, int p, double *out, long out_ld);
 
 // k_burg.hip
 bool burg_supported(int n, int p);
@@ -45,7 +45,7 @@ void launch_formant_resonances(hipStream_t s, const double *coeffs, long F, int 
 // k_tracker.hip
 void launch_tracker(hipStream_t s, const res_t *res, long F, int n_res, const int32_t *res_count,
                     const int64_t *seg_start, long n_seg, const res_t *est_init, int n_est,
-                    const int32_t *frame_status, res_t *out);
+                    const int32_t *frame_status, res_t *out, long out_ld /* doubles per output row, >= 2*n_est */);
 
 // k_pitch.hip
 size_t pitch_lds_bytes(int n);
@@ -53,7 +53,8 @@ size_t pitch_lds_bytes(int n);
 constexpr int PITCH_WORK_SLOTS = 64;
 void launch_pitch(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                   const double *lag_window, double sample_rate, double threshold, double fmin, double fmax,
-                  int kmax, pitch_t *out_cand, int32_t *out_count, int32_t *status, unsigned long long *work);
+                  int kmax, pitch_t *out_cand, long cand_ld /* doubles per output row, >= 2*kmax, even */,
+                  int32_t *out_count, int32_t *status, unsigned long long *work);
 void launch_sinc_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *xs, long m,
                         long depth, double *out, int32_t *status);
 void launch_extremum_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *ix, long m,
@@ -66,18 +67,19 @@ mfcc_plan_t mfcc_plan(int n, int nb);
 void launch_mfcc_dft2(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                       const mfcc_plan_t &pl, const double *ctab /* [n1][nc] */, const double *twid /* [n][2] */,
                       const int32_t *bins_dev, const double *slopes, const double *dct_table, int num_coeffs, double *out,
-                      int nb, int cu_count);
+                      long out_ld /* doubles per output row */, int32_t *status /* set to 0 per frame, or NULL */, int nb, int cu_count);
 // k_mfcc_mfma.hip: both DFT stages on the matrix cores
 struct mfcc_mplan_t { bool ok; int n1, n2, k2, mt, ntd, ntm, src0, src1; };
 mfcc_mplan_t mfcc_mfma_plan(int n, int b_lo, int nb);
 void launch_mfcc_mfma(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                       const mfcc_mplan_t &pl, const double *ctab, const double *twd, const double *twm, const double *wm,
                       const int32_t *bins_dev, const double *slopes, const double *dct_table, int num_coeffs, double *out,
-                      int nb, int cu_count);
+                      long out_ld /* doubles per output row */, int32_t *status /* set to 0 per frame, or NULL */, int nb, int cu_count);
 void launch_mfcc(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                  const double *kappa_sigma /* [nb][2] Goertzel-Reinsch constants */, const int32_t *bins /* K+2 */,
                  const double *slopes /* [nb][2] */, const double *dct_table /* [K][K] */,
-                 int num_coeffs, double *out, int32_t *status, int nb /* bins[K+1]-bins[0] */);
+                 int num_coeffs, double *out, long out_ld, int32_t *status, int nb /* bins[K+1]-bins[0] */);
+void launch_fill_rows(hipStream_t s, double *out, long rows, int n, long ld, double value, int32_t *status, int32_t code);
 void launch_dct_rows(hipStream_t s, const double *in, long rows, int n, const double *dct_table, double *out);
 
 // k_front.hip

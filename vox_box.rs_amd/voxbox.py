@@ -35,6 +35,45 @@ class _Complex(C.Structure):
     _fields_ = [("re", C.c_double), ("im", C.c_double)]
 
 
+class _Resonance(C.Structure):
+    _fields_ = [("frequency", C.c_double), ("bandwidth", C.c_double)]
+
+
+class AnalysisParams(C.Structure):
+    """vbx_analysis_params (include/voxbox_hip.h): the parts of the user's frame loop that vbx_analyze_frames_f64 runs."""
+    _fields_ = [("sample_rate", C.c_double),
+                ("pitch_threshold", C.c_double), ("pitch_fmin", C.c_double), ("pitch_fmax", C.c_double),
+                ("lpc_order", C.c_size_t), ("formant_order", C.c_size_t), ("n_est", C.c_size_t),
+                ("est_init", _Resonance * 6),
+                ("mfcc_coeffs", C.c_size_t), ("mfcc_lo_hz", C.c_double), ("mfcc_hi_hz", C.c_double)]
+
+    @classmethod
+    def make(cls, sample_rate, pitch=(0.2, 75.0, 600.0), lpc_order=12, formant_order=12, est_init=None,
+             mfcc=(13, 100.0, 8000.0)):
+        p = cls()
+        p.sample_rate = sample_rate
+        p.pitch_threshold, p.pitch_fmin, p.pitch_fmax = pitch
+        p.lpc_order = lpc_order
+        p.formant_order = formant_order
+        est = np.asarray(est_init if est_init is not None else [[f, 1.0] for f in MALE_FORMANT_ESTIMATES], dtype=np.float64)
+        p.n_est = est.shape[0] if formant_order else 0
+        for i in range(int(p.n_est)):
+            p.est_init[i].frequency, p.est_init[i].bandwidth = float(est[i, 0]), float(est[i, 1])
+        p.mfcc_coeffs, p.mfcc_lo_hz, p.mfcc_hi_hz = (mfcc if mfcc else (0, 0.0, 0.0))
+        return p
+
+    def columns(self):
+        """name -> (first column, width) of the per-frame record."""
+        cols, c = {"pitch": (0, 2)}, 2
+        if self.formant_order:
+            cols["formants"] = (c, 2 * int(self.n_est)); c += 2 * int(self.n_est)
+        if self.mfcc_coeffs:
+            cols["mfcc"] = (c, int(self.mfcc_coeffs)); c += int(self.mfcc_coeffs)
+        if self.lpc_order:
+            cols["lpc"] = (c, int(self.lpc_order) + 1); c += int(self.lpc_order) + 1
+        return cols
+
+
 _lib = None
 
 
@@ -110,6 +149,17 @@ def load_library():
         "vbx_preemphasis_f64": (C.c_int, [vp, vp, sz, sz, sz, dbl, vp]),
         "vbx_synth_speech_f64": (C.c_int, [vp, vp, sz, C.c_uint64, dbl, C.c_uint64]),
         "vbx_selftest_lanes": (C.c_int, [vp, vp]),
+        "vbx_record_doubles": (sz, [C.POINTER(AnalysisParams)]),
+        "vbx_analyze_frames_f64": (C.c_int, [vp, vp, sz, sz, sz, C.POINTER(AnalysisParams), vp, sz, vp, sz, vp]),
+        "vbx_shard_range": (C.c_int, [sz, i32, i32, vp, sz, C.POINTER(sz), C.POINTER(sz)]),
+        "vbx_shard_samples": (C.c_int, [sz, sz, sz, sz, C.POINTER(sz), C.POINTER(sz)]),
+        "vbx_comm_unique_id": (C.c_int, [vp]),
+        "vbx_comm_create": (C.c_int, [vp, vp, i32, i32, C.POINTER(vp)]),
+        "vbx_comm_destroy": (None, [vp]),
+        "vbx_gather_records_f64": (C.c_int, [vp, vp, vp, vp, sz, i32, vp, i32]),
+        "vbx_comm_wait": (C.c_int, [vp, vp, i32]),
+        "vbx_comm_sync": (C.c_int, [vp]),
+        "vbx_comm_selftest": (C.c_int, [vp, vp, sz]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here = symbol missing from the build
@@ -151,6 +201,62 @@ def hz_to_mel(hz):
 
 def mel_to_hz(mel):
     return load_library().vbx_mel_to_hz(mel)
+
+
+def shard_range(n_frames, world, rank, seg_start=None):
+    """vbx_shard_range: frames [lo, hi) of `rank`; with seg_start the cuts fall on utterance boundaries."""
+    lo, hi = C.c_size_t(), C.c_size_t()
+    seg = None if seg_start is None else np.ascontiguousarray(seg_start, dtype=np.int64)
+    rc = load_library().vbx_shard_range(n_frames, world, rank, None if seg is None else seg.ctypes.data,
+                                        0 if seg is None else seg.size, C.byref(lo), C.byref(hi))
+    if rc != 0:
+        raise VoxBoxError("vbx_shard_range: bad argument")
+    return lo.value, hi.value
+
+
+def shard_samples(lo, hi, frame_len, hop):
+    s0, s1 = C.c_size_t(), C.c_size_t()
+    if load_library().vbx_shard_samples(lo, hi, frame_len, hop, C.byref(s0), C.byref(s1)) != 0:
+        raise VoxBoxError("vbx_shard_samples: bad argument")
+    return s0.value, s1.value
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library (rank 0); ship the bytes to the other ranks."""
+    buf = C.create_string_buffer(128)
+    if load_library().vbx_comm_unique_id(buf) != 0:
+        msg = load_library().vbx_last_error(None)
+        raise VoxBoxError(f"vbx_comm_unique_id failed: {msg.decode() if msg else ''}")
+    return buf.raw
+
+
+class Comm:
+    """vbx_comm: this rank's RCCL communicator for the record gather (one per VoxBox context)."""
+
+    def __init__(self, vb, unique_id, world, rank):
+        self.vb, self.world, self.rank = vb, world, rank
+        h = C.c_void_p()
+        vb._check(vb.L.vbx_comm_create(vb.ctx, C.c_char_p(unique_id), world, rank, C.byref(h)))
+        self.h = h
+
+    def gather_records(self, local, rows, row_doubles, dst=0, out=None, slot=0):
+        r = np.ascontiguousarray(rows, dtype=np.int64)
+        self.vb._check(self.vb.L.vbx_gather_records_f64(self.vb.ctx, self.h, _ptr(local), r.ctypes.data, row_doubles, dst,
+                                                        _ptr(out), slot))
+
+    def wait(self, slot):
+        self.vb._check(self.vb.L.vbx_comm_wait(self.vb.ctx, self.h, slot))
+
+    def sync(self):
+        self.vb._check(self.vb.L.vbx_comm_sync(self.h))
+
+    def selftest(self, n=1 << 16):
+        self.vb._check(self.vb.L.vbx_comm_selftest(self.vb.ctx, self.h, n))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.vb.L.vbx_comm_destroy(self.h)
+            self.h = None
 
 
 class DeviceArray:
@@ -528,6 +634,27 @@ class VoxBox:
         for v in list(bufs.values()) + [tmp]:
             if v is not None:
                 v.free()
+        return res
+
+    # -- the fused frame loop ---------------------------------------------------------
+    def analyze_frames(self, x, params, seg_start=None, frame_len=None, stride=None, n_frames=None, out=None,
+                       record_ld=None, status=None):
+        """vbx_analyze_frames_f64: pitch + LPC + find_formants + MFCC records [F, record_ld] (see AnalysisParams.columns)."""
+        ptr, F, N, S, tmp = self._frames(x, frame_len, stride, n_frames)
+        rec = int(self.L.vbx_record_doubles(C.byref(params)))
+        ld = record_ld if record_ld is not None else rec + (rec & 1)
+        seg = None if seg_start is None else np.ascontiguousarray(seg_start, dtype=np.int64)
+        o = out if out is not None else self.empty((F, ld))
+        st = status if status is not None else (self.empty((3, F), np.int32) if out is None else None)
+        self._check(self.L.vbx_analyze_frames_f64(self.ctx, ptr, F, N, S, C.byref(params),
+                                                  None if seg is None else seg.ctypes.data, 0 if seg is None else seg.size,
+                                                  _ptr(o), ld, _ptr(st)))
+        if out is not None:
+            return None
+        res = (o.numpy(), st.numpy())
+        for d in (o, st, tmp):
+            if d is not None:
+                d.free()
         return res
 
     # -- spectrum.rs: MFCC ------------------------------------------------------------
