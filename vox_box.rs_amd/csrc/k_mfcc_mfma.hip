@@ -17,42 +17,11 @@
 // Plans that do not fit (k2 > 8 rows, n1 > 63, n2 > 64) use the vector kernels of k_mfcc.hip.
 #include "vbx_device.hpp"
 #include "vbx_kernels.hpp"
+#include "vbx_mfcc_tail.hpp"
 
 namespace vbx {
 
 typedef double mf_d4 __attribute__((ext_vector_type(4)));
-
-// mel energies and dct of one frame: the tail of k_mfcc.hip (kept identical)
-__device__ __forceinline__ void mfcc_tail_m(const double *pu, const double *pd, double *en, const int32_t *bins,
-                                            const double *dct_table, int num_coeffs, int b_lo, int lane,
-                                            double *out_row) {
-    if (lane < num_coeffs) {                              // lane w <-> filter w
-        const int w0 = bins[lane], w1 = bins[lane + 1], w2 = bins[lane + 2];
-        double up_sum = 0.0, down_sum = 0.0;
-        for (int b = w0 - b_lo; b < w1 - b_lo; b += 4) {
-            double v[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) v[j] = (b + j < w1 - b_lo) ? pu[b + j] : 0.0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) up_sum = up_sum + v[j];
-        }
-        for (int b = w1 - b_lo; b < w2 - b_lo; b += 4) {
-            double v[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) v[j] = (b + j < w2 - b_lo) ? pd[b + j] : 0.0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) down_sum = down_sum + v[j];
-        }
-        const double lg = log10(up_sum + down_sum);
-        en[lane] = (lg != lg || lg < 1.0e-10) ? 1.0e-10 : lg;   // f64::max(1e-10): NaN yields the other operand
-    }
-    wave_sync();
-    if (lane < num_coeffs) {                              // dct (:391-397)
-        double acc = 0.0;
-        for (int j = 0; j < num_coeffs; j++) acc = acc + en[j] * dct_table[lane * num_coeffs + j];
-        out_row[lane] = 2.0 * acc;
-    }
-}
 
 // LDS: per block  ctab[n1p][32*NTD] | twd[MT*NTD*4][64][2] | twm[MT*NTM*4][64][2]
 //      per wave   xp[n1p][n2p] | X[2][nbp] | en[64]                        (n1p = 4*ceil(n1/4), n2p = 16*MT)

@@ -1,0 +1,468 @@
+// k_spectral.hip -- one spectral pass per frame feeding pitch, LPC and MFCC (frame length 1200 = 25 ms at 48 kHz).
+//
+// Reference rows served: A1-A3 (autocorrelate, normalize, lag window), A4-A9 (pitch, through
+// vbx_pitch_refine.hpp), A10 (lpc on r[0..12]), A14 (mfcc).  What the reference computes with an O(N^2) fold per lag
+// (src/periodic.rs:276-289) and a separate rustfft call (src/spectrum.rs:416-419) is here ONE real FFT of the
+// zero-padded windowed frame, length M = 2N = 2400:
+//     X = FFT_M(x_w padded)                      |X[k]|^2 -> inverse FFT -> S[lag] = sum_i x[i] x[i+lag], every lag
+//     X[2k'] = the N-point DFT bin k' of the frame  -> the |X|^2 and |X| the mel filters of MFCC::mfcc read
+//     S[0..12]                                      -> the Levinson recursion of LPC::lpc
+// (Q1: the reference's fold is seeded with x[0], r[lag] = S[lag] - x0*x[lag] + x0; applied afterwards.)  This replaces
+// 1.44 MFLOP of autocorrelation MACs per frame by about 0.3 MFLOP and removes the MFCC and LPC kernels' passes over the
+// same frame.  Accuracy: forward + inverse f64 FFT, error ~1e-16 * S[0] per lag (measured against the oracle in
+// tests/test_gpu_parity.py), far inside the 1e-6 relative tolerance of the autocorrelation / LPC / MFCC rows.
+//
+// One wavefront per frame, the transform lives in registers:
+//   real FFT by the packing trick: z[j] = x[2j] + i x[2j+1], complex FFT of length N_c = 1200 = 20 * 20 * 3, then the
+//   split into the spectrum of the real sequence; the inverse likewise with the roles exchanged.
+//   complex FFT (decimation in frequency, n = 60 a + 3 b + c, k = ka + 20 kb + 400 kc):
+//     stage 1  lane n' = 3b + c (60 lanes): 20-point DFT over a in registers (4 x 5 prime-factor form, no twiddles
+//              inside), times W_1200^(n' ka)
+//     stage 2  lane (ka, c) (60 lanes): 20-point DFT over b, times W_60^(c kb)
+//     stage 3  lane q = ka + 20 kb, 7 per lane: 3-point DFT over c -> X[q + 400 kc], natural order
+//   between the stages the values change lanes through LDS, real and imaginary parts in two passes (one 1200-double
+//   buffer, which the lag curve y later overwrites: the frame state stays at 13.5 KB = 12 wavefronts per CU).
+#include "vbx_device.hpp"
+#include "vbx_kernels.hpp"
+#include "vbx_mfcc_tail.hpp"
+#include "vbx_pitch_refine.hpp"
+
+namespace vbx {
+
+constexpr int SP_N = SPECTRAL_N;             // frame length = complex FFT length
+constexpr int SP_M = 2 * SP_N;               // real FFT length
+constexpr int SP_S1 = 61;                    // exchange 1 row stride [ka][n']   (odd: the 20 rows hit distinct banks)
+constexpr int SP_S2 = 404;                   // exchange 2 row stride [c][ka + 20 kb]
+constexpr int SP_T1 = 0;                     // twiddle table (complex entries): T1[60][20] = W_1200^(n' ka)
+constexpr int SP_T2 = SP_T1 + 60 * 20;       //                                  T2[3][20]  = W_60^(c kb)
+constexpr int SP_TM = SP_T2 + 3 * 20;        //                                  WM[601]    = W_2400^m
+constexpr double SP_UNC_EPS = 6.0 * 400.0 * 2.220446049250313e-16;   // 1 / min w_lag * margin * eps
+static_assert(SP_TM + 601 == SPECTRAL_TAB_COMPLEX, "table layout");
+
+// ---- small DFTs on separate re / im registers (forward: e^{-i...}) -------------------------------------------------
+__device__ __forceinline__ void dft4(double &r0, double &i0, double &r1, double &i1, double &r2, double &i2,
+                                     double &r3, double &i3) {
+    const double t0r = r0 + r2, t0i = i0 + i2, t1r = r0 - r2, t1i = i0 - i2;
+    const double t2r = r1 + r3, t2i = i1 + i3, t3r = r1 - r3, t3i = i1 - i3;
+    r0 = t0r + t2r; i0 = t0i + t2i;
+    r2 = t0r - t2r; i2 = t0i - t2i;
+    r1 = t1r + t3i; i1 = t1i - t3r;          // t1 - i t3
+    r3 = t1r - t3i; i3 = t1i + t3r;          // t1 + i t3
+}
+
+__device__ __forceinline__ void dft5(double &r0, double &i0, double &r1, double &i1, double &r2, double &i2,
+                                     double &r3, double &i3, double &r4, double &i4) {
+    constexpr double C5 = 0.55901699437494742410;    // (cos 72 - cos 144) / 2
+    constexpr double S1 = 0.95105651629515357212;    // sin 72
+    constexpr double S2 = 0.58778525229247312917;    // sin 144
+    const double t1r = r1 + r4, t1i = i1 + i4, t3r = r1 - r4, t3i = i1 - i4;
+    const double t2r = r2 + r3, t2i = i2 + i3, t4r = r2 - r3, t4i = i2 - i3;
+    const double t5r = t1r + t2r, t5i = t1i + t2i;
+    const double m1r = fma(-0.25, t5r, r0), m1i = fma(-0.25, t5i, i0);
+    const double m2r = C5 * (t1r - t2r), m2i = C5 * (t1i - t2i);
+    const double s1r = m1r + m2r, s1i = m1i + m2i, s2r = m1r - m2r, s2i = m1i - m2i;
+    // u = S1 t3 + S2 t4, v = S2 t3 - S1 t4;  X1 = s1 - i u, X4 = s1 + i u, X2 = s2 - i v, X3 = s2 + i v
+    const double ur = fma(S1, t3r, S2 * t4r), ui = fma(S1, t3i, S2 * t4i);
+    const double vr = fma(S2, t3r, -(S1 * t4r)), vi = fma(S2, t3i, -(S1 * t4i));
+    r0 = r0 + t5r; i0 = i0 + t5i;
+    r1 = s1r + ui; i1 = s1i - ur;
+    r4 = s1r - ui; i4 = s1i + ur;
+    r2 = s2r + vi; i2 = s2i - vr;
+    r3 = s2r - vi; i3 = s2i + vr;
+}
+
+// 20-point DFT in place, prime-factor form (gcd(4, 5) = 1: no twiddles between the 4- and the 5-point parts).
+// Input index a sits in slot a; output index k is left in slot dft20_slot(k).
+__host__ __device__ constexpr int dft20_in(int n1, int n2) { return (5 * n1 + 4 * n2) % 20; }
+__host__ __device__ constexpr int dft20_slot(int k) { return (5 * (k % 4) + 4 * (k % 5)) % 20; }
+
+__device__ __forceinline__ void dft20(double (&re)[20], double (&im)[20]) {
+#pragma unroll
+    for (int n2 = 0; n2 < 5; n2++)
+        dft4(re[dft20_in(0, n2)], im[dft20_in(0, n2)], re[dft20_in(1, n2)], im[dft20_in(1, n2)],
+             re[dft20_in(2, n2)], im[dft20_in(2, n2)], re[dft20_in(3, n2)], im[dft20_in(3, n2)]);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++)
+        dft5(re[dft20_in(k1, 0)], im[dft20_in(k1, 0)], re[dft20_in(k1, 1)], im[dft20_in(k1, 1)],
+             re[dft20_in(k1, 2)], im[dft20_in(k1, 2)], re[dft20_in(k1, 3)], im[dft20_in(k1, 3)],
+             re[dft20_in(k1, 4)], im[dft20_in(k1, 4)]);
+}
+
+// Complex FFT of length 1200.  In: lane n' < 60 holds z[60 a + n'] in (re[a], im[a]).  Out: lane l holds
+// X[l + 64 t + 400 kc] in (xr[t][kc], xi[t][kc]) for l + 64 t < 400 (KC = 3: every output; KC = 2: kc = 0, 1 only).
+// ex: LDS exchange buffer (>= 20 * SP_S1 doubles).  tab: twiddle table.
+template <int KC>
+__device__ __forceinline__ void fft1200(double (&re)[20], double (&im)[20], double (&xr)[7][3], double (&xi)[7][3],
+                                        double *ex, const double2 *__restrict__ tab) {
+    const int lane = lane_id();
+    const int np = (lane < 60) ? lane : 59;                 // lanes 60..63 shadow lane 59 (they never write)
+    const bool act = lane < 60;
+    // stage 1 (the twiddles arrive in two batches of ten: the 20-point DFT needs the registers)
+    dft20(re, im);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        double2 tw[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) tw[k] = tab[SP_T1 + np * 20 + 10 * h + k];
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            if (10 * h + k == 0) continue;
+            const int s = dft20_slot(10 * h + k);
+            const double a = re[s], b = im[s];
+            re[s] = fma(a, tw[k].x, -(b * tw[k].y));
+            im[s] = fma(a, tw[k].y, b * tw[k].x);
+        }
+    }
+    // exchange 1: [ka][n'] -> lane (ka2, c2) = (lane % 20, lane / 20) reads n' = 3 b + c2
+    const int ka2 = np % 20, c2 = np / 20;
+    double br[20], bi[20];
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 20; k++) if (act) ex[k * SP_S1 + lane] = re[dft20_slot(k)];
+    wave_sync();
+#pragma unroll
+    for (int b = 0; b < 20; b++) br[b] = ex[ka2 * SP_S1 + 3 * b + c2];
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 20; k++) if (act) ex[k * SP_S1 + lane] = im[dft20_slot(k)];
+    wave_sync();
+#pragma unroll
+    for (int b = 0; b < 20; b++) bi[b] = ex[ka2 * SP_S1 + 3 * b + c2];
+    // stage 2
+    dft20(br, bi);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        double2 tw[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) tw[k] = tab[SP_T2 + c2 * 20 + 10 * h + k];
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            if (10 * h + k == 0) continue;
+            const int s = dft20_slot(10 * h + k);
+            const double a = br[s], b = bi[s];
+            br[s] = fma(a, tw[k].x, -(b * tw[k].y));
+            bi[s] = fma(a, tw[k].y, b * tw[k].x);
+        }
+    }
+    // exchange 2: [c][ka + 20 kb] -> lane l reads q = l + 64 t for c = 0..2
+    double vr[7][3], vi[7][3];
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 20; k++) if (act) ex[c2 * SP_S2 + ka2 + 20 * k] = br[dft20_slot(k)];
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < 7; t++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) vr[t][c] = (t < 6 || lane < 16) ? ex[c * SP_S2 + lane + 64 * t] : 0.0;
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 20; k++) if (act) ex[c2 * SP_S2 + ka2 + 20 * k] = bi[dft20_slot(k)];
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < 7; t++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) vi[t][c] = (t < 6 || lane < 16) ? ex[c * SP_S2 + lane + 64 * t] : 0.0;
+    wave_sync();
+    // stage 3: X[kc] = v0 + v1 W3^kc + v2 W3^(2 kc)
+    constexpr double H3 = 0.86602540378443864676;           // sin 60
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+        const double sr = vr[t][1] + vr[t][2], si = vi[t][1] + vi[t][2];
+        const double dr = vr[t][1] - vr[t][2], di = vi[t][1] - vi[t][2];
+        xr[t][0] = vr[t][0] + sr; xi[t][0] = vi[t][0] + si;
+        const double mr = fma(-0.5, sr, vr[t][0]), mi = fma(-0.5, si, vi[t][0]);
+        xr[t][1] = fma(H3, di, mr); xi[t][1] = fma(-H3, dr, mi);           // m - i H3 d
+        if (KC == 3) { xr[t][2] = fma(-H3, di, mr); xi[t][2] = fma(H3, dr, mi); }
+        else { xr[t][2] = 0.0; xi[t][2] = 0.0; }
+    }
+}
+
+struct spectral_args_t {
+    const double *frames; long n_frames; long stride; const double *window; const double *lag_window;
+    const double2 *tab;
+    pitch_params_t pp;
+    double *out_cand; long cand_ld; int32_t *out_count; int32_t *pitch_status; unsigned long long *work;
+    double *out_lpc; long lpc_ld;
+    double *out_mfcc; long mfcc_ld; int32_t *mfcc_status;
+    const int32_t *bins; const double *slopes; const double *dct; int num_coeffs; int nb;
+    int32_t *unsure_list; int32_t *unsure_count;
+};
+
+// Levinson-Durbin on r[0..P] (src/spectrum.rs:63-84), every lane on the same (uniform) values
+template <int P>
+__device__ __forceinline__ void levinson_regs(const double (&r)[P + 1], double (&ac)[P + 1]) {
+    double tmp[P + 1];
+    double err = r[0];
+    ac[0] = 1.0;
+#pragma unroll
+    for (int i = 1; i <= P; i++) ac[i] = 0.0;
+#pragma unroll
+    for (int i = 1; i <= P; i++) {
+        double acc = r[i];
+#pragma unroll
+        for (int j = 1; j < i; j++) acc = acc + ac[j] * r[i - j];
+        const double k = -acc / err;
+        ac[i] = k;
+#pragma unroll
+        for (int j = 0; j < P; j++) tmp[j] = ac[j];
+#pragma unroll
+        for (int j = 1; j < i; j++) ac[j] = ac[j] + k * tmp[i - j];
+        err = err * (1.0 - k * k);
+    }
+}
+
+constexpr int SP_LPC_P = SPECTRAL_LPC_ORDER;
+
+template <bool LPC, bool MFCC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void analyze_kernel(const spectral_args_t a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const long f = blockIdx.x;
+    if (f >= a.n_frames) return;
+    const int lane = lane_id();
+    const int np = (lane < 60) ? lane : 59;
+    double *ex = smem;                                       // exchange buffer, later the lag curve y
+    const double *xf = a.frames + f * a.stride;
+
+    // ---- load: z[60 a + n'] = (xw[120 a + 2 n'], xw[120 a + 2 n' + 1]), a < 10 (the rest is the zero padding) ----
+    double re[20], im[20];
+    {
+        const bool al = ((((uintptr_t)xf) | ((uintptr_t)a.window)) & 15) == 0;      // uniform
+        double2 xv[10], wv[10];
+#pragma unroll
+        for (int q = 0; q < 10; q++) {
+            const int i = 120 * q + 2 * np;
+            if (al) {
+                xv[q] = *reinterpret_cast<const double2 *>(xf + i);
+                wv[q] = (a.window != nullptr) ? *reinterpret_cast<const double2 *>(a.window + i) : double2{1.0, 1.0};
+            } else {
+                xv[q].x = xf[i]; xv[q].y = xf[i + 1];
+                wv[q].x = (a.window != nullptr) ? a.window[i] : 1.0; wv[q].y = (a.window != nullptr) ? a.window[i + 1] : 1.0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 10; q++) {
+            re[q] = (a.window != nullptr) ? xv[q].x * wv[q].x : xv[q].x;
+            im[q] = (a.window != nullptr) ? xv[q].y * wv[q].y : xv[q].y;
+        }
+#pragma unroll
+        for (int q = 10; q < 20; q++) { re[q] = 0.0; im[q] = 0.0; }
+    }
+    const double x0 = readlane_f64(re[0], 0);               // x_w[0], for the fold seed (Q1)
+
+    // ---- forward transform of the packed frame ----
+    double xr[7][3], xi[7][3];
+    fft1200<3>(re, im, xr, xi, ex, a.tab);
+
+    // ---- exchange 3: natural order, then each lane takes the pairs (m, N - m), m = lane + 64 t <= 600 ----
+    double ar[10], ai[10], br[10], bi[10];
+#pragma unroll
+    for (int t = 0; t < 7; t++)
+#pragma unroll
+        for (int kc = 0; kc < 3; kc++) if (t < 6 || lane < 16) ex[lane + 64 * t + 400 * kc] = xr[t][kc];
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < 10; t++) {
+        const int m = lane + 64 * t;
+        const bool ok = m <= 600;
+        ar[t] = ok ? ex[m] : 0.0;
+        br[t] = ok ? ex[(m == 0) ? 0 : SP_N - m] : 0.0;
+    }
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < 7; t++)
+#pragma unroll
+        for (int kc = 0; kc < 3; kc++) if (t < 6 || lane < 16) ex[lane + 64 * t + 400 * kc] = xi[t][kc];
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < 10; t++) {
+        const int m = lane + 64 * t;
+        const bool ok = m <= 600;
+        ai[t] = ok ? ex[m] : 0.0;
+        bi[t] = ok ? ex[(m == 0) ? 0 : SP_N - m] : 0.0;
+    }
+    wave_sync();
+
+    // ---- spectrum of the real sequence: X[m] = E + T, X[N - m] = conj(E - T); powers; the inverse transform's input ----
+    //   E = (A + conj B) / 2, O = -i (A - conj B) / 2, T = W_M^m O;   P[m] = |E + T|^2, P[N - m] = |E - T|^2
+    //   the inverse's input G[m] = S - i D w, G[N - m] = S - i D conj(w)   (S = P[m] + P[N-m], D = P[m] - P[N-m], w = W_M^m)
+    const int b_lo = MFCC ? a.bins[0] : 0;
+    double pk[10], pn[10];                                   // P[m], P[N - m]
+#pragma unroll
+    for (int t = 0; t < 10; t++) {
+        const int m = lane + 64 * t;
+        const double2 w = a.tab[SP_TM + ((m <= 600) ? m : 0)];
+        const double er = 0.5 * (ar[t] + br[t]), ei = 0.5 * (ai[t] - bi[t]);
+        const double o_r = 0.5 * (ai[t] + bi[t]), o_i = -0.5 * (ar[t] - br[t]);
+        const double tr = fma(w.x, o_r, -(w.y * o_i)), ti = fma(w.x, o_i, w.y * o_r);
+        const double pr = er + tr, pi = ei + ti, qr = er - tr, qi = ei - ti;
+        pk[t] = fma(pr, pr, pi * pi);
+        pn[t] = fma(qr, qr, qi * qi);
+    }
+
+    // ---- exchange 4: G in natural order -> stage-1 layout of the second transform ----
+#pragma unroll
+    for (int t = 0; t < 10; t++) {
+        const int m = lane + 64 * t;
+        if (m <= 600) {
+            const double2 w = a.tab[SP_TM + m];
+            const double sm = pk[t] + pn[t], d = pk[t] - pn[t];
+            ex[m] = fma(d, w.y, sm);
+            if (m >= 1 && m < 600) ex[SP_N - m] = fma(-d, w.y, sm);
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < 20; q++) re[q] = ex[60 * q + np];
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < 10; t++) {
+        const int m = lane + 64 * t;
+        if (m <= 600) {
+            const double2 w = a.tab[SP_TM + m];
+            const double gi = -((pk[t] - pn[t]) * w.x);
+            ex[m] = gi;
+            if (m >= 1 && m < 600) ex[SP_N - m] = gi;
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < 20; q++) im[q] = ex[60 * q + np];
+    wave_sync();
+
+    // ---- MFCC::mfcc from the powers: X_N[k'] = X_M[2 k'], i.e. bin m/2 from P[m] and bin 600 - m/2 from P[N - m] ----
+    if (MFCC) {
+        const int nbp = (a.nb + 1) & ~1;
+        double *pu = ex, *pd = ex + nbp, *en = ex + 2 * nbp; // the exchange buffer is free between the two transforms
+#pragma unroll
+        for (int t = 0; t < 10; t++) {
+            const int m = lane + 64 * t;
+            if (m <= 600 && (m & 1) == 0) {
+                const int b1 = (m >> 1) - b_lo, b2 = (SP_N / 2 - (m >> 1)) - b_lo;
+                if (b1 >= 0 && b1 < a.nb) {
+                    const double2 sl = *reinterpret_cast<const double2 *>(a.slopes + 2 * b1);
+                    pu[b1] = fabs(pk[t]) * sl.x;             // norm_sqr * multiplier (src/spectrum.rs:426-428)
+                    pd[b1] = fabs(sqrt(pk[t])) * sl.y;       // norm * multiplier (:432-434)
+                }
+                if (b2 >= 0 && b2 < a.nb && b2 != b1) {
+                    const double2 sl = *reinterpret_cast<const double2 *>(a.slopes + 2 * b2);
+                    pu[b2] = fabs(pn[t]) * sl.x;
+                    pd[b2] = fabs(sqrt(pn[t])) * sl.y;
+                }
+            }
+        }
+        wave_sync();
+        mfcc_tail_m(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
+        if (a.mfcc_status != nullptr && lane == 0) a.mfcc_status[f] = 0;
+        wave_sync();
+    }
+
+    // ---- second transform: Y = FFT(G);  S[2j] = Re Y[j] / M, S[2j+1] = -Im Y[j] / M, j < 600 only ----
+    fft1200<2>(re, im, xr, xi, ex, a.tab);
+
+    // r[lag] = (S[lag] - x0 x[lag]) + x0 (Q1), lane l: j = l + 64 t (kc = 0) and j = 400 + l + 64 t < 600 (kc = 1)
+    constexpr double INV_M = 1.0 / (double)SP_M;
+    double r_e[11], r_o[11];                                 // slots 0..6: kc = 0, t = 0..6;  7..10: kc = 1, t = 0..3
+    int jj[11];
+#pragma unroll
+    for (int s = 0; s < 11; s++) {
+        const int t = (s < 7) ? s : s - 7, kc = (s < 7) ? 0 : 1;
+        const int q = lane + 64 * t;
+        const bool ok = (kc == 0) ? (q < 400) : (q < 200);
+        jj[s] = ok ? q + 400 * kc : -1;
+        r_e[s] = xr[t][kc] * INV_M;
+        r_o[s] = -(xi[t][kc] * INV_M);
+    }
+    const double s0 = readlane_f64(r_e[0], 0);               // S[0], the scale of the transform's rounding error
+    if (x0 != 0.0) {                                         // rectangular frames: the fold seed differs from S (uniform branch)
+#pragma unroll
+        for (int s = 0; s < 11; s++) {
+            if (jj[s] >= 0) {
+                const int i = 2 * jj[s];
+                const double xe = (a.window != nullptr) ? xf[i] * a.window[i] : xf[i];
+                const double xo = (a.window != nullptr) ? xf[i + 1] * a.window[i + 1] : xf[i + 1];
+                r_e[s] = (r_e[s] - x0 * xe) + x0;
+                r_o[s] = (r_o[s] - x0 * xo) + x0;
+            }
+        }
+    }
+    if (LPC) {                                               // LPC::lpc(12) on the raw autocorrelation r[0..12]
+        double rr[SP_LPC_P + 1], ac[SP_LPC_P + 1];
+#pragma unroll
+        for (int k = 0; k <= SP_LPC_P; k++) rr[k] = readlane_f64((k & 1) ? r_o[0] : r_e[0], k >> 1);
+        levinson_regs<SP_LPC_P>(rr, ac);
+        double mine = 0.0;
+#pragma unroll
+        for (int k = 0; k <= SP_LPC_P; k++) mine = (lane == k) ? ac[k] : mine;
+        if (lane <= SP_LPC_P) a.out_lpc[f * a.lpc_ld + lane] = mine;
+    }
+    double amax = -1.0;                                      // max_amplitude over ALL lags (Q2; NaN never wins)
+#pragma unroll
+    for (int s = 0; s < 11; s++) {
+        if (jj[s] >= 0) {
+            const double ae = fabs(r_e[s]), ao = fabs(r_o[s]);
+            amax = (ae > amax) ? ae : amax;
+            amax = (ao > amax) ? ao : amax;
+        }
+    }
+    amax = wave_max(amax);
+    const double scale = 1.0 / amax;                         // normalize (:404), then / lag window (:406-408)
+    double *ys = smem;
+    wave_sync();                                             // every lane is done with the exchange buffer
+#pragma unroll
+    for (int s = 0; s < 11; s++) {
+        if (jj[s] >= 0) {
+            const double2 lw = *reinterpret_cast<const double2 *>(a.lag_window + 2 * jj[s]);
+            double2 y;
+            y.x = (r_e[s] * scale) / lw.x;
+            y.y = (r_o[s] * scale) / lw.y;
+            *reinterpret_cast<double2 *>(ys + 2 * jj[s]) = y;
+        }
+    }
+    if (lane < Y_PAD) ys[SP_N + lane] = 0.0;
+    wave_sync();
+    // Rounding error of the two transforms: a few ulp of S[0] per lag (measured: < 8 eps S[0]); y = r * scale / w_lag
+    // with w_lag >= 1/6 on the searched half.  SP_UNC_EPS bounds the error of a DIFFERENCE of two entries with a wide
+    // margin; frames with a peak decision inside it go to the direct-sum kernel (launch_pitch_list).
+    const double unc_tol = SP_UNC_EPS * fabs(s0) * scale;
+    if (!pitch_refine_store(ys, SP_N, a.pp, f, a.out_cand, a.cand_ld, a.out_count, a.pitch_status, a.work, unc_tol)) {
+        if (lane == 0) a.unsure_list[atomicAdd(a.unsure_count, 1)] = (int32_t)f;
+    }
+}
+
+size_t spectral_lds_bytes() {
+    size_t need = (size_t)pitch_refine_lds_bytes(SP_N);
+    const size_t exch = (size_t)(20 * SP_S1 > 3 * SP_S2 ? 20 * SP_S1 : 3 * SP_S2) * sizeof(double);
+    const size_t mel = (size_t)(2 * 602 + 64) * sizeof(double);
+    if (exch > need) need = exch;
+    if (mel > need) need = mel;
+    return (need + 15) & ~(size_t)15;
+}
+
+bool spectral_supported(int n, int lpc_order, int mfcc_nb, int mfcc_b_lo, int num_coeffs) {
+    if (n != SP_N) return false;
+    if (lpc_order != 0 && lpc_order != SP_LPC_P) return false;
+    if (num_coeffs != 0 && (num_coeffs > 64 || mfcc_nb < 1 || mfcc_b_lo < 0 || mfcc_b_lo + mfcc_nb > SP_N / 2)) return false;
+    return true;
+}
+
+void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
+    spectral_args_t a;
+    a.frames = L.x; a.n_frames = L.F; a.stride = L.stride; a.window = L.window; a.lag_window = L.lag_window;
+    a.tab = reinterpret_cast<const double2 *>(L.tab);
+    a.pp.sample_rate = L.sample_rate; a.pp.threshold = L.threshold; a.pp.fmin = L.fmin; a.pp.fmax = L.fmax; a.pp.kmax = L.kmax;
+    a.out_cand = reinterpret_cast<double *>(L.out_cand); a.cand_ld = L.cand_ld; a.out_count = L.out_count;
+    a.pitch_status = L.pitch_status; a.work = L.work;
+    a.out_lpc = L.out_lpc; a.lpc_ld = L.lpc_ld;
+    a.out_mfcc = L.out_mfcc; a.mfcc_ld = L.mfcc_ld; a.mfcc_status = L.mfcc_status;
+    a.bins = L.bins; a.slopes = L.slopes; a.dct = L.dct; a.num_coeffs = L.num_coeffs; a.nb = L.nb;
+    a.unsure_list = L.unsure_list; a.unsure_count = L.unsure_count;
+    const dim3 grid((unsigned)L.F), block(64);
+    const size_t lds = spectral_lds_bytes();
+    const bool lpc = L.out_lpc != nullptr, mf = L.out_mfcc != nullptr;
+    if (lpc && mf) hipLaunchKernelGGL((analyze_kernel<true, true>), grid, block, lds, s, a);
+    else if (lpc) hipLaunchKernelGGL((analyze_kernel<true, false>), grid, block, lds, s, a);
+    else if (mf) hipLaunchKernelGGL((analyze_kernel<false, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((analyze_kernel<false, false>), grid, block, lds, s, a);
+}
+
+}  // namespace vbx

@@ -37,7 +37,7 @@ struct vbx_ctx {
     std::string arch;
     int cu_count = 0;
     // workspaces (grown on demand, never shrunk)
-    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_N };
+    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_UNSURE, WS_N };
     void *ws[WS_N] = {nullptr};
     size_t ws_bytes[WS_N] = {0};
     // cached device tables
@@ -54,6 +54,8 @@ struct vbx_ctx {
     bool prof = false;
     std::vector<ProfRec> recs;
     std::map<std::string, std::pair<double, long>> prof_acc;
+    double *spectral_tab = nullptr;                       // twiddles of k_spectral.hip
+    bool pitch_force_mfma = false;                        // test hook: VBX_PITCH_MFMA=1 keeps the matrix-core pitch kernel on 1200-sample frames
     bool mfcc_force_goertzel = false;                     // test hooks: VBX_MFCC_GOERTZEL=1 / VBX_MFCC_DFT2=1 keep the
     bool mfcc_force_dft2 = false;                         //   fallback kernels covered on lengths the MFMA kernel takes
     unsigned long long *pitch_work = nullptr;             // [PITCH_WORK_SLOTS][4], counted while profiling
@@ -296,6 +298,26 @@ int get_dct_dev(vbx_ctx *ctx, size_t k, const double **out) {
     return VBX_SUCCESS;
 }
 
+// twiddles of the fused spectral kernel (k_spectral.hip), evaluated in long double and rounded once
+int get_spectral_tab(vbx_ctx *ctx, const double **out) {
+    if (!ctx->spectral_tab) {
+        const long double two_pi = 6.283185307179586476925286766559005768L;
+        std::vector<double> h(2 * (size_t)SPECTRAL_TAB_COMPLEX);
+        size_t o = 0;
+        auto put = [&](long num, long den) {             // e^{-2 pi i num / den}
+            const long double ang = two_pi * (long double)(num % den) / (long double)den;
+            h[o++] = (double)cosl(ang); h[o++] = (double)(-sinl(ang));
+        };
+        for (long np = 0; np < 60; np++) for (long ka = 0; ka < 20; ka++) put(np * ka, 1200);
+        for (long c = 0; c < 3; c++) for (long kb = 0; kb < 20; kb++) put(c * kb, 60);
+        for (long m = 0; m <= 600; m++) put(m, 2400);
+        VBX_HIP(ctx, hipMalloc((void **)&ctx->spectral_tab, h.size() * sizeof(double)));
+        VBX_HIP(ctx, hipMemcpy(ctx->spectral_tab, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    *out = ctx->spectral_tab;
+    return VBX_SUCCESS;
+}
+
 // src/spectrum.rs:411-414 (Q14)
 void mel_bins_host(size_t n, size_t k, double lo, double hi, double sr, std::vector<int32_t> &bins, bool &overflow) {
     const double mlo = vbx_hz_to_mel(lo), mel_range = vbx_hz_to_mel(hi) - mlo;
@@ -439,6 +461,7 @@ int vbx_ctx_create(vbx_ctx **out, int device, void *hip_stream) {
     ctx->cu_count = prop.multiProcessorCount;
     { const char *e = std::getenv("VBX_MFCC_GOERTZEL"); ctx->mfcc_force_goertzel = e && e[0] == '1'; }
     { const char *e = std::getenv("VBX_MFCC_DFT2"); ctx->mfcc_force_dft2 = e && e[0] == '1'; }
+    { const char *e = std::getenv("VBX_PITCH_MFMA"); ctx->pitch_force_mfma = e && e[0] == '1'; }
     if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->owns_stream = false; }
     else {
         e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -457,6 +480,7 @@ void vbx_ctx_destroy(vbx_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < vbx_ctx::WS_N; i++) if (ctx->ws[i]) hipFree(ctx->ws[i]);
     if (ctx->pitch_work) hipFree(ctx->pitch_work);
+    if (ctx->spectral_tab) hipFree(ctx->spectral_tab);
     for (auto &kv : ctx->windows) hipFree(kv.second);
     for (auto &kv : ctx->goertzel) hipFree(kv.second);
     for (auto &kv : ctx->dct_tables) hipFree(kv.second);
@@ -665,6 +689,26 @@ int vbx_improve_extremum_f64(vbx_ctx *ctx, const double *y, size_t ylen, long of
     return check_launch(ctx, __func__);
 }
 
+// The FFT-based kernel (k_spectral.hip) followed by the direct-sum kernel on the frames whose peak decisions lie
+// inside the FFT's rounding error (normally none; curves that are exactly zero over a stretch, e.g. a few impulses).
+static int launch_spectral(vbx_ctx *ctx, hipStream_t st, spectral_launch_t &L, const char *prof_name) {
+    void *w = nullptr;
+    int rc = ws_get(ctx, vbx_ctx::WS_UNSURE, ((size_t)L.F + 4) * sizeof(int32_t), &w);
+    if (rc != VBX_SUCCESS) return rc;
+    L.unsure_count = (int32_t *)w;                       // [0]: count, [4..]: frame indices
+    L.unsure_list = (int32_t *)w + 4;
+    VBX_HIP(ctx, hipMemsetAsync(L.unsure_count, 0, sizeof(int32_t), st));
+    { Prof p(ctx, prof_name, st); launch_analyze(st, L); }
+    {
+        Prof p(ctx, "pitch_direct_fallback", st);
+        const int grid = ctx->cu_count > 0 ? ctx->cu_count * 4 : 1024;
+        launch_pitch_list(st, L.unsure_list, L.unsure_count, grid, L.x, SPECTRAL_N, L.stride, L.window, L.lag_window,
+                          L.sample_rate, L.threshold, L.fmin, L.fmax, L.kmax, L.out_cand, L.cand_ld, L.out_count,
+                          L.pitch_status, L.work);
+    }
+    return check_launch(ctx, "launch_spectral");
+}
+
 static int run_pitch(vbx_ctx *ctx, hipStream_t st, const double *x, size_t n_frames, size_t frame_len, size_t stride,
                      const double *window, double sample_rate, double threshold, double fmin, double fmax,
                      size_t kmax, vbx_pitch *out_cand, size_t cand_ld, int32_t *out_count, int32_t *status) {
@@ -680,6 +724,18 @@ static int run_pitch(vbx_ctx *ctx, hipStream_t st, const double *x, size_t n_fra
         const size_t wb = PITCH_WORK_SLOTS * 4 * sizeof(unsigned long long);
         VBX_HIP(ctx, hipMalloc((void **)&ctx->pitch_work, wb));
         VBX_HIP(ctx, hipMemsetAsync(ctx->pitch_work, 0, wb, st));
+    }
+    if (!ctx->pitch_force_mfma && spectral_supported((int)frame_len, 0, 0, 0, 0)) {
+        // autocorrelation by one real FFT of the frame (k_spectral.hip) instead of the O(N^2) lag sums
+        const double *tab = nullptr;
+        rc = get_spectral_tab(ctx, &tab);
+        if (rc != VBX_SUCCESS) return rc;
+        spectral_launch_t L{};
+        L.x = x; L.F = (long)n_frames; L.stride = (long)stride; L.window = window; L.lag_window = lagw; L.tab = tab;
+        L.sample_rate = sample_rate; L.threshold = threshold; L.fmin = fmin; L.fmax = fmax; L.kmax = (int)kmax;
+        L.out_cand = (pitch_t *)out_cand; L.cand_ld = (long)cand_ld; L.out_count = out_count; L.pitch_status = status;
+        L.work = ctx->prof ? ctx->pitch_work : nullptr;
+        return launch_spectral(ctx, st, L, "pitch");
     }
     {
         Prof p(ctx, "pitch", st);
@@ -1131,21 +1187,63 @@ int vbx_analyze_frames_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_
     } else if (st_form) {
         VBX_HIP(ctx, hipMemsetAsync(st_form, 0, n_frames * sizeof(int32_t), ctx->side));
     }
-    if (h_p->lpc_order) {
-        rc = run_autocorr_lpc(ctx, ctx->side, x, n_frames, frame_len, stride, hann, h_p->lpc_order, 0, nullptr,
-                              out_records + c_lpc, record_ld);
-        if (rc != VBX_SUCCESS) return rc;
-    }
+    // One spectral pass for pitch + LPC + MFCC when the shape has a fused kernel (k_spectral.hip); otherwise the LPC
+    // and MFCC kernels run on the side stream and the pitch kernel alone on the main one.
+    std::vector<int32_t> hb; bool bad_bins = false; const int32_t *d_bins = nullptr;
+    const double *dct = nullptr, *slopes = nullptr;
+    int nb = 0;
     if (h_p->mfcc_coeffs) {
-        rc = run_mfcc(ctx, ctx->side, x, n_frames, frame_len, stride, hann, h_p->mfcc_coeffs, h_p->mfcc_lo_hz, h_p->mfcc_hi_hz,
-                      h_p->sample_rate, out_records + c_mfcc, record_ld, st_mfcc);
+        VBX_REQUIRE(ctx, h_p->mfcc_coeffs <= 64, "mfcc_coeffs must be in [0, 64]");
+        rc = get_bins_dev(ctx, frame_len, h_p->mfcc_coeffs, h_p->mfcc_lo_hz, h_p->mfcc_hi_hz, h_p->sample_rate, &d_bins, hb, bad_bins);
         if (rc != VBX_SUCCESS) return rc;
-    } else if (st_mfcc) {
-        VBX_HIP(ctx, hipMemsetAsync(st_mfcc, 0, n_frames * sizeof(int32_t), ctx->side));
+        nb = hb.back() - hb.front();
     }
+    const bool fused = !ctx->pitch_force_mfma && !bad_bins &&
+                       spectral_supported((int)frame_len, (int)h_p->lpc_order, nb, h_p->mfcc_coeffs ? hb.front() : 0, (int)h_p->mfcc_coeffs);
+    if (!fused) {
+        if (h_p->lpc_order) {
+            rc = run_autocorr_lpc(ctx, ctx->side, x, n_frames, frame_len, stride, hann, h_p->lpc_order, 0, nullptr,
+                                  out_records + c_lpc, record_ld);
+            if (rc != VBX_SUCCESS) return rc;
+        }
+        if (h_p->mfcc_coeffs) {
+            rc = run_mfcc(ctx, ctx->side, x, n_frames, frame_len, stride, hann, h_p->mfcc_coeffs, h_p->mfcc_lo_hz, h_p->mfcc_hi_hz,
+                          h_p->sample_rate, out_records + c_mfcc, record_ld, st_mfcc);
+            if (rc != VBX_SUCCESS) return rc;
+        }
+    }
+    if (!h_p->mfcc_coeffs && st_mfcc) VBX_HIP(ctx, hipMemsetAsync(st_mfcc, 0, n_frames * sizeof(int32_t), ctx->side));
     VBX_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
-    rc = run_pitch(ctx, ctx->stream, x, n_frames, frame_len, stride, hann, h_p->sample_rate, h_p->pitch_threshold,
-                   h_p->pitch_fmin, h_p->pitch_fmax, 1, (vbx_pitch *)out_records, record_ld, nullptr, st_pitch);
+    if (fused) {
+        const double *lagw = nullptr, *tab = nullptr;
+        rc = get_window_dev(ctx, VBX_WINDOW_HANNING_LAG, frame_len, &lagw); if (rc != VBX_SUCCESS) return rc;
+        rc = get_spectral_tab(ctx, &tab); if (rc != VBX_SUCCESS) return rc;
+        if (h_p->mfcc_coeffs) {
+            rc = get_dct_dev(ctx, h_p->mfcc_coeffs, &dct); if (rc != VBX_SUCCESS) return rc;
+            rc = get_slopes_dev(ctx, frame_len, h_p->mfcc_coeffs, h_p->mfcc_lo_hz, h_p->mfcc_hi_hz, h_p->sample_rate, hb, &slopes);
+            if (rc != VBX_SUCCESS) return rc;
+        }
+        if (ctx->prof && !ctx->pitch_work) {
+            const size_t wb = PITCH_WORK_SLOTS * 4 * sizeof(unsigned long long);
+            VBX_HIP(ctx, hipMalloc((void **)&ctx->pitch_work, wb));
+            VBX_HIP(ctx, hipMemsetAsync(ctx->pitch_work, 0, wb, ctx->stream));
+        }
+        spectral_launch_t L{};
+        L.x = x; L.F = (long)n_frames; L.stride = (long)stride; L.window = hann; L.lag_window = lagw; L.tab = tab;
+        L.sample_rate = h_p->sample_rate; L.threshold = h_p->pitch_threshold; L.fmin = h_p->pitch_fmin; L.fmax = h_p->pitch_fmax;
+        L.kmax = 1;
+        L.out_cand = (pitch_t *)out_records; L.cand_ld = (long)record_ld; L.out_count = nullptr; L.pitch_status = st_pitch;
+        L.work = ctx->prof ? ctx->pitch_work : nullptr;
+        if (h_p->lpc_order) { L.out_lpc = out_records + c_lpc; L.lpc_ld = (long)record_ld; }
+        if (h_p->mfcc_coeffs) {
+            L.out_mfcc = out_records + c_mfcc; L.mfcc_ld = (long)record_ld; L.mfcc_status = st_mfcc;
+            L.bins = d_bins; L.slopes = slopes; L.dct = dct; L.num_coeffs = (int)h_p->mfcc_coeffs; L.nb = nb;
+        }
+        rc = launch_spectral(ctx, ctx->stream, L, "analyze");
+    } else {
+        rc = run_pitch(ctx, ctx->stream, x, n_frames, frame_len, stride, hann, h_p->sample_rate, h_p->pitch_threshold,
+                       h_p->pitch_fmin, h_p->pitch_fmax, 1, (vbx_pitch *)out_records, record_ld, nullptr, st_pitch);
+    }
     if (rc != VBX_SUCCESS) return rc;
     VBX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));       // join: the records are complete on ctx's stream
     return VBX_SUCCESS;

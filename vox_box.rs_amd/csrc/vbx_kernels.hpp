@@ -55,10 +55,32 @@ void launch_pitch(hipStream_t s, const double *x, long F, int n, long stride, co
                   const double *lag_window, double sample_rate, double threshold, double fmin, double fmax,
                   int kmax, pitch_t *out_cand, long cand_ld /* doubles per output row, >= 2*kmax, even */,
                   int32_t *out_count, int32_t *status, unsigned long long *work);
+// the same kernel over a device-resident list of frame indices (fallback of k_spectral.hip), fixed grid
+void launch_pitch_list(hipStream_t s, const int32_t *frame_list, const int32_t *list_count, int grid,
+                       const double *x, int n, long stride, const double *window,
+                       const double *lag_window, double sample_rate, double threshold, double fmin, double fmax,
+                       int kmax, pitch_t *out_cand, long cand_ld, int32_t *out_count, int32_t *status,
+                       unsigned long long *work);
 void launch_sinc_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *xs, long m,
                         long depth, double *out, int32_t *status);
 void launch_extremum_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *ix, long m,
                             long depth, double *out_xy, int32_t *status);
+
+// k_spectral.hip: pitch + LPC + MFCC from one FFT of the frame (frame length 1200)
+constexpr int SPECTRAL_N = 1200;
+constexpr int SPECTRAL_LPC_ORDER = 12;
+constexpr int SPECTRAL_TAB_COMPLEX = 60 * 20 + 3 * 20 + 601;    // W_1200^(n' ka) | W_60^(c kb) | W_2400^m
+struct spectral_launch_t {
+    const double *x; long F; long stride; const double *window; const double *lag_window; const double *tab;
+    double sample_rate, threshold, fmin, fmax; int kmax;
+    pitch_t *out_cand; long cand_ld; int32_t *out_count; int32_t *pitch_status; unsigned long long *work;
+    double *out_lpc; long lpc_ld;                                // NULL: no LPC
+    double *out_mfcc; long mfcc_ld; int32_t *mfcc_status;        // NULL: no MFCC
+    const int32_t *bins; const double *slopes; const double *dct; int num_coeffs; int nb;
+    int32_t *unsure_list; int32_t *unsure_count;                 // frames handed to launch_pitch_list
+};
+bool spectral_supported(int n, int lpc_order, int mfcc_nb, int mfcc_b_lo, int num_coeffs);
+void launch_analyze(hipStream_t s, const spectral_launch_t &L);
 
 // k_mfcc.hip
 bool mfcc_fits(int n, int nb);

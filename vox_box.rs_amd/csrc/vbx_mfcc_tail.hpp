@@ -1,0 +1,41 @@
+// vbx_mfcc_tail.hpp -- the tail of MFCC::mfcc shared by the matrix-core MFCC kernel and the fused spectral kernel:
+// mel filter sums in reference order, clamped log10, DCT (src/spectrum.rs:421-439, :391-397; Q14).
+#pragma once
+
+#include "vbx_device.hpp"
+
+namespace vbx {
+
+// mel energies and dct of one frame: the tail of k_mfcc.hip (kept identical)
+__device__ __forceinline__ void mfcc_tail_m(const double *pu, const double *pd, double *en, const int32_t *bins,
+                                            const double *dct_table, int num_coeffs, int b_lo, int lane,
+                                            double *out_row) {
+    if (lane < num_coeffs) {                              // lane w <-> filter w
+        const int w0 = bins[lane], w1 = bins[lane + 1], w2 = bins[lane + 2];
+        double up_sum = 0.0, down_sum = 0.0;
+        for (int b = w0 - b_lo; b < w1 - b_lo; b += 4) {
+            double v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = (b + j < w1 - b_lo) ? pu[b + j] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) up_sum = up_sum + v[j];
+        }
+        for (int b = w1 - b_lo; b < w2 - b_lo; b += 4) {
+            double v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = (b + j < w2 - b_lo) ? pd[b + j] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) down_sum = down_sum + v[j];
+        }
+        const double lg = log10(up_sum + down_sum);
+        en[lane] = (lg != lg || lg < 1.0e-10) ? 1.0e-10 : lg;   // f64::max(1e-10): NaN yields the other operand
+    }
+    wave_sync();
+    if (lane < num_coeffs) {                              // dct (:391-397)
+        double acc = 0.0;
+        for (int j = 0; j < num_coeffs; j++) acc = acc + en[j] * dct_table[lane * num_coeffs + j];
+        out_row[lane] = 2.0 * acc;
+    }
+}
+
+}  // namespace vbx

@@ -1,0 +1,689 @@
+// vbx_pitch_refine.hpp -- the part of Pitched::pitch that follows the autocorrelation: peak scan, exact top-k
+// bounds, Brent/sinc refinement and the sorted candidate list.  Shared by the two kernels that produce the lag curve
+// y in LDS: pitch_kernel (k_pitch.hip: all-lag autocorrelation on the FP64 matrix cores, any frame length) and
+// analyze_kernel (k_spectral.hip: autocorrelation, LPC and MFCC from one FFT of the frame).
+//
+// Reference: src/periodic.rs:29-87 (interpolate_sinc), :103-188 (brent_maximize), :192-229 (improve_extremum),
+//            :362-375 (local_maxima), :413-455 (pitch, after the lag window division).  Quirks Q4-Q10 reproduced.
+#pragma once
+
+#include "vbx_device.hpp"
+#include "vbx_kernels.hpp"
+
+namespace vbx {
+
+
+// reciprocal of a normal, well-scaled double: v_rcp_f64 (4.6e-8) + Newton steps
+__device__ __forceinline__ double rcp_nr1(double a) {       // ~2e-15 relative
+    double r = __builtin_amdgcn_rcp(a);
+    return fma(fma(-a, r, 1.0), r, r);
+}
+__device__ __forceinline__ double rcp_nr2(double a) {       // correctly rounded in practice
+    double r = __builtin_amdgcn_rcp(a);
+    r = fma(fma(-a, r, 1.0), r, r);
+    return fma(fma(-a, r, 1.0), r, r);
+}
+
+// sin(x), cos(x) for |x| <= pi/2 (a little beyond is fine): Taylor to x^21 / x^22 (< 2e-18 truncation)
+__device__ __forceinline__ double sin_poly(double x) {
+    const double x2 = x * x;
+    double p = -1.9572941063391261231e-20;           // -1/21!
+    p = fma(p, x2, 8.2206352466243297170e-18);       //  1/19!
+    p = fma(p, x2, -2.8114572543455207632e-15);      // -1/17!
+    p = fma(p, x2, 7.6471637318198164759e-13);       //  1/15!
+    p = fma(p, x2, -1.6059043836821614599e-10);      // -1/13!
+    p = fma(p, x2, 2.5052108385441718775e-08);       //  1/11!
+    p = fma(p, x2, -2.7557319223985890653e-06);      // -1/9!
+    p = fma(p, x2, 1.9841269841269841270e-04);       //  1/7!
+    p = fma(p, x2, -8.3333333333333333333e-03);      // -1/5!
+    p = fma(p, x2, 1.6666666666666666667e-01);       //  1/3!
+    return x * fma(-x2, p, 1.0);
+}
+__device__ __forceinline__ double cos_poly(double x) {
+    const double x2 = x * x;
+    double p = 8.8967913924505732867e-22;            //  1/22!
+    p = fma(p, x2, -4.1103176233121648585e-19);      // -1/20!
+    p = fma(p, x2, 1.5619206968586226462e-16);       //  1/18!
+    p = fma(p, x2, -4.7794773323873852974e-14);      // -1/16!
+    p = fma(p, x2, 1.1470745597729724714e-11);       //  1/14!
+    p = fma(p, x2, -2.0876756987868098979e-09);      // -1/12!
+    p = fma(p, x2, 2.7557319223985890653e-07);       //  1/10!
+    p = fma(p, x2, -2.4801587301587301587e-05);      // -1/8!
+    p = fma(p, x2, 1.3888888888888888889e-03);       //  1/6!
+    p = fma(p, x2, -4.1666666666666666667e-02);      // -1/4!
+    p = fma(p, x2, 0.5);                             //  1/2!
+    return fma(-x2, p, 1.0);
+}
+
+// cos(theta) for theta in [0, pi]: -sin(theta - pi/2)
+__device__ __forceinline__ double cos_0_pi(double theta) { return -sin_poly(theta - 1.57079632679489661923); }
+
+// y lookup: entries [nvalid, ylen) are the zeros of self_lag.resize(2N, 0) (src/periodic.rs:411)
+__device__ __forceinline__ double y_at(const double *y, int nvalid, int idx) {
+    return (idx < nvalid) ? y[idx] : 0.0;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// lane groups: G consecutive lanes cooperate on one candidate / query point (group_sum<G> in
+// vbx_device.hpp)
+// ------------------------------------------------------------------------------------------
+// General form of the sinc sum (src/periodic.rs:59-84): any index may need the reference's
+// clamps.  Even lanes of a group take "left" terms, odd lanes "right" terms.  No cross-lane ops.
+template <int G>
+__device__ __forceinline__ double sinc_terms_general(const double *y, int nvalid, int ylen, int offset, int nl, int nr,
+                                                     double phil, double phir, int max_depth) {
+    const int lig = lane_id() & (G - 1);
+    const int side = lig & 1;
+    const double ph = side ? phir : phil;
+    const double s0 = sinpi(ph);               // sin(pi*(ph+n)) = (-1)^n * s0
+    const double inv_dd = 1.0 / (ph + (double)max_depth);
+    const int ibase = side ? (offset + nl) : (offset + nr);
+    double acc = 0.0;
+    for (int n = (lig >> 1); n <= max_depth; n += G / 2) {
+        const double a = M_PI * (ph + (double)n);
+        int idx = side ? (ibase + n) : (ibase - n);
+        idx = (idx < 0) ? 0 : idx;
+        idx = (idx >= ylen) ? (ylen - 1) : idx;          // only reachable on the right side (:78)
+        const double r_lag = y_at(y, nvalid, idx);
+        const double sgn_s0 = (n & 1) ? -s0 : s0;
+        const double first = sgn_s0 * rcp_nr2(a);
+        const double second = fma(0.5, cos_0_pi(a * inv_dd), 0.5);
+        acc = fma(r_lag * first, second, acc);
+    }
+    return acc;
+}
+
+// The same terms when every index is known to be in [0, nvalid): no clamps, and the per-term work
+// is reduced with exact identities (no change of the reference's formula):
+//   sin(pi*(ph+n))          = (-1)^n * sin(pi*ph)                       one polynomial per evaluation
+//   0.5 + 0.5*cos(a/(ph+D)) = 0.5 + 0.5*cos(theta0 + j*delta)           a lane's terms (n = n0 + j*G/2) are
+//                             equally spaced in angle: Reinsch's stable cosine recurrence
+//                             d += -kappa*C; C += d  (kappa = 4 sin^2(delta/2)) replaces the cosine
+//   1/(ph+n)                = four terms share ONE v_rcp_f64 (+ a Newton step): 1/(p0 p1 p2 p3), then products
+// Returns the lane's partial sum already scaled (sum over the group = interpolate_sinc).
+template <int G>
+__device__ __forceinline__ double sinc_terms_fast(const double *y, int ibase_l, int ibase_r,
+                                                  double phil, double phir, int max_depth) {
+    constexpr int NSTEP = G / 2;
+    constexpr double S = (double)NSTEP;
+    const int lig = lane_id() & (G - 1);
+    const int side = lig & 1;
+    const int n0 = lig >> 1;
+    const double ph = side ? phir : phil;
+    const double s0 = sin_poly(M_PI * fmin(phil, phir));      // sin(pi*phil) == sin(pi*phir)
+    const double h2 = M_PI * rcp_nr2(ph + (double)max_depth); // theta = h2 * (ph + n)  in [0, pi]
+    double pn = ph + (double)n0;
+    const int nterms = (n0 <= max_depth) ? (max_depth - n0) / NSTEP + 1 : 0;
+    // cosine recurrence state: C = cos(theta_j), d = C_j - C_{j-1}
+    const double theta0 = h2 * pn, delta = h2 * S;
+    double C = cos_0_pi(theta0);
+    double d = cos_0_pi(theta0 + delta) - C;                   // only used when the lane has >= 2 terms
+    const double sh = sin_poly(0.5 * delta);
+    const double kappa = 4.0 * sh * sh;
+    const int step = side ? NSTEP : -NSTEP;
+    const double *yp = y + (side ? (ibase_r + n0) : (ibase_l - n0));
+    double acc0 = 0.0, acc1 = 0.0;                             // sum t, sum t*C   (t = y/(ph+n))
+    int j = 0;
+    for (; j + 4 <= nterms; j += 4) {
+        const double y0 = yp[0], y1 = yp[step], y2 = yp[2 * step], y3 = yp[3 * step];
+        const double p0 = pn, p1 = pn + S, p2 = pn + 2.0 * S, p3 = pn + 3.0 * S;
+        const double q01 = p0 * p1, q23 = p2 * p3;
+        const double r = rcp_nr1(q01 * q23);
+        const double r01 = r * q23, r23 = r * q01;
+        const double t0 = y0 * (r01 * p1), t1 = y1 * (r01 * p0), t2 = y2 * (r23 * p3), t3 = y3 * (r23 * p2);
+        acc0 += t0; acc1 = fma(t0, C, acc1);
+        C += d; d = fma(-kappa, C, d);                         // after the first step d_1 was preset: see below
+        acc0 += t1; acc1 = fma(t1, C, acc1);
+        C += d; d = fma(-kappa, C, d);
+        acc0 += t2; acc1 = fma(t2, C, acc1);
+        C += d; d = fma(-kappa, C, d);
+        acc0 += t3; acc1 = fma(t3, C, acc1);
+        C += d; d = fma(-kappa, C, d);
+        pn += 4.0 * S;
+        yp += 4 * step;
+    }
+    if (j < nterms) {      // 1..3 terms left: one more block, padded with zero-weight terms
+        const int rem = nterms - j;
+        const double y0 = yp[0], y1 = (rem > 1) ? yp[step] : 0.0, y2 = (rem > 2) ? yp[2 * step] : 0.0;
+        const double p0 = pn, p1 = pn + S, p2 = pn + 2.0 * S;
+        const double q01 = p0 * p1;
+        const double r = rcp_nr1(q01 * p2);
+        const double r01 = r * p2;
+        const double t0 = y0 * (r01 * p1), t1 = y1 * (r01 * p0), t2 = y2 * (r * q01);
+        acc0 += t0; acc1 = fma(t0, C, acc1);
+        C += d; d = fma(-kappa, C, d);
+        acc0 += t1; acc1 = fma(t1, C, acc1);
+        C += d;
+        acc0 += t2; acc1 = fma(t2, C, acc1);
+    }
+    const double k = s0 * (0.5 * 0.31830988618379067154);     // sin(pi*ph) / pi, and the 0.5 of the taper
+    const double acc = acc0 + acc1;
+    return ((n0 & 1) ? -acc : acc) * k;
+}
+
+// interpolate_sinc (src/periodic.rs:29-87), cooperative over groups of G lanes; the arguments are
+// uniform inside a group and the result is bit-identical in all its lanes.  Lanes with
+// active == false contribute nothing.  st |= 4 where the reference would index out of bounds.
+// y[0..nvalid) is readable (entries past the data are zero), ylen >= nvalid is the logical length
+// after self_lag.resize(2N, 0).  Must be called from converged code.
+template <int G>
+__device__ __forceinline__ double sinc_interp(const double *y, int nvalid, int ylen, int offset, int nx,
+                                              double x, int max_depth, bool active, int &st,
+                                              unsigned *terms = nullptr) {
+    bool summed = false, fast = false;
+    double special = 0.0, phil = 0.5, phir = 0.5;
+    int nl = 0, nr = 1;
+    if (active) {
+        if (nx < 1) special = __builtin_nan("");                                   // :38
+        else if (x > (double)nx) {                                                 // :39
+            const int idx = offset + nx - 1;
+            if (idx < 0 || idx >= ylen) st |= 4; else special = y_at(y, nvalid, idx);
+        } else if (x < 0.0) special = y_at(y, nvalid, 0);                          // :40
+        else {
+            const double fl = floor(x);
+            nl = (fl > 0.0) ? (int)fl : 0;                                          // NaN -> 0
+            nr = nl + 1;
+            phil = x - (double)nl;
+            phir = 1.0 - phil;
+            if (fabs(x - (double)nl) < 1.0e-10) {                                   // :41
+                const int idx = offset + nl;
+                if (idx < 0 || idx >= ylen) st |= 4; else special = y_at(y, nvalid, idx);
+            } else if (fabs(x - (double)nr) < 1.0e-10) {                            // :42
+                const int idx = offset + nr;
+                if (idx < 0 || idx >= ylen) st |= 4; else special = y_at(y, nvalid, idx);
+            } else {
+                if ((offset + nr) < max_depth) max_depth = ((offset + nr) < 0) ? 0 : (offset + nr);   // :46-52
+                if ((offset + nl + max_depth) >= nx) max_depth = nx - offset + nl - 1;                  // :55-57
+                if (max_depth < 0 || offset + nr >= ylen) st |= 4;   // usize wrap / left index at n = 0 out of bounds
+                else {
+                    summed = true;
+                    // all left indices [offset+nr-D, offset+nr] and right indices [offset+nl, offset+nl+D] readable
+                    fast = !(x != x) && max_depth <= offset + nr && offset + nl >= 0 &&
+                           offset + nl + max_depth < nvalid && offset + nr < nvalid;
+                }
+            }
+        }
+    }
+    double acc = 0.0;
+    if (terms != nullptr && summed) *terms += 2u * (unsigned)(max_depth + 1);
+    if (summed) {
+        if (fast) acc = sinc_terms_fast<G>(y, offset + nr, offset + nl, phil, phir, max_depth);
+        else acc = sinc_terms_general<G>(y, nvalid, ylen, offset, nl, nr, phil, phir, max_depth);
+    }
+    const double total = group_sum<G>(acc);
+    return summed ? total : special;
+}
+
+// improve_extremum(.., Interpolation::Sinc(depth), true) (src/periodic.rs:192-229) around
+// brent_maximize (:103-188): a MINIMISER of the un-negated interpolant (Q8).  One candidate per
+// group of G lanes; `active` lanes carry a candidate.  Must be called from converged code.
+template <int G>
+__device__ __forceinline__ void improve_extremum_sinc(const double *y, int nvalid, int ylen, int offset, int nx,
+                                                      double ixmid, int depth, bool active,
+                                                      double &xmid, double &ymid, int &st,
+                                                      unsigned *terms = nullptr, unsigned *evals = nullptr,
+                                                      double bar = -__builtin_inf(), bool *pruned = nullptr) {
+#pragma clang fp contract(off)   // keep the scalar iteration bit-identical to the unfused CPU arithmetic
+    const double golden = 1. - 0.6180339887498948482045868343656381177203091798057628621;
+    const double sqrt_epsilon = 1.4901161193847656e-08;   // sqrt(f64::EPSILON)
+    const double eps = 2.220446049250313e-16;
+    const double tol = 1e-10;
+    xmid = 0.; ymid = 0.;
+    bool run = active;
+    if (active) {
+        if (ixmid == 0.) { xmid = 0.; ymid = y_at(y, nvalid, 0); run = false; }                 // :193
+        else if (ixmid >= (double)nx) {                                                          // :194
+            run = false;
+            if (nx < 1 || nx - 1 >= ylen) st |= 4;
+            else { xmid = (double)nx; ymid = y_at(y, nvalid, nx - 1); }
+        } else if (!(ixmid - 1. < ixmid + 1.)) { st |= 4; run = false; }                        // assert!(a < b), :113
+    }
+    double a = ixmid - 1., b = ixmid + 1.;
+    double v = a + golden * (b - a);
+    double fv = sinc_interp<G>(y, nvalid, ylen, offset, nx, v, depth, run, st, terms);
+    if (evals != nullptr && run) *evals += 1u;
+    double x = v, w = v, fx = fv, fw = fv;
+    bool done = !run;
+    if (pruned != nullptr) {     // exact top-k pruning (pitch_refine_kernel): f(v0) already caps the final strength
+        const double ub = (fv <= 1.) ? fv : 1.;
+        *pruned = run && ub < bar && a >= (double)(-offset);
+        done = done || *pruned;
+    }
+    for (int it = 1; it <= 60; it++) {
+        const double range = b - a;
+        const double middle_range = (a + b) * 0.5;
+        const double tol_act = sqrt_epsilon * fabs(x) + tol / 3.;
+        if (!done && fabs(x - middle_range) + range * 0.5 <= 2. * tol_act) done = true;
+        if (!__any(!done)) break;
+        double new_step = (x < middle_range) ? golden * (b - x) : golden * (a - x);
+        if (fabs(x - w) >= tol_act) {
+            const double t = (x - w) * (fx - fv);
+            double q = (x - v) * (fx - fw);
+            double p = (x - v) * q - (x - w) * t;
+            q = 2. * q - t;
+            if (q > 0.) p = -p; else q = -q;
+            if (fabs(p) < fabs(new_step * q) && p > q * (a - x + 2. * tol_act) && p < q * (b - x - 2. * tol_act))
+                new_step = p / q;
+        }
+        if (fabs(new_step) < tol_act) new_step = (new_step > 0.) ? tol_act : -tol_act;
+        const double t = x + new_step;
+        const double ft = sinc_interp<G>(y, nvalid, ylen, offset, nx, t, depth, !done, st, terms);
+        if (evals != nullptr && !done) *evals += 1u;
+        if (!done) {
+            if (ft <= fx) {
+                if (t < x) b = x; else a = x;
+                v = w; w = x; x = t;
+                fv = fw; fw = fx; fx = ft;
+            } else {
+                if (t < x) a = t; else b = t;
+                if (ft <= fw || fabs(w - x) < eps) {
+                    v = w; w = t;
+                    fv = fw; fw = ft;
+                } else if (ft <= fv || fabs(v - x) < eps || fabs(v - w) < eps) {
+                    v = t;
+                    fv = ft;
+                }
+            }
+        }
+    }
+    if (run) { xmid = x; ymid = fx; }
+}
+
+// ------------------------------------------------------------------------------------------
+// Pitched::pitch after the lag curve (src/periodic.rs:413-455), one wavefront per frame:
+//  a) peak scan, lane-parallel: strict local maxima of y[0..N/2) (Q4), the "parabolic" lag (Q5) and
+//     the frequency filter (:439); survivors are compacted in index order into an LDS list.
+//     The sinc(30) strength of :433 is dead in the reference (overwritten at :448 for every
+//     candidate that passes the filter, dropped otherwise) and is not evaluated.
+//  b, c) refinement (improve_extremum_sinc) and the sorted candidate list, see pitch_refine_store.
+// ------------------------------------------------------------------------------------------
+constexpr int Y_PAD = 16;                       // zeros kept after y[n) (stand for the head of resize(2N, 0))
+constexpr int PB = 5;                           // lags per block of the |y| prefix sums
+typedef unsigned short cand_t;                  // candidate lags (< 2048)
+constexpr int PG = 16;                          // lanes per query point (sinc_points / extremum_points kernels)
+constexpr int PNG = 64 / PG;                    // points per wavefront
+constexpr int GROUP_PATH_MIN_CAND = 32;         // pitch frames with more candidates refine them 4 at a time, 16 lanes each
+
+__device__ __forceinline__ void cand_from_peak(const double *ys, int kk, double sample_rate, int offset,
+                                               double &freq, double &nn) {
+    const double peak = ys[kk], peak_rev = ys[kk - 1], peak_fwd = ys[kk + 1];
+    const double dr = 0.5 * (peak_fwd - peak_rev);                    // :423
+    const double d2r = 2. * peak - (peak_rev - peak_fwd);             // :424 (Q5)
+    freq = sample_rate / ((double)kk + dr / d2r);                     // :425
+    nn = sample_rate / freq - (double)offset;                         // :432, :443
+}
+
+constexpr int BOUND_HEAD = 8;                   // nearest terms per side evaluated by the first-evaluation bound
+
+// sum of |y_i| over i in [i0, i1], rounded outward to blocks of PB (p16[j] = sum_{i < PB j} |y_i|, j <= nblk)
+__device__ __forceinline__ double abs_range_bound(const double *p16, int nblk, int i0, int i1) {
+    i0 = (i0 < 0) ? 0 : i0;
+    const int last = PB * nblk - 1;
+    i1 = (i1 > last) ? last : i1;
+    if (i1 < i0) return 0.0;
+    return p16[i1 / PB + 1] - p16[i0 / PB];
+}
+
+// Upper bound of f(v0), the FIRST value brent_maximize (src/periodic.rs:103-188) takes on the bracket
+// [nn-1, nn+1]: v0 = a + golden*(b-a).  Every later accepted value is <= f(v0), so this bounds the candidate's
+// final strength from above.  One lane per candidate: the 2*BOUND_HEAD terms nearest to v0 are summed, the rest
+// is bounded by  sum |y_i| * c(n)  with  c(n) = |sin(pi ph)| * taper(n) / (pi (ph + n)),  decreasing in n, taken
+// at the start of geometrically growing ranges.  +inf (= "refine it") for everything that is not the plain
+// clamp-free sum, and for NaN/inf data.
+__device__ __forceinline__ double first_eval_bound(const double *ys, const double *p16, int nblk, int nvalid, int ylen,
+                                                   int offset, int nx, double nn, int depth) {
+    const double INF = __builtin_inf();
+    if (nn == 0. || nn >= (double)nx || !(nn - 1. < nn + 1.)) return INF;
+    double v0;
+    {
+#pragma clang fp contract(off)
+        const double golden = 1. - 0.6180339887498948482045868343656381177203091798057628621;
+        const double ba = nn - 1., bb = nn + 1.;
+        if (!(ba >= (double)(-offset))) return INF;
+        v0 = ba + golden * (bb - ba);
+    }
+    if (nx < 1 || v0 > (double)nx || v0 < 0.0) return INF;
+    const double fl = floor(v0);
+    const int nl = (int)fl, nr = nl + 1;
+    const double phil = v0 - (double)nl, phir = 1.0 - phil;
+    if (fabs(v0 - (double)nl) < 1.0e-10 || fabs(v0 - (double)nr) < 1.0e-10) return INF;
+    int D = depth;
+    if ((offset + nr) < D) D = ((offset + nr) < 0) ? 0 : (offset + nr);            // :46-52
+    if ((offset + nl + D) >= nx) D = nx - offset + nl - 1;                          // :55-57
+    if (D < 0 || offset + nr >= ylen || D > offset + nr || offset + nl < 0 || offset + nl + D >= ylen) return INF;
+    const double s0 = sin_poly(M_PI * fmin(phil, phir)) * 0.31830988618379067154;   // |sin(pi ph)| / pi >= 0
+    const double hl = M_PI * rcp_nr1(phil + (double)D), hr = M_PI * rcp_nr1(phir + (double)D);
+    double head = 0.0;
+    const int nh = (BOUND_HEAD < D + 1) ? BOUND_HEAD : D + 1;
+    for (int m = 0; m < nh; m++) {
+        const double pl = phil + (double)m, pr = phir + (double)m;
+        const double tl = y_at(ys, nvalid, offset + nr - m) * rcp_nr1(pl) * fma(0.5, cos_0_pi(hl * pl), 0.5);
+        const double tr = y_at(ys, nvalid, offset + nl + m) * rcp_nr1(pr) * fma(0.5, cos_0_pi(hr * pr), 0.5);
+        const double t = tl + tr;
+        head += (m & 1) ? -t : t;
+    }
+    head *= s0;
+    double tail = 0.0;
+    for (int lo = nh; lo <= D; lo *= 2) {
+        const int hi = (2 * lo < D + 1) ? 2 * lo : D + 1;                            // terms [lo, hi)
+        const double pl = phil + (double)lo, pr = phir + (double)lo;
+        const double cl = rcp_nr1(pl) * fma(0.5, cos_0_pi(hl * pl), 0.5);
+        const double cr = rcp_nr1(pr) * fma(0.5, cos_0_pi(hr * pr), 0.5);
+        tail = fma(cl, abs_range_bound(p16, nblk, offset + nr - (hi - 1), offset + nr - lo), tail);
+        tail = fma(cr, abs_range_bound(p16, nblk, offset + nl + lo, offset + nl + hi - 1), tail);
+    }
+    tail *= s0;
+    const double ub = head + tail * (1.0 + 1.0e-9) + (1.0e-9 + 1.0e-11 * p16[nblk]);   // rounding of either sum is far below this
+    return (ub != ub) ? INF : ub;
+}
+
+// index of the largest key >= bar among keys[0, ncand) (lowest index on ties), or -1; the winner is retired
+__device__ __forceinline__ int pick_best(float *keys, int ncand, double bar, int lane) {
+    double bv = -__builtin_inf(); int bi = 0x7fffffff;
+    for (int i = lane; i < ncand; i += 64) { const double v = (double)keys[i]; if (v > bv) { bv = v; bi = i; } }
+    const double gm = wave_max(bv);
+    int pick = (bv == gm) ? bi : 0x7fffffff;
+    for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(pick, o, 64); pick = (other < pick) ? other : pick; }
+    if (pick == 0x7fffffff || !(gm >= bar)) return -1;
+    if (lane == 0) keys[pick] = -__builtin_inff();
+    wave_sync();
+    return pick;
+}
+
+
+// LDS of the refinement, in this order from `ys`:  y[n + Y_PAD] | p16[nblk + 1 (+pad)] | keys[n/4 + 8] (float) |
+// candidate list (uint16).  pitch_refine_lds_doubles(n) is that footprint in doubles (rounded up).
+__host__ __device__ constexpr int pitch_refine_lds_bytes(int n) {
+    return (n + Y_PAD + ((((n + PB - 1) / PB) + 2) & ~1)) * 8 + (n / 4 + 8) * (int)(sizeof(float) + sizeof(cand_t));
+}
+
+struct pitch_params_t { double sample_rate, threshold, fmin, fmax; int kmax; };
+
+// Phases a-c of Pitched::pitch on the lag curve ys[0..n) (zero padded to n + Y_PAD; the curve is
+// (r / max|r|) / w_lag, src/periodic.rs:404-408), one wavefront per frame; writes the frame's outputs.
+// unc_tol > 0: the curve carries an absolute error of up to unc_tol per entry (FFT-based autocorrelation).  The one
+// place where the path turns y into a DISCRETE decision is the strict 3-point peak test (:370-374): if any lag's test
+// could come out differently within that error (a peak or a non-peak by less than unc_tol, e.g. a curve that is
+// exactly zero over a stretch), nothing is written and the function returns false: the caller hands the frame to the
+// kernel that computes the lag sums directly.  Returns true when the frame's outputs were written.
+__device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitch_params_t &pp, long f,
+                                                   double *__restrict__ out_cand, long cand_ld,
+                                                   int32_t *__restrict__ out_count, int32_t *__restrict__ status,
+                                                   unsigned long long *__restrict__ work, double unc_tol = 0.0) {
+    const int lane = lane_id();
+    const double sample_rate = pp.sample_rate, threshold = pp.threshold, fmin = pp.fmin, fmax = pp.fmax;
+    const int kmax = pp.kmax;
+    const int nblk = (n + PB - 1) / PB;              // blocks of PB lags for the |y| prefix sums
+    double *p16 = ys + n + Y_PAD;
+    float *keys = reinterpret_cast<float *>(p16 + ((nblk + 2) & ~1));
+    cand_t *cand_list = reinterpret_cast<cand_t *>(keys + (n / 4 + 8));
+    const int b = (int)floor(0.5 * (double)n);      // brent_ixmax, :414
+    const int offset = -b - 1;                      // :429
+    const int nx = b - offset;                      // :430
+    const int ylen = 2 * n;                         // :411
+    const int nvalid = n + Y_PAD;
+
+    // a) peaks -> filtered candidate list.  Two passes so that the two divisions of the frequency filter run once per
+    // 64 PEAKS, not once per 64 lags: first every strict local maximum is compacted (index order), then the filter.
+    int npeak = 0;
+    bool unsure = false;
+    for (int base = 0; base < b; base += 64) {
+        const int k = base + lane;
+        bool peak = false;
+        if (k >= 1 && k + 1 < b) {                  // windows(3) over self_lag[0..b] (Q4)
+            const double c = ys[k];
+            const double d1 = c - ys[k - 1], d2 = c - ys[k + 1];
+            peak = (ys[k - 1] < c) && (ys[k + 1] < c);
+            unsure = unsure || (fabs((d1 < d2) ? d1 : d2) <= unc_tol);    // NaN and unc_tol = 0 with a clear margin: false
+        }
+        const unsigned long long mask = __ballot(peak);
+        if (peak) cand_list[npeak + __popcll(mask & ((1ull << lane) - 1ull))] = (cand_t)k;
+        npeak += __popcll(mask);
+    }
+    wave_sync();
+    if (unc_tol > 0.0 && __any(unsure)) return false;
+    int ncand = 0;
+    for (int base = 0; base < npeak; base += 64) {  // in place: the write position never passes the read position
+        const int i = base + lane;
+        bool pass = false;
+        int k = 0;
+        if (i < npeak) {
+            k = cand_list[i];
+            double freq, nn;
+            cand_from_peak(ys, k, sample_rate, offset, freq, nn);
+            pass = (freq == 0.0) || (freq > fmin && freq < fmax);             // :439
+        }
+        wave_sync();                                // all reads of this pass before its writes
+        const unsigned long long mask = __ballot(pass);
+        if (pass) cand_list[ncand + __popcll(mask & ((1ull << lane) - 1ull))] = (cand_t)k;
+        ncand += __popcll(mask);
+        wave_sync();
+    }
+
+    // a') first-evaluation bounds.  p16: prefix sums of |y| over blocks of PB; keys[c]: upper bound of candidate c's
+    // strength, stored as a float rounded UP (still an upper bound; the whole frame then fits 12 wavefronts per CU)
+    {
+        // lane l owns the consecutive blocks [l*per, (l+1)*per): local sums, one scan over the lanes, prefix written back
+        const int per = (nblk + 63) >> 6;
+        double tot = 0.0;
+        for (int q = 0; q < per; q++) {
+            const int j = lane * per + q;
+            if (j < nblk) { const double *yp = ys + PB * j; tot += ((fabs(yp[0]) + fabs(yp[1])) + (fabs(yp[2]) + fabs(yp[3]))) + fabs(yp[4]); }   // entries past n are zero
+        }
+        double incl = tot;                                   // inclusive scan over the lanes
+        for (int o = 1; o < 64; o <<= 1) { const double up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+        double run = incl - tot;
+        if (lane == 0) p16[0] = 0.0;
+        for (int q = 0; q < per; q++) {
+            const int j = lane * per + q;
+            if (j < nblk) {
+                const double *yp = ys + PB * j;
+                run += ((fabs(yp[0]) + fabs(yp[1])) + (fabs(yp[2]) + fabs(yp[3]))) + fabs(yp[4]);
+                p16[j + 1] = run;
+            }
+        }
+        wave_sync();
+        for (int c = lane; c < ncand; c += 64) {
+            double freq, nn;
+            cand_from_peak(ys, cand_list[c], sample_rate, offset, freq, nn);
+            const double ub = first_eval_bound(ys, p16, nblk, nvalid, ylen, offset, nx, nn, 1200);
+            const double kb = (ub <= 1.) ? ub : ((ub != ub) ? __builtin_inf() : ((ub == __builtin_inf()) ? ub : 1.));
+            keys[c] = __double2float_ru(kb);
+        }
+        wave_sync();
+    }
+
+    int st = 0;
+    int kept = 0;
+    double lf = 0.0, ls = 0.0;                      // lane j holds sorted candidate j
+    bool any_nan = false;
+    int li = 0;                                     // candidate index of the list entry held by this lane
+    // maxima.push(Pitch::new(0, threshold)) (:452) carries the largest index; it enters the list first so
+    // that the pruning bar below is armed from the start
+    { lf = 0.0; ls = threshold; li = ncand; kept = 1; }
+
+    // Exact top-k pruning.  The caller asked for the first kmax entries of the sorted list.  brent_maximize only
+    // ever replaces fx by a value <= fx (:162), so a candidate's final strength is <= min(f(v0), 1): v0 is its
+    // first abscissa and the "> 1 -> 1/s" reflection of :446 keeps strengths <= 1.  A candidate whose bound
+    // (keys[], or the exact f(v0) once evaluated) is strictly below the kmax-th best strength already in the
+    // list cannot be among the entries returned, and is skipped.  Candidates are taken best-bound-first, so the
+    // bar rises as early as possible; when the best remaining bound is below the bar, all the rest is too.
+    // A list that never fills (kmax >= count) keeps bar = -inf: everything is refined.
+#define VBX_BAR() ((kept == kmax) ? readlane_f64(ls, kmax - 1) : -__builtin_inf())
+    auto insert = [&](double f_g, double s_g, int c_g) {
+        if (s_g != s_g) any_nan = true;
+        const int pos = __popcll(__ballot(lane < kept && (ls > s_g || (ls == s_g && li < c_g))));
+        const double pf = from_prev_lane(lf), ps = from_prev_lane(ls);
+        const int pi = __builtin_amdgcn_update_dpp(0, li, DPP_WAVE_SHR1, 0xf, 0xf, true);
+        if (lane > pos) { lf = pf; ls = ps; li = pi; }
+        if (lane == pos) { lf = f_g; ls = s_g; li = c_g; }
+        kept = (kept + 1 < kmax) ? kept + 1 : kmax;
+    };
+    unsigned cterms = 0, cevals = 0;                // sinc terms / evaluations executed (uniform)
+
+    // b, c) refinement, best bound first, one candidate at a time with all 64 lanes on its sinc sums
+    // (improve_extremum, :192-229): every lane runs the reference's Brent iteration on identical values (the wave
+    // sums are bit-identical in all lanes).  In a voiced frame the first strength becomes the bar that retires every
+    // other candidate without an evaluation.  Finished candidates enter the lane-resident list ordered by
+    // (strength desc, candidate index asc) == the reference's stable sort (:453).
+    // Frames with many candidates (noise-like frames: short lags, little work per evaluation) use four groups of 16
+    // lanes instead, each refining one candidate and taking the next-best as soon as its own has converged.  Which of
+    // the two paths a frame takes depends on its candidate count only, never on kmax: a candidate's result does not
+    // depend on which others are refined, and the returned list is the same head of the same full list.
+    unsigned nterms = 0, nevals = 0;                // group path: work executed (group leaders' counts are summed)
+    if (ncand <= GROUP_PATH_MIN_CAND) {
+        for (;;) {
+            const double bar = VBX_BAR();
+            const int c = pick_best(keys, ncand, bar, lane);
+            if (c < 0) break;
+            double freq, nn, xmid, ymid;
+            cand_from_peak(ys, cand_list[c], sample_rate, offset, freq, nn);
+            bool dropped = false;
+            improve_extremum_sinc<64>(ys, nvalid, ylen, offset, nx, nn, 1200, true, xmid, ymid, st, &cterms, &cevals, bar, &dropped);
+            if (dropped) continue;
+            double xm, ym;
+            {
+#pragma clang fp contract(off)
+                xm = xmid + (double)offset;                                   // :445
+                ym = ymid;
+                if (ym > 1.) ym = 1. / ym;                                    // :446
+                xm = sample_rate / xm;                                        // :447
+            }
+            insert(xm, ym, c);
+        }
+    } else {
+        bool exhausted = false;
+        const int gid = lane / PG;
+        int ci = -1, it = 0;
+        bool special = false;
+        double ba = 0., bb = 0., v = 0., w = 0., x = 0., fv = 0., fw = 0., fx = 0., xmid = 0., ymid = 0.;
+        constexpr unsigned long long LEADERS = (PG == 16) ? 0x0001000100010001ull : (PG == 8) ? 0x0101010101010101ull
+                                             : (PG == 32) ? 0x0000000100000001ull : (PG == 4) ? 0x1111111111111111ull : 1ull;
+        for (;;) {
+#pragma clang fp contract(off)   // the scalar Brent arithmetic stays bit-identical to the unfused CPU arithmetic
+            {   // hand the best remaining candidates to the idle groups, in group order
+                unsigned long long im = __ballot(ci < 0) & LEADERS;
+                while (im != 0ull && !exhausted) {
+                    const int c = pick_best(keys, ncand, VBX_BAR(), lane);
+                    if (c < 0) { exhausted = true; break; }
+                    const int g = __builtin_ctzll(im) / PG;
+                    im &= im - 1ull;
+                    if (gid == g) {
+                        ci = c;
+                        double freq, nn;
+                        cand_from_peak(ys, cand_list[ci], sample_rate, offset, freq, nn);
+                        it = 0; special = false; xmid = 0.; ymid = 0.;
+                        if (nn == 0.) { special = true; xmid = 0.; ymid = ys[0]; }                              // :193
+                        else if (nn >= (double)nx) { special = true; xmid = (double)nx; ymid = y_at(ys, nvalid, nx - 1); }   // :194
+                        else if (!(nn - 1. < nn + 1.)) { special = true; st |= 4; }                             // assert!(a < b), :113
+                        ba = nn - 1.; bb = nn + 1.;
+                    }
+                }
+            }
+            if (!__any(ci >= 0)) break;
+            const double bar = VBX_BAR();
+
+            const double golden = 1. - 0.6180339887498948482045868343656381177203091798057628621;
+            const double sqrt_epsilon = 1.4901161193847656e-08, eps = 2.220446049250313e-16, tol = 1e-10;
+            bool finished = false, need = false, pruned = false;
+            double t = 0.;
+            if (ci >= 0) {
+                if (special) finished = true;
+                else if (it == 0) { v = ba + golden * (bb - ba); t = v; need = true; }
+                else {
+                    const double range = bb - ba;
+                    const double middle_range = (ba + bb) * 0.5;
+                    const double tol_act = sqrt_epsilon * fabs(x) + tol / 3.;
+                    if (it > 60 || fabs(x - middle_range) + range * 0.5 <= 2. * tol_act) { finished = true; xmid = x; ymid = fx; }
+                    else {
+                        double new_step = (x < middle_range) ? golden * (bb - x) : golden * (ba - x);
+                        if (fabs(x - w) >= tol_act) {
+                            const double tt = (x - w) * (fx - fv);
+                            double q = (x - v) * (fx - fw);
+                            double pp = (x - v) * q - (x - w) * tt;
+                            q = 2. * q - tt;
+                            if (q > 0.) pp = -pp; else q = -q;
+                            if (fabs(pp) < fabs(new_step * q) && pp > q * (ba - x + 2. * tol_act) && pp < q * (bb - x - 2. * tol_act))
+                                new_step = pp / q;
+                        }
+                        if (fabs(new_step) < tol_act) new_step = (new_step > 0.) ? tol_act : -tol_act;
+                        t = x + new_step;
+                        need = true;
+                    }
+                }
+            }
+            const double ft = sinc_interp<PG>(ys, nvalid, ylen, offset, nx, t, 1200, need, st, &nterms);
+            nevals += need ? 1u : 0u;
+            if (need) {
+                if (it == 0) {
+                    x = v; w = v; fv = ft; fx = ft; fw = ft; it = 1;
+                    const double ub = (ft <= 1.) ? ft : 1.;          // NaN -> 1: never pruned
+                    // ba >= -offset: every abscissa of the bracket has its left neighbour at index >= 0, so none of
+                    // the skipped evaluations could have been an out-of-bounds panic of the reference
+                    if (ub < bar && ba >= (double)(-offset)) { finished = true; pruned = true; }
+                } else {
+                    if (ft <= fx) {
+                        if (t < x) bb = x; else ba = x;
+                        v = w; w = x; x = t;
+                        fv = fw; fw = fx; fx = ft;
+                    } else {
+                        if (t < x) ba = t; else bb = t;
+                        if (ft <= fw || fabs(w - x) < eps) {
+                            v = w; w = t;
+                            fv = fw; fw = ft;
+                        } else if (ft <= fv || fabs(v - x) < eps || fabs(v - w) < eps) {
+                            v = t;
+                            fv = ft;
+                        }
+                    }
+                    it++;
+                }
+            }
+            // finished candidates -> sorted list
+            if (__any(finished)) {
+                unsigned long long fm = __ballot(finished && !pruned) & LEADERS;
+                double xm = xmid + (double)offset;                                // :445
+                double ym = ymid;
+                if (ym > 1.) ym = 1. / ym;                                        // :446
+                const double cf = sample_rate / xm, cs = ym;                      // :447-448
+                while (fm) {
+                    const int ld = __builtin_ctzll(fm);
+                    fm &= fm - 1;
+                    insert(readlane_f64(cf, ld), readlane_f64(cs, ld), __builtin_amdgcn_readlane(ci, ld));
+                }
+                if (finished) ci = -1;
+            }
+        }
+    }
+#undef VBX_BAR
+    const int total_cand = ncand + 1;
+    st = __any(st & 4) ? 4 : 0;
+    if (total_cand > 1 && (any_nan || threshold != threshold)) st |= 8;   // partial_cmp().unwrap() panics (Q10)
+    int code = 0;
+    if (st & 4) code = 4; else if (st & 8) code = 3;
+    if (lane < kmax) {
+        const bool valid = (code == 0) && lane < kept;
+        double2 o;
+        o.x = valid ? lf : 0.0;                     // Pitch { frequency, strength }
+        o.y = valid ? ls : 0.0;
+        *reinterpret_cast<double2 *>(out_cand + f * cand_ld + 2 * lane) = o;   // row f of a [F, cand_ld] array of doubles
+    }
+    if (lane == 0) {
+        if (out_count != nullptr) out_count[f] = (code == 0) ? total_cand : 0;
+        if (status != nullptr) status[f] = code;
+    }
+    if (work != nullptr) {                          // profiling only: frames, candidates, sinc evaluations, sinc terms
+        const bool leader = (lane & (PG - 1)) == 0;
+        unsigned long long te = leader ? nterms : 0u, ev = leader ? nevals : 0u;
+        for (int o = 32; o > 0; o >>= 1) { te += __shfl_xor(te, o, 64); ev += __shfl_xor(ev, o, 64); }
+        if (lane == 0) {
+            unsigned long long *w = work + 4 * (f & (PITCH_WORK_SLOTS - 1));
+            atomicAdd(w + 0, 1ull); atomicAdd(w + 1, (unsigned long long)ncand);
+            atomicAdd(w + 2, ev + cevals); atomicAdd(w + 3, te + cterms);
+        }
+    }
+    return true;
+}
+
+}  // namespace vbx
