@@ -62,7 +62,10 @@ extern "C" {
 #define VBX_FORMANT_SLOTS 6         /* FormantSlots, src/spectrum.rs:228 */
 #define VBX_MAX_LPC_ORDER 30        /* 2*order resonances must fit the tracker's fixed arrays */
 #define VBX_MAX_FRAME_LEN 4096      /* register/LDS-resident frame kernels */
-#define VBX_MAX_PITCH_CANDIDATES 64 /* kmax upper bound of vbx_pitch_f64 */
+#define VBX_MAX_PITCH_CANDIDATES 1026 /* kmax upper bound of vbx_pitch_f64: frame_len/4 strict local maxima in
+                                        [0, frame_len/2) + the unvoiced candidate, at VBX_MAX_FRAME_LEN */
+/* the whole Vec of a frame never has more than this many entries (out_count <= vbx_pitch_max_candidates) */
+#define VBX_PITCH_MAX_CANDIDATES(frame_len) ((frame_len) / 4 + 2)
 
 typedef struct vbx_ctx vbx_ctx;
 
@@ -163,7 +166,12 @@ int vbx_improve_extremum_f64(vbx_ctx *ctx, const double *y, size_t ylen, long of
  * (may exceed kmax).  PitchExtractor (src/periodic.rs:337-353) output = out_cand[f*kmax + 0].
  * Only the kmax entries that are returned are guaranteed to have been refined: a candidate whose strength
  * is provably below the kmax-th best is skipped (exact -- the returned entries, the count and the status
- * are the reference's; DESIGN.md "exact top-k pruning").  kmax = 1 is the fast path. */
+ * are the reference's; DESIGN.md "exact top-k pruning").  kmax = 1 is the fast path.
+ * The WHOLE Vec of every frame (src/periodic.rs:452-454 returns all of it) is retrievable: either
+ * kmax = VBX_PITCH_MAX_CANDIDATES(frame_len), which no frame can exceed, or the two-call protocol -- a first call
+ * with kmax = 1 yields out_count[F], a second call with kmax = max(out_count) returns every entry.  kmax > 64
+ * switches the kernel from its lane-resident list to an LDS-resident one (nothing is pruned, every candidate is
+ * refined as in the reference; slower). */
 int vbx_pitch_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
                   const double *window, double sample_rate, double threshold, double fmin, double fmax,
                   size_t kmax, vbx_pitch *out_cand, int32_t *out_count, int32_t *status);
@@ -174,6 +182,10 @@ int vbx_pitch_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_l
  * r: [F, r_stride] with r_stride >= n_coeffs+1; out: [F, n_coeffs+1] = [1, a1..ap]. */
 int vbx_lpc_f64(vbx_ctx *ctx, const double *r, size_t n_frames, size_t r_stride,
                 size_t n_coeffs, double *out);
+/* LPC::lpc_mut(n_coeffs, ac, kc, tmp) (src/spectrum.rs:62-84): as vbx_lpc_f64, and out_kc: [F, n_coeffs]
+ * (optional) receives the reflection coefficients the reference leaves in `kc` (`tmp` is scratch there). */
+int vbx_lpc_mut_f64(vbx_ctx *ctx, const double *r, size_t n_frames, size_t r_stride,
+                    size_t n_coeffs, double *out_ac, double *out_kc);
 
 /* frame.autocorrelate(n_coeffs+1) [-> .normalize()] -> .lpc(n_coeffs) fused, one pass over the
  * samples (LPCSolver usage, src/spectrum.rs:40-42,470-479).  out_r: [F, n_coeffs+1] (after the

@@ -28,7 +28,7 @@ def test_misuse_is_reported_not_fatal(vb, pkg):
     assert rc == -1 and "frame_len" in msg
     rc, msg = _rc(vb, L.vbx_lpc_burg_f64, x.ptr, 4, 512, 512, None, 31, out.ptr, None)       # order > 30
     assert rc == -1
-    rc, msg = _rc(vb, L.vbx_pitch_f64, x.ptr, 4, 512, 512, None, 48000.0, 0.2, 75.0, 600.0, 65, out.ptr, None, None)
+    rc, msg = _rc(vb, L.vbx_pitch_f64, x.ptr, 4, 512, 512, None, 48000.0, 0.2, 75.0, 600.0, 1027, out.ptr, None, None)
     assert rc == -1 and "kmax" in msg
     est = np.array([[320.0, 1.0]] * 7)
     rc, msg = _rc(vb, L.vbx_find_formants_f64, x.ptr, 4, 512, 512, 48000.0, 12, None, 0, est.ctypes.data, 7,

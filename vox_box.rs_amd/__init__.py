@@ -17,5 +17,6 @@ from .voxbox import (  # noqa: F401
     MALE_FORMANT_ESTIMATES, FEMALE_FORMANT_ESTIMATES,
     FRAME_OK, FRAME_ERR_LPC, FRAME_ERR_POLYNOMIAL, FRAME_ERR_NAN, FRAME_ERR_PANIC,
     AnalysisParams, Comm, comm_unique_id, shard_range, shard_samples,
+    MAX_PITCH_CANDIDATES, pitch_max_candidates,
 )
 from . import shard  # noqa: F401

@@ -210,8 +210,9 @@ __global__ __launch_bounds__(64) void normalize_rows_kernel(double *__restrict__
 }
 
 // LPC::lpc on autocorrelation rows: one thread per row (src/spectrum.rs:63-92).
+// out_kc (optional, [rows, p]): the reflection coefficients lpc_mut leaves in its `kc` argument (:74).
 __global__ void levinson_rows_kernel(const double *__restrict__ r, long n_rows, long r_stride, int p,
-                                     double *__restrict__ out, long out_ld) {
+                                     double *__restrict__ out, long out_ld, double *__restrict__ out_kc) {
     const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
     const double *rr = r + row * r_stride;
@@ -225,6 +226,7 @@ __global__ void levinson_rows_kernel(const double *__restrict__ r, long n_rows, 
         for (int j = 1; j < i; j++) acc = acc + ac[j] * rr[i - j];
         const double k = -acc / err;
         ac[i] = k;
+        if (out_kc != nullptr) out_kc[row * (long)p + (i - 1)] = k;
         for (int j = 0; j < p; j++) tmp[j] = ac[j];
         for (int j = 1; j < i; j++) ac[j] = ac[j] + k * tmp[i - j];
         err = err * (1.0 - k * k);
@@ -287,9 +289,10 @@ void launch_normalize_rows(hipStream_t s, double *data, long rows, int n) {
     hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)rows), dim3(64), 0, s, data, rows, n);
 }
 
-void launch_levinson_rows(hipStream_t s, const double *r, long rows, long r_stride, int p, double *out, long out_ld) {
+void launch_levinson_rows(hipStream_t s, const double *r, long rows, long r_stride, int p, double *out, long out_ld,
+                          double *out_kc) {
     const int bs = 64;
-    hipLaunchKernelGGL(levinson_rows_kernel, dim3((unsigned)((rows + bs - 1) / bs)), dim3(bs), 0, s, r, rows, r_stride, p, out, out_ld);
+    hipLaunchKernelGGL(levinson_rows_kernel, dim3((unsigned)((rows + bs - 1) / bs)), dim3(bs), 0, s, r, rows, r_stride, p, out, out_ld, out_kc);
 }
 
 }  // namespace vbx

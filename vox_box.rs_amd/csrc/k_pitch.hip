@@ -38,8 +38,8 @@ template <bool ALIAS>
 __device__ __forceinline__ void pitch_frame_mfma(
     double *smem, const long f, const double *__restrict__ frames, int n, long stride, const double *__restrict__ window,
     const double *__restrict__ lag_window, double sample_rate, double threshold, double fmin, double fmax,
-    int kmax, double *__restrict__ out_cand, long cand_ld, int32_t *__restrict__ out_count, int32_t *__restrict__ status,
-    unsigned long long *__restrict__ work) {
+    int kmax, int full_off, double *__restrict__ out_cand, long cand_ld, int32_t *__restrict__ out_count,
+    int32_t *__restrict__ status, unsigned long long *__restrict__ work) {
     const int lane = lane_id();
     double *zs = smem;                              // padded image of the windowed frame (vbx_autocorr.hpp)
     // refinement state (vbx_pitch_refine.hpp): y[n + Y_PAD] | p16 | keys | candidate list
@@ -104,21 +104,22 @@ __device__ __forceinline__ void pitch_frame_mfma(
     wave_sync();
 
     pitch_params_t pp;
-    pp.sample_rate = sample_rate; pp.threshold = threshold; pp.fmin = fmin; pp.fmax = fmax; pp.kmax = kmax;
-    pitch_refine_store(ys, n, pp, f, out_cand, cand_ld, out_count, status, work);
+    pp.sample_rate = sample_rate; pp.threshold = threshold; pp.fmin = fmin; pp.fmax = fmax; pp.kmax = kmax; pp.full_off = full_off;
+    double2 *full = full_off ? reinterpret_cast<double2 *>(reinterpret_cast<char *>(smem) + full_off) : nullptr;
+    pitch_refine_store(ys, n, pp, f, out_cand, cand_ld, out_count, status, work, 0.0, full);
 }
 
 template <bool ALIAS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void pitch_kernel(
     const double *__restrict__ frames, long n_frames, int n, long stride, const double *__restrict__ window,
     const double *__restrict__ lag_window, double sample_rate, double threshold, double fmin, double fmax,
-    int kmax, double *__restrict__ out_cand, long cand_ld, int32_t *__restrict__ out_count, int32_t *__restrict__ status,
-    unsigned long long *__restrict__ work) {
+    int kmax, int full_off, double *__restrict__ out_cand, long cand_ld, int32_t *__restrict__ out_count,
+    int32_t *__restrict__ status, unsigned long long *__restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const long f = blockIdx.x;
     if (f >= n_frames) return;
     pitch_frame_mfma<ALIAS>(smem, f, frames, n, stride, window, lag_window, sample_rate, threshold, fmin, fmax, kmax,
-                            out_cand, cand_ld, out_count, status, work);
+                            full_off, out_cand, cand_ld, out_count, status, work);
 }
 
 // The same per-frame routine over a list of frame indices: the frames the FFT-based kernel (k_spectral.hip) could not
@@ -128,13 +129,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const int32_t *__restrict__ frame_list, const int32_t *__restrict__ list_count,
     const double *__restrict__ frames, int n, long stride, const double *__restrict__ window,
     const double *__restrict__ lag_window, double sample_rate, double threshold, double fmin, double fmax,
-    int kmax, double *__restrict__ out_cand, long cand_ld, int32_t *__restrict__ out_count, int32_t *__restrict__ status,
-    unsigned long long *__restrict__ work) {
+    int kmax, int full_off, double *__restrict__ out_cand, long cand_ld, int32_t *__restrict__ out_count,
+    int32_t *__restrict__ status, unsigned long long *__restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int count = *list_count;
     for (int i = blockIdx.x; i < count; i += gridDim.x) {
         pitch_frame_mfma<ALIAS>(smem, (long)frame_list[i], frames, n, stride, window, lag_window, sample_rate, threshold,
-                                fmin, fmax, kmax, out_cand, cand_ld, out_count, status, work);
+                                fmin, fmax, kmax, full_off, out_cand, cand_ld, out_count, status, work);
         wave_sync();
     }
 }
@@ -178,17 +179,25 @@ size_t pitch_lds_bytes(int n) {
     return image + refine;
 }
 
+// kmax > PITCH_LIST_LANES: the whole candidate Vec is wanted; its entries are parked in an extra LDS region behind
+// the frame state (vbx_pitch_refine.hpp, `full`) and rank-sorted at the end of the frame
+size_t pitch_full_list_bytes(int n, int kmax) {
+    return kmax > PITCH_LIST_LANES ? (size_t)pitch_full_list_entries(n) * sizeof(double2) : 0;
+}
+
 void launch_pitch(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                   const double *lag_window, double sample_rate, double threshold, double fmin, double fmax,
                   int kmax, pitch_t *out_cand, long cand_ld, int32_t *out_count, int32_t *status,
                   unsigned long long *work) {
+    const size_t base = (pitch_lds_bytes(n) + 15) & ~(size_t)15, extra = pitch_full_list_bytes(n, kmax);
+    const int full_off = extra ? (int)base : 0;
     if (n <= AC_MF_NT * AC_MF_TILE)
-        hipLaunchKernelGGL((pitch_kernel<true>), dim3((unsigned)F), dim3(64), pitch_lds_bytes(n), s,
-                           x, F, n, stride, window, lag_window, sample_rate, threshold, fmin, fmax, kmax,
+        hipLaunchKernelGGL((pitch_kernel<true>), dim3((unsigned)F), dim3(64), base + extra, s,
+                           x, F, n, stride, window, lag_window, sample_rate, threshold, fmin, fmax, kmax, full_off,
                            reinterpret_cast<double *>(out_cand), cand_ld, out_count, status, work);
     else
-        hipLaunchKernelGGL((pitch_kernel<false>), dim3((unsigned)F), dim3(64), pitch_lds_bytes(n), s,
-                           x, F, n, stride, window, lag_window, sample_rate, threshold, fmin, fmax, kmax,
+        hipLaunchKernelGGL((pitch_kernel<false>), dim3((unsigned)F), dim3(64), base + extra, s,
+                           x, F, n, stride, window, lag_window, sample_rate, threshold, fmin, fmax, kmax, full_off,
                            reinterpret_cast<double *>(out_cand), cand_ld, out_count, status, work);
 }
 
@@ -197,14 +206,16 @@ void launch_pitch_list(hipStream_t s, const int32_t *frame_list, const int32_t *
                        const double *lag_window, double sample_rate, double threshold, double fmin, double fmax,
                        int kmax, pitch_t *out_cand, long cand_ld, int32_t *out_count, int32_t *status,
                        unsigned long long *work) {
+    const size_t base = (pitch_lds_bytes(n) + 15) & ~(size_t)15, extra = pitch_full_list_bytes(n, kmax);
+    const int full_off = extra ? (int)base : 0;
     if (n <= AC_MF_NT * AC_MF_TILE)
-        hipLaunchKernelGGL((pitch_list_kernel<true>), dim3((unsigned)grid), dim3(64), pitch_lds_bytes(n), s,
+        hipLaunchKernelGGL((pitch_list_kernel<true>), dim3((unsigned)grid), dim3(64), base + extra, s,
                            frame_list, list_count, x, n, stride, window, lag_window, sample_rate, threshold, fmin, fmax, kmax,
-                           reinterpret_cast<double *>(out_cand), cand_ld, out_count, status, work);
+                           full_off, reinterpret_cast<double *>(out_cand), cand_ld, out_count, status, work);
     else
-        hipLaunchKernelGGL((pitch_list_kernel<false>), dim3((unsigned)grid), dim3(64), pitch_lds_bytes(n), s,
+        hipLaunchKernelGGL((pitch_list_kernel<false>), dim3((unsigned)grid), dim3(64), base + extra, s,
                            frame_list, list_count, x, n, stride, window, lag_window, sample_rate, threshold, fmin, fmax, kmax,
-                           reinterpret_cast<double *>(out_cand), cand_ld, out_count, status, work);
+                           full_off, reinterpret_cast<double *>(out_cand), cand_ld, out_count, status, work);
 }
 
 void launch_sinc_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *xs, long m,

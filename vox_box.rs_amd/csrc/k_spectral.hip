@@ -424,7 +424,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     // with w_lag >= 1/6 on the searched half.  SP_UNC_EPS bounds the error of a DIFFERENCE of two entries with a wide
     // margin; frames with a peak decision inside it go to the direct-sum kernel (launch_pitch_list).
     const double unc_tol = SP_UNC_EPS * fabs(s0) * scale;
-    if (!pitch_refine_store(ys, SP_N, a.pp, f, a.out_cand, a.cand_ld, a.out_count, a.pitch_status, a.work, unc_tol)) {
+    double2 *full = a.pp.full_off ? reinterpret_cast<double2 *>(reinterpret_cast<char *>(smem) + a.pp.full_off) : nullptr;
+    if (!pitch_refine_store(ys, SP_N, a.pp, f, a.out_cand, a.cand_ld, a.out_count, a.pitch_status, a.work, unc_tol, full)) {
         if (lane == 0) a.unsure_list[atomicAdd(a.unsure_count, 1)] = (int32_t)f;
     }
 }
@@ -457,7 +458,9 @@ void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
     a.bins = L.bins; a.slopes = L.slopes; a.dct = L.dct; a.num_coeffs = L.num_coeffs; a.nb = L.nb;
     a.unsure_list = L.unsure_list; a.unsure_count = L.unsure_count;
     const dim3 grid((unsigned)L.F), block(64);
-    const size_t lds = spectral_lds_bytes();
+    const size_t base = spectral_lds_bytes(), extra = pitch_full_list_bytes(SP_N, L.kmax);
+    a.pp.full_off = extra ? (int)base : 0;
+    const size_t lds = base + extra;
     const bool lpc = L.out_lpc != nullptr, mf = L.out_mfcc != nullptr;
     if (lpc && mf) hipLaunchKernelGGL((analyze_kernel<true, true>), grid, block, lds, s, a);
     else if (lpc) hipLaunchKernelGGL((analyze_kernel<true, false>), grid, block, lds, s, a);

@@ -713,10 +713,11 @@ static int run_pitch(vbx_ctx *ctx, hipStream_t st, const double *x, size_t n_fra
                      const double *window, double sample_rate, double threshold, double fmin, double fmax,
                      size_t kmax, vbx_pitch *out_cand, size_t cand_ld, int32_t *out_count, int32_t *status) {
     VBX_REQUIRE(ctx, out_cand != nullptr, "null output");
-    VBX_REQUIRE(ctx, kmax >= 1 && kmax <= VBX_MAX_PITCH_CANDIDATES, "kmax must be in [1, 64]");
+    VBX_REQUIRE(ctx, kmax >= 1 && kmax <= VBX_MAX_PITCH_CANDIDATES, "kmax must be in [1, VBX_MAX_PITCH_CANDIDATES]");
     VBX_REQUIRE(ctx, cand_ld >= 2 * kmax && cand_ld % 2 == 0, "candidate rows must be 16-byte aligned and hold kmax entries");
     VBX_REQUIRE(ctx, frame_len >= 4, "frame_len must be >= 4");
-    VBX_REQUIRE(ctx, pitch_lds_bytes((int)frame_len) <= 160 * 1024, "frame does not fit the LDS");
+    VBX_REQUIRE(ctx, pitch_lds_bytes((int)frame_len) + pitch_full_list_bytes((int)frame_len, (int)kmax) + 16 <= 160 * 1024,
+                "frame does not fit the LDS");
     const double *lagw = nullptr;
     int rc = get_window_dev(ctx, VBX_WINDOW_HANNING_LAG, frame_len, &lagw);
     if (rc != VBX_SUCCESS) return rc;
@@ -758,15 +759,20 @@ int vbx_pitch_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_l
 
 // ---- spectrum.rs: LPC ---------------------------------------------------------------------
 
-int vbx_lpc_f64(vbx_ctx *ctx, const double *r, size_t n_frames, size_t r_stride, size_t n_coeffs, double *out) {
+int vbx_lpc_mut_f64(vbx_ctx *ctx, const double *r, size_t n_frames, size_t r_stride, size_t n_coeffs, double *out_ac,
+                    double *out_kc) {
     VBX_REQUIRE(ctx, ctx != nullptr, "null context");
     if (n_frames == 0) return VBX_SUCCESS;
-    VBX_REQUIRE(ctx, r && out, "null argument");
+    VBX_REQUIRE(ctx, r && out_ac, "null argument");
     VBX_REQUIRE(ctx, n_coeffs >= 1 && n_coeffs <= VBX_MAX_LPC_ORDER && r_stride >= n_coeffs + 1, "bad order / stride");
     VBX_REQUIRE(ctx, n_frames <= 0x7fffffffull, "too many rows");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
-    { Prof p(ctx, "levinson_rows"); launch_levinson_rows(ctx->stream, r, (long)n_frames, (long)r_stride, (int)n_coeffs, out, (long)n_coeffs + 1); }
+    { Prof p(ctx, "levinson_rows"); launch_levinson_rows(ctx->stream, r, (long)n_frames, (long)r_stride, (int)n_coeffs, out_ac, (long)n_coeffs + 1, out_kc); }
     return check_launch(ctx, __func__);
+}
+
+int vbx_lpc_f64(vbx_ctx *ctx, const double *r, size_t n_frames, size_t r_stride, size_t n_coeffs, double *out) {
+    return vbx_lpc_mut_f64(ctx, r, n_frames, r_stride, n_coeffs, out, nullptr);
 }
 
 static int run_autocorr_lpc(vbx_ctx *ctx, hipStream_t st, const double *x, size_t n_frames, size_t frame_len,

@@ -23,7 +23,8 @@ void launch_autocorr_fewlags(hipStream_t s, const double *x, long F, int n, long
 void launch_autocorr_tiles(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                            int n_lags, double *out);
 void launch_normalize_rows(hipStream_t s, double *data, long rows, int n);
-void launch_levinson_rows(hipStream_t s, const double *r, long rows, long r_stride, int p, double *out, long out_ld);
+void launch_levinson_rows(hipStream_t s, const double *r, long rows, long r_stride, int p, double *out, long out_ld,
+                          double *out_kc = nullptr /* [rows, p] reflection coefficients */);
 
 // k_burg.hip
 bool burg_supported(int n, int p);
@@ -49,6 +50,10 @@ void launch_tracker(hipStream_t s, const res_t *res, long F, int n_res, const in
 
 // k_pitch.hip
 size_t pitch_lds_bytes(int n);
+// the sorted candidate list lives one entry per lane up to this many entries; a larger kmax parks the whole
+// candidate Vec in an extra LDS region of pitch_full_list_bytes(n, kmax) and rank-sorts it (nothing is pruned)
+constexpr int PITCH_LIST_LANES = 64;
+size_t pitch_full_list_bytes(int n, int kmax);
 // profiling counters of the refine kernel: [PITCH_WORK_SLOTS][4] = frames, candidates, sinc evaluations, sinc terms
 constexpr int PITCH_WORK_SLOTS = 64;
 void launch_pitch(hipStream_t s, const double *x, long F, int n, long stride, const double *window,

@@ -398,7 +398,11 @@ __host__ __device__ constexpr int pitch_refine_lds_bytes(int n) {
     return (n + Y_PAD + ((((n + PB - 1) / PB) + 2) & ~1)) * 8 + (n / 4 + 8) * (int)(sizeof(float) + sizeof(cand_t));
 }
 
-struct pitch_params_t { double sample_rate, threshold, fmin, fmax; int kmax; };
+struct pitch_params_t { double sample_rate, threshold, fmin, fmax; int kmax; int full_off; };   // full_off: byte offset of
+                                                                                                // the full-list region in the
+                                                                                                // dynamic LDS, 0 = none
+// entries of the full-list region: at most n/4 strict local maxima in [0, n/2) plus the unvoiced candidate
+__host__ __device__ constexpr int pitch_full_list_entries(int n) { return n / 4 + 2; }
 
 // Phases a-c of Pitched::pitch on the lag curve ys[0..n) (zero padded to n + Y_PAD; the curve is
 // (r / max|r|) / w_lag, src/periodic.rs:404-408), one wavefront per frame; writes the frame's outputs.
@@ -407,10 +411,15 @@ struct pitch_params_t { double sample_rate, threshold, fmin, fmax; int kmax; };
 // could come out differently within that error (a peak or a non-peak by less than unc_tol, e.g. a curve that is
 // exactly zero over a stretch), nothing is written and the function returns false: the caller hands the frame to the
 // kernel that computes the lag sums directly.  Returns true when the frame's outputs were written.
+// full != nullptr (LDS, pitch_full_list_entries(n) entries): the WHOLE Vec of :452-454 is wanted (kmax > 64, more than
+// the lane-resident list holds).  Nothing is pruned; every refined candidate is parked at its candidate index, and the
+// frame ends with a rank sort by (strength desc, candidate index asc) == the reference's stable sort, whose first kmax
+// entries are written.
 __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitch_params_t &pp, long f,
                                                    double *__restrict__ out_cand, long cand_ld,
                                                    int32_t *__restrict__ out_count, int32_t *__restrict__ status,
-                                                   unsigned long long *__restrict__ work, double unc_tol = 0.0) {
+                                                   unsigned long long *__restrict__ work, double unc_tol = 0.0,
+                                                   double2 *full = nullptr) {
     const int lane = lane_id();
     const double sample_rate = pp.sample_rate, threshold = pp.threshold, fmin = pp.fmin, fmax = pp.fmax;
     const int kmax = pp.kmax;
@@ -502,6 +511,8 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
     // maxima.push(Pitch::new(0, threshold)) (:452) carries the largest index; it enters the list first so
     // that the pruning bar below is armed from the start
     { lf = 0.0; ls = threshold; li = ncand; kept = 1; }
+    const bool fullm = full != nullptr;
+    if (fullm && lane == 0) full[ncand] = double2{0.0, threshold};
 
     // Exact top-k pruning.  The caller asked for the first kmax entries of the sorted list.  brent_maximize only
     // ever replaces fx by a value <= fx (:162), so a candidate's final strength is <= min(f(v0), 1): v0 is its
@@ -510,9 +521,10 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
     // list cannot be among the entries returned, and is skipped.  Candidates are taken best-bound-first, so the
     // bar rises as early as possible; when the best remaining bound is below the bar, all the rest is too.
     // A list that never fills (kmax >= count) keeps bar = -inf: everything is refined.
-#define VBX_BAR() ((kept == kmax) ? readlane_f64(ls, kmax - 1) : -__builtin_inf())
+#define VBX_BAR() ((!fullm && kept == kmax) ? readlane_f64(ls, kmax - 1) : -__builtin_inf())
     auto insert = [&](double f_g, double s_g, int c_g) {
         if (s_g != s_g) any_nan = true;
+        if (fullm) { if (lane == 0) full[c_g] = double2{f_g, s_g}; return; }
         const int pos = __popcll(__ballot(lane < kept && (ls > s_g || (ls == s_g && li < c_g))));
         const double pf = from_prev_lane(lf), ps = from_prev_lane(ls);
         const int pi = __builtin_amdgcn_update_dpp(0, li, DPP_WAVE_SHR1, 0xf, 0xf, true);
@@ -662,7 +674,22 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
     if (total_cand > 1 && (any_nan || threshold != threshold)) st |= 8;   // partial_cmp().unwrap() panics (Q10)
     int code = 0;
     if (st & 4) code = 4; else if (st & 8) code = 3;
-    if (lane < kmax) {
+    if (fullm) {
+        wave_sync();
+        double *row = out_cand + f * cand_ld;
+        const int total = (code == 0) ? total_cand : 0;
+        for (int i0 = 0; i0 < total; i0 += 64) {
+            const int i = i0 + lane;
+            const double2 me = (i < total) ? full[i] : double2{0.0, 0.0};
+            int rank = 0;
+            for (int j = 0; j < total; j++) {
+                const double sj = full[j].y;                 // same address in every lane: one broadcast read
+                rank += (sj > me.y || (sj == me.y && j < i)) ? 1 : 0;
+            }
+            if (i < total && rank < kmax) *reinterpret_cast<double2 *>(row + 2 * rank) = me;
+        }
+        for (int i = total + lane; i < kmax; i += 64) *reinterpret_cast<double2 *>(row + 2 * i) = double2{0.0, 0.0};
+    } else if (lane < kmax) {
         const bool valid = (code == 0) && lane < kept;
         double2 o;
         o.x = valid ? lf : 0.0;                     // Pitch { frequency, strength }

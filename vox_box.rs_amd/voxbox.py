@@ -21,6 +21,12 @@ FRAME_OK, FRAME_ERR_LPC, FRAME_ERR_POLYNOMIAL, FRAME_ERR_NAN, FRAME_ERR_PANIC = 
 MALE_FORMANT_ESTIMATES = (320.0, 1440.0, 2760.0, 3200.0)      # src/lib.rs:27
 FEMALE_FORMANT_ESTIMATES = (480.0, 1760.0, 3200.0, 3520.0)    # src/lib.rs:28
 MAX_RESONANCES = 32
+MAX_PITCH_CANDIDATES = 1026           # VBX_MAX_PITCH_CANDIDATES
+
+
+def pitch_max_candidates(frame_len):
+    """VBX_PITCH_MAX_CANDIDATES(frame_len): no frame's candidate Vec (src/periodic.rs:452-454) is longer."""
+    return frame_len // 4 + 2
 
 
 class VoxBoxError(RuntimeError):
@@ -456,7 +462,8 @@ class VoxBox:
     def pitch(self, x, sample_rate, threshold, fmin, fmax, kmax=8, frame_len=None, stride=None, n_frames=None,
               window=None, out=None):
         """Returns (cand[F, kmax, 2], count[F], status[F]) as numpy, or writes into `out`
-        = (cand, count, status) device buffers and returns None."""
+        = (cand, count, status) device buffers and returns None.  kmax = pitch_max_candidates(frame_len) returns
+        the reference's whole Vec for every frame."""
         ptr, F, N, S, tmp = self._frames(x, frame_len, stride, n_frames)
         if out is None:
             cand, cnt, st = self.empty((F, kmax, 2)), self.empty(F, np.int32), self.empty(F, np.int32)
