@@ -155,3 +155,34 @@ def test_cpp_example_runs(pkg, tmp_path):
     assert len(rows) == 4
     for got, e in zip(rows, exp):
         assert all(abs(a - b) <= 1e-4 * b + 0.006 for a, b in zip(got, e)), (got, e)      # printed to 2 decimals
+
+
+def test_rust_binding_is_complete_and_in_sync(pkg):
+    """bindings/rust ships as source (no rustc in the image), so what CAN be checked is: src/ffi.rs is exactly what
+    tools/gen_rust_ffi.py generates from the header (every entry point declared, none invented), every symbol it
+    declares is exported by the library, every `ffi::vbx_*` the safe layer calls is declared, and no method body
+    is a stub."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ffi_path = os.path.join(root, "bindings", "rust", "src", "ffi.rs")
+    before = open(ffi_path).read()
+    subprocess.run(["python3", os.path.join(root, "tools", "gen_rust_ffi.py")], check=True, capture_output=True)
+    assert open(ffi_path).read() == before, "bindings/rust/src/ffi.rs is stale: run tools/gen_rust_ffi.py"
+    declared = set(re.findall(r"pub fn (vbx_\w+)\(", before))
+    assert declared == set(pkg.exported_symbols())
+    lib = pkg.load_library()
+    for n in declared:
+        assert hasattr(lib, n), n
+    gpu = open(os.path.join(root, "bindings", "rust", "src", "gpu.rs")).read()
+    used = set(re.findall(r"ffi::(vbx_\w+)\(", gpu))
+    assert used - {"vbx_pitch_max_candidates"} <= declared, used - declared      # that one is a const fn of ffi.rs
+    # the trait surface north_star names, each implemented by calling the ABI
+    for trait, entry in (("Autocorrelate<f64> for GpuFrame", "vbx_autocorrelate_f64"), ("LPC<f64> for GpuFrame", "vbx_lpc_mut_f64"),
+                         ("LPC<f64> for GpuFrame", "vbx_lpc_burg_f64"), ("Pitched<f64, f64> for GpuFrame", "vbx_pitch_f64"),
+                         ("MFCC<f64> for GpuFrame", "vbx_mfcc_f64"), ("ToResonance<f64> for RootRow", "vbx_to_resonance_c64"),
+                         ("pub fn find_formants", "vbx_find_formants_f64")):
+        assert trait in gpu and entry in used, (trait, entry)
+    for stub in ("unimplemented!", "todo!", "unreachable!"):
+        assert stub not in gpu and stub not in before, stub
+    for f in ("Cargo.toml", "build.rs", os.path.join("src", "lib.rs"), os.path.join("examples", "pitch_detection.rs")):
+        assert os.path.getsize(os.path.join(root, "bindings", "rust", f)) > 0

@@ -117,6 +117,12 @@ def test_lpc_kat(vb, oracle):
     assert np.all(np.abs(lpc[0] - [1.0, -1.3122, 0.8660, -0.0875, -0.0103]) < 1e-4)
     r2, a2 = vb.autocorr_lpc(s[None, :], 4, normalize=True)
     assert np.all(np.abs(a2[0] - lpc[0]) < 1e-12)
+    # lpc_mut (src/spectrum.rs:62-84) also leaves the reflection coefficients in `kc`: kc[i-1] is ac[i] as first set
+    ac, kc = vb.lpc_mut(auto, 4)
+    assert np.array_equal(ac, lpc) and kc.shape == (1, 4) and kc[0, 3] == ac[0, 4]
+    a1, k1 = vb.lpc_mut(auto, 1)
+    assert k1[0, 0] == a1[0, 1] == kc[0, 0]              # order-1 solution: a1 = k1 = -r1/r0
+    assert abs(kc[0, 0] + auto[0, 1] / auto[0, 0]) < 1e-15
 
 
 @pytest.mark.parametrize("n,p,norm", [(512, 12, False), (512, 12, True), (1200, 12, False), (256, 8, False),

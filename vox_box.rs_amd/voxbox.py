@@ -133,6 +133,7 @@ def load_library():
         "vbx_improve_extremum_f64": (C.c_int, [vp, vp, sz, C.c_long, sz, vp, sz, sz, vp, vp]),
         "vbx_pitch_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, dbl, dbl, dbl, dbl, sz, vp, vp, vp]),
         "vbx_lpc_f64": (C.c_int, [vp, vp, sz, sz, sz, vp]),
+        "vbx_lpc_mut_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, vp]),
         "vbx_autocorr_lpc_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, i32, vp, vp]),
         "vbx_lpc_burg_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, vp, vp]),
         "vbx_find_roots_c64": (C.c_int, [vp, vp, sz, sz, vp]),
@@ -487,6 +488,16 @@ class VoxBox:
         self._check(self.L.vbx_lpc_f64(self.ctx, d.ptr, r.shape[0], r.shape[1], n_coeffs, o.ptr))
         res = o.numpy()
         d.free(); o.free()
+        return res
+
+    def lpc_mut(self, r, n_coeffs):
+        """LPC::lpc_mut: returns (ac[F, n_coeffs + 1], kc[F, n_coeffs]) -- coefficients and reflection coefficients."""
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        d = self.to_device(r)
+        o, k = self.empty((r.shape[0], n_coeffs + 1)), self.empty((r.shape[0], n_coeffs))
+        self._check(self.L.vbx_lpc_mut_f64(self.ctx, d.ptr, r.shape[0], r.shape[1], n_coeffs, o.ptr, k.ptr))
+        res = (o.numpy(), k.numpy())
+        d.free(); o.free(); k.free()
         return res
 
     def autocorr_lpc(self, x, n_coeffs, normalize=False, frame_len=None, stride=None, n_frames=None, window=None,
