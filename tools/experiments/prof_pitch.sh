@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 rm -rf gpurun_out/prof_pitch; mkdir -p gpurun_out/prof_pitch
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_pitch/trace -- python3 scratch/pitch_full.py > gpurun_out/prof_pitch/log.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_pitch/trace -- python3 tools/experiments/pitch_full.py > gpurun_out/prof_pitch/log.txt 2>&1
 tail -2 gpurun_out/prof_pitch/log.txt | cut -c1-200
 python3 - <<'PY'
 import csv,glob
