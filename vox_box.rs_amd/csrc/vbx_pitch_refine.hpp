@@ -245,9 +245,12 @@ __device__ __forceinline__ void improve_extremum_sinc(const double *y, int nvali
     if (evals != nullptr && run) *evals += 1u;
     double x = v, w = v, fx = fv, fw = fv;
     bool done = !run;
+    // a >= -offset: every abscissa of the bracket has its left neighbour at index >= 0, so none of the evaluations a
+    // pruned candidate skips could have been an out-of-bounds panic of the reference
+    const bool prunable = pruned != nullptr && run && a >= (double)(-offset);
     if (pruned != nullptr) {     // exact top-k pruning (pitch_refine_kernel): f(v0) already caps the final strength
         const double ub = (fv <= 1.) ? fv : 1.;
-        *pruned = run && ub < bar && a >= (double)(-offset);
+        *pruned = prunable && ub < bar;
         done = done || *pruned;
     }
     for (int it = 1; it <= 60; it++) {
@@ -285,6 +288,9 @@ __device__ __forceinline__ void improve_extremum_sinc(const double *y, int nvali
                     fv = ft;
                 }
             }
+            // brent_maximize only ever replaces fx by a smaller value (:162): the final strength is <= the current fx
+            // (<= 1 here, so the reflection of :446 does not apply).  Strictly below the bar it cannot be returned.
+            if (prunable && fx < bar) { *pruned = true; done = true; }
         }
     }
     if (run) { xmid = x; ymid = fx; }
@@ -376,6 +382,70 @@ __device__ __forceinline__ double first_eval_bound(const double *ys, const doubl
     tail *= s0;
     const double ub = head + tail * (1.0 + 1.0e-9) + (1.0e-9 + 1.0e-11 * p16[nblk]);   // rounding of either sum is far below this
     return (ub != ub) ? INF : ub;
+}
+
+// The same bound with one candidate's work spread over FOUR consecutive lanes (sub = lane & 3): the head terms and the
+// tail ranges are dealt round-robin and summed over the quad.  Frames with few candidates (voiced speech: ~10) would
+// otherwise run the whole bound on a fifth of the lanes.  The sums are associated differently from first_eval_bound;
+// both are upper bounds with the same margin, and only the ORDER and the amount of refinement work depend on them.
+// Must be called from converged code (every lane of the quad, `have` = the quad holds a candidate).
+__device__ __forceinline__ double first_eval_bound_quad(const double *ys, const double *p16, int nblk, int nvalid, int ylen,
+                                                        int offset, int nx, double nn, int depth, int sub, bool have) {
+    const double INF = __builtin_inf();
+    bool inf = !have;
+    double v0 = 0.;
+    if (!inf) {
+        if (nn == 0. || nn >= (double)nx || !(nn - 1. < nn + 1.)) inf = true;
+        else {
+#pragma clang fp contract(off)
+            const double golden = 1. - 0.6180339887498948482045868343656381177203091798057628621;
+            const double ba = nn - 1., bb = nn + 1.;
+            if (!(ba >= (double)(-offset))) inf = true;
+            v0 = ba + golden * (bb - ba);
+        }
+    }
+    if (!inf && (nx < 1 || v0 > (double)nx || v0 < 0.0)) inf = true;
+    int nl = 0, nr = 1, D = 0;
+    double phil = 0.5, phir = 0.5;
+    if (!inf) {
+        const double fl = floor(v0);
+        nl = (int)fl; nr = nl + 1;
+        phil = v0 - (double)nl; phir = 1.0 - phil;
+        if (fabs(v0 - (double)nl) < 1.0e-10 || fabs(v0 - (double)nr) < 1.0e-10) inf = true;
+        D = depth;
+        if ((offset + nr) < D) D = ((offset + nr) < 0) ? 0 : (offset + nr);            // :46-52
+        if ((offset + nl + D) >= nx) D = nx - offset + nl - 1;                          // :55-57
+        if (D < 0 || offset + nr >= ylen || D > offset + nr || offset + nl < 0 || offset + nl + D >= ylen) inf = true;
+    }
+    double head = 0.0, tail = 0.0;
+    if (!inf) {
+        const double s0 = sin_poly(M_PI * fmin(phil, phir)) * 0.31830988618379067154;   // |sin(pi ph)| / pi >= 0
+        const double hl = M_PI * rcp_nr1(phil + (double)D), hr = M_PI * rcp_nr1(phir + (double)D);
+        const int nh = (BOUND_HEAD < D + 1) ? BOUND_HEAD : D + 1;
+        for (int m = sub; m < nh; m += 4) {
+            const double pl = phil + (double)m, pr = phir + (double)m;
+            const double tl = y_at(ys, nvalid, offset + nr - m) * rcp_nr1(pl) * fma(0.5, cos_0_pi(hl * pl), 0.5);
+            const double tr = y_at(ys, nvalid, offset + nl + m) * rcp_nr1(pr) * fma(0.5, cos_0_pi(hr * pr), 0.5);
+            const double t = tl + tr;
+            head += (m & 1) ? -t : t;
+        }
+        head *= s0;
+        int r = 0;
+        for (int lo = nh; lo <= D; lo *= 2, r++) {
+            if ((r & 3) != sub) continue;
+            const int hi = (2 * lo < D + 1) ? 2 * lo : D + 1;                            // terms [lo, hi)
+            const double pl = phil + (double)lo, pr = phir + (double)lo;
+            const double cl = rcp_nr1(pl) * fma(0.5, cos_0_pi(hl * pl), 0.5);
+            const double cr = rcp_nr1(pr) * fma(0.5, cos_0_pi(hr * pr), 0.5);
+            tail = fma(cl, abs_range_bound(p16, nblk, offset + nr - (hi - 1), offset + nr - lo), tail);
+            tail = fma(cr, abs_range_bound(p16, nblk, offset + nl + lo, offset + nl + hi - 1), tail);
+        }
+        tail *= s0;
+    }
+    head = group_sum<4>(head);
+    tail = group_sum<4>(tail);
+    const double ub = head + tail * (1.0 + 1.0e-9) + (1.0e-9 + 1.0e-11 * p16[nblk]);   // rounding of the sums is far below this
+    return (inf || ub != ub) ? INF : ub;
 }
 
 // index of the largest key >= bar among keys[0, ncand) (lowest index on ties), or -1; the winner is retired
@@ -493,12 +563,27 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
             }
         }
         wave_sync();
-        for (int c = lane; c < ncand; c += 64) {
-            double freq, nn;
-            cand_from_peak(ys, cand_list[c], sample_rate, offset, freq, nn);
-            const double ub = first_eval_bound(ys, p16, nblk, nvalid, ylen, offset, nx, nn, 1200);
-            const double kb = (ub <= 1.) ? ub : ((ub != ub) ? __builtin_inf() : ((ub == __builtin_inf()) ? ub : 1.));
-            keys[c] = __double2float_ru(kb);
+        // one lane per candidate, or -- when that would leave most lanes idle -- four lanes per candidate
+        // (cost model: 16 candidates per pass at about 7/25 of the cost of a 64-candidate pass)
+        const bool quad = ((ncand + 15) / 16) * 7 < ((ncand + 63) / 64) * 25;
+        if (quad) {
+            for (int base = 0; base < ncand; base += 16) {
+                const int c = base + (lane >> 2);
+                const bool have = c < ncand;
+                double freq = 0., nn = 0.;
+                if (have) cand_from_peak(ys, cand_list[c], sample_rate, offset, freq, nn);
+                const double ub = first_eval_bound_quad(ys, p16, nblk, nvalid, ylen, offset, nx, nn, 1200, lane & 3, have);
+                const double kb = (ub <= 1.) ? ub : ((ub != ub) ? __builtin_inf() : ((ub == __builtin_inf()) ? ub : 1.));
+                if (have && (lane & 3) == 0) keys[c] = __double2float_ru(kb);
+            }
+        } else {
+            for (int c = lane; c < ncand; c += 64) {
+                double freq, nn;
+                cand_from_peak(ys, cand_list[c], sample_rate, offset, freq, nn);
+                const double ub = first_eval_bound(ys, p16, nblk, nvalid, ylen, offset, nx, nn, 1200);
+                const double kb = (ub <= 1.) ? ub : ((ub != ub) ? __builtin_inf() : ((ub == __builtin_inf()) ? ub : 1.));
+                keys[c] = __double2float_ru(kb);
+            }
         }
         wave_sync();
     }
@@ -568,7 +653,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
         bool exhausted = false;
         const int gid = lane / PG;
         int ci = -1, it = 0;
-        bool special = false;
+        bool special = false, safe = false;
         double ba = 0., bb = 0., v = 0., w = 0., x = 0., fv = 0., fw = 0., fx = 0., xmid = 0., ymid = 0.;
         constexpr unsigned long long LEADERS = (PG == 16) ? 0x0001000100010001ull : (PG == 8) ? 0x0101010101010101ull
                                              : (PG == 32) ? 0x0000000100000001ull : (PG == 4) ? 0x1111111111111111ull : 1ull;
@@ -590,6 +675,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
                         else if (nn >= (double)nx) { special = true; xmid = (double)nx; ymid = y_at(ys, nvalid, nx - 1); }   // :194
                         else if (!(nn - 1. < nn + 1.)) { special = true; st |= 4; }                             // assert!(a < b), :113
                         ba = nn - 1.; bb = nn + 1.;
+                        safe = ba >= (double)(-offset);      // no abscissa of the bracket can index out of bounds
                     }
                 }
             }
@@ -631,9 +717,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
                 if (it == 0) {
                     x = v; w = v; fv = ft; fx = ft; fw = ft; it = 1;
                     const double ub = (ft <= 1.) ? ft : 1.;          // NaN -> 1: never pruned
-                    // ba >= -offset: every abscissa of the bracket has its left neighbour at index >= 0, so none of
-                    // the skipped evaluations could have been an out-of-bounds panic of the reference
-                    if (ub < bar && ba >= (double)(-offset)) { finished = true; pruned = true; }
+                    if (ub < bar && safe) { finished = true; pruned = true; }
                 } else {
                     if (ft <= fx) {
                         if (t < x) bb = x; else ba = x;
@@ -650,6 +734,8 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
                         }
                     }
                     it++;
+                    // the final strength is <= the current fx (:162): strictly below the bar it cannot be returned
+                    if (safe && fx < bar) { finished = true; pruned = true; }
                 }
             }
             // finished candidates -> sorted list

@@ -13,7 +13,8 @@ import re
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvoxbox_hip.so")
+# VBX_LIB_PATH: experiment hook (tools/experiments/ab.py times variant builds of the library side by side)
+LIB_PATH = os.environ.get("VBX_LIB_PATH") or os.path.join(_HERE, "lib", "libvoxbox_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "voxbox_hip.h")
 
 WINDOW_HANNING, WINDOW_HANNING_LAG, WINDOW_HANNING_PERIODIC, WINDOW_RECTANGLE = 0, 1, 2, 3
