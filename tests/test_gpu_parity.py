@@ -747,15 +747,38 @@ def test_mfcc_and_formants_odd_signals(vb, oracle):
         assert ms[f] == es
         assert np.all(rel_close(m[f], em, 1e-6)), (f, np.max(np.abs(m[f] - em)))
     est0 = np.array([[fq, 1.0] for fq in (320.0, 1440.0, 2760.0, 3200.0)])
-    out = vb.find_formants(X, SR, 12, est0, seg_start=np.arange(0, X.shape[0], 1), want=("formants", "status"))
-    broadband = {0, 3, 5, 7}                                 # pure tones / impulses / 1e100 tones give an order-12 Burg
-    for f in range(X.shape[0]):                              # polynomial with clustered roots: root positions are then
-        es, ef, _, _ = oracle.find_formants(X[f], SR, 12, est0)   # ill-conditioned (1 % moves under ANY rounding change)
+    out = vb.find_formants(X, SR, 12, est0, seg_start=np.arange(0, X.shape[0], 1))
+    # EVERY signal class is compared, with a metric that follows the conditioning of the frame:
+    #  * always: status exact, and every resonance the GPU reports is a root of the frame's
+    #    LPC polynomial in the backward sense -- |P(z)| <= 1e-8 * sum |c_k| |z|^(p-k) at z = r e^(i theta) rebuilt from
+    #    (frequency, bandwidth) (or at 1/conj(z) for a root that was reflected into the unit circle, src/spectrum.rs:171-174);
+    #  * Burg coefficients within 1e-6 and formant Hz within 1e-4 wherever the ORACLE's own answer is stable: pure tones, impulses and 1e100 tones give a
+    #    Burg polynomial with clustered roots that move by percents when the frame is perturbed by 1e-13 -- for those
+    #    frames no implementation, the reference included, has digits to compare; the probe below detects them per frame.
+    n_hz = {k: 0 for k in range(len(gens))}
+    n_co = {k: 0 for k in range(len(gens))}
+    for f in range(X.shape[0]):
+        es, ef, eres, eco = oracle.find_formants(X[f], SR, 12, est0)
         assert out["status"][f] == es, (f, out["status"][f], es)  # every frame its own segment: no carried state
-        if es == 0:
-            assert np.all(np.isfinite(out["formants"][f]))
-            if f % len(gens) in broadband:
-                assert np.all(np.abs(out["formants"][f, :, 0] - ef[:, 0]) <= 1e-4 * np.abs(ef[:, 0]) + 1e-9), f
+        if es != 0:
+            continue
+        assert np.all(np.isfinite(out["formants"][f]))
+        probe = X[f] * (1.0 + 1e-13 * rng.standard_normal(N))
+        ps, pf, _, pco = oracle.find_formants(probe, SR, 12, est0)
+        if ps == 0 and np.all(rel_close(pco, eco, 1e-8)):        # the Burg recursion itself loses its digits on a pure tone
+            assert np.all(rel_close(out["coeffs"][f], eco)), (f, np.max(np.abs(out["coeffs"][f] - eco)))
+            n_co[f % len(gens)] += 1
+        c = np.concatenate([[1.0], out["coeffs"][f]])            # P(x) = sum_k c_k x^(p-k)  (src/lib.rs:83-93)
+        for fr, bw in out["res"][f, :int(out["count"][f])]:
+            z = np.exp(-np.pi * bw / SR) * np.exp(2j * np.pi * fr / SR)
+            be = min(abs(np.polyval(c, zz)) / np.polyval(np.abs(c), abs(zz)) for zz in (z, 1.0 / np.conj(z)))
+            assert be <= 1e-8, (f, fr, bw, be)
+        stable = ps == 0 and np.all(np.abs(pf[:, 0] - ef[:, 0]) <= 1e-7 * np.abs(ef[:, 0]) + 1e-12)
+        if stable:
+            assert np.all(np.abs(out["formants"][f, :, 0] - ef[:, 0]) <= 1e-4 * np.abs(ef[:, 0]) + 1e-9), f
+            n_hz[f % len(gens)] += 1
+    print("\nframes per signal class with Burg coefficients / formant Hz compared:", n_co, n_hz)
+    assert n_hz[0] == 6 and n_hz[3] == 6 and n_hz[7] == 6        # noise, DC + noise, square + noise: all well conditioned
 
 
 def test_mfcc_bins_beyond_spectrum_is_panic_status(vb, oracle):

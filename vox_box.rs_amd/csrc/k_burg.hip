@@ -42,10 +42,12 @@ __global__ __launch_bounds__(64) void burg_kernel(
 #pragma unroll
         for (int e = 0; e < EPL - 1; e++) b2[e] = b1[e + 1];
         b2[EPL - 1] = nxt;
+        // the slot index is the same in every lane: a scalar compare per slot, one masked move for the slot that matches
+        // (as a per-lane select chain this cost 4 vector instructions per slot and order)
         const int last = n - 1;
-        const int kb = last % EPL, lb = last / EPL;
+        const int kb = __builtin_amdgcn_readfirstlane(last % EPL), lb = last / EPL;
 #pragma unroll
-        for (int e = 0; e < EPL; e++) if (e == kb && lig == lb) b1[e] = 0.0;
+        for (int e = 0; e < EPL; e++) if (e == kb) { asm volatile("" : "+v"(b1[e])); if (lig == lb) b1[e] = 0.0; }   // the empty asm pins the branch
     }
 
     int st = 0;
@@ -88,9 +90,10 @@ __global__ __launch_bounds__(64) void burg_kernel(
             // element n-i-1 leaves the valid range (the update loop runs j-1 < n-i-1)
             const int drop = n - i - 1;
             if (drop >= 0) {
-                const int kb = drop % EPL, lb = drop / EPL;
+                const int kb = __builtin_amdgcn_readfirstlane(drop % EPL), lb = drop / EPL;
 #pragma unroll
-                for (int e = 0; e < EPL; e++) if (e == kb && lig == lb) { b1[e] = 0.0; b2[e] = 0.0; }
+                for (int e = 0; e < EPL; e++)
+                    if (e == kb) { asm volatile("" : "+v"(b1[e]), "+v"(b2[e])); if (lig == lb) { b1[e] = 0.0; b2[e] = 0.0; } }
             }
         }
     }

@@ -283,6 +283,12 @@ class DeviceArray:
         self.vb._check(self.vb.L.vbx_memcpy_d2h(self.vb.ctx, out.ctypes.data, self.ptr, out.nbytes))
         return out
 
+    def numpy_slice(self, start, count):
+        """`count` elements from flat element index `start` (a partial download of a large buffer)."""
+        out = np.empty(int(count), dtype=self.dtype)
+        self.vb._check(self.vb.L.vbx_memcpy_d2h(self.vb.ctx, out.ctypes.data, self.ptr + int(start) * self.dtype.itemsize, out.nbytes))
+        return out
+
     def free(self):
         if self.ptr:
             self.vb.L.vbx_free(self.vb.ctx, self.ptr)
