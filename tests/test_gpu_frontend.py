@@ -61,6 +61,21 @@ def test_preemphasis(vb, oracle, n, factor):
         assert np.all(rel_close(got[f], exp, 1e-12, 1e-3)), (f, np.max(np.abs(got[f] - exp)))
 
 
+@pytest.mark.parametrize("n,factor", [(1200, 0.25), (1200, 0.5), (4096, 0.25), (4096, 0.5), (512, -0.3), (4096, 1.0 / (2 * np.pi))])
+def test_preemphasis_unstable_factors(vb, oracle, n, factor):
+    """|2*pi*factor| >= 1: the recurrence grows like c^n (to inf at n = 4096); the reference's sequential values --
+    finite, inf, and where it produces them NaN -- must come out position by position (no NaN where it has none)."""
+    x = np.random.default_rng(n + 1).uniform(-1, 1, (5, n))
+    x[1, n // 2:] = 0.0                                   # zeros meeting overflowing powers: the inf * 0 hazard
+    x[2, :] = 0.0
+    got = vb.preemphasis(x, factor)
+    for f in range(5):
+        exp = oracle.preemphasis(x[f], factor)
+        assert np.array_equal(np.isnan(got[f]), np.isnan(exp)) and np.array_equal(np.isinf(got[f]), np.isinf(exp)), f
+        fin = np.isfinite(exp)
+        assert np.all(np.abs(got[f][fin] - exp[fin]) <= 1e-12 * np.abs(exp[fin]) + 1e-300), f
+
+
 def test_preemphasis_strided_view(vb, oracle, pkg):
     audio = vb.synth_speech(48000, sample_offset=99)
     a = audio.numpy()

@@ -65,6 +65,18 @@ __global__ __launch_bounds__(64) void preemphasis_kernel(const double *__restric
     const int E = (n + 63) / 64;
     for (int i = lane; i < 64 * E; i += 64) smem[i] = (i < n) ? xf[i] : 0.0;
     __syncthreads();
+    if (!(fabs(c) < 1.0)) {
+        // |2 pi factor| >= 1: the recurrence grows like c^n, and the powers c^(E 2^k) of the lane scan overflow long
+        // before the reference's sequential values do (inf * 0 would poison finite entries with NaN).  Unstable
+        // filters take the reference's own order: one lane walks the frame backwards (src/waves.rs:88-94).
+        if (lane == 0) {
+            double carry = 0.0;
+            for (int i = n - 1; i >= 0; i--) { carry = fma(c, carry, smem[i]); smem[i] = carry; }
+        }
+        __syncthreads();
+        for (int i = lane; i < n; i += 64) yo[i] = smem[i];
+        return;
+    }
     double *mine = smem + lane * E;
     double carry = 0.0;
     for (int e = E - 1; e >= 0; e--) { carry = fma(c, carry, mine[e]); mine[e] = carry; }
