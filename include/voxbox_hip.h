@@ -21,8 +21,10 @@
  *    `window` (device, frame_len doubles, or NULL) is multiplied onto the
  *    samples on load: the batched form of window::Windower::hanning, whose
  *    frames the reference's traits receive already windowed.
- *  - all arithmetic is f64 ("Sample = f64" instantiation of the traits); the only f32 entry points are the
- *    Complex<f32> Polynomial ones (vbx_*_c32).
+ *  - all arithmetic is f64 ("Sample = f64" instantiation of the traits).  The f32 instantiation (vbx_*_f32: float
+ *    frames in, float results out; vbx_*_c32: Complex<f32> Polynomial) widens on load, computes in f64 and rounds
+ *    each result to f32 once -- except the Complex<f32> root finder, which follows the reference's f32 arithmetic
+ *    step by step because its iteration counts and root ORDER depend on it.
  *  - calls are asynchronous on the context's HIP stream; vbx_sync() waits.
  *  - a context (stream, cached tables, scratch) is not internally synchronised: one host thread per context at
  *    a time.  Contexts are independent of each other and cheap; use one per thread / stream.
@@ -43,7 +45,7 @@
 extern "C" {
 #endif
 
-#define VBX_ABI_VERSION 2
+#define VBX_ABI_VERSION 3
 
 /* API return codes */
 #define VBX_SUCCESS 0
@@ -303,6 +305,29 @@ int vbx_resample_linear_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size
  * entry point above accepts with stride = frame_len.  Requires (n_frames-1)*stride + frame_len <= capacity. */
 int vbx_ring_frames_f64(vbx_ctx *ctx, const double *ring, size_t capacity, size_t head, size_t n_frames,
                         size_t frame_len, size_t stride, double *out);
+
+/* ------------------------------------------------------------------ Sample = f32 (N4) */
+
+/* The slice traits are generic over the Sample type: `impl<T: Sample> Autocorrelate<T> for [T]`
+ * (src/periodic.rs:276-289), `impl<T: Float> LPC<T> for [T]` (src/spectrum.rs:56), `Normalize` (src/waves.rs:60-76),
+ * `MFCC<T>` (src/spectrum.rs:401-409).  These are their f32 instantiation: the arguments mean what they mean in the
+ * _f64 entry points with float in place of double (frames, windows, outputs).  Arithmetic: see the header comment.
+ * vbx_window_table_f32: the f64 table rounded to f32 (the sample crate's own f32 window path is not verifiable
+ * here: parity unpinned). */
+int vbx_window_table_f32(int kind, size_t n, float *h_out);
+int vbx_autocorrelate_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
+                          size_t stride, const float *window, size_t n_lags, float *out);
+int vbx_normalize_f32(vbx_ctx *ctx, float *data, size_t n_rows, size_t n);
+int vbx_lpc_mut_f32(vbx_ctx *ctx, const float *r, size_t n_frames, size_t r_stride,
+                    size_t n_coeffs, float *out_ac, float *out_kc);
+int vbx_autocorr_lpc_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
+                         size_t stride, const float *window, size_t n_coeffs, int normalize,
+                         float *out_r, float *out_lpc);
+int vbx_lpc_burg_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
+                     size_t stride, const float *window, size_t n_coeffs, float *out, int32_t *status);
+int vbx_mfcc_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len, size_t stride,
+                 const float *window, size_t num_coeffs, double lo_hz, double hi_hz,
+                 double sample_rate, float *out, int32_t *status);
 
 /* ------------------------------------------------------------------ the user's frame loop, fused */
 

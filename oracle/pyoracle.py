@@ -225,6 +225,46 @@ def find_roots_mut_f32(p):
     return st, p
 
 
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def autocorrelate_f32(x, n_lags):
+    x = _f32(x)
+    out = np.empty(n_lags, dtype=np.float32)
+    lib().vbxo_autocorrelate_f32(_p(x), C.c_size_t(x.size), _p(out), C.c_size_t(n_lags))
+    return out
+
+
+def normalize_f32(x):
+    x = _f32(x).copy()
+    lib().vbxo_normalize_f32(_p(x), C.c_size_t(x.size))
+    return x
+
+
+def lpc_f32(r, n_coeffs):
+    """Returns (ac[n_coeffs + 1], kc[n_coeffs]) in f32 arithmetic."""
+    r = _f32(r)
+    ac, kc = np.empty(n_coeffs + 1, dtype=np.float32), np.empty(n_coeffs, dtype=np.float32)
+    lib().vbxo_lpc_f32(_p(r), C.c_size_t(n_coeffs), _p(ac), _p(kc))
+    return ac, kc
+
+
+def lpc_burg_f32(x, n_coeffs):
+    x = _f32(x)
+    out = np.zeros(n_coeffs, dtype=np.float32)
+    st = lib().vbxo_lpc_burg_f32(_p(x), C.c_size_t(x.size), C.c_size_t(n_coeffs), _p(out))
+    return st, out
+
+
+def mfcc_f32(x, num_coeffs, lo, hi, sr):
+    x = _f32(x)
+    out = np.zeros(num_coeffs, dtype=np.float32)
+    st = lib().vbxo_mfcc_f32(_p(x), C.c_size_t(x.size), C.c_size_t(num_coeffs), C.c_double(lo), C.c_double(hi),
+                             C.c_double(sr), _p(out))
+    return st, out
+
+
 def to_resonance(roots, sample_rate):
     roots = _c128(roots)
     out = np.zeros((max(roots.size, 1), 2), dtype=np.float64)

@@ -135,4 +135,11 @@ void vbxo_counters_get(vbxo_counters_t *out);
 #ifdef __cplusplus
 }
 #endif
+/* Sample = f32 instantiation of the slice traits (vbx_oracle_f32.c; parity unpinned: no reference test runs them) */
+void vbxo_autocorrelate_f32(const float *x, size_t n, float *coeffs, size_t n_lags);
+void vbxo_normalize_f32(float *x, size_t n);
+void vbxo_lpc_f32(const float *r, size_t n_coeffs, float *ac /* n_coeffs+1 */, float *kc /* n_coeffs or NULL */);
+int vbxo_lpc_burg_f32(const float *x, size_t n, size_t n_coeffs, float *coeffs);
+int vbxo_mfcc_f32(const float *x, size_t n, size_t num_coeffs, double lo, double hi, double sample_rate, float *out);
+
 #endif

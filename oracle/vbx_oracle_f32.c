@@ -11,6 +11,9 @@
 #include "vbx_oracle.h"
 
 #include <math.h>
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
 #include <stdlib.h>
 #include <string.h>
 
@@ -156,4 +159,124 @@ int vbxo_find_roots_f32(const vbxo_c32 *p, size_t len, vbxo_c32 *roots, size_t *
     } else *n_roots = 0;
     free(other);
     return st;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Sample = f32 instantiation of the slice traits: the same statements as vbx_oracle.c with every
+ * value and every intermediate held in `float`, which is what the generic code monomorphised at T = f32 computes
+ * (src/periodic.rs:276-289 add_amp / mul_amp on f32; src/waves.rs:60-76; src/spectrum.rs:62-146; :401-441).
+ * The build uses -ffp-contract=off and no fast-math, so each operation rounds to f32 once, as in Rust.
+ * Parity unpinned by the reference: none of its tests instantiates these traits at f32.
+ * ------------------------------------------------------------------------------------------------------------------ */
+void vbxo_autocorrelate_f32(const float *x, size_t n, float *coeffs, size_t n_lags) {        /* periodic.rs:280-287 */
+    for (size_t lag = 0; lag < n_lags; lag++) {
+        float accum = x[0];
+        for (size_t i = 1; i + lag < n; i++) accum = accum + x[i] * x[i + lag];
+        coeffs[lag] = accum;
+    }
+}
+
+void vbxo_normalize_f32(float *x, size_t n) {                                                  /* waves.rs:44-75 */
+    float m = (x[0] < 0.0f) ? x[0] * -1.0f : x[0];
+    for (size_t i = 1; i < n; i++) {
+        float a = (x[i] < 0.0f) ? x[i] * -1.0f : x[i];
+        if (a > m) m = a;
+    }
+    float scale = 1.0f / m;
+    for (size_t i = 0; i < n; i++) x[i] = x[i] * scale;
+}
+
+void vbxo_lpc_f32(const float *r, size_t n_coeffs, float *ac, float *kc_out) {                 /* spectrum.rs:62-92 */
+    float kc[64], tmp[64];
+    for (size_t i = 0; i < n_coeffs + 1; i++) ac[i] = 0.0f;
+    for (size_t i = 0; i < n_coeffs; i++) { kc[i] = 0.0f; tmp[i] = 0.0f; }
+    float err = r[0];
+    ac[0] = 1.0f;
+    for (size_t i = 1; i < n_coeffs + 1; i++) {
+        float acc = r[i];
+        for (size_t j = 1; j < i; j++) acc = acc + (ac[j] * r[i - j]);
+        kc[i - 1] = -acc / err;
+        ac[i] = kc[i - 1];
+        for (size_t j = 0; j < n_coeffs; j++) tmp[j] = ac[j];
+        for (size_t j = 1; j < i; j++) ac[j] = ac[j] + (kc[i - 1] * tmp[i - j]);
+        err = err * (1.0f - (kc[i - 1] * kc[i - 1]));
+    }
+    if (kc_out) for (size_t i = 0; i < n_coeffs; i++) kc_out[i] = kc[i];
+}
+
+int vbxo_lpc_burg_f32(const float *x, size_t n, size_t n_coeffs, float *coeffs) {              /* spectrum.rs:101-146 */
+    if (n < 2) return 4;
+    float *b1 = (float *)calloc(n, sizeof(float));
+    float *b2 = (float *)calloc(n, sizeof(float));
+    float *aa = (float *)calloc(n_coeffs ? n_coeffs : 1, sizeof(float));
+    int status = 0;
+    b1[0] = x[0];
+    b2[n - 2] = x[n - 1];
+    for (size_t j = 2; j < n; j++) { b1[j - 1] = x[j - 1]; b2[j - 2] = x[j - 1]; }
+    for (size_t i = 1; i < n_coeffs + 1; i++) {
+        float num = 0.0f, denum = 0.0f;
+        for (size_t j = 1; j + i < n + 1; j++) {
+            num = num + b1[j - 1] * b2[j - 1];
+            denum = denum + b1[j - 1] * b1[j - 1] + b2[j - 1] * b2[j - 1];     /* powi(2) == x * x */
+        }
+        if (denum <= 0.0f) { status = 1; break; }
+        coeffs[i - 1] = 2.0f * num / denum;
+        for (size_t j = 1; j < i; j++) coeffs[j - 1] = aa[j - 1] - coeffs[i - 1] * aa[i - j - 1];
+        if (i < n_coeffs) {
+            for (size_t j = 1; j < i + 1; j++) aa[j - 1] = coeffs[j - 1];
+            for (size_t j = 1; j + i < n; j++) {
+                b1[j - 1] = b1[j - 1] - aa[i - 1] * b2[j - 1];
+                b2[j - 1] = b2[j] - aa[i - 1] * b1[j];
+            }
+        }
+    }
+    if (status == 0) for (size_t c = 0; c < n_coeffs; c++) coeffs[c] = coeffs[c] * -1.0f;
+    free(b1); free(b2); free(aa);
+    return status;
+}
+
+/* MFCC at T = f32 (spectrum.rs:410-441): the transform runs on Complex<f32> (rustfft, un-vendored: the mathematical DFT is
+ * evaluated in double and each bin rounded to f32, i.e. an ideally rounded f32 transform); norm_sqr / norm in f32; the
+ * filter sums, the log and the clamp in f64 (`to_f64`, `0f64` fold); the energies are rounded to f32 (`T::from_f64`) and
+ * dct() on &[f32] widens each energy, accumulates in f64 and rounds the doubled sum to f32 once. */
+void vbxo_mfcc_bins(size_t n, size_t num_coeffs, double lo, double hi, double sample_rate, size_t *bins);
+int vbxo_mfcc_f32(const float *x, size_t n, size_t num_coeffs, double lo, double hi, double sample_rate, float *out) {
+    size_t *bins = (size_t *)malloc((num_coeffs + 2) * sizeof(size_t));
+    vbxo_mfcc_bins(n, num_coeffs, lo, hi, sample_rate, bins);
+    size_t top = bins[num_coeffs + 1];
+    if (top > n) { free(bins); return 4; }
+    float *sre = (float *)calloc(n, sizeof(float)), *sim = (float *)calloc(n, sizeof(float));
+    double *ct = (double *)malloc(n * sizeof(double)), *st = (double *)malloc(n * sizeof(double));
+    for (size_t i = 0; i < n; i++) { double ang = 2.0 * M_PI * (double)i / (double)n; ct[i] = cos(ang); st[i] = sin(ang); }
+    for (size_t k = bins[0]; k < top; k++) {
+        double re = 0., im = 0.;
+        size_t idx = 0;
+        for (size_t i = 0; i < n; i++) { re += (double)x[i] * ct[idx]; im -= (double)x[i] * st[idx]; idx += k; if (idx >= n) idx -= n; }
+        sre[k] = (float)re; sim[k] = (float)im;
+    }
+    free(ct); free(st);
+    float *energies = (float *)malloc(num_coeffs * sizeof(float));
+    for (size_t wdx = 0; wdx < num_coeffs; wdx++) {
+        size_t w0 = bins[wdx], w1 = bins[wdx + 1], w2 = bins[wdx + 2];
+        size_t up = w1 - w0, down = w2 - w1;
+        double up_sum = 0., down_sum = 0.;
+        for (size_t i = 0, bin = w0; bin < w1; i++, bin++) {
+            float ns = sre[bin] * sre[bin] + sim[bin] * sim[bin];                    /* Complex<f32>::norm_sqr */
+            up_sum = up_sum + fabs((double)ns) * ((double)i / (double)up);
+        }
+        for (size_t i = 0, bin = w1; bin < w2; i++, bin++) {
+            float nm = hypotf(sre[bin], sim[bin]);                                   /* Complex<f32>::norm */
+            down_sum = down_sum + fabs((double)nm) * ((double)i / (double)down);
+        }
+        double lg = log10(up_sum + down_sum);
+        energies[wdx] = (float)((isnan(lg) || lg < 1.0e-10) ? 1.0e-10 : lg);
+    }
+    for (size_t k = 0; k < num_coeffs; k++) {                                        /* dct_mut on &[f32], spectrum.rs:391-398 */
+        double acc = 0.;                                                             /* fold(0., ..): f64 accumulator */
+        for (size_t i = 0; i < num_coeffs; i++)
+            acc = acc + (double)energies[i] * cos(M_PI * (double)k * (2. * (double)i + 1.) / (2. * (double)num_coeffs));
+        out[k] = (float)(2. * acc);                                                  /* T::from_f64 */
+    }
+    free(bins); free(sre); free(sim); free(energies);
+    return 0;
 }

@@ -14,24 +14,26 @@
 
 namespace vbx {
 
-template <int G, int EPL>
+// T: Sample type of the frames and of the coefficients (double; float = the f32 instantiation: widened on load, the
+// windowed product rounded to T first, the recursion in f64, one rounding to T on the store).
+template <int G, int EPL, typename T>
 __global__ __launch_bounds__(64) void burg_kernel(
-    const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
-    int p, double *__restrict__ out, int32_t *__restrict__ status) {
+    const T *__restrict__ x, long n_frames, int n, long stride, const T *__restrict__ window,
+    int p, T *__restrict__ out, int32_t *__restrict__ status) {
     constexpr int NG = 64 / G;
     static_assert(G >= VBX_MAX_LPC_ORDER_K || G == 16, "one coefficient per lane of the group");
     const int lane = lane_id();
     const int gid = lane / G, lig = lane % G;
     const long f = (long)blockIdx.x * NG + gid;
     const bool have = f < n_frames;
-    const double *xf = x + (have ? f : 0) * stride;
+    const T *xf = x + (have ? f : 0) * stride;
 
     double b1[EPL], b2[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; e++) {
         const int j = lig * EPL + e;
-        double v = (have && j < n) ? xf[j] : 0.0;
-        if (window != nullptr && j < n) v *= window[j];
+        double v = (have && j < n) ? (double)xf[j] : 0.0;
+        if (window != nullptr && j < n) v = (double)(T)(v * (double)window[j]);
         b1[e] = v;
     }
     const bool last_lane = (lig == G - 1);          // its "next lane" belongs to another frame
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(64) void burg_kernel(
         }
     }
     if (have) {
-        if (lig < p) out[f * (long)p + lig] = (st == 0) ? co * -1.0 : 0.0;   // :142-144
+        if (lig < p) out[f * (long)p + lig] = (T)((st == 0) ? co * -1.0 : 0.0);   // :142-144
         if (status != nullptr && lig == 0) status[f] = st;
     }
 }
@@ -110,11 +112,12 @@ bool burg_supported(int n, int p) {
 // orders above 16 need more than 16 lanes per frame (one coefficient per lane)
 static bool burg_small_groups_ok(int p) { return p <= 16; }
 
-void launch_burg(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
-                 int p, double *out, int32_t *status) {
+template <typename T>
+static void launch_burg_t(hipStream_t s, const T *x, long F, int n, long stride, const T *window,
+                          int p, T *out, int32_t *status) {
     dim3 b(64);
-#define VBX_BURG(GG, E)                                                                                   \
-    hipLaunchKernelGGL((burg_kernel<GG, E>), dim3((unsigned)((F + (64 / GG) - 1) / (64 / GG))), b, 0, s, \
+#define VBX_BURG(GG, E)                                                                                      \
+    hipLaunchKernelGGL((burg_kernel<GG, E, T>), dim3((unsigned)((F + (64 / GG) - 1) / (64 / GG))), b, 0, s, \
                        x, F, n, stride, window, p, out, status)
     const bool g16 = burg_small_groups_ok(p);
     if (g16 && n <= 16 * 8) VBX_BURG(16, 8);
@@ -125,6 +128,15 @@ void launch_burg(hipStream_t s, const double *x, long F, int n, long stride, con
     else if (n <= 64 * 32) VBX_BURG(64, 32);
     else VBX_BURG(64, 64);
 #undef VBX_BURG
+}
+
+void launch_burg(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
+                 int p, double *out, int32_t *status) {
+    launch_burg_t<double>(s, x, F, n, stride, window, p, out, status);
+}
+void launch_burg_f32(hipStream_t s, const float *x, long F, int n, long stride, const float *window,
+                     int p, float *out, int32_t *status) {
+    launch_burg_t<float>(s, x, F, n, stride, window, p, out, status);
 }
 
 }  // namespace vbx

@@ -161,4 +161,33 @@ void launch_preemphasis(hipStream_t s, const double *x, long F, int n, long stri
     hipLaunchKernelGGL(preemphasis_kernel, dim3((unsigned)F), dim3(64), lds, s, x, F, n, stride, c, out);
 }
 
+// f32 instantiation helpers: the frames of a (strided, optionally windowed) f32 batch as a dense f64 batch -- the windowed
+// product rounded to f32 first, as the reference's Windower<f32> produces it -- and f64 result rows rounded to f32.
+__global__ void widen_frames_kernel(const float *__restrict__ x, long n_frames, int n, long stride,
+                                    const float *__restrict__ window, double *__restrict__ out) {
+    const long total = n_frames * (long)n;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long t = e / n; const int i = (int)(e - t * n);
+        float v = x[t * stride + i];
+        if (window != nullptr) v = v * window[i];
+        out[e] = (double)v;
+    }
+}
+
+__global__ void narrow_kernel(const double *__restrict__ in, long count, float *__restrict__ out) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long)gridDim.x * blockDim.x) out[e] = (float)in[e];
+}
+
+void launch_widen_frames(hipStream_t s, const float *x, long F, int n, long stride, const float *window, double *out) {
+    long blocks = (F * (long)n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(widen_frames_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, F, n, stride, window, out);
+}
+
+void launch_narrow(hipStream_t s, const double *in, long count, float *out) {
+    long blocks = (count + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(narrow_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, count, out);
+}
+
 }  // namespace vbx

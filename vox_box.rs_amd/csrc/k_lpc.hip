@@ -49,13 +49,16 @@ constexpr int AC_FPW = 16;   // frames per wavefront: short enough that the last
 //   per FPW frames  lane f runs Levinson-Durbin for frame f (one division chain per FPW frames, not
 //               per frame) and the [FPW, NL] result blocks leave through LDS as coalesced stores.
 // Two frames are kept in flight ahead of the one being reduced.
-template <int EPL, int NL>
+// T: the Sample type of the frames and of the outputs (double, or float for the f32 instantiation of the traits: the
+// samples are widened on load, the windowed product is rounded to T first -- the reference's Windower hands the traits
+// frames of T -- all sums run in f64 and the results are rounded to T once, on the store).
+template <int EPL, int NL, typename T>
 __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
-    const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
-    int n_lags, int normalize, double *__restrict__ out_r, double *__restrict__ out_lpc, long lpc_ld) {
+    const T *__restrict__ x, long n_frames, int n, long stride, const T *__restrict__ window,
+    int n_lags, int normalize, T *__restrict__ out_r, T *__restrict__ out_lpc, long lpc_ld) {
     constexpr int FPW = AC_FPW;
     constexpr int TS = NL | 1;                       // odd row stride: conflict-free column reads
-    __shared__ double T[64 * TS];                    // per-frame transpose buffer [lane][lag]
+    __shared__ double TR[64 * TS];                   // per-frame transpose buffer [lane][lag]
     __shared__ double R[FPW * TS];                   // results of the wave's frames [frame][lag]
     const int lane = lane_id();
     const long f0 = (long)blockIdx.x * FPW;
@@ -66,17 +69,17 @@ __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
 #pragma unroll
     for (int e = 0; e < EPL; e++) {
         const int i = lane * EPL + e;
-        wreg[e] = (i < n) ? ((window != nullptr) ? window[i] : 1.0) : 0.0;
+        wreg[e] = (i < n) ? ((window != nullptr) ? (double)window[i] : 1.0) : 0.0;
     }
     const bool full = (n == 64 * EPL);               // uniform: unguarded, mergeable loads
     auto load_frame = [&](int g, double (&dst)[EPL]) {
-        const double *xf = x + (f0 + g) * stride + lane * EPL;
+        const T *xf = x + (f0 + g) * stride + lane * EPL;
         if (full) {
 #pragma unroll
-            for (int e = 0; e < EPL; e++) dst[e] = xf[e];
+            for (int e = 0; e < EPL; e++) dst[e] = (double)xf[e];
         } else {
 #pragma unroll
-            for (int e = 0; e < EPL; e++) dst[e] = (lane * EPL + e < n) ? xf[e] : 0.0;
+            for (int e = 0; e < EPL; e++) dst[e] = (lane * EPL + e < n) ? (double)xf[e] : 0.0;
         }
     };
     double cur[EPL], nxt[EPL], nx2[EPL];
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
         // ext[0..EPL) own samples, ext[EPL..EPL+NL-1) the following samples (from lanes l+1, l+2, ..)
         double ext[EPL + NL - 1];
 #pragma unroll
-        for (int e = 0; e < EPL; e++) ext[e] = cur[e] * wreg[e];
+        for (int e = 0; e < EPL; e++) ext[e] = (double)(T)(cur[e] * wreg[e]);
 #pragma unroll
         for (int e = EPL; e < EPL + NL - 1; e++) ext[e] = from_next_lane(ext[e - EPL]);
         double part[NL];
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
             }
         }
 #pragma unroll
-        for (int lag = 0; lag < NL; lag++) T[lane * TS + lag] = part[lag];
+        for (int lag = 0; lag < NL; lag++) TR[lane * TS + lag] = part[lag];
         wave_sync();
 #pragma unroll
         for (int lbase = 0; lbase < NL; lbase += 16) {   // 16 lags per sweep (4 lanes per lag)
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
             double tot = 0.0;
             if (rl < NL) {
 #pragma unroll
-                for (int t = 0; t < 16; t++) tot += T[(red_part * 16 + t) * TS + rl];
+                for (int t = 0; t < 16; t++) tot += TR[(red_part * 16 + t) * TS + rl];
             }
             tot += dpp_f64<DPP_QUAD_XOR1>(tot);
             tot += dpp_f64<0x4E>(tot);               // quad_perm [2,3,0,1]
@@ -145,10 +148,10 @@ __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
         wave_sync();
     }
     if (out_r != nullptr) {          // [nf, n_lags] block, contiguous in the output
-        double *o = out_r + f0 * (long)n_lags;
+        T *o = out_r + f0 * (long)n_lags;
         for (int idx = lane; idx < nf * n_lags; idx += 64) {
             const int fr = idx / n_lags, k = idx - fr * n_lags;
-            o[idx] = R[fr * TS + k];
+            o[idx] = (T)R[fr * TS + k];
         }
     }
     if (out_lpc != nullptr) {        // only instantiated/called with n_lags == NL
@@ -158,10 +161,10 @@ __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
 #pragma unroll
         for (int k = 0; k < NL; k++) R[lane * TS + k] = ac[k];
         wave_sync();
-        double *o = out_lpc + f0 * lpc_ld;       // rows lpc_ld doubles apart (NL when dense)
+        T *o = out_lpc + f0 * lpc_ld;            // rows lpc_ld elements apart (NL when dense)
         for (int idx = lane; idx < nf * NL; idx += 64) {
             const int fr = idx / NL, k = idx - fr * NL;
-            o[fr * lpc_ld + k] = R[fr * TS + k];
+            o[fr * lpc_ld + k] = (T)R[fr * TS + k];
         }
     }
 }
@@ -170,87 +173,91 @@ __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
 // Many-lag path (n_lags up to frame_len): frame staged in LDS as the padded image of vbx_autocorr.hpp, lags on the
 // FP64 matrix cores, 256 per tile; only the tiles that hold requested lags are computed.
 // ------------------------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(64) void autocorr_tiles_kernel(
-    const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
-    int n_lags, double *__restrict__ out) {
+    const T *__restrict__ x, long n_frames, int n, long stride, const T *__restrict__ window,
+    int n_lags, T *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const long f = blockIdx.x;
     if (f >= n_frames) return;
     const int lane = lane_id();
-    const double *xf = x + f * stride;
+    const T *xf = x + f * stride;
     double *zs = smem;
     const int total = ac_mf_lds_doubles(n);
     for (int p = lane; p < total; p += 64) zs[p] = 0.0;
     wave_sync();
     for (int i = lane; i < n; i += 64) {
-        double v = xf[i];
-        if (window != nullptr) v *= window[i];
+        double v = (double)xf[i];
+        if (window != nullptr) v = (double)(T)(v * (double)window[i]);
         zs[ac_mf_phys(i)] = v;
     }
     wave_sync();
     const double x0 = zs[ac_mf_phys(0)];
-    double *o = out + f * (long)n_lags;
+    T *o = out + f * (long)n_lags;
     autocorr_mfma(zs, n, n_lags, [&](int, int lag, double s) {
-        if (lag < n_lags) o[lag] = (s - x0 * zs[ac_mf_phys(lag < n ? lag : n)]) + x0;   // lags >= n: empty sum, r = x0
+        if (lag < n_lags) o[lag] = (T)((s - x0 * zs[ac_mf_phys(lag < n ? lag : n)]) + x0);   // lags >= n: empty sum, r = x0
     });
 }
 
 // Normalize::normalize on rows (src/waves.rs:68-75): one wavefront per row.
-__global__ __launch_bounds__(64) void normalize_rows_kernel(double *__restrict__ data, long n_rows, int n) {
+template <typename T>
+__global__ __launch_bounds__(64) void normalize_rows_kernel(T *__restrict__ data, long n_rows, int n) {
     const long row = blockIdx.x;
     if (row >= n_rows) return;
     const int lane = lane_id();
-    double *d = data + row * (long)n;
+    T *d = data + row * (long)n;
     // max_amplitude: fold keeps acc unless amp is strictly greater (NaN never wins)
     double m = -1.0;
-    for (int i = lane; i < n; i += 64) { double a = fabs(d[i]); m = (a > m) ? a : m; }
+    for (int i = lane; i < n; i += 64) { double a = fabs((double)d[i]); m = (a > m) ? a : m; }
     m = wave_max(m);
-    const double scale = 1.0 / m;
+    const T scale = (T)1 / (T)m;                          // identity / max in the Sample's own float type (:69-71)
     for (int i = lane; i < n; i += 64) d[i] = d[i] * scale;
 }
 
 // LPC::lpc on autocorrelation rows: one thread per row (src/spectrum.rs:63-92).
 // out_kc (optional, [rows, p]): the reflection coefficients lpc_mut leaves in its `kc` argument (:74).
-__global__ void levinson_rows_kernel(const double *__restrict__ r, long n_rows, long r_stride, int p,
-                                     double *__restrict__ out, long out_ld, double *__restrict__ out_kc) {
+template <typename T>
+__global__ void levinson_rows_kernel(const T *__restrict__ r, long n_rows, long r_stride, int p,
+                                     T *__restrict__ out, long out_ld, T *__restrict__ out_kc) {
     const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
-    const double *rr = r + row * r_stride;
-    double *ac = out + row * out_ld;
-    double tmp[VBX_MAX_LPC_ORDER_K + 1];
-    double err = rr[0];
+    const T *rr = r + row * r_stride;
+    T *aco = out + row * out_ld;
+    double ac[VBX_MAX_LPC_ORDER_K + 1], tmp[VBX_MAX_LPC_ORDER_K + 1];
+    double err = (double)rr[0];
     ac[0] = 1.0;
     for (int i = 1; i <= p; i++) ac[i] = 0.0;
     for (int i = 1; i <= p; i++) {
-        double acc = rr[i];
-        for (int j = 1; j < i; j++) acc = acc + ac[j] * rr[i - j];
+        double acc = (double)rr[i];
+        for (int j = 1; j < i; j++) acc = acc + ac[j] * (double)rr[i - j];
         const double k = -acc / err;
         ac[i] = k;
-        if (out_kc != nullptr) out_kc[row * (long)p + (i - 1)] = k;
+        if (out_kc != nullptr) out_kc[row * (long)p + (i - 1)] = (T)k;
         for (int j = 0; j < p; j++) tmp[j] = ac[j];
         for (int j = 1; j < i; j++) ac[j] = ac[j] + k * tmp[i - j];
         err = err * (1.0 - k * k);
     }
+    for (int i = 0; i <= p; i++) aco[i] = (T)ac[i];
 }
 
 // ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
 
-template <int EPL, int NL>
-static void launch_fewlags(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
-                           int n_lags, int normalize, double *out_r, double *out_lpc, long lpc_ld) {
-    hipLaunchKernelGGL((autocorr_fewlags_kernel<EPL, NL>), dim3((unsigned)((F + AC_FPW - 1) / AC_FPW)), dim3(64), 0, s,
+template <int EPL, int NL, typename T>
+static void launch_fewlags(hipStream_t s, const T *x, long F, int n, long stride, const T *window,
+                           int n_lags, int normalize, T *out_r, T *out_lpc, long lpc_ld) {
+    hipLaunchKernelGGL((autocorr_fewlags_kernel<EPL, NL, T>), dim3((unsigned)((F + AC_FPW - 1) / AC_FPW)), dim3(64), 0, s,
                        x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
 }
 
-template <int NL>
-static bool dispatch_epl(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
-                         int n_lags, int normalize, double *out_r, double *out_lpc, long lpc_ld) {
-    if (n <= 64 * 8) launch_fewlags<8, NL>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
-    else if (n <= 64 * 16) launch_fewlags<16, NL>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
-    else if (n <= 64 * 20) launch_fewlags<20, NL>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
-    else if (n <= 64 * 32) launch_fewlags<32, NL>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
+template <int NL, typename T>
+static bool dispatch_epl(hipStream_t s, const T *x, long F, int n, long stride, const T *window,
+                         int n_lags, int normalize, T *out_r, T *out_lpc, long lpc_ld) {
+    if (n <= 64 * 8) launch_fewlags<8, NL, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
+    else if (n <= 64 * 16) launch_fewlags<16, NL, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
+    else if (n <= 64 * 20) launch_fewlags<20, NL, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
+    else if (n <= 64 * 32) launch_fewlags<32, NL, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
     else return false;
     return true;
 }
@@ -262,37 +269,60 @@ bool fewlags_supported(int n, int n_lags, bool want_lpc) {
     return n_lags <= 17;
 }
 
-void launch_autocorr_fewlags(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
-                             int n_lags, int normalize, double *out_r, double *out_lpc, long lpc_ld) {
+template <typename T>
+static void launch_autocorr_fewlags_t(hipStream_t s, const T *x, long F, int n, long stride, const T *window,
+                                      int n_lags, int normalize, T *out_r, T *out_lpc, long lpc_ld) {
     if (lpc_ld <= 0) lpc_ld = n_lags;
     if (out_lpc != nullptr) {
         switch (n_lags) {
-            case 9:  dispatch_epl<9>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld); break;
-            case 11: dispatch_epl<11>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld); break;
-            case 13: dispatch_epl<13>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld); break;
-            case 17: dispatch_epl<17>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld); break;
+            case 9:  dispatch_epl<9, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld); break;
+            case 11: dispatch_epl<11, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld); break;
+            case 13: dispatch_epl<13, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld); break;
+            case 17: dispatch_epl<17, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld); break;
         }
         return;
     }
-    if (n_lags <= 9) dispatch_epl<9>(s, x, F, n, stride, window, n_lags, normalize, out_r, nullptr, lpc_ld);
-    else if (n_lags <= 13) dispatch_epl<13>(s, x, F, n, stride, window, n_lags, normalize, out_r, nullptr, lpc_ld);
-    else dispatch_epl<17>(s, x, F, n, stride, window, n_lags, normalize, out_r, nullptr, lpc_ld);
+    if (n_lags <= 9) dispatch_epl<9, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, (T *)nullptr, lpc_ld);
+    else if (n_lags <= 13) dispatch_epl<13, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, (T *)nullptr, lpc_ld);
+    else dispatch_epl<17, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, (T *)nullptr, lpc_ld);
+}
+
+void launch_autocorr_fewlags(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
+                             int n_lags, int normalize, double *out_r, double *out_lpc, long lpc_ld) {
+    launch_autocorr_fewlags_t<double>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
+}
+void launch_autocorr_fewlags_f32(hipStream_t s, const float *x, long F, int n, long stride, const float *window,
+                                 int n_lags, int normalize, float *out_r, float *out_lpc, long lpc_ld) {
+    launch_autocorr_fewlags_t<float>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
 }
 
 void launch_autocorr_tiles(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                            int n_lags, double *out) {
     const size_t lds = (size_t)ac_mf_lds_doubles(n) * sizeof(double);
-    hipLaunchKernelGGL(autocorr_tiles_kernel, dim3((unsigned)F), dim3(64), lds, s, x, F, n, stride, window, n_lags, out);
+    hipLaunchKernelGGL(autocorr_tiles_kernel<double>, dim3((unsigned)F), dim3(64), lds, s, x, F, n, stride, window, n_lags, out);
+}
+void launch_autocorr_tiles_f32(hipStream_t s, const float *x, long F, int n, long stride, const float *window,
+                               int n_lags, float *out) {
+    const size_t lds = (size_t)ac_mf_lds_doubles(n) * sizeof(double);
+    hipLaunchKernelGGL(autocorr_tiles_kernel<float>, dim3((unsigned)F), dim3(64), lds, s, x, F, n, stride, window, n_lags, out);
 }
 
 void launch_normalize_rows(hipStream_t s, double *data, long rows, int n) {
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)rows), dim3(64), 0, s, data, rows, n);
+    hipLaunchKernelGGL(normalize_rows_kernel<double>, dim3((unsigned)rows), dim3(64), 0, s, data, rows, n);
+}
+void launch_normalize_rows_f32(hipStream_t s, float *data, long rows, int n) {
+    hipLaunchKernelGGL(normalize_rows_kernel<float>, dim3((unsigned)rows), dim3(64), 0, s, data, rows, n);
 }
 
 void launch_levinson_rows(hipStream_t s, const double *r, long rows, long r_stride, int p, double *out, long out_ld,
                           double *out_kc) {
     const int bs = 64;
-    hipLaunchKernelGGL(levinson_rows_kernel, dim3((unsigned)((rows + bs - 1) / bs)), dim3(bs), 0, s, r, rows, r_stride, p, out, out_ld, out_kc);
+    hipLaunchKernelGGL(levinson_rows_kernel<double>, dim3((unsigned)((rows + bs - 1) / bs)), dim3(bs), 0, s, r, rows, r_stride, p, out, out_ld, out_kc);
+}
+void launch_levinson_rows_f32(hipStream_t s, const float *r, long rows, long r_stride, int p, float *out, long out_ld,
+                              float *out_kc) {
+    const int bs = 64;
+    hipLaunchKernelGGL(levinson_rows_kernel<float>, dim3((unsigned)((rows + bs - 1) / bs)), dim3(bs), 0, s, r, rows, r_stride, p, out, out_ld, out_kc);
 }
 
 }  // namespace vbx

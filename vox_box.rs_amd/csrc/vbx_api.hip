@@ -37,7 +37,7 @@ struct vbx_ctx {
     std::string arch;
     int cu_count = 0;
     // workspaces (grown on demand, never shrunk)
-    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_UNSURE, WS_N };
+    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_UNSURE, WS_F32_IN, WS_F32_OUT, WS_N };
     void *ws[WS_N] = {nullptr};
     size_t ws_bytes[WS_N] = {0};
     // cached device tables
@@ -1253,6 +1253,126 @@ int vbx_analyze_frames_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_
     if (rc != VBX_SUCCESS) return rc;
     VBX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));       // join: the records are complete on ctx's stream
     return VBX_SUCCESS;
+}
+
+// ---- Sample = f32 ----------------------------------------------------------
+// The traits are generic over the Sample type (src/periodic.rs:276-289 `T: Sample`, src/spectrum.rs:56 `T: Float`,
+// :401-409).  The f32 instantiation takes float frames and returns float results; samples are widened on load, the
+// arithmetic runs in f64 and every result is rounded to f32 once -- at least as accurate as the reference's own f32
+// folds, whose rounding (not ours) bounds the agreement (tests/test_gpu_f32.py).
+
+int vbx_window_table_f32(int kind, size_t n, float *h_out) {
+    if (!h_out || n == 0) return fail(nullptr, VBX_E_INVALID, "vbx_window_table_f32: bad argument");
+    std::vector<double> t(n);
+    int rc = vbx_window_table_f64(kind, n, t.data());
+    if (rc != VBX_SUCCESS) return rc;
+    for (size_t i = 0; i < n; i++) h_out[i] = (float)t[i];
+    return VBX_SUCCESS;
+}
+
+int vbx_autocorrelate_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
+                          size_t stride, const float *window, size_t n_lags, float *out) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_REQUIRE(ctx, out != nullptr, "null output");
+    VBX_REQUIRE(ctx, n_lags >= 1 && n_lags <= frame_len, "n_lags must be in [1, frame_len] (the reference panics beyond)");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    if (fewlags_supported((int)frame_len, (int)n_lags, false)) {
+        Prof p(ctx, "autocorr_fewlags_f32");
+        launch_autocorr_fewlags_f32(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_lags, 0, out, nullptr);
+    } else {
+        Prof p(ctx, "autocorr_tiles_f32");
+        launch_autocorr_tiles_f32(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_lags, out);
+    }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_normalize_f32(vbx_ctx *ctx, float *data, size_t n_rows, size_t n) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    if (n_rows == 0) return VBX_SUCCESS;
+    VBX_REQUIRE(ctx, data && n >= 1 && n <= 0x7fffffff && n_rows <= 0x7fffffff, "bad argument");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    { Prof p(ctx, "normalize_rows_f32"); launch_normalize_rows_f32(ctx->stream, data, (long)n_rows, (int)n); }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_lpc_mut_f32(vbx_ctx *ctx, const float *r, size_t n_frames, size_t r_stride, size_t n_coeffs, float *out_ac,
+                    float *out_kc) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    if (n_frames == 0) return VBX_SUCCESS;
+    VBX_REQUIRE(ctx, r && out_ac, "null argument");
+    VBX_REQUIRE(ctx, n_coeffs >= 1 && n_coeffs <= VBX_MAX_LPC_ORDER && r_stride >= n_coeffs + 1, "bad order / stride");
+    VBX_REQUIRE(ctx, n_frames <= 0x7fffffffull, "too many rows");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    { Prof p(ctx, "levinson_rows_f32"); launch_levinson_rows_f32(ctx->stream, r, (long)n_frames, (long)r_stride, (int)n_coeffs, out_ac, (long)n_coeffs + 1, out_kc); }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_autocorr_lpc_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
+                         size_t stride, const float *window, size_t n_coeffs, int normalize,
+                         float *out_r, float *out_lpc) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_REQUIRE(ctx, out_r || out_lpc, "both outputs null");
+    VBX_REQUIRE(ctx, n_coeffs >= 1 && n_coeffs <= VBX_MAX_LPC_ORDER && n_coeffs + 1 <= frame_len, "bad order");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    const int n_lags = (int)n_coeffs + 1;
+    hipStream_t st = ctx->stream;
+    if (fewlags_supported((int)frame_len, n_lags, out_lpc != nullptr)) {
+        Prof p(ctx, "autocorr_lpc_f32", st);
+        launch_autocorr_fewlags_f32(st, x, (long)n_frames, (int)frame_len, (long)stride, window, n_lags, normalize, out_r, out_lpc, (long)n_lags);
+        return check_launch(ctx, __func__);
+    }
+    float *r = out_r;
+    if (!r) {
+        void *w = nullptr;
+        rc = ws_get(ctx, vbx_ctx::WS_F32_OUT, n_frames * (size_t)n_lags * sizeof(float), &w);
+        if (rc != VBX_SUCCESS) return rc;
+        r = (float *)w;
+    }
+    if (fewlags_supported((int)frame_len, n_lags, false)) {
+        Prof p(ctx, "autocorr_fewlags_f32", st);
+        launch_autocorr_fewlags_f32(st, x, (long)n_frames, (int)frame_len, (long)stride, window, n_lags, 0, r, nullptr);
+    } else {
+        Prof p(ctx, "autocorr_tiles_f32", st);
+        launch_autocorr_tiles_f32(st, x, (long)n_frames, (int)frame_len, (long)stride, window, n_lags, r);
+    }
+    if (normalize) { Prof p(ctx, "normalize_rows_f32", st); launch_normalize_rows_f32(st, r, (long)n_frames, n_lags); }
+    if (out_lpc) { Prof p(ctx, "levinson_rows_f32", st); launch_levinson_rows_f32(st, r, (long)n_frames, n_lags, (int)n_coeffs, out_lpc, (long)n_lags); }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_lpc_burg_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
+                     size_t stride, const float *window, size_t n_coeffs, float *out, int32_t *status) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_REQUIRE(ctx, out != nullptr, "null output");
+    VBX_REQUIRE(ctx, burg_supported((int)frame_len, (int)n_coeffs), "frame_len must be in [2, 4096], order in [1, 30]");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    { Prof p(ctx, "burg_f32"); launch_burg_f32(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_coeffs, out, status); }
+    return check_launch(ctx, __func__);
+}
+
+// MFCC is bound by its transforms, not by HBM: the f32 frames are widened into a dense f64 batch (windowed product
+// rounded to f32 first) and take the f64 kernels; the coefficients are rounded to f32 on the way out.
+int vbx_mfcc_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len, size_t stride,
+                 const float *window, size_t num_coeffs, double lo_hz, double hi_hz,
+                 double sample_rate, float *out, int32_t *status) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_REQUIRE(ctx, out != nullptr && num_coeffs >= 1, "bad argument");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    void *wi = nullptr, *wo = nullptr;
+    rc = ws_get(ctx, vbx_ctx::WS_F32_IN, n_frames * frame_len * sizeof(double), &wi);
+    if (rc != VBX_SUCCESS) return rc;
+    rc = ws_get(ctx, vbx_ctx::WS_F32_OUT, n_frames * num_coeffs * sizeof(double), &wo);
+    if (rc != VBX_SUCCESS) return rc;
+    { Prof p(ctx, "widen_frames"); launch_widen_frames(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, (double *)wi); }
+    rc = run_mfcc(ctx, ctx->stream, (const double *)wi, n_frames, frame_len, frame_len, nullptr, num_coeffs, lo_hz, hi_hz,
+                  sample_rate, (double *)wo, num_coeffs, status);
+    if (rc != VBX_SUCCESS) return rc;
+    { Prof p(ctx, "narrow"); launch_narrow(ctx->stream, (const double *)wo, (long)(n_frames * num_coeffs), out); }
+    return check_launch(ctx, __func__);
 }
 
 // ---- bench utility ------------------------------------------------------------------------

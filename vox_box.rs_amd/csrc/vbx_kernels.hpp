@@ -87,6 +87,19 @@ struct spectral_launch_t {
 bool spectral_supported(int n, int lpc_order, int mfcc_nb, int mfcc_b_lo, int num_coeffs);
 void launch_analyze(hipStream_t s, const spectral_launch_t &L);
 
+// the f32 instantiation (Sample = f32): the same kernels with float frames and float outputs
+void launch_autocorr_fewlags_f32(hipStream_t s, const float *x, long F, int n, long stride, const float *window,
+                                 int n_lags, int normalize, float *out_r, float *out_lpc, long lpc_ld = 0);
+void launch_autocorr_tiles_f32(hipStream_t s, const float *x, long F, int n, long stride, const float *window,
+                               int n_lags, float *out);
+void launch_normalize_rows_f32(hipStream_t s, float *data, long rows, int n);
+void launch_levinson_rows_f32(hipStream_t s, const float *r, long rows, long r_stride, int p, float *out, long out_ld,
+                              float *out_kc = nullptr);
+void launch_burg_f32(hipStream_t s, const float *x, long F, int n, long stride, const float *window,
+                     int p, float *out, int32_t *status);
+void launch_widen_frames(hipStream_t s, const float *x, long F, int n, long stride, const float *window, double *out);
+void launch_narrow(hipStream_t s, const double *in, long count, float *out);
+
 // k_mfcc.hip
 bool mfcc_fits(int n, int nb);
 struct mfcc_plan_t { bool ok; int n1, n2, nc, tm; };     // two-stage DFT geometry: n = n1*n2, nc = padded stage-1 columns

@@ -135,6 +135,13 @@ def load_library():
         "vbx_pitch_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, dbl, dbl, dbl, dbl, sz, vp, vp, vp]),
         "vbx_lpc_f64": (C.c_int, [vp, vp, sz, sz, sz, vp]),
         "vbx_lpc_mut_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, vp]),
+        "vbx_window_table_f32": (C.c_int, [i32, sz, vp]),
+        "vbx_autocorrelate_f32": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, vp]),
+        "vbx_normalize_f32": (C.c_int, [vp, vp, sz, sz]),
+        "vbx_lpc_mut_f32": (C.c_int, [vp, vp, sz, sz, sz, vp, vp]),
+        "vbx_autocorr_lpc_f32": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, i32, vp, vp]),
+        "vbx_lpc_burg_f32": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, vp, vp]),
+        "vbx_mfcc_f32": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, dbl, dbl, dbl, vp, vp]),
         "vbx_autocorr_lpc_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, i32, vp, vp]),
         "vbx_lpc_burg_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, vp, vp]),
         "vbx_find_roots_c64": (C.c_int, [vp, vp, sz, sz, vp]),
@@ -659,6 +666,77 @@ class VoxBox:
         for v in list(bufs.values()) + [tmp]:
             if v is not None:
                 v.free()
+        return res
+
+    # -- Sample = f32: float frames in, float results out ---------------
+    def _frames32(self, x):
+        """Dense [F, N] float32 host batch -> device."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        assert x.ndim == 2
+        return self.to_device(x, np.float32), x.shape[0], x.shape[1]
+
+    def _win32(self, window):
+        return None if window is None else self.to_device(np.ascontiguousarray(window, dtype=np.float32), np.float32)
+
+    def autocorrelate_f32(self, x, n_lags, window=None):
+        d, F, N = self._frames32(x)
+        w = self._win32(window)
+        o = self.empty((F, n_lags), np.float32)
+        self._check(self.L.vbx_autocorrelate_f32(self.ctx, d.ptr, F, N, N, _ptr(w), n_lags, o.ptr))
+        r = o.numpy()
+        for b in (d, w, o):
+            if b is not None:
+                b.free()
+        return r
+
+    def normalize_f32(self, rows):
+        d, F, N = self._frames32(rows)
+        self._check(self.L.vbx_normalize_f32(self.ctx, d.ptr, F, N))
+        r = d.numpy()
+        d.free()
+        return r
+
+    def lpc_mut_f32(self, r, n_coeffs):
+        d, F, N = self._frames32(r)
+        o, k = self.empty((F, n_coeffs + 1), np.float32), self.empty((F, n_coeffs), np.float32)
+        self._check(self.L.vbx_lpc_mut_f32(self.ctx, d.ptr, F, N, n_coeffs, o.ptr, k.ptr))
+        res = (o.numpy(), k.numpy())
+        for b in (d, o, k):
+            b.free()
+        return res
+
+    def autocorr_lpc_f32(self, x, n_coeffs, normalize=False, window=None):
+        d, F, N = self._frames32(x)
+        w = self._win32(window)
+        r, a = self.empty((F, n_coeffs + 1), np.float32), self.empty((F, n_coeffs + 1), np.float32)
+        self._check(self.L.vbx_autocorr_lpc_f32(self.ctx, d.ptr, F, N, N, _ptr(w), n_coeffs, int(bool(normalize)), r.ptr, a.ptr))
+        res = (r.numpy(), a.numpy())
+        for b in (d, w, r, a):
+            if b is not None:
+                b.free()
+        return res
+
+    def lpc_praat_f32(self, x, n_coeffs, window=None):
+        d, F, N = self._frames32(x)
+        w = self._win32(window)
+        o, st = self.empty((F, n_coeffs), np.float32), self.empty(F, np.int32)
+        self._check(self.L.vbx_lpc_burg_f32(self.ctx, d.ptr, F, N, N, _ptr(w), n_coeffs, o.ptr, st.ptr))
+        res = (o.numpy(), st.numpy())
+        for b in (d, w, o, st):
+            if b is not None:
+                b.free()
+        return res
+
+    def mfcc_f32(self, x, num_coeffs, freq_bounds, sample_rate, window=None):
+        d, F, N = self._frames32(x)
+        w = self._win32(window)
+        o, st = self.empty((F, num_coeffs), np.float32), self.empty(F, np.int32)
+        self._check(self.L.vbx_mfcc_f32(self.ctx, d.ptr, F, N, N, _ptr(w), num_coeffs, freq_bounds[0], freq_bounds[1],
+                                        sample_rate, o.ptr, st.ptr))
+        res = (o.numpy(), st.numpy())
+        for b in (d, w, o, st):
+            if b is not None:
+                b.free()
         return res
 
     # -- the fused frame loop ---------------------------------------------------------
