@@ -213,8 +213,14 @@ __device__ __forceinline__ void levinson_regs(const double (&r)[P + 1], double (
 
 constexpr int SP_LPC_P = SPECTRAL_LPC_ORDER;
 
+// Two wavefronts per SIMD: the two transforms need ~230 registers.  At three (168 registers) 55 of them spill, which the
+// refinement's arithmetic hides in time (measured: the same frames/s) but which costs 36 KB of scratch traffic per
+// frame -- 46 KB against 10 KB of HBM traffic per frame (profiles/r02*_pmc_counters.json).
+#ifndef VBX_SPECTRAL_WAVES
+#define VBX_SPECTRAL_WAVES 2
+#endif
 template <bool LPC, bool MFCC>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void analyze_kernel(const spectral_args_t a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VBX_SPECTRAL_WAVES, VBX_SPECTRAL_WAVES))) void analyze_kernel(const spectral_args_t a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const long f = blockIdx.x;
     if (f >= a.n_frames) return;
@@ -351,7 +357,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             }
         }
         wave_sync();
-        mfcc_tail_m(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
+        if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
+        else mfcc_tail_m(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
         if (a.mfcc_status != nullptr && lane == 0) a.mfcc_status[f] = 0;
         wave_sync();
     }

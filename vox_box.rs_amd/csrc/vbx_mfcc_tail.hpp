@@ -38,4 +38,32 @@ __device__ __forceinline__ void mfcc_tail_m(const double *pu, const double *pd, 
     }
 }
 
+// The same tail with FOUR lanes per filter (num_coeffs <= 16): a filter's bins are dealt round-robin to its quad and the
+// partial sums meet in a quad reduction -- the widest filter spans ~80 bins, a serial chain of that length per frame
+// otherwise.  The association of the sums differs from the reference's left-to-right fold (a few ulp, tolerance 1e-6).
+// Must be called from converged code.
+__device__ __forceinline__ void mfcc_tail_q(const double *pu, const double *pd, double *en, const int32_t *bins,
+                                            const double *dct_table, int num_coeffs, int b_lo, int lane,
+                                            double *out_row) {
+    const int w = lane >> 2, sub = lane & 3;
+    const bool have = w < num_coeffs;
+    double up_sum = 0.0, down_sum = 0.0;
+    if (have) {
+        const int w0 = bins[w] - b_lo, w1 = bins[w + 1] - b_lo, w2 = bins[w + 2] - b_lo;
+        for (int b = w0 + sub; b < w1; b += 4) up_sum += pu[b];
+        for (int b = w1 + sub; b < w2; b += 4) down_sum += pd[b];
+    }
+    const double tot = group_sum<4>(up_sum + down_sum);
+    if (have && sub == 0) {
+        const double lg = log10(tot);
+        en[w] = (lg != lg || lg < 1.0e-10) ? 1.0e-10 : lg;    // f64::max(1e-10): NaN yields the other operand
+    }
+    wave_sync();
+    if (lane < num_coeffs) {                              // dct (:391-397)
+        double acc = 0.0;
+        for (int j = 0; j < num_coeffs; j++) acc = acc + en[j] * dct_table[lane * num_coeffs + j];
+        out_row[lane] = 2.0 * acc;
+    }
+}
+
 }  // namespace vbx
