@@ -19,13 +19,13 @@ namespace vbx {
 template <int G, int EPL, typename T>
 __global__ __launch_bounds__(64) void burg_kernel(
     const T *__restrict__ x, long n_frames, int n, long stride, const T *__restrict__ window,
-    int p, T *__restrict__ out, int32_t *__restrict__ status) {
+    int p, T *__restrict__ out, int32_t *__restrict__ status, const frame_map_t map) {
     constexpr int NG = 64 / G;
     static_assert(G >= VBX_MAX_LPC_ORDER_K || G == 16, "one coefficient per lane of the group");
     const int lane = lane_id();
     const int gid = lane / G, lig = lane % G;
-    const long f = (long)blockIdx.x * NG + gid;
-    const bool have = f < n_frames;
+    const long f = frame_map(map, (long)blockIdx.x * NG + gid, n_frames);
+    const bool have = f >= 0;
     const T *xf = x + (have ? f : 0) * stride;
 
     double b1[EPL], b2[EPL];
@@ -114,11 +114,12 @@ static bool burg_small_groups_ok(int p) { return p <= 16; }
 
 template <typename T>
 static void launch_burg_t(hipStream_t s, const T *x, long F, int n, long stride, const T *window,
-                          int p, T *out, int32_t *status) {
+                          int p, T *out, int32_t *status, frame_map_t map) {
     dim3 b(64);
-#define VBX_BURG(GG, E)                                                                                      \
-    hipLaunchKernelGGL((burg_kernel<GG, E, T>), dim3((unsigned)((F + (64 / GG) - 1) / (64 / GG))), b, 0, s, \
-                       x, F, n, stride, window, p, out, status)
+    const long items = frame_map_items(map, F);
+#define VBX_BURG(GG, E)                                                                                          \
+    hipLaunchKernelGGL((burg_kernel<GG, E, T>), dim3((unsigned)((items + (64 / GG) - 1) / (64 / GG))), b, 0, s, \
+                       x, F, n, stride, window, p, out, status, map)
     const bool g16 = burg_small_groups_ok(p);
     if (g16 && n <= 16 * 8) VBX_BURG(16, 8);
     else if (g16 && n <= 16 * 16) VBX_BURG(16, 16);
@@ -131,12 +132,12 @@ static void launch_burg_t(hipStream_t s, const T *x, long F, int n, long stride,
 }
 
 void launch_burg(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
-                 int p, double *out, int32_t *status) {
-    launch_burg_t<double>(s, x, F, n, stride, window, p, out, status);
+                 int p, double *out, int32_t *status, frame_map_t map) {
+    launch_burg_t<double>(s, x, F, n, stride, window, p, out, status, map);
 }
 void launch_burg_f32(hipStream_t s, const float *x, long F, int n, long stride, const float *window,
                      int p, float *out, int32_t *status) {
-    launch_burg_t<float>(s, x, F, n, stride, window, p, out, status);
+    launch_burg_t<float>(s, x, F, n, stride, window, p, out, status, frame_map_t{0, 0, 0});
 }
 
 }  // namespace vbx

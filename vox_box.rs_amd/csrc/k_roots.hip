@@ -244,11 +244,11 @@ __global__ void to_resonance_kernel(const cplx_t *__restrict__ roots, long n_row
 // resonances [32] sorted, zero padded.  One lane per frame.
 __global__ __launch_bounds__(ROOTS_BLOCK) void formant_resonances_kernel(
     const double *__restrict__ coeffs, long n_frames, int p, double sample_rate,
-    res_t *__restrict__ out_res, int32_t *__restrict__ out_count, int32_t *__restrict__ status) {
+    res_t *__restrict__ out_res, int32_t *__restrict__ out_count, int32_t *__restrict__ status, const frame_map_t map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     c64 *lds = reinterpret_cast<c64 *>(lds_raw);
-    const long f = (long)blockIdx.x * ROOTS_BLOCK + threadIdx.x;
-    const bool active = f < n_frames;
+    const long f = frame_map(map, (long)blockIdx.x * ROOTS_BLOCK + threadIdx.x, n_frames);
+    const bool active = f >= 0;
     const int len = p + 1;
     lds_poly co{lds + threadIdx.x};
     const long fr = active ? f : n_frames - 1;
@@ -313,10 +313,11 @@ void launch_to_resonance(hipStream_t s, const cplx_t *roots, long F, int n_roots
 }
 
 void launch_formant_resonances(hipStream_t s, const double *coeffs, long F, int p, double sample_rate,
-                               res_t *out_res, int32_t *out_count, int32_t *status) {
+                               res_t *out_res, int32_t *out_count, int32_t *status, frame_map_t map) {
     const size_t lds = (size_t)(p + 1) * ROOTS_BLOCK * sizeof(c64);
-    hipLaunchKernelGGL(formant_resonances_kernel, dim3((unsigned)((F + ROOTS_BLOCK - 1) / ROOTS_BLOCK)), dim3(ROOTS_BLOCK), lds, s,
-                       coeffs, F, p, sample_rate, out_res, out_count, status);
+    const long items = frame_map_items(map, F);
+    hipLaunchKernelGGL(formant_resonances_kernel, dim3((unsigned)((items + ROOTS_BLOCK - 1) / ROOTS_BLOCK)), dim3(ROOTS_BLOCK), lds, s,
+                       coeffs, F, p, sample_rate, out_res, out_count, status, map);
 }
 
 }  // namespace vbx

@@ -62,6 +62,8 @@ struct vbx_ctx {
     // second stream of vbx_analyze_frames_f64 (the formant chain runs beside the pitch kernel) + fork/join events
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t trk = nullptr;                            // the tracker's time slices (run_find_formants)
+    hipEvent_t ev_slice[8] = {nullptr}, ev_trk = nullptr;
     // pinned staging of the small host arrays (segment starts, initial estimates): the caller's arrays may be
     // freed on return, and an upload whose content has not changed since the last call is skipped
     void *stage[2] = {nullptr, nullptr};
@@ -110,6 +112,7 @@ int ws_get(vbx_ctx *ctx, int slot, size_t bytes, void **out) {
         if (ctx->ws[slot]) {
             VBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->side) VBX_HIP(ctx, hipStreamSynchronize(ctx->side));
+            if (ctx->trk) VBX_HIP(ctx, hipStreamSynchronize(ctx->trk));
             VBX_HIP(ctx, hipFree(ctx->ws[slot]));
             ctx->ws[slot] = nullptr; ctx->ws_bytes[slot] = 0;
         }
@@ -493,6 +496,9 @@ void vbx_ctx_destroy(vbx_ctx *ctx) {
     if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+    for (auto &e : ctx->ev_slice) if (e) hipEventDestroy(e);
+    if (ctx->ev_trk) hipEventDestroy(ctx->ev_trk);
+    if (ctx->trk) { hipStreamSynchronize(ctx->trk); hipStreamDestroy(ctx->trk); }
     for (int i = 0; i < 2; i++) { if (ctx->stage[i]) hipHostFree(ctx->stage[i]); if (ctx->stage_ev[i]) hipEventDestroy(ctx->stage_ev[i]); }
     if (ctx->t0) hipEventDestroy(ctx->t0);
     if (ctx->t1) hipEventDestroy(ctx->t1);
@@ -564,6 +570,7 @@ static int prof_flush(vbx_ctx *ctx) {
     if (ctx->recs.empty()) return VBX_SUCCESS;
     VBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->side) VBX_HIP(ctx, hipStreamSynchronize(ctx->side));
+    if (ctx->trk) VBX_HIP(ctx, hipStreamSynchronize(ctx->trk));
     for (auto &r : ctx->recs) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
@@ -967,9 +974,38 @@ static int run_find_formants(vbx_ctx *ctx, hipStream_t stm, const double *x, siz
     if (rc != VBX_SUCCESS) return rc;
     rc = upload_estimates(ctx, stm, h_est_init, n_est, &d_est);
     if (rc != VBX_SUCCESS) return rc;
-    { Prof pr(ctx, "burg", stm); launch_burg(stm, x, F, (int)frame_len, (long)stride, hann, p, coeffs, st); }                 // :75
-    { Prof pr(ctx, "formant_resonances", stm); launch_formant_resonances(stm, coeffs, F, p, sample_rate, res, cnt, st); }      // :80-110
-    { Prof pr(ctx, "tracker", stm); launch_tracker(stm, res, F, VBX_MAX_RESONANCES, cnt, d_seg, (long)nseg, d_est, (int)n_est, st, (res_t *)out_formants, (long)formants_ld); }  // :114
+    // The tracker is a chain of dependent steps per utterance (~5 us per frame, whatever the batch size), so on a large
+    // batch of equal-length utterances the work is cut into time slices: while the tracker walks frames [t0, t0 + tc) of
+    // every utterance on its own stream, Burg and the root finder already produce the next slice.
+    long seg_len = 0;
+    if (h_seg_start != nullptr && n_segments >= 64 && F >= 65536) {
+        seg_len = (n_segments > 1) ? (long)h_seg_start[1] : 0;
+        for (size_t i = 0; i < n_segments && seg_len > 0; i++) if (h_seg_start[i] != (int64_t)i * seg_len) seg_len = 0;
+        if (seg_len > 0 && ((long)(n_segments - 1) * seg_len >= F || seg_len < 64)) seg_len = 0;
+    }
+    const int n_slices = seg_len > 0 ? 4 : 1;
+    if (n_slices == 1) {
+        { Prof pr(ctx, "burg", stm); launch_burg(stm, x, F, (int)frame_len, (long)stride, hann, p, coeffs, st); }                 // :75
+        { Prof pr(ctx, "formant_resonances", stm); launch_formant_resonances(stm, coeffs, F, p, sample_rate, res, cnt, st); }      // :80-110
+        { Prof pr(ctx, "tracker", stm); launch_tracker(stm, res, F, VBX_MAX_RESONANCES, cnt, d_seg, (long)nseg, d_est, (int)n_est, st, (res_t *)out_formants, (long)formants_ld); }  // :114
+        return check_launch(ctx, "vbx_find_formants_f64");
+    }
+    if (!ctx->trk) {
+        VBX_HIP(ctx, hipStreamCreateWithFlags(&ctx->trk, hipStreamNonBlocking));
+        for (auto &e : ctx->ev_slice) VBX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        VBX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_trk, hipEventDisableTiming));
+    }
+    const long tc = (seg_len + n_slices - 1) / n_slices;
+    for (int j = 0; j < n_slices; j++) {
+        const frame_map_t map{seg_len, j * tc, tc};
+        { Prof pr(ctx, "burg", stm); launch_burg(stm, x, F, (int)frame_len, (long)stride, hann, p, coeffs, st, map); }
+        { Prof pr(ctx, "formant_resonances", stm); launch_formant_resonances(stm, coeffs, F, p, sample_rate, res, cnt, st, map); }
+        VBX_HIP(ctx, hipEventRecord(ctx->ev_slice[j], stm));
+        VBX_HIP(ctx, hipStreamWaitEvent(ctx->trk, ctx->ev_slice[j], 0));
+        { Prof pr(ctx, "tracker", ctx->trk); launch_tracker(ctx->trk, res, F, VBX_MAX_RESONANCES, cnt, d_seg, (long)nseg, d_est, (int)n_est, st, (res_t *)out_formants, (long)formants_ld, j * tc, tc); }
+    }
+    VBX_HIP(ctx, hipEventRecord(ctx->ev_trk, ctx->trk));
+    VBX_HIP(ctx, hipStreamWaitEvent(stm, ctx->ev_trk, 0));                // join: the formant tracks are complete on stm
     return check_launch(ctx, "vbx_find_formants_f64");
 }
 

@@ -11,6 +11,20 @@
 
 namespace vbx {
 
+// A launch over a TIME SLICE of equal-length segments: item i is frame (i / tc) * seg_len + t0 + i % tc (skipped when
+// it falls outside its segment or the batch).  seg_len == 0: the identity (item i is frame i).  Lets the sequential
+// tracker start on the first frames of every utterance while the resonances of the later frames are still computed.
+struct frame_map_t { long seg_len, t0, tc; };
+__host__ __device__ inline long frame_map(const frame_map_t &m, long i, long n_frames) {
+    if (m.seg_len == 0) return (i < n_frames) ? i : -1;
+    const long t = m.t0 + i % m.tc, f = (i / m.tc) * m.seg_len + t;
+    return (t < m.seg_len && t < m.t0 + m.tc && f < n_frames) ? f : -1;
+}
+inline long frame_map_items(const frame_map_t &m, long n_frames) {
+    return m.seg_len == 0 ? n_frames : ((n_frames + m.seg_len - 1) / m.seg_len) * m.tc;
+}
+
+
 struct res_t { double frequency, bandwidth; };
 struct pitch_t { double frequency, strength; };
 struct cplx_t { double re, im; };
@@ -29,7 +43,7 @@ void launch_levinson_rows(hipStream_t s, const double *r, long rows, long r_stri
 // k_burg.hip
 bool burg_supported(int n, int p);
 void launch_burg(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
-                 int p, double *out, int32_t *status);
+                 int p, double *out, int32_t *status, frame_map_t map = frame_map_t{0, 0, 0});
 
 // k_roots.hip
 void launch_find_roots(hipStream_t s, cplx_t *polys, long F, int len, int32_t *status);
@@ -41,12 +55,13 @@ void launch_to_resonance(hipStream_t s, const cplx_t *roots, long F, int n_roots
                          int strict_im, res_t *out, int out_stride, int32_t *out_count, const int32_t *status);
 // Burg coefficients [F,p] -> reversed complex polynomial -> roots -> resonances [F,32] (find_formants core)
 void launch_formant_resonances(hipStream_t s, const double *coeffs, long F, int p, double sample_rate,
-                               res_t *out_res, int32_t *out_count, int32_t *status);
+                               res_t *out_res, int32_t *out_count, int32_t *status, frame_map_t map = frame_map_t{0, 0, 0});
 
 // k_tracker.hip
 void launch_tracker(hipStream_t s, const res_t *res, long F, int n_res, const int32_t *res_count,
                     const int64_t *seg_start, long n_seg, const res_t *est_init, int n_est,
-                    const int32_t *frame_status, res_t *out, long out_ld /* doubles per output row, >= 2*n_est */);
+                    const int32_t *frame_status, res_t *out, long out_ld /* doubles per output row, >= 2*n_est */,
+                    long t0 = 0 /* first frame of every segment's slice */, long tc = 0x7fffffffffffffffL /* frames per slice */);
 
 // k_pitch.hip
 size_t pitch_lds_bytes(int n);
