@@ -39,15 +39,22 @@ __device__ __forceinline__ int poly_off_low(const lds_poly_t<T> &p, int len) {
 }
 
 // src/polynomial.rs:34-72.  n = len - 1 stays fixed across deflations (Q11).
+// top (<= n): every coefficient above index `top` is zero (deflation clears them).  The reference's Horner chains run
+// through those zeros -- 0 * z + 0 three times per index, which leaves all three accumulators exactly zero for finite
+// z -- so starting at `top` is the same arithmetic with the no-ops left out (37 % of the Horner steps of an order-12
+// polynomial).  A non-finite z (0 * inf = NaN in the reference) takes the full chain.
 template <typename T>
-__device__ __forceinline__ cx<T> laguerre(const lds_poly_t<T> &p, int len, cx<T> start) {
+__device__ __forceinline__ cx<T> laguerre(const lds_poly_t<T> &p, int len, cx<T> start, int top = -1) {
     const int n = len - 1;
     const T dn = (T)n, dnn1 = (T)(n - 1) * (T)n;
     cx<T> z = start;
     bool done = false;
+    if (top < 0 || top > n) top = n;
     for (int it = 0; it < 20; it++) {
-        cx<T> a0 = p.get(n), a1 = cmk<T>(T(0), T(0)), a2 = cmk<T>(T(0), T(0));
-        for (int j = n - 1; j >= 0; j--) {
+        const bool zfin = (z.re - z.re == T(0)) && (z.im - z.im == T(0));
+        const int hi = __all(zfin || done) ? top : n;
+        cx<T> a0 = p.get(hi), a1 = cmk<T>(T(0), T(0)), a2 = cmk<T>(T(0), T(0));
+        for (int j = hi - 1; j >= 0; j--) {
             a2 = cmad(a2, z, a1);
             a1 = cmad(a1, z, a0);
             a0 = cmad(a0, z, p.get(j));
@@ -81,7 +88,10 @@ __device__ __forceinline__ int find_roots_emit(const lds_poly_t<T> &co, int len,
     const int clen = coeff_high + 1;
     int zi = 0;
     for (int k = m; k >= 3; k--) {                      // (3..m+1).rev()
-        const cx<T> z = laguerre(co, clen, cmk<T>(T(-2), T(-2)));
+        // the lanes of a wave hold different polynomials: the chain starts at the highest degree among them
+        int top = poly_degree(co, clen);
+        for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(top, o, 64); top = other > top ? other : top; }
+        const cx<T> z = laguerre(co, clen, cmk<T>(T(-2), T(-2)), top);
         emit(zi++, z);
         if (ciszero(z)) return 2;                       // div by zero -> Err, :123,:192
         // divide by (x - z): other = -z; q[i] = c[i+1] - q[i+1]*other
