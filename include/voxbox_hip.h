@@ -328,6 +328,12 @@ int vbx_lpc_burg_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame
 int vbx_mfcc_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len, size_t stride,
                  const float *window, size_t num_coeffs, double lo_hz, double hi_hz,
                  double sample_rate, float *out, int32_t *status);
+/* Pitched<f32, f32>::pitch (src/periodic.rs:356-358,396-455 at S = T = f32): as vbx_pitch_f64 with float frames, float
+ * parameters and Pitch<f32> candidates.  The lag curve and the refinement run in f64 on the widened frame. */
+typedef struct { float frequency; float strength; } vbx_pitch32;
+int vbx_pitch_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len, size_t stride,
+                  const float *window, float sample_rate, float threshold, float fmin, float fmax,
+                  size_t kmax, vbx_pitch32 *out_cand, int32_t *out_count, int32_t *status);
 
 /* ------------------------------------------------------------------ the user's frame loop, fused */
 

@@ -265,6 +265,17 @@ def mfcc_f32(x, num_coeffs, lo, hi, sr):
     return st, out
 
 
+def pitch_f32(x, sample_rate, threshold, fmin, fmax, cap=None):
+    """Pitched<f32, f32>::pitch: (status, candidates[count, 2] as float64 holders of f32 values, count)."""
+    x = _f32(x)
+    cap = cap if cap is not None else x.size // 2 + 2
+    out = np.zeros((cap, 2), dtype=np.float64)
+    cnt = C.c_size_t()
+    st = lib().vbxo_pitch_f32(_p(x), C.c_size_t(x.size), C.c_float(sample_rate), C.c_float(threshold), C.c_float(fmin),
+                              C.c_float(fmax), _p(out), C.c_size_t(cap), C.byref(cnt))
+    return st, out[:min(cnt.value, cap)].copy(), cnt.value
+
+
 def to_resonance(roots, sample_rate):
     roots = _c128(roots)
     out = np.zeros((max(roots.size, 1), 2), dtype=np.float64)

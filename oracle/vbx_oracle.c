@@ -283,21 +283,17 @@ int vbxo_improve_extremum_sinc(const double *y, size_t ylen, long offset, size_t
     return p.status;
 }
 
-/* periodic.rs:396-455 (Q2..Q10). */
-int vbxo_pitch(const double *x, size_t n, double sample_rate, double threshold,
-               double fmin, double fmax, vbxo_pitch_t *out, size_t cap, size_t *count) {
+/* periodic.rs:413-455 (Q4..Q10): everything after the lag curve.  self_lag: 2n entries, [n, 2n) zero (:411).
+ * f32 != 0: the Sample / Float types are f32 -- the curve's entries are f32 values, and the frequency arithmetic of
+ * :421-432, :443 and :447 rounds to f32 where the generic code computes in T (the sinc / Brent routines are f64 in
+ * either instantiation). */
+static int pitch_from_lag(const double *self_lag, size_t n, double sample_rate, double threshold,
+                          double fmin, double fmax, vbxo_pitch_t *out, size_t cap, size_t *count, int f32) {
     int status = VBXO_OK;
-    double *window_lag = (double *)malloc(n * sizeof(double));
-    double *self_lag = (double *)calloc(2 * n, sizeof(double));   /* :411 resize(2N, 0) */
     size_t max_maxima = n / 2 + 2;
     vbxo_pitch_t *maxima = (vbxo_pitch_t *)malloc(max_maxima * sizeof(vbxo_pitch_t));
     size_t n_max = 0;
-
-    vbxo_window_hanning_lag(window_lag, n);                                        /* :400 */
-    vbxo_autocorrelate(x, n, self_lag, n);                                         /* :403 */
-    vbxo_normalize(self_lag, n);                                                   /* :404 */
-    for (size_t i = 0; i < n; i++) self_lag[i] = self_lag[i] / window_lag[i];      /* :406-408 */
-
+#define RT(v) (f32 ? (double)(float)(v) : (double)(v))      /* a value of type T */
     const double interpolation_depth = 0.5;
     size_t brent_ixmax = (size_t)floor(interpolation_depth * (double)n);           /* :414 */
     long offset = -(long)brent_ixmax - 1;                                          /* :429,:441 */
@@ -308,10 +304,10 @@ int vbxo_pitch(const double *x, size_t n, double sample_rate, double threshold,
     for (size_t k = 1; k + 1 < brent_ixmax; k++) {
         if (!(self_lag[k - 1] < self_lag[k] && self_lag[k + 1] < self_lag[k])) continue;
         double peak = self_lag[k], peak_rev = self_lag[k - 1], peak_fwd = self_lag[k + 1];
-        double dr = 0.5 * (peak_fwd - peak_rev);                                   /* :423 */
-        double d2r = 2. * peak - (peak_rev - peak_fwd);                            /* :424 (Q5) */
-        double freq = sample_rate / ((double)k + dr / d2r);                        /* :425 */
-        double nn = sample_rate / freq - (double)offset;                           /* :432 */
+        double dr = 0.5 * RT(peak_fwd - peak_rev);                                 /* :423 */
+        double d2r = 2. * peak - RT(peak_rev - peak_fwd);                          /* :424 (Q5) */
+        double freq = RT(sample_rate / RT((double)k + dr / d2r));                  /* :425 */
+        double nn = RT(RT(sample_rate / freq) - (double)offset);                   /* :432 */
         double strn = NAN;
         int st = vbxo_interpolate_sinc(self_lag, ylen, offset, nx, nn, 30, &strn); /* :433 */
         if (st != VBXO_OK) { status = st; break; }
@@ -320,16 +316,17 @@ int vbxo_pitch(const double *x, size_t n, double sample_rate, double threshold,
         if (!((freq == 0.0) || (freq > fmin && freq < fmax))) continue;
         g_cnt.candidates++;
         /* :440-450 refine */
-        double n2 = sample_rate / freq - (double)offset;                           /* :443 */
+        double n2 = RT(RT(sample_rate / freq) - (double)offset);                   /* :443 */
         double xmid = 0., ymid = 0.;
         st = vbxo_improve_extremum_sinc(self_lag, ylen, offset, nx, n2, 1200, &xmid, &ymid); /* :444 */
         if (st != VBXO_OK) { status = st; break; }
         xmid += (double)offset;                                                    /* :445 */
         if (ymid > 1.) ymid = 1. / ymid;                                           /* :446 */
-        maxima[n_max].frequency = sample_rate / xmid;                              /* :447 */
-        maxima[n_max].strength = ymid;                                             /* :448 */
+        maxima[n_max].frequency = RT(sample_rate / RT(xmid));                      /* :447 */
+        maxima[n_max].strength = RT(ymid);                                         /* :448 */
         n_max++;
     }
+#undef RT
     if (status == VBXO_OK) {
         maxima[n_max].frequency = 0.; maxima[n_max].strength = threshold;          /* :452 */
         n_max++;
@@ -353,7 +350,39 @@ int vbxo_pitch(const double *x, size_t n, double sample_rate, double threshold,
     } else {
         *count = 0;
     }
-    free(window_lag); free(self_lag); free(maxima);
+    free(maxima);
+    return status;
+}
+
+/* periodic.rs:396-455 (Q2..Q10). */
+int vbxo_pitch(const double *x, size_t n, double sample_rate, double threshold,
+               double fmin, double fmax, vbxo_pitch_t *out, size_t cap, size_t *count) {
+    double *window_lag = (double *)malloc(n * sizeof(double));
+    double *self_lag = (double *)calloc(2 * n, sizeof(double));   /* :411 resize(2N, 0) */
+    vbxo_window_hanning_lag(window_lag, n);                                        /* :400 */
+    vbxo_autocorrelate(x, n, self_lag, n);                                         /* :403 */
+    vbxo_normalize(self_lag, n);                                                   /* :404 */
+    for (size_t i = 0; i < n; i++) self_lag[i] = self_lag[i] / window_lag[i];      /* :406-408 */
+    int status = pitch_from_lag(self_lag, n, sample_rate, threshold, fmin, fmax, out, cap, count, 0);
+    free(window_lag); free(self_lag);
+    return status;
+}
+
+/* The S = T = f32 instantiation (parity unpinned): the lag curve in f32 arithmetic (vbx_oracle_f32.c), the lag window
+ * as the f64 table rounded to f32, then the rest on the widened curve with T = f32 roundings. */
+void vbxo_autocorrelate_f32(const float *x, size_t n, float *coeffs, size_t n_lags);
+void vbxo_normalize_f32(float *x, size_t n);
+int vbxo_pitch_f32(const float *x, size_t n, float sample_rate, float threshold, float fmin, float fmax,
+                   vbxo_pitch_t *out, size_t cap, size_t *count) {
+    double *window_lag = (double *)malloc(n * sizeof(double));
+    float *lag32 = (float *)malloc(n * sizeof(float));
+    double *self_lag = (double *)calloc(2 * n, sizeof(double));
+    vbxo_window_hanning_lag(window_lag, n);
+    vbxo_autocorrelate_f32(x, n, lag32, n);
+    vbxo_normalize_f32(lag32, n);
+    for (size_t i = 0; i < n; i++) self_lag[i] = (double)(lag32[i] / (float)window_lag[i]);
+    int status = pitch_from_lag(self_lag, n, (double)sample_rate, (double)threshold, (double)fmin, (double)fmax, out, cap, count, 1);
+    free(window_lag); free(lag32); free(self_lag);
     return status;
 }
 

@@ -141,5 +141,7 @@ void vbxo_normalize_f32(float *x, size_t n);
 void vbxo_lpc_f32(const float *r, size_t n_coeffs, float *ac /* n_coeffs+1 */, float *kc /* n_coeffs or NULL */);
 int vbxo_lpc_burg_f32(const float *x, size_t n, size_t n_coeffs, float *coeffs);
 int vbxo_mfcc_f32(const float *x, size_t n, size_t num_coeffs, double lo, double hi, double sample_rate, float *out);
+int vbxo_pitch_f32(const float *x, size_t n, float sample_rate, float threshold, float fmin, float fmax,
+                   vbxo_pitch_t *out, size_t cap, size_t *count);
 
 #endif

@@ -111,3 +111,27 @@ def test_mfcc_f32(vb, oracle, audio, n):
     print("\nmfcc_f32 n=%d max rel error: gpu %.2e, f32 restatement %.2e" % ((n,) + _accuracy(m, m32, r64, "mfcc")))
     bad, stb = vb.mfcc_f32(np.ones((2, 64), np.float32), 13, (100.0, 30000.0), 22050.0)     # bins beyond the spectrum
     assert np.all(stb == 4) and np.all(bad == 0.0)
+
+
+def test_pitch_f32(vb, oracle, audio):
+    """Pitched<f32, f32>::pitch: identity with the f64 path on the widened frames (rounded once), and against the f32
+    restatement -- whose lag curve carries the rounding of 1200 f32 folds, so candidate COUNTS may differ on peaks of
+    that size (counted, bounded); the top candidate of voiced frames agrees within 1e-4 / 1e-3."""
+    n, hop = 1200, 480
+    F = 60
+    x = _frames32(audio, n, hop, F, oracle.window("hanning", n))
+    cand, cnt, st = vb.pitch_f32(x, SR, 0.2, 75.0, 600.0, kmax=4)
+    assert cand.dtype == np.float32 and np.all(st == 0)
+    c64, k64, s64 = vb.pitch(x.astype(np.float64), SR, 0.2, 75.0, 600.0, kmax=4)
+    assert np.array_equal(cand, c64.astype(np.float32)) and np.array_equal(cnt, k64) and np.array_equal(st, s64)
+    n_count_diff = n_voiced = 0
+    for f in range(F):
+        es, ec, en = oracle.pitch_f32(x[f], SR, 0.2, 75.0, 600.0)
+        assert es == 0
+        n_count_diff += int(en != cnt[f])
+        if ec[0, 0] > 0 and (en == 1 or ec[0, 1] - ec[1, 1] > 1e-2):      # clearly voiced: the decision is not a near tie
+            n_voiced += 1
+            assert abs(cand[f, 0, 0] - ec[0, 0]) <= 1e-4 * ec[0, 0] and abs(cand[f, 0, 1] - ec[0, 1]) <= 1e-3, (f, cand[f, 0], ec[0])
+    print("\npitch_f32: %d clearly voiced frames compared, candidate count differs from the f32 restatement in %d of %d frames"
+          % (n_voiced, n_count_diff, F))
+    assert n_voiced >= 20 and n_count_diff <= F // 4

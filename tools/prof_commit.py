@@ -39,10 +39,12 @@ def frames_of(run):
 KEYS = {   # bench.py profile name -> (workload, kernel-name prefix in the counter files)
     "analyze": ("pipeline", "void analyze_kernel<true, true>"),
     "pitch": ("config3", "void analyze_kernel<false, false>"),
-    "burg": ("config4", "void burg_kernel<16, 32>"),
-    "burg_1200": ("pipeline", "void burg_kernel<64, 20>"),
-    "formant_resonances": ("config4", "formant_resonances_kernel"),
-    "tracker": ("config4", "tracker_kernel"),
+    "burg_512": ("config4", "void burg_kernel<16, 32, double>"),
+    "burg": ("pipeline", "void burg_kernel<64, 20, double>"),
+    "formant_resonances_512": ("config4", "formant_resonances_kernel"),
+    "formant_resonances": ("pipeline", "formant_resonances_kernel"),
+    "tracker_512": ("config4", "void tracker_kernel<4>"),
+    "tracker": ("pipeline", "void tracker_kernel<4>"),
     "autocorr_lpc_512": ("config2", "void autocorr_fewlags_kernel<8, 13>"),
 }
 traffic = {}
@@ -52,6 +54,9 @@ for key, (wl, kern) in KEYS.items():
     F = frames_of("pmc_fetch_" + wl)
     if not fe or not wr or not F:
         continue
+    # sliced kernels run several launches per step: the counter averages are per launch, the frames too
+    per_step = {"burg_512": 4, "formant_resonances_512": 4, "tracker_512": 4, "burg": 4, "formant_resonances": 4, "tracker": 4}.get(key, 1)
+    F = F / per_step
     fetch_b, write_b = fe["avg"] * 1024.0 * 2.0, wr["avg"] * 1024.0
     traffic[key] = {"bytes_per_frame": (fetch_b + write_b) / F, "fetch_bytes_per_frame": fetch_b / F,
                     "write_bytes_per_frame": write_b / F, "frames_per_launch": F, "kernel": kern,

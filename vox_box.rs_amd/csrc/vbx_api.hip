@@ -1411,6 +1411,28 @@ int vbx_mfcc_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len
     return check_launch(ctx, __func__);
 }
 
+// Pitched::pitch at S = T = f32 (src/periodic.rs:396-455 is generic over the Sample): the frames are widened (windowed
+// product rounded to f32 first), the candidates come from the f64 path and are rounded to f32 once.
+int vbx_pitch_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len, size_t stride,
+                  const float *window, float sample_rate, float threshold, float fmin, float fmax,
+                  size_t kmax, vbx_pitch32 *out_cand, int32_t *out_count, int32_t *status) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_REQUIRE(ctx, out_cand != nullptr, "null output");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    void *wi = nullptr, *wo = nullptr;
+    rc = ws_get(ctx, vbx_ctx::WS_F32_IN, n_frames * frame_len * sizeof(double), &wi);
+    if (rc != VBX_SUCCESS) return rc;
+    rc = ws_get(ctx, vbx_ctx::WS_F32_OUT, n_frames * (kmax ? kmax : 1) * sizeof(vbx_pitch), &wo);
+    if (rc != VBX_SUCCESS) return rc;
+    { Prof p(ctx, "widen_frames"); launch_widen_frames(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, (double *)wi); }
+    rc = run_pitch(ctx, ctx->stream, (const double *)wi, n_frames, frame_len, frame_len, nullptr, (double)sample_rate,
+                   (double)threshold, (double)fmin, (double)fmax, kmax, (vbx_pitch *)wo, 2 * kmax, out_count, status);
+    if (rc != VBX_SUCCESS) return rc;
+    { Prof p(ctx, "narrow"); launch_narrow(ctx->stream, (const double *)wo, (long)(n_frames * kmax * 2), (float *)out_cand); }
+    return check_launch(ctx, __func__);
+}
+
 // ---- bench utility ------------------------------------------------------------------------
 
 int vbx_synth_speech_f64(vbx_ctx *ctx, double *out, size_t n_samples, uint64_t sample_offset,

@@ -142,6 +142,7 @@ def load_library():
         "vbx_autocorr_lpc_f32": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, i32, vp, vp]),
         "vbx_lpc_burg_f32": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, vp, vp]),
         "vbx_mfcc_f32": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, dbl, dbl, dbl, vp, vp]),
+        "vbx_pitch_f32": (C.c_int, [vp, vp, sz, sz, sz, vp, C.c_float, C.c_float, C.c_float, C.c_float, sz, vp, vp, vp]),
         "vbx_autocorr_lpc_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, i32, vp, vp]),
         "vbx_lpc_burg_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, vp, vp]),
         "vbx_find_roots_c64": (C.c_int, [vp, vp, sz, sz, vp]),
@@ -735,6 +736,18 @@ class VoxBox:
                                         sample_rate, o.ptr, st.ptr))
         res = (o.numpy(), st.numpy())
         for b in (d, w, o, st):
+            if b is not None:
+                b.free()
+        return res
+
+    def pitch_f32(self, x, sample_rate, threshold, fmin, fmax, kmax=8, window=None):
+        d, F, N = self._frames32(x)
+        w = self._win32(window)
+        cand, cnt, st = self.empty((F, kmax, 2), np.float32), self.empty(F, np.int32), self.empty(F, np.int32)
+        self._check(self.L.vbx_pitch_f32(self.ctx, d.ptr, F, N, N, _ptr(w), sample_rate, threshold, fmin, fmax, kmax,
+                                         cand.ptr, cnt.ptr, st.ptr))
+        res = (cand.numpy(), cnt.numpy(), st.numpy())
+        for b in (d, w, cand, cnt, st):
             if b is not None:
                 b.free()
         return res
