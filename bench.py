@@ -11,19 +11,20 @@ library's own grouped ncclSend/ncclRecv (vbx_gather_records_f64).
 
 A "step" is one pass of the whole per-frame path over this rank's shard of a long synthetic 48 kHz recording
 (25 ms window = 1200 samples, 10 ms hop = 480 samples): vbx_analyze_frames_f64 = Boersma pitch candidates,
-autocorrelation + Levinson LPC(12), find_formants (Burg(12) -> Laguerre roots -> resonances -> formant tracker),
-MFCC(13), written as one fixed-size record per frame; at N > 1 the step ends by queueing the gather of the records
+autocorrelation + Levinson LPC(12) and MFCC(13) from one FFT of each frame (analyze_kernel), find_formants (Burg(12) ->
+Laguerre roots -> resonances -> formant tracker) beside it, written as one fixed-size record per frame; at N > 1 the step ends by queueing the gather of the records
 to rank 0 (it overlaps the next step's kernels; every gather is complete when the timed region ends).  The audio is
 generated on the device before the timed region (inputs resident in HBM); frames are range-split over ranks (weak
 scaling: --hours is per GPU; the default 12.5 h/GPU is BASELINE config 5's 100 h over 8 GPUs).
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline      the kernel with the largest measured time against the roof that binds it: pitch -> FP64 matrix/vector
-                peak; everything else -> HBM (algorithmic bytes).  `traffic` = measured HBM bytes per launch from the
-                PMC passes committed under profiles/ (profiles/pmc_traffic.json), scaled to this launch's frames.
+  roofline      the kernel with the largest measured time against the roof that binds it: pitch / analyze -> FP64 vector
+                (= matrix) peak, algorithmic flops in `frac` and executed flops in `executed`; everything else -> HBM
+                (algorithmic bytes).  `traffic` = measured HBM bytes per launch from the PMC passes committed under
+                profiles/ (profiles/pmc_traffic.json), scaled to this launch's frames.
   roofline_hbm  the pitch kernel against the HBM roof, as north_star asks (tiny by construction)
   cpu_baseline  the CPU oracle (C restatement of the reference path) timed natively (oracle/vbx_cpu_bench.c) on
-                1 core and on all host cores
+                1 core and on all the cores the process may use (affinity mask capped by the cgroup CPU quota)
 Other workloads (--workload config2|config3|config4|frontend) time a single BASELINE config.
 """
 import argparse
@@ -449,6 +450,16 @@ def run_rank(args):
                                         "(oracle MAC counter) + 13*sinc terms the kernel evaluated (device counters; the "
                                         "reference evaluates reference_sinc_terms); peak = FP64 vector = FP64 matrix peak "
                                         "(the kernel issues no MFMA: one FFT replaced the matrix-core autocorrelation)"}
+        if wl == "config4":
+            # the tracker's slices run on their own stream beside Burg and the root finder (only the last slice is
+            # exposed), so no single kernel is "the step": the whole config against both roofs (4264 B and
+            # ~135 kflop per frame)
+            step_s = dt / args.steps
+            out["whole_config"] = {"bytes_per_frame": 4264, "GBps": F * 4264 / step_s / 1e9, "hbm_frac": F * 4264 / step_s / 1e9 / HBM_PEAK_GBS,
+                                   "flops_per_frame": 135e3, "TFLOPs": F * 135e3 / step_s / 1e12,
+                                   "fp64_frac": F * 135e3 / step_s / 1e12 / FP64_PEAK_TFLOPS,
+                                   "main_stream_ms": sum(v["ms_avg"] * v["launches"] for k, v in kernels.items() if k != "tracker") / args.steps,
+                                   "tracker_ms_overlapped": kernels.get("tracker", {"ms_avg": 0, "launches": 0})["ms_avg"] * kernels.get("tracker", {"launches": 0})["launches"] / args.steps}
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
         print(json.dumps(out), flush=True)
