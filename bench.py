@@ -269,6 +269,8 @@ def run_rank(args):
             print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": seen, "gpus_arg": args.gpus}), flush=True)
         dist.destroy_process_group()
         return 0
+    if os.environ.get("VBX_BENCH_ONE_GPU"):     # test hook: every rank on GPU 0 (whether RCCL accepts that is up to RCCL)
+        local = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: the product has no CPU path")
     if local >= torch.cuda.device_count():
@@ -289,11 +291,31 @@ def run_rank(args):
     if wl == "frontend":
         return bench_frontend(args, torch, dev, vb, pkg)
     comm = None
+    gather_via = "library (vbx_gather_records_f64: grouped ncclSend/ncclRecv on the communicator's own stream)"
     if world > 1:
-        # the library's own RCCL communicator for the record gather; the 128-byte id travels over torch.distributed
-        ids = [pkg.comm_unique_id() if rank == 0 else None]
+        # the library's own RCCL communicator for the record gather; the 128-byte id travels over torch.distributed.
+        # Should the library's communicator fail to come up on any rank (it is a second RCCL instance in a process that
+        # already runs torch's), every rank falls back to the same grouped send/recv through torch.distributed.
+        ok = 1
+        try:
+            ids = [pkg.comm_unique_id() if rank == 0 else None]
+        except pkg.VoxBoxError as e:
+            sys.stderr.write(f"bench.py rank {rank}: {e}\n"); ids = [None]; ok = 0
         dist.broadcast_object_list(ids, src=0, device=dev)
-        comm = pkg.Comm(vb, ids[0], world, rank)
+        if ids[0] is None:
+            ok = 0
+        else:
+            try:
+                comm = pkg.Comm(vb, ids[0], world, rank)
+            except pkg.VoxBoxError as e:
+                sys.stderr.write(f"bench.py rank {rank}: {e}\n"); ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if comm is not None:
+                comm.close()
+            comm = None
+            gather_via = "torch.distributed batch_isend_irecv (fallback: the library's communicator did not come up)"
 
     est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
     if wl in ("pipeline", "config3"):
@@ -357,6 +379,13 @@ def run_rank(args):
                               out=rec[b], record_ld=REC, status=st3)
             if comm is not None:   # per-frame records to rank 0 over RCCL/xGMI (no other collective on the path)
                 comm.gather_records(rec[b], counts, REC, 0, out=gathered[b], slot=b)
+            elif world > 1:
+                if rank == 0:
+                    ops = [dist.P2POp(dist.irecv, gathered[b][r * F:(r + 1) * F], r) for r in range(1, world)]
+                else:
+                    ops = [dist.P2POp(dist.isend, rec[b], 0)]
+                for w_ in dist.batch_isend_irecv(ops):
+                    w_.wait()
         elif wl == "config4":
             vb.find_formants(audio, SR, P, est0, seg_start=seg, frame_len=frame_len, stride=stride, n_frames=F, out=ff)
         elif wl == "config2":
@@ -407,7 +436,8 @@ def run_rank(args):
             "config": {"workload": desc, "frames_per_gpu": F, "frame_len": frame_len, "hop": stride,
                        "lpc_order": P, "mfcc": 13, "pitch_kmax": args.kmax if wl != "pipeline" else 1,
                        "record_bytes": REC * 8,
-                       "parallelism": f"frame-range split x{world}, one process per GPU, RCCL gather of the records to rank 0"},
+                       "parallelism": f"frame-range split x{world}, one process per GPU, RCCL gather of the records to rank 0",
+                       "gather": gather_via if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                          "algorithmic_bytes_per_frame": bytes_per_frame, "ms_avg": dom_ms, "frames_per_launch": Fl,
