@@ -160,6 +160,16 @@ int vbx_interpolate_sinc_f64(vbx_ctx *ctx, const double *y, size_t ylen, long of
  * at M starting points; out_xy: [M, 2] = (xmid, ymid). */
 int vbx_improve_extremum_f64(vbx_ctx *ctx, const double *y, size_t ylen, long offset, size_t nx,
                              const double *ixmid, size_t m, size_t depth, double *out_xy, int32_t *status);
+/* improve_extremum with every arm of `Interpolation` (src/periodic.rs:89-93,192-229) and the is_max flag: NONE returns
+ * (0, y[0]) (:197-199), PARABOLIC the three-point fit around floor(ixmid) (:200-207; status PANIC where the reference indexes
+ * out of bounds), SINC(depth) the Brent search of the interpolant -- negated by the closure when is_max == 0 (:219-222).
+ * Only SINC with is_max != 0 is on the pitch path; the rest is the crate's public surface. */
+#define VBX_INTERP_NONE 0
+#define VBX_INTERP_PARABOLIC 1
+#define VBX_INTERP_SINC 2
+int vbx_improve_extremum_ex_f64(vbx_ctx *ctx, const double *y, size_t ylen, long offset, size_t nx,
+                                const double *ixmid, size_t m, int interpolation, size_t depth, int is_max,
+                                double *out_xy, int32_t *status);
 
 /* Pitched::pitch::<Hanning>(sample_rate, threshold, _, _, min, max) per frame
  * (src/periodic.rs:356-358,396-455; local_peak/global_peak are unused by the reference).

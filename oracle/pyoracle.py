@@ -120,6 +120,15 @@ def improve_extremum_sinc(y, offset, nx, ixmid, depth):
     return st, xm.value, ym.value
 
 
+def improve_extremum(y, offset, nx, ixmid, interp, depth=0, is_max=True):
+    """improve_extremum with any Interpolation arm: interp 0 None, 1 Parabolic, 2 Sinc(depth).  Returns (status, xmid, ymid)."""
+    y = _f64(y)
+    xm, ym = C.c_double(), C.c_double()
+    st = lib().vbxo_improve_extremum(_p(y), C.c_size_t(y.size), C.c_long(offset), C.c_size_t(nx), C.c_double(ixmid),
+                                     C.c_int(interp), C.c_size_t(depth), C.c_int(1 if is_max else 0), C.byref(xm), C.byref(ym))
+    return st, xm.value, ym.value
+
+
 def pitch(x, sample_rate, threshold, fmin, fmax, cap=None):
     """Returns (status, candidates[count,2]) -- (frequency, strength), sorted as the reference."""
     x = _f64(x)

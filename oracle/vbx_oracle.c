@@ -195,15 +195,15 @@ int vbxo_interpolate_sinc(const double *y, size_t ylen, long offset, size_t nx,
 }
 
 typedef struct {
-    const double *y; size_t ylen; long offset; size_t depth; size_t ixmax; int status;
+    const double *y; size_t ylen; long offset; size_t depth; size_t ixmax; int status; int negate;
 } brent_params;
 
-/* closure at periodic.rs:216-223 with is_max == true: NOT negated (Q8). */
+/* closure at periodic.rs:216-223: the interpolant for is_max == true (NOT negated, Q8), its negative otherwise. */
 static double brent_f(double x, brent_params *p) {
     double out = NAN;
     int st = vbxo_interpolate_sinc(p->y, p->ylen, p->offset, p->ixmax, x, p->depth, &out);
     if (st != VBXO_OK) p->status = st;
-    return out;
+    return p->negate ? -out : out;
 }
 
 /* periodic.rs:103-188: Brent golden/parabolic MINIMISER, tol 1e-10, <= 60 iterations. */
@@ -274,9 +274,41 @@ int vbxo_improve_extremum_sinc(const double *y, size_t ylen, long offset, size_t
         if (nx < 1 || nx - 1 >= ylen) return VBXO_ERR_PANIC;
         *xmid = (double)nx; *ymid = y[nx - 1]; return VBXO_OK;
     }
-    brent_params p = { y, ylen, offset, depth, nx, VBXO_OK };
+    brent_params p = { y, ylen, offset, depth, nx, VBXO_OK, 0 };
     double a = ixmid - 1., b = ixmid + 1.;
     if (!(a < b)) return VBXO_ERR_PANIC;                                            /* assert, :113 */
+    double result = 0.;
+    *xmid = brent_maximize(a, b, &p, 1e-10, &result);
+    *ymid = result;
+    return p.status;
+}
+
+/* periodic.rs:192-229 with every arm: interp 0 = Interpolation::None, 1 = Parabolic, 2 = Sinc(depth); is_max as given.
+ * Only the Sinc arm with is_max == true is on the pitch path; the others are public API. */
+int vbxo_improve_extremum(const double *y, size_t ylen, long offset, size_t nx, double ixmid, int interp, size_t depth,
+                          int is_max, double *xmid, double *ymid) {
+    if (ylen < 1) return VBXO_ERR_PANIC;
+    if (ixmid == 0.) { *xmid = 0.; *ymid = y[0]; return VBXO_OK; }                 /* :193 */
+    if (ixmid >= (double)nx) {                                                      /* :194 */
+        if (nx < 1 || nx - 1 >= ylen) return VBXO_ERR_PANIC;
+        *xmid = (double)nx; *ymid = y[nx - 1]; return VBXO_OK;
+    }
+    if (interp == 0) { *xmid = 0.; *ymid = y[0]; return VBXO_OK; }                 /* :197-199 */
+    if (interp == 1) {                                                              /* :200-207 */
+        double fl = floor(ixmid);
+        if (!(fl >= 1.) || !(fl + 1. < (double)ylen)) return VBXO_ERR_PANIC;       /* usize underflow / out of bounds (NaN too) */
+        size_t i = (size_t)fl;
+        double diff = y[i + 1] - y[i - 1];
+        double mid = y[i];
+        double dy = 0.5 * diff;
+        double d2y = 2.0 * mid - diff;
+        *xmid = ixmid + dy / d2y;
+        *ymid = mid + 0.5 * dy * dy / d2y;
+        return VBXO_OK;
+    }
+    brent_params p = { y, ylen, offset, depth, nx, VBXO_OK, is_max ? 0 : 1 };
+    double a = ixmid - 1., b = ixmid + 1.;
+    if (!(a < b)) return VBXO_ERR_PANIC;
     double result = 0.;
     *xmid = brent_maximize(a, b, &p, 1e-10, &result);
     *ymid = result;

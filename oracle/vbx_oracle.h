@@ -135,6 +135,10 @@ void vbxo_counters_get(vbxo_counters_t *out);
 #ifdef __cplusplus
 }
 #endif
+/* improve_extremum with every Interpolation arm (0 None, 1 Parabolic, 2 Sinc(depth)) and is_max, src/periodic.rs:192-229 */
+int vbxo_improve_extremum(const double *y, size_t ylen, long offset, size_t nx, double ixmid, int interp, size_t depth,
+                          int is_max, double *xmid, double *ymid);
+
 /* Sample = f32 instantiation of the slice traits (vbx_oracle_f32.c; parity unpinned: no reference test runs them) */
 void vbxo_autocorrelate_f32(const float *x, size_t n, float *coeffs, size_t n_lags);
 void vbxo_normalize_f32(float *x, size_t n);

@@ -440,6 +440,30 @@ def test_improve_extremum_points(vb, oracle, audio):
         assert abs(got[i, 1] - ey) <= 1e-6 * max(1.0, abs(ey)), (v, got[i], ex, ey)
 
 
+def test_improve_extremum_every_arm(vb, oracle, audio):
+    """`Interpolation::{None, Parabolic, Sinc}` and `is_max` (src/periodic.rs:89-93,192-229): only Sinc with is_max = true
+    is on the pitch path, the other arms are public surface of the crate."""
+    x = audio[20000:20000 + N48] * oracle.window("hanning", N48)
+    y = _lag_curve(oracle, x)
+    b = N48 // 2
+    offset, nx = -b - 1, 2 * b + 1
+    peaks = [k for k in range(1, b - 1) if y[k - 1] < y[k] > y[k + 1] and 80 < k < 590]
+    ix = np.array([k + 0.01 * ((k * 7) % 10) - offset for k in peaks[:12]] + [0.0, float(nx), nx + 3.0, 0.5, 1.25, 2.0])
+    for interp, depth, is_max in ((0, 0, True), (1, 0, True), (1, 0, False), (2, 1200, False), (2, 30, True)):
+        got, st = vb.improve_extremum_ex(y, offset, nx, ix, interp, depth, is_max)
+        for i, v in enumerate(ix):
+            es, ex, ey = oracle.improve_extremum(y, offset, nx, v, interp, depth, is_max)
+            assert st[i] == es, (interp, is_max, v, st[i], es)
+            if es == 0:
+                tol = 1e-6 if interp == 2 else 1e-14
+                assert abs(got[i, 0] - ex) <= tol * max(1.0, abs(ex)), (interp, is_max, v, got[i], ex, ey)
+                assert abs(got[i, 1] - ey) <= tol * max(1.0, abs(ey)), (interp, is_max, v, got[i], ex, ey)
+    # the parabolic arm indexes y[floor(ixmid) - 1 .. + 1] of the slice it is given: out of bounds is the reference's panic
+    got, st = vb.improve_extremum_ex(y[:64], 0, 200, np.array([0.25, 62.5, 63.5, 100.0]), 1)
+    exp = [oracle.improve_extremum(y[:64], 0, 200, v, 1)[0] for v in (0.25, 62.5, 63.5, 100.0)]
+    assert list(st) == exp and exp[0] == 4 and exp[2] == 4
+
+
 # ---- pitch ----------------------------------------------------------------------------------------
 
 def test_pitch_kat(vb, oracle, pkg):

@@ -156,14 +156,40 @@ __global__ __launch_bounds__(64) void sinc_points_kernel(const double *__restric
     }
 }
 
+// interp: 0 Interpolation::None, 1 Parabolic, 2 Sinc(depth) (src/periodic.rs:192-229); is_max == 0 negates the interpolant
 __global__ __launch_bounds__(64) void extremum_points_kernel(const double *__restrict__ y, int ylen, int offset, int nx,
                                                              const double *__restrict__ ix, long m, int depth,
-                                                             double *__restrict__ out_xy, int32_t *__restrict__ status) {
+                                                             double *__restrict__ out_xy, int32_t *__restrict__ status,
+                                                             int interp, int is_max) {
     const long q = (long)blockIdx.x * PNG + lane_id() / PG;
     const bool have = q < m;
     int st = 0;
-    double xmid, ymid;
-    improve_extremum_sinc<PG>(y, ylen, ylen, offset, nx, have ? ix[q] : 1.0, depth, have, xmid, ymid, st);
+    double xmid = 0., ymid = 0.;
+    if (interp == 2) {
+        improve_extremum_sinc<PG>(y, ylen, ylen, offset, nx, have ? ix[q] : 1.0, depth, have, xmid, ymid, st, nullptr, nullptr,
+                                  -__builtin_inf(), nullptr, is_max == 0);
+    } else if (have) {
+        const double ixmid = ix[q];
+        if (ylen < 1) st |= 4;
+        else if (ixmid == 0.) { xmid = 0.; ymid = y[0]; }                                              // :193
+        else if (ixmid >= (double)nx) {                                                                // :194
+            if (nx < 1 || nx - 1 >= ylen) st |= 4; else { xmid = (double)nx; ymid = y[nx - 1]; }
+        } else if (interp == 0) { xmid = 0.; ymid = y[0]; }                                            // :197-199
+        else {                                                                                         // :200-207
+#pragma clang fp contract(off)
+            const double fl = floor(ixmid);
+            if (!(fl >= 1.) || !(fl + 1. < (double)ylen)) st |= 4;       // usize underflow / index out of bounds (NaN too)
+            else {
+                const int i = (int)fl;
+                const double diff = y[i + 1] - y[i - 1];
+                const double mid = y[i];
+                const double dy = 0.5 * diff;
+                const double d2y = 2.0 * mid - diff;
+                xmid = ixmid + dy / d2y;
+                ymid = mid + 0.5 * dy * dy / d2y;
+            }
+        }
+    }
     if (have && (lane_id() & (PG - 1)) == 0) {
         out_xy[2 * q] = (st & 4) ? 0.0 : xmid;
         out_xy[2 * q + 1] = (st & 4) ? 0.0 : ymid;
@@ -225,9 +251,9 @@ void launch_sinc_points(hipStream_t s, const double *y, int ylen, long offset, l
 }
 
 void launch_extremum_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *ix, long m,
-                            long depth, double *out_xy, int32_t *status) {
+                            long depth, double *out_xy, int32_t *status, int interp, int is_max) {
     hipLaunchKernelGGL(extremum_points_kernel, dim3((unsigned)((m + PNG - 1) / PNG)), dim3(64), 0, s,
-                       y, ylen, (int)offset, (int)nx, ix, m, (int)depth, out_xy, status);
+                       y, ylen, (int)offset, (int)nx, ix, m, (int)depth, out_xy, status, interp, is_max);
 }
 
 }  // namespace vbx

@@ -684,16 +684,23 @@ int vbx_interpolate_sinc_f64(vbx_ctx *ctx, const double *y, size_t ylen, long of
     return check_launch(ctx, __func__);
 }
 
-int vbx_improve_extremum_f64(vbx_ctx *ctx, const double *y, size_t ylen, long offset, size_t nx,
-                             const double *ixmid, size_t m, size_t depth, double *out_xy, int32_t *status) {
+int vbx_improve_extremum_ex_f64(vbx_ctx *ctx, const double *y, size_t ylen, long offset, size_t nx,
+                                const double *ixmid, size_t m, int interpolation, size_t depth, int is_max,
+                                double *out_xy, int32_t *status) {
     VBX_REQUIRE(ctx, ctx != nullptr, "null context");
     if (m == 0) return VBX_SUCCESS;
     VBX_REQUIRE(ctx, y && ixmid && out_xy && ylen >= 1 && ylen <= 0x7fffffff && m <= 0x7fffffff, "bad argument");
+    VBX_REQUIRE(ctx, interpolation >= VBX_INTERP_NONE && interpolation <= VBX_INTERP_SINC, "interpolation must be NONE, PARABOLIC or SINC");
     VBX_REQUIRE(ctx, depth <= 0x3fffffff && nx <= 0x3fffffff && ylen <= 0x3fffffff &&
                 offset > -0x3fffffffL && offset < 0x3fffffffL, "depth / nx / offset / ylen too large");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
-    { Prof p(ctx, "extremum_points"); launch_extremum_points(ctx->stream, y, (int)ylen, offset, (long)nx, ixmid, (long)m, (long)depth, out_xy, status); }
+    { Prof p(ctx, "extremum_points"); launch_extremum_points(ctx->stream, y, (int)ylen, offset, (long)nx, ixmid, (long)m, (long)depth, out_xy, status, interpolation, is_max ? 1 : 0); }
     return check_launch(ctx, __func__);
+}
+
+int vbx_improve_extremum_f64(vbx_ctx *ctx, const double *y, size_t ylen, long offset, size_t nx,
+                             const double *ixmid, size_t m, size_t depth, double *out_xy, int32_t *status) {
+    return vbx_improve_extremum_ex_f64(ctx, y, ylen, offset, nx, ixmid, m, VBX_INTERP_SINC, depth, 1, out_xy, status);
 }
 
 // The FFT-based kernel (k_spectral.hip) followed by the direct-sum kernel on the frames whose peak decisions lie

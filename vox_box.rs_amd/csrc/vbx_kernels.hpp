@@ -84,7 +84,8 @@ void launch_pitch_list(hipStream_t s, const int32_t *frame_list, const int32_t *
 void launch_sinc_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *xs, long m,
                         long depth, double *out, int32_t *status);
 void launch_extremum_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *ix, long m,
-                            long depth, double *out_xy, int32_t *status);
+                            long depth, double *out_xy, int32_t *status, int interp = 2 /* 0 None, 1 Parabolic, 2 Sinc */,
+                            int is_max = 1);
 
 // k_spectral.hip: pitch + LPC + MFCC from one FFT of the frame (frame length 1200)
 constexpr int SPECTRAL_N = 1200;

@@ -223,7 +223,8 @@ __device__ __forceinline__ void improve_extremum_sinc(const double *y, int nvali
                                                       double ixmid, int depth, bool active,
                                                       double &xmid, double &ymid, int &st,
                                                       unsigned *terms = nullptr, unsigned *evals = nullptr,
-                                                      double bar = -__builtin_inf(), bool *pruned = nullptr) {
+                                                      double bar = -__builtin_inf(), bool *pruned = nullptr,
+                                                      bool negate = false /* is_max == false: the closure negates, :219-222 */) {
 #pragma clang fp contract(off)   // keep the scalar iteration bit-identical to the unfused CPU arithmetic
     const double golden = 1. - 0.6180339887498948482045868343656381177203091798057628621;
     const double sqrt_epsilon = 1.4901161193847656e-08;   // sqrt(f64::EPSILON)
@@ -242,6 +243,7 @@ __device__ __forceinline__ void improve_extremum_sinc(const double *y, int nvali
     double a = ixmid - 1., b = ixmid + 1.;
     double v = a + golden * (b - a);
     double fv = sinc_interp<G>(y, nvalid, ylen, offset, nx, v, depth, run, st, terms);
+    if (negate) fv = -fv;
     if (evals != nullptr && run) *evals += 1u;
     double x = v, w = v, fx = fv, fw = fv;
     bool done = !run;
@@ -271,7 +273,8 @@ __device__ __forceinline__ void improve_extremum_sinc(const double *y, int nvali
         }
         if (fabs(new_step) < tol_act) new_step = (new_step > 0.) ? tol_act : -tol_act;
         const double t = x + new_step;
-        const double ft = sinc_interp<G>(y, nvalid, ylen, offset, nx, t, depth, !done, st, terms);
+        double ft = sinc_interp<G>(y, nvalid, ylen, offset, nx, t, depth, !done, st, terms);
+        if (negate) ft = -ft;
         if (evals != nullptr && !done) *evals += 1u;
         if (!done) {
             if (ft <= fx) {

@@ -132,6 +132,7 @@ def load_library():
         "vbx_normalize_f64": (C.c_int, [vp, vp, sz, sz]),
         "vbx_interpolate_sinc_f64": (C.c_int, [vp, vp, sz, C.c_long, sz, vp, sz, sz, vp, vp]),
         "vbx_improve_extremum_f64": (C.c_int, [vp, vp, sz, C.c_long, sz, vp, sz, sz, vp, vp]),
+        "vbx_improve_extremum_ex_f64": (C.c_int, [vp, vp, sz, C.c_long, sz, vp, sz, i32, sz, i32, vp, vp]),
         "vbx_pitch_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, dbl, dbl, dbl, dbl, sz, vp, vp, vp]),
         "vbx_lpc_f64": (C.c_int, [vp, vp, sz, sz, sz, vp]),
         "vbx_lpc_mut_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, vp]),
@@ -470,6 +471,19 @@ class VoxBox:
         dy, dx = self.to_device(y), self.to_device(ix)
         o, st = self.empty((ix.size, 2)), self.empty(ix.size, np.int32)
         self._check(self.L.vbx_improve_extremum_f64(self.ctx, dy.ptr, y.size, offset, nx, dx.ptr, ix.size, depth, o.ptr, st.ptr))
+        r = (o.numpy(), st.numpy())
+        for d in (dy, dx, o, st):
+            d.free()
+        return r
+
+    def improve_extremum_ex(self, y, offset, nx, ixmid, interpolation, depth=0, is_max=True):
+        """improve_extremum with any Interpolation arm (0 None, 1 Parabolic, 2 Sinc(depth)) and is_max."""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        ix = np.ascontiguousarray(ixmid, dtype=np.float64)
+        dy, dx = self.to_device(y), self.to_device(ix)
+        o, st = self.empty((ix.size, 2)), self.empty(ix.size, np.int32)
+        self._check(self.L.vbx_improve_extremum_ex_f64(self.ctx, dy.ptr, y.size, offset, nx, dx.ptr, ix.size, interpolation, depth,
+                                                       1 if is_max else 0, o.ptr, st.ptr))
         r = (o.numpy(), st.numpy())
         for d in (dy, dx, o, st):
             d.free()
