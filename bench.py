@@ -480,6 +480,15 @@ def run_rank(args):
                                         "(oracle MAC counter) + 13*sinc terms the kernel evaluated (device counters; the "
                                         "reference evaluates reference_sinc_terms); peak = FP64 vector = FP64 matrix peak "
                                         "(the kernel issues no MFMA: one FFT replaced the matrix-core autocorrelation)"}
+        # what "parity" means for this line: GPU == oracle is tested; oracle == reference is pinned
+        # by the reference's own known-answer tests where it has any, and is NOT where it has none
+        out["parity"] = {
+            "checked_against": "oracle/vbx_oracle.c (C restatement of the reference, pinned by its 26 inline known-answer tests "
+                               "and both WAV fixtures: tests/test_oracle_kat.py), through the C ABI in tests/ -m gpu",
+            "unpinned_by_the_reference": ["MFCC values (rustfft un-vendored; the reference asserts finiteness only)",
+                                          "find_formants end to end (the reference's test prints)",
+                                          "sinc / Brent values beyond the one 150 Hz vector (1e-2 Hz)",
+                                          "sample 0.10 window phase recurrence and the linear resampler (crate un-vendored)"]}
         if wl == "config4":
             # the tracker's slices run on their own stream beside Burg and the root finder (only the last slice is
             # exposed), so no single kernel is "the step": the whole config against both roofs (4264 B and
