@@ -24,7 +24,9 @@ __global__ __launch_bounds__(64) void burg_kernel(
     static_assert(G >= VBX_MAX_LPC_ORDER_K || G == 16, "one coefficient per lane of the group");
     const int lane = lane_id();
     const int gid = lane / G, lig = lane % G;
-    const long f = frame_map(map, (long)blockIdx.x * NG + gid, n_frames);
+    // one-frame workgroups of a hop-strided view: neighbouring frames on the same XCD (vbx_device.hpp, xcd_item)
+    const long blk = (NG == 1) ? xcd_item(blockIdx.x, gridDim.x) : (long)blockIdx.x;
+    const long f = frame_map(map, blk * NG + gid, n_frames);
     const bool have = f >= 0;
     const T *xf = x + (have ? f : 0) * stride;
 

@@ -36,7 +36,7 @@ __global__ void pcm16_kernel(const int16_t *__restrict__ pcm, size_t n, double d
 // rms: one wavefront per frame
 __global__ __launch_bounds__(64) void rms_kernel(const double *__restrict__ x, long n_frames, int n, long stride,
                                                  const double *__restrict__ window, double *__restrict__ out) {
-    const long f = blockIdx.x;
+    const long f = xcd_item(blockIdx.x, n_frames);
     if (f >= n_frames) return;
     const int lane = lane_id();
     const double *xf = x + f * stride;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64) void rms_kernel(const double *__restrict__ x, l
 __global__ __launch_bounds__(64) void preemphasis_kernel(const double *__restrict__ x, long n_frames, int n, long stride,
                                                          double c, double *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const long f = blockIdx.x;
+    const long f = xcd_item(blockIdx.x, n_frames);
     if (f >= n_frames) return;
     const int lane = lane_id();
     const double *xf = x + f * stride;

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64) void autocorr_tiles_kernel(
     const T *__restrict__ x, long n_frames, int n, long stride, const T *__restrict__ window,
     int n_lags, T *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const long f = blockIdx.x;
+    const long f = xcd_item(blockIdx.x, n_frames);
     if (f >= n_frames) return;
     const int lane = lane_id();
     const T *xf = x + f * stride;

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     int kmax, int full_off, double *__restrict__ out_cand, long cand_ld, int32_t *__restrict__ out_count,
     int32_t *__restrict__ status, unsigned long long *__restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const long f = blockIdx.x;
+    const long f = xcd_item(blockIdx.x, n_frames);          // neighbouring frames on the same XCD: their overlap hits its L2
     if (f >= n_frames) return;
     pitch_frame_mfma<ALIAS>(smem, f, frames, n, stride, window, lag_window, sample_rate, threshold, fmin, fmax, kmax,
                             full_off, out_cand, cand_ld, out_count, status, work);

@@ -222,7 +222,7 @@ constexpr int SP_LPC_P = SPECTRAL_LPC_ORDER;
 template <bool LPC, bool MFCC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VBX_SPECTRAL_WAVES, VBX_SPECTRAL_WAVES))) void analyze_kernel(const spectral_args_t a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const long f = blockIdx.x;
+    const long f = xcd_item(blockIdx.x, a.n_frames);            // neighbouring frames on the same XCD: their overlap hits its L2
     if (f >= a.n_frames) return;
     const int lane = lane_id();
     const int np = (lane < 60) ? lane : 59;

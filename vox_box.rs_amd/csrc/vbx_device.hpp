@@ -74,6 +74,20 @@ __device__ __forceinline__ double wave_sum_shfl(double v) {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
+// Workgroup -> item mapping for one-wavefront workgroups over a hop-strided frame view.  Workgroups are dealt round-robin
+// to the 8 XCDs (workgroup b runs on XCD b % 8), each with its own L2; neighbouring frames share frame_len - hop of their
+// samples (60 % at 25 ms / 10 ms), so with the identity mapping every XCD fetches those samples from HBM again.  Inside a
+// tile of 8 * XCD_RUN items, XCD x takes the XCD_RUN CONSECUTIVE items [x * XCD_RUN, (x + 1) * XCD_RUN) in dispatch order:
+// the overlap is then served by that XCD's L2.  The incomplete last tile keeps the identity mapping.
+constexpr long XCD_RUN = 1024;
+__device__ __forceinline__ long xcd_item(long b, long n) {
+    constexpr long T = 8 * XCD_RUN;
+    const long tile = b / T;
+    if ((tile + 1) * T > n) return b;
+    const long j = b - tile * T;
+    return tile * T + (j & 7) * XCD_RUN + (j >> 3);
+}
+
 constexpr int DPP_QUAD_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
 constexpr int DPP_QUAD_REV = 0x1B;          // quad_perm [3,2,1,0]
 constexpr int DPP_ROW_HALF_MIRROR = 0x141;  // i <-> 7-i inside each 8 lanes
