@@ -826,3 +826,62 @@ def test_zz_pitch_parity_report():
         with open(os.path.join(out, "pitch_parity_stats.json"), "w") as fh:
             json.dump({"total": tot, "calls": PITCH_STATS}, fh, indent=1)
     assert tot["n_top_bad"] == 0 and tot["n_vuv_outside_tol"] == 0
+
+
+def test_pitch_fft_path_and_direct_path_agree(pkg, oracle, audio, monkeypatch):
+    """N = 1200 takes the FFT-based kernel; VBX_PITCH_MFMA=1 keeps the direct-sum (matrix-core) kernel that also serves
+    every other frame length and the FFT path's fallback list.  The two produce the lag curve in different arithmetic
+    (errors ~1e-16 S[0]): statuses and candidate COUNTS must be identical (the peak decisions are guarded by the
+    fallback), values within the pitch tolerance."""
+    rng = np.random.default_rng(5)
+    F = pkg.frame_count(audio.size, N48, H48)
+    x = _frames(audio, N48, H48, list(range(0, F, 3))) * oracle.window("hanning", N48)
+    t = np.arange(N48) / SR
+    odd = np.array([rng.standard_normal(N48), np.sin(2 * np.pi * 173.0 * t), np.sign(np.sin(2 * np.pi * 120 * t)),
+                    np.bincount(rng.integers(0, N48, 5), minlength=N48).astype(np.float64), np.zeros(N48),
+                    0.5 + 0.01 * rng.standard_normal(N48)]) * oracle.window("hanning", N48)
+    X = np.concatenate([x, odd])
+    res = {}
+    for name, var in (("fft", None), ("direct", "VBX_PITCH_MFMA")):
+        if var:
+            monkeypatch.setenv(var, "1")
+        v = pkg.VoxBox(0)
+        if var:
+            monkeypatch.delenv(var)
+        try:
+            res[name] = v.pitch(X, SR, 0.2, 75.0, 600.0, kmax=8)
+        finally:
+            v.close()
+    (ca, ka, sa), (cb, kb, sb) = res["fft"], res["direct"]
+    assert np.array_equal(ka, kb) and np.array_equal(sa, sb)
+    ok = sa == 0
+    n = np.minimum(ka[ok], 8)
+    A, B = ca[ok], cb[ok]
+    assert np.all(np.abs(A[:, 0, 0] - B[:, 0, 0]) <= 1e-4 * np.abs(B[:, 0, 0]) + 1e-12)         # the PitchExtractor output
+    dfreq = np.abs(np.sort(A[:, :, 0], axis=1) - np.sort(B[:, :, 0], axis=1))                      # the candidate sets
+    assert np.all(dfreq <= 1e-4 * np.abs(np.sort(B[:, :, 0], axis=1)) + 1e-12)
+    flips = np.abs(np.sort(A[:, :, 1], axis=1) - np.sort(B[:, :, 1], axis=1)) > 1e-4
+    assert flips.sum() <= max(1, int(n.sum()) // 100), int(flips.sum())
+    assert not np.array_equal(A, B)                                                              # two kernels really ran
+
+
+def test_pitch_fft_path_defers_undecidable_frames(vb, oracle):
+    """Frames whose strict 3-point peak test lies inside the transforms' rounding error (a lag curve that is exactly zero
+    or flat over a stretch: a few impulses, a constant) are not decided by the FFT kernel: they are listed and redone by
+    the direct-sum kernel, so their candidate count is the oracle's.  Ordinary frames are not deferred."""
+    N, rng = 1200, np.random.default_rng(11)
+    w = oracle.window("hanning", N)
+    ordinary = rng.standard_normal((6, N)) * w
+    imp = np.zeros((4, N))
+    for i in range(4):
+        imp[i, rng.integers(100, 1100, 3)] = rng.uniform(0.5, 1.0, 3)
+    cand, cnt, st = vb.pitch(ordinary, SR, 0.2, 75.0, 600.0, kmax=4)
+    assert vb.last_unsure_count() == 0
+    cand, cnt, st = vb.pitch(imp, SR, 0.2, 75.0, 600.0, kmax=4)
+    assert vb.last_unsure_count() == 4
+    for f in range(4):
+        es, ec, en = oracle.pitch(imp[f], SR, 0.2, 75.0, 600.0)
+        assert st[f] == es and cnt[f] == (en if es == 0 else 0), (f, st[f], es, cnt[f], en)
+        if es == 0:
+            k = min(4, en)
+            assert np.all(np.abs(cand[f, :k, 0] - ec[:k, 0]) <= 1e-4 * np.abs(ec[:k, 0]) + 1e-12)

@@ -1452,6 +1452,18 @@ int vbx_synth_speech_f64(vbx_ctx *ctx, double *out, size_t n_samples, uint64_t s
     return check_launch(ctx, __func__);
 }
 
+// internal (tests only; not part of the public header): how many frames of the last FFT-path pitch / analyze call were
+// handed to the direct-sum kernel because a peak decision lay inside the transforms' rounding error
+int vbx_internal_last_unsure_count(vbx_ctx *ctx, int32_t *h_count) {
+    VBX_REQUIRE(ctx, ctx && h_count, "null argument");
+    *h_count = 0;
+    if (!ctx->ws[vbx_ctx::WS_UNSURE]) return VBX_SUCCESS;
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    VBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VBX_HIP(ctx, hipMemcpy(h_count, ctx->ws[vbx_ctx::WS_UNSURE], sizeof(int32_t), hipMemcpyDeviceToHost));
+    return VBX_SUCCESS;
+}
+
 // internal: cross-lane helper self-test (tests only; not part of the public header)
 int vbx_selftest_lanes(vbx_ctx *ctx, double *h_out512) {   // h_out512: 1024 doubles
     VBX_REQUIRE(ctx, ctx && h_out512, "null argument");

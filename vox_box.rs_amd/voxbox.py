@@ -166,6 +166,7 @@ def load_library():
         "vbx_preemphasis_f64": (C.c_int, [vp, vp, sz, sz, sz, dbl, vp]),
         "vbx_synth_speech_f64": (C.c_int, [vp, vp, sz, C.c_uint64, dbl, C.c_uint64]),
         "vbx_selftest_lanes": (C.c_int, [vp, vp]),
+        "vbx_internal_last_unsure_count": (C.c_int, [vp, vp]),
         "vbx_record_doubles": (sz, [C.POINTER(AnalysisParams)]),
         "vbx_analyze_frames_f64": (C.c_int, [vp, vp, sz, sz, sz, C.POINTER(AnalysisParams), vp, sz, vp, sz, vp]),
         "vbx_shard_range": (C.c_int, [sz, i32, i32, vp, sz, C.POINTER(sz), C.POINTER(sz)]),
@@ -855,6 +856,12 @@ class VoxBox:
         o = out if out is not None else self.empty(n_samples)
         self._check(self.L.vbx_synth_speech_f64(self.ctx, _ptr(o), n_samples, sample_offset, sample_rate, seed))
         return o
+
+    def last_unsure_count(self):
+        """Frames of the last FFT-path pitch / analyze call that were redone by the direct-sum kernel (test probe)."""
+        n = C.c_int32(0)
+        self._check(self.L.vbx_internal_last_unsure_count(self.ctx, C.byref(n)))
+        return int(n.value)
 
     def selftest_lanes(self):
         out = np.zeros((2, 64, 8), dtype=np.float64)
