@@ -167,14 +167,30 @@ __device__ __forceinline__ double sinc_terms_fast(const double *y, int ibase_l, 
 // active == false contribute nothing.  st |= 4 where the reference would index out of bounds.
 // y[0..nvalid) is readable (entries past the data are zero), ylen >= nvalid is the logical length
 // after self_lag.resize(2N, 0).  Must be called from converged code.
+// trusted: sinc_bracket_trusted() has shown that EVERY abscissa of the caller's bracket takes the clamp-free sum or one of
+// the two exact-integer early-outs with readable indices; the range tests of :38-40 and the index checks are then skipped
+// (they cannot fire), the arithmetic is the same.
 template <int G>
 __device__ __forceinline__ double sinc_interp(const double *y, int nvalid, int ylen, int offset, int nx,
                                               double x, int max_depth, bool active, int &st,
-                                              unsigned *terms = nullptr) {
+                                              unsigned *terms = nullptr, bool trusted = false) {
     bool summed = false, fast = false;
     double special = 0.0, phil = 0.5, phir = 0.5;
     int nl = 0, nr = 1;
-    if (active) {
+    if (active && trusted) {
+        const double fl = floor(x);
+        nl = (int)fl;
+        nr = nl + 1;
+        phil = x - fl;
+        phir = 1.0 - phil;
+        if (fabs(x - (double)nl) < 1.0e-10) special = y[offset + nl];                          // :41
+        else if (fabs(x - (double)nr) < 1.0e-10) special = y[offset + nr];                     // :42
+        else {
+            if ((offset + nr) < max_depth) max_depth = offset + nr;                            // :46-52 (offset + nr >= 1 here)
+            if ((offset + nl + max_depth) >= nx) max_depth = nx - offset + nl - 1;             // :55-57
+            summed = true; fast = true;
+        }
+    } else if (active) {
         if (nx < 1) special = __builtin_nan("");                                   // :38
         else if (x > (double)nx) {                                                 // :39
             const int idx = offset + nx - 1;
@@ -215,6 +231,24 @@ __device__ __forceinline__ double sinc_interp(const double *y, int nvalid, int y
     return summed ? total : special;
 }
 
+// True when every abscissa in [a0, b0] is handled by sinc_interp's clamp-free sum or by an exact-integer early-out whose
+// index is readable: the same conditions sinc_interp tests per evaluation, tested once for each of the (at most three)
+// unit cells the bracket touches.  False for NaN bounds.
+__device__ __forceinline__ bool sinc_bracket_trusted(double a0, double b0, int nvalid, int ylen, int offset, int nx, int depth) {
+    if (!(a0 >= 0.0 && b0 <= (double)nx && b0 - a0 <= 2.5)) return false;
+    const int lo = (int)floor(a0), hi = (int)floor(b0);
+    bool ok = true;
+    for (int nl = lo; nl <= hi; nl++) {
+        const int nr = nl + 1;
+        int D = depth;
+        if ((offset + nr) < D) D = ((offset + nr) < 0) ? 0 : (offset + nr);
+        if ((offset + nl + D) >= nx) D = nx - offset + nl - 1;
+        ok = ok && D >= 0 && offset + nr < ylen && D <= offset + nr && offset + nl >= 0 && offset + nl + D < nvalid &&
+             offset + nr < nvalid && offset + nr >= 1;
+    }
+    return ok;
+}
+
 // improve_extremum(.., Interpolation::Sinc(depth), true) (src/periodic.rs:192-229) around
 // brent_maximize (:103-188): a MINIMISER of the un-negated interpolant (Q8).  One candidate per
 // group of G lanes; `active` lanes carry a candidate.  Must be called from converged code.
@@ -241,8 +275,9 @@ __device__ __forceinline__ void improve_extremum_sinc(const double *y, int nvali
         } else if (!(ixmid - 1. < ixmid + 1.)) { st |= 4; run = false; }                        // assert!(a < b), :113
     }
     double a = ixmid - 1., b = ixmid + 1.;
+    const bool trusted = run && sinc_bracket_trusted(a, b, nvalid, ylen, offset, nx, depth);
     double v = a + golden * (b - a);
-    double fv = sinc_interp<G>(y, nvalid, ylen, offset, nx, v, depth, run, st, terms);
+    double fv = sinc_interp<G>(y, nvalid, ylen, offset, nx, v, depth, run, st, terms, trusted);
     if (negate) fv = -fv;
     if (evals != nullptr && run) *evals += 1u;
     double x = v, w = v, fx = fv, fw = fv;
@@ -273,7 +308,7 @@ __device__ __forceinline__ void improve_extremum_sinc(const double *y, int nvali
         }
         if (fabs(new_step) < tol_act) new_step = (new_step > 0.) ? tol_act : -tol_act;
         const double t = x + new_step;
-        double ft = sinc_interp<G>(y, nvalid, ylen, offset, nx, t, depth, !done, st, terms);
+        double ft = sinc_interp<G>(y, nvalid, ylen, offset, nx, t, depth, !done, st, terms, trusted);
         if (negate) ft = -ft;
         if (evals != nullptr && !done) *evals += 1u;
         if (!done) {
@@ -656,7 +691,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
         bool exhausted = false;
         const int gid = lane / PG;
         int ci = -1, it = 0;
-        bool special = false, safe = false;
+        bool special = false, safe = false, trusted = false;
         double ba = 0., bb = 0., v = 0., w = 0., x = 0., fv = 0., fw = 0., fx = 0., xmid = 0., ymid = 0.;
         constexpr unsigned long long LEADERS = (PG == 16) ? 0x0001000100010001ull : (PG == 8) ? 0x0101010101010101ull
                                              : (PG == 32) ? 0x0000000100000001ull : (PG == 4) ? 0x1111111111111111ull : 1ull;
@@ -679,6 +714,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
                         else if (!(nn - 1. < nn + 1.)) { special = true; st |= 4; }                             // assert!(a < b), :113
                         ba = nn - 1.; bb = nn + 1.;
                         safe = ba >= (double)(-offset);      // no abscissa of the bracket can index out of bounds
+                        trusted = !special && sinc_bracket_trusted(ba, bb, nvalid, ylen, offset, nx, 1200);
                     }
                 }
             }
@@ -714,7 +750,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
                     }
                 }
             }
-            const double ft = sinc_interp<PG>(ys, nvalid, ylen, offset, nx, t, 1200, need, st, &nterms);
+            const double ft = sinc_interp<PG>(ys, nvalid, ylen, offset, nx, t, 1200, need, st, &nterms, trusted);
             nevals += need ? 1u : 0u;
             if (need) {
                 if (it == 0) {
