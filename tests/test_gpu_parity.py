@@ -628,7 +628,9 @@ def test_pitch_work_counters(vb, oracle, audio, pkg):
     assert work[64][2] >= work[64][1]                                  # unpruned: every candidate is evaluated
 
 
-@pytest.mark.parametrize("n", [64, 100, 256, 513, 1280, 1281, 2048, 4096])   # 1280 / 1281: one / two autocorrelation passes
+# 1280 / 1281: one / two autocorrelation passes of the direct kernel (VBX_PITCH_MFMA=1); 512..2048 take the FFT kernels
+@pytest.mark.parametrize("n", [64, 100, 256, 511, 512, 513, 703, 704, 800, 1023, 1024, 1025, 1103, 1199, 1201, 1280, 1281, 1600, 2047, 2048,
+                               2049, 4096])
 def test_pitch_other_frame_lengths(vb, oracle, audio, n):
     x = _frames(audio, n, 211, range(0, 40, 3 if n <= 2048 else 8)) * oracle.window("hanning", n)
     assert _check_pitch(vb, oracle, x, SR, 0.45, 60.0, 2000.0, 8) == 0
@@ -828,18 +830,24 @@ def test_zz_pitch_parity_report():
     assert tot["n_top_bad"] == 0 and tot["n_vuv_outside_tol"] == 0
 
 
-def test_pitch_fft_path_and_direct_path_agree(pkg, oracle, audio, monkeypatch):
-    """N = 1200 takes the FFT-based kernel; VBX_PITCH_MFMA=1 keeps the direct-sum (matrix-core) kernel that also serves
-    every other frame length and the FFT path's fallback list.  The two produce the lag curve in different arithmetic
-    (errors ~1e-16 S[0]): statuses and candidate COUNTS must be identical (the peak decisions are guarded by the
-    fallback), values within the pitch tolerance."""
+@pytest.mark.parametrize("n,hop,rect", [(1200, 480, False), (1200, 480, True), (1024, 512, False), (1024, 512, True),
+                                        (2048, 1024, False), (2048, 1024, True), (1103, 441, False), (1102, 441, True),
+                                        (512, 256, True), (513, 200, False), (704, 300, False), (901, 333, True), (1025, 400, False), (1199, 480, True),
+                                        (1201, 480, False), (1600, 640, False), (2047, 900, True)])
+def test_pitch_fft_path_and_direct_path_agree(pkg, oracle, audio, monkeypatch, n, hop, rect):
+    """Frame lengths 512..2048 take an FFT-based kernel (complex length 1024, 1200 or 2048, the frame zero padded);
+    VBX_PITCH_MFMA=1 keeps the direct-sum (matrix-core) kernel that also serves every other frame length and the FFT path's
+    fallback list.  The two produce the lag curve in different arithmetic (errors ~1e-16 S[0]): statuses and candidate
+    COUNTS must be identical (the peak decisions are guarded by the fallback), values within the pitch tolerance.
+    rect: rectangular frames, x[0] != 0 -- the fold seed (Q1) is then part of every lag."""
     rng = np.random.default_rng(5)
-    F = pkg.frame_count(audio.size, N48, H48)
-    x = _frames(audio, N48, H48, list(range(0, F, 3))) * oracle.window("hanning", N48)
-    t = np.arange(N48) / SR
-    odd = np.array([rng.standard_normal(N48), np.sin(2 * np.pi * 173.0 * t), np.sign(np.sin(2 * np.pi * 120 * t)),
-                    np.bincount(rng.integers(0, N48, 5), minlength=N48).astype(np.float64), np.zeros(N48),
-                    0.5 + 0.01 * rng.standard_normal(N48)]) * oracle.window("hanning", N48)
+    F = pkg.frame_count(audio.size, n, hop)
+    w = np.ones(n) if rect else oracle.window("hanning", n)
+    x = _frames(audio, n, hop, list(range(0, F, max(3, F // 400)))) * w
+    t = np.arange(n) / SR
+    odd = np.array([rng.standard_normal(n), np.sin(2 * np.pi * 173.0 * t), np.sign(np.sin(2 * np.pi * 120 * t)),
+                    np.bincount(rng.integers(0, n, 5), minlength=n).astype(np.float64), np.zeros(n),
+                    0.5 + 0.01 * rng.standard_normal(n)]) * w
     X = np.concatenate([x, odd])
     res = {}
     for name, var in (("fft", None), ("direct", "VBX_PITCH_MFMA")):
@@ -855,13 +863,13 @@ def test_pitch_fft_path_and_direct_path_agree(pkg, oracle, audio, monkeypatch):
     (ca, ka, sa), (cb, kb, sb) = res["fft"], res["direct"]
     assert np.array_equal(ka, kb) and np.array_equal(sa, sb)
     ok = sa == 0
-    n = np.minimum(ka[ok], 8)
+    nk = np.minimum(ka[ok], 8)
     A, B = ca[ok], cb[ok]
     assert np.all(np.abs(A[:, 0, 0] - B[:, 0, 0]) <= 1e-4 * np.abs(B[:, 0, 0]) + 1e-12)         # the PitchExtractor output
     dfreq = np.abs(np.sort(A[:, :, 0], axis=1) - np.sort(B[:, :, 0], axis=1))                      # the candidate sets
     assert np.all(dfreq <= 1e-4 * np.abs(np.sort(B[:, :, 0], axis=1)) + 1e-12)
     flips = np.abs(np.sort(A[:, :, 1], axis=1) - np.sort(B[:, :, 1], axis=1)) > 1e-4
-    assert flips.sum() <= max(1, int(n.sum()) // 100), int(flips.sum())
+    assert flips.sum() <= max(1, int(nk.sum()) // 100), int(flips.sum())
     assert not np.array_equal(A, B)                                                              # two kernels really ran
 
 

@@ -26,6 +26,7 @@
 #include "vbx_kernels.hpp"
 #include "vbx_mfcc_tail.hpp"
 #include "vbx_pitch_refine.hpp"
+#include "vbx_spectral.hpp"
 
 namespace vbx {
 
@@ -36,19 +37,7 @@ constexpr int SP_S2 = 404;                   // exchange 2 row stride [c][ka + 2
 constexpr int SP_T1 = 0;                     // twiddle table (complex entries): T1[60][20] = W_1200^(n' ka)
 constexpr int SP_T2 = SP_T1 + 60 * 20;       //                                  T2[3][20]  = W_60^(c kb)
 constexpr int SP_TM = SP_T2 + 3 * 20;        //                                  WM[601]    = W_2400^m
-constexpr double SP_UNC_EPS = 6.0 * 400.0 * 2.220446049250313e-16;   // 1 / min w_lag * margin * eps
 static_assert(SP_TM + 601 == SPECTRAL_TAB_COMPLEX, "table layout");
-
-// ---- small DFTs on separate re / im registers (forward: e^{-i...}) -------------------------------------------------
-__device__ __forceinline__ void dft4(double &r0, double &i0, double &r1, double &i1, double &r2, double &i2,
-                                     double &r3, double &i3) {
-    const double t0r = r0 + r2, t0i = i0 + i2, t1r = r0 - r2, t1i = i0 - i2;
-    const double t2r = r1 + r3, t2i = i1 + i3, t3r = r1 - r3, t3i = i1 - i3;
-    r0 = t0r + t2r; i0 = t0i + t2i;
-    r2 = t0r - t2r; i2 = t0i - t2i;
-    r1 = t1r + t3i; i1 = t1i - t3r;          // t1 - i t3
-    r3 = t1r - t3i; i3 = t1i + t3r;          // t1 + i t3
-}
 
 __device__ __forceinline__ void dft5(double &r0, double &i0, double &r1, double &i1, double &r2, double &i2,
                                      double &r3, double &i3, double &r4, double &i4) {
@@ -177,55 +166,21 @@ __device__ __forceinline__ void fft1200(double (&re)[20], double (&im)[20], doub
     }
 }
 
-struct spectral_args_t {
-    const double *frames; long n_frames; long stride; const double *window; const double *lag_window;
-    const double2 *tab;
-    pitch_params_t pp;
-    double *out_cand; long cand_ld; int32_t *out_count; int32_t *pitch_status; unsigned long long *work;
-    double *out_lpc; long lpc_ld;
-    double *out_mfcc; long mfcc_ld; int32_t *mfcc_status;
-    const int32_t *bins; const double *slopes; const double *dct; int num_coeffs; int nb;
-    int32_t *unsure_list; int32_t *unsure_count;
-};
-
-// Levinson-Durbin on r[0..P] (src/spectrum.rs:63-84), every lane on the same (uniform) values
-template <int P>
-__device__ __forceinline__ void levinson_regs(const double (&r)[P + 1], double (&ac)[P + 1]) {
-    double tmp[P + 1];
-    double err = r[0];
-    ac[0] = 1.0;
-#pragma unroll
-    for (int i = 1; i <= P; i++) ac[i] = 0.0;
-#pragma unroll
-    for (int i = 1; i <= P; i++) {
-        double acc = r[i];
-#pragma unroll
-        for (int j = 1; j < i; j++) acc = acc + ac[j] * r[i - j];
-        const double k = -acc / err;
-        ac[i] = k;
-#pragma unroll
-        for (int j = 0; j < P; j++) tmp[j] = ac[j];
-#pragma unroll
-        for (int j = 1; j < i; j++) ac[j] = ac[j] + k * tmp[i - j];
-        err = err * (1.0 - k * k);
-    }
-}
-
-constexpr int SP_LPC_P = SPECTRAL_LPC_ORDER;
-
 // Two wavefronts per SIMD: the two transforms need ~230 registers.  At three (168 registers) 55 of them spill, which the
 // refinement's arithmetic hides in time (measured: the same frames/s) but which costs 36 KB of scratch traffic per
 // frame -- 46 KB against 10 KB of HBM traffic per frame (profiles/r02*_pmc_counters.json).
 #ifndef VBX_SPECTRAL_WAVES
 #define VBX_SPECTRAL_WAVES 2
 #endif
-template <bool LPC, bool MFCC>
+// FULL: the frame fills the transform (n == 1200, the bounds tests fold away); otherwise 1025 <= n < 1200, zero padded.
+template <bool LPC, bool MFCC, bool FULL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VBX_SPECTRAL_WAVES, VBX_SPECTRAL_WAVES))) void analyze_kernel(const spectral_args_t a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const long f = xcd_item(blockIdx.x, a.n_frames);            // neighbouring frames on the same XCD: their overlap hits its L2
     if (f >= a.n_frames) return;
     const int lane = lane_id();
     const int np = (lane < 60) ? lane : 59;
+    const int n = FULL ? SP_N : a.n;                         // frame length, <= SP_N (shorter: longer zero padding)
     double *ex = smem;                                       // exchange buffer, later the lag curve y
     const double *xf = a.frames + f * a.stride;
 
@@ -237,12 +192,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VBX_SPECTRAL
 #pragma unroll
         for (int q = 0; q < 10; q++) {
             const int i = 120 * q + 2 * np;
-            if (al) {
+            if (al && i + 1 < n) {
                 xv[q] = *reinterpret_cast<const double2 *>(xf + i);
                 wv[q] = (a.window != nullptr) ? *reinterpret_cast<const double2 *>(a.window + i) : double2{1.0, 1.0};
             } else {
-                xv[q].x = xf[i]; xv[q].y = xf[i + 1];
-                wv[q].x = (a.window != nullptr) ? a.window[i] : 1.0; wv[q].y = (a.window != nullptr) ? a.window[i + 1] : 1.0;
+                xv[q] = double2{0.0, 0.0}; wv[q] = double2{1.0, 1.0};
+                if (i < n) { xv[q].x = xf[i]; if (a.window != nullptr) wv[q].x = a.window[i]; }
+                if (i + 1 < n) { xv[q].y = xf[i + 1]; if (a.window != nullptr) wv[q].y = a.window[i + 1]; }
             }
         }
 #pragma unroll
@@ -383,11 +339,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VBX_SPECTRAL
     if (x0 != 0.0) {                                         // rectangular frames: the fold seed differs from S (uniform branch)
 #pragma unroll
         for (int s = 0; s < 11; s++) {
-            if (jj[s] >= 0) {
-                const int i = 2 * jj[s];
+            const int i = 2 * jj[s];
+            if (jj[s] >= 0 && i < n) {
                 const double xe = (a.window != nullptr) ? xf[i] * a.window[i] : xf[i];
-                const double xo = (a.window != nullptr) ? xf[i + 1] * a.window[i + 1] : xf[i + 1];
                 r_e[s] = (r_e[s] - x0 * xe) + x0;
+            }
+            if (jj[s] >= 0 && i + 1 < n) {
+                const double xo = (a.window != nullptr) ? xf[i + 1] * a.window[i + 1] : xf[i + 1];
                 r_o[s] = (r_o[s] - x0 * xo) + x0;
             }
         }
@@ -402,14 +360,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VBX_SPECTRAL
         for (int k = 0; k <= SP_LPC_P; k++) mine = (lane == k) ? ac[k] : mine;
         if (lane <= SP_LPC_P) a.out_lpc[f * a.lpc_ld + lane] = mine;
     }
-    double amax = -1.0;                                      // max_amplitude over ALL lags (Q2; NaN never wins)
+    double amax = -1.0;                                      // max_amplitude over ALL n lags (Q2; NaN never wins)
 #pragma unroll
     for (int s = 0; s < 11; s++) {
-        if (jj[s] >= 0) {
-            const double ae = fabs(r_e[s]), ao = fabs(r_o[s]);
-            amax = (ae > amax) ? ae : amax;
-            amax = (ao > amax) ? ao : amax;
-        }
+        const int i = 2 * jj[s];
+        const double ae = fabs(r_e[s]), ao = fabs(r_o[s]);
+        if (jj[s] >= 0 && i < n) amax = (ae > amax) ? ae : amax;
+        if (jj[s] >= 0 && i + 1 < n) amax = (ao > amax) ? ao : amax;
     }
     amax = wave_max(amax);
     const double scale = 1.0 / amax;                         // normalize (:404), then / lag window (:406-408)
@@ -417,28 +374,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VBX_SPECTRAL
     wave_sync();                                             // every lane is done with the exchange buffer
 #pragma unroll
     for (int s = 0; s < 11; s++) {
-        if (jj[s] >= 0) {
-            const double2 lw = *reinterpret_cast<const double2 *>(a.lag_window + 2 * jj[s]);
+        const int i = 2 * jj[s];
+        if (jj[s] >= 0 && i + 1 < n) {
+            const double2 lw = *reinterpret_cast<const double2 *>(a.lag_window + i);
             double2 y;
             y.x = (r_e[s] * scale) / lw.x;
             y.y = (r_o[s] * scale) / lw.y;
-            *reinterpret_cast<double2 *>(ys + 2 * jj[s]) = y;
+            *reinterpret_cast<double2 *>(ys + i) = y;
+        } else if (jj[s] >= 0 && i < n) {                    // the last lag of an odd n
+            ys[i] = (r_e[s] * scale) / a.lag_window[i];
         }
     }
-    if (lane < Y_PAD) ys[SP_N + lane] = 0.0;
+    if (lane < Y_PAD) ys[n + lane] = 0.0;
     wave_sync();
     // Rounding error of the two transforms: a few ulp of S[0] per lag (measured: < 8 eps S[0]); y = r * scale / w_lag
     // with w_lag >= 1/6 on the searched half.  SP_UNC_EPS bounds the error of a DIFFERENCE of two entries with a wide
     // margin; frames with a peak decision inside it go to the direct-sum kernel (launch_pitch_list).
     const double unc_tol = SP_UNC_EPS * fabs(s0) * scale;
     double2 *full = a.pp.full_off ? reinterpret_cast<double2 *>(reinterpret_cast<char *>(smem) + a.pp.full_off) : nullptr;
-    if (!pitch_refine_store(ys, SP_N, a.pp, f, a.out_cand, a.cand_ld, a.out_count, a.pitch_status, a.work, unc_tol, full)) {
+    if (!pitch_refine_store(ys, n, a.pp, f, a.out_cand, a.cand_ld, a.out_count, a.pitch_status, a.work, unc_tol, full)) {
         if (lane == 0) a.unsure_list[atomicAdd(a.unsure_count, 1)] = (int32_t)f;
     }
 }
 
-size_t spectral_lds_bytes() {
-    size_t need = (size_t)pitch_refine_lds_bytes(SP_N);
+static size_t spectral_lds_bytes(int n) {
+    size_t need = (size_t)pitch_refine_lds_bytes(n);
     const size_t exch = (size_t)(20 * SP_S1 > 3 * SP_S2 ? 20 * SP_S1 : 3 * SP_S2) * sizeof(double);
     const size_t mel = (size_t)(2 * 602 + 64) * sizeof(double);
     if (exch > need) need = exch;
@@ -446,10 +406,44 @@ size_t spectral_lds_bytes() {
     return (need + 15) & ~(size_t)15;
 }
 
+int spectral_plan(int n) {
+    static const int min_n = [] { const char *e = getenv("VBX_SPECTRAL_MIN_N"); return e ? atoi(e) : SPECTRAL_MIN_N; }();
+    if (n < min_n || n < 64) return SPECTRAL_PLAN_NONE;
+    if (n <= 1024) return SPECTRAL_PLAN_1024;
+    if (n <= SP_N) return SPECTRAL_PLAN_1200;
+    if (n <= 2048) return SPECTRAL_PLAN_2048;
+    return SPECTRAL_PLAN_NONE;
+}
+
+int spectral_plan_nc(int plan) {
+    return plan == SPECTRAL_PLAN_1200 ? SP_N : plan == SPECTRAL_PLAN_1024 ? 1024 : plan == SPECTRAL_PLAN_2048 ? 2048 : 0;
+}
+
+int spectral_tab_complex(int plan) {
+    return plan == SPECTRAL_PLAN_1200 ? SPECTRAL_TAB_COMPLEX : spectral_pow2_tab_complex(plan);
+}
+
+// twiddles, evaluated in long double and rounded once
+void spectral_fill_tab(int plan, double *h) {
+    if (plan != SPECTRAL_PLAN_1200) { spectral_pow2_fill_tab(plan, h); return; }
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    size_t o = 0;
+    auto put = [&](long num, long den) {             // e^{-2 pi i num / den}
+        const long double ang = two_pi * (long double)(num % den) / (long double)den;
+        h[o++] = (double)cosl(ang); h[o++] = (double)(-sinl(ang));
+    };
+    for (long np = 0; np < 60; np++) for (long ka = 0; ka < 20; ka++) put(np * ka, 1200);
+    for (long c = 0; c < 3; c++) for (long kb = 0; kb < 20; kb++) put(c * kb, 60);
+    for (long m = 0; m <= 600; m++) put(m, 2400);
+}
+
+// The fused kernel serves: pitch for every frame length with a plan; LPC of order 12 with it; MFCC with it when the frame
+// fills the transform exactly (the mel filters read the n-point DFT bins = every second bin of the 2n-point transform).
 bool spectral_supported(int n, int lpc_order, int mfcc_nb, int mfcc_b_lo, int num_coeffs) {
-    if (n != SP_N) return false;
+    const int plan = spectral_plan(n);
+    if (plan == SPECTRAL_PLAN_NONE) return false;
     if (lpc_order != 0 && lpc_order != SP_LPC_P) return false;
-    if (num_coeffs != 0 && (num_coeffs > 64 || mfcc_nb < 1 || mfcc_b_lo < 0 || mfcc_b_lo + mfcc_nb > SP_N / 2)) return false;
+    if (num_coeffs != 0 && (n != spectral_plan_nc(plan) || num_coeffs > 64 || mfcc_nb < 1 || mfcc_b_lo < 0 || mfcc_b_lo + mfcc_nb > n / 2)) return false;
     return true;
 }
 
@@ -457,6 +451,7 @@ void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
     spectral_args_t a;
     a.frames = L.x; a.n_frames = L.F; a.stride = L.stride; a.window = L.window; a.lag_window = L.lag_window;
     a.tab = reinterpret_cast<const double2 *>(L.tab);
+    a.n = L.n;
     a.pp.sample_rate = L.sample_rate; a.pp.threshold = L.threshold; a.pp.fmin = L.fmin; a.pp.fmax = L.fmax; a.pp.kmax = L.kmax;
     a.out_cand = reinterpret_cast<double *>(L.out_cand); a.cand_ld = L.cand_ld; a.out_count = L.out_count;
     a.pitch_status = L.pitch_status; a.work = L.work;
@@ -464,15 +459,19 @@ void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
     a.out_mfcc = L.out_mfcc; a.mfcc_ld = L.mfcc_ld; a.mfcc_status = L.mfcc_status;
     a.bins = L.bins; a.slopes = L.slopes; a.dct = L.dct; a.num_coeffs = L.num_coeffs; a.nb = L.nb;
     a.unsure_list = L.unsure_list; a.unsure_count = L.unsure_count;
+    if (L.plan != SPECTRAL_PLAN_1200) { launch_analyze_pow2(s, L, a); return; }
     const dim3 grid((unsigned)L.F), block(64);
-    const size_t base = spectral_lds_bytes(), extra = pitch_full_list_bytes(SP_N, L.kmax);
+    const size_t base = spectral_lds_bytes(L.n), extra = pitch_full_list_bytes(L.n, L.kmax);
     a.pp.full_off = extra ? (int)base : 0;
     const size_t lds = base + extra;
     const bool lpc = L.out_lpc != nullptr, mf = L.out_mfcc != nullptr;
-    if (lpc && mf) hipLaunchKernelGGL((analyze_kernel<true, true>), grid, block, lds, s, a);
-    else if (lpc) hipLaunchKernelGGL((analyze_kernel<true, false>), grid, block, lds, s, a);
-    else if (mf) hipLaunchKernelGGL((analyze_kernel<false, true>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((analyze_kernel<false, false>), grid, block, lds, s, a);
+    if (L.n != SP_N) {                                       // spectral_supported(): no MFCC from a padded transform
+        if (lpc) hipLaunchKernelGGL((analyze_kernel<true, false, false>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((analyze_kernel<false, false, false>), grid, block, lds, s, a);
+    } else if (lpc && mf) hipLaunchKernelGGL((analyze_kernel<true, true, true>), grid, block, lds, s, a);
+    else if (lpc) hipLaunchKernelGGL((analyze_kernel<true, false, true>), grid, block, lds, s, a);
+    else if (mf) hipLaunchKernelGGL((analyze_kernel<false, true, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((analyze_kernel<false, false, true>), grid, block, lds, s, a);
 }
 
 }  // namespace vbx

@@ -54,7 +54,7 @@ struct vbx_ctx {
     bool prof = false;
     std::vector<ProfRec> recs;
     std::map<std::string, std::pair<double, long>> prof_acc;
-    double *spectral_tab = nullptr;                       // twiddles of k_spectral.hip
+    double *spectral_tab[4] = {nullptr, nullptr, nullptr, nullptr};   // twiddles of k_spectral*.hip, by plan
     bool pitch_force_mfma = false;                        // test hook: VBX_PITCH_MFMA=1 keeps the matrix-core pitch kernel on 1200-sample frames
     bool mfcc_force_goertzel = false;                     // test hooks: VBX_MFCC_GOERTZEL=1 / VBX_MFCC_DFT2=1 keep the
     bool mfcc_force_dft2 = false;                         //   fallback kernels covered on lengths the MFMA kernel takes
@@ -301,23 +301,15 @@ int get_dct_dev(vbx_ctx *ctx, size_t k, const double **out) {
     return VBX_SUCCESS;
 }
 
-// twiddles of the fused spectral kernel (k_spectral.hip), evaluated in long double and rounded once
-int get_spectral_tab(vbx_ctx *ctx, const double **out) {
-    if (!ctx->spectral_tab) {
-        const long double two_pi = 6.283185307179586476925286766559005768L;
-        std::vector<double> h(2 * (size_t)SPECTRAL_TAB_COMPLEX);
-        size_t o = 0;
-        auto put = [&](long num, long den) {             // e^{-2 pi i num / den}
-            const long double ang = two_pi * (long double)(num % den) / (long double)den;
-            h[o++] = (double)cosl(ang); h[o++] = (double)(-sinl(ang));
-        };
-        for (long np = 0; np < 60; np++) for (long ka = 0; ka < 20; ka++) put(np * ka, 1200);
-        for (long c = 0; c < 3; c++) for (long kb = 0; kb < 20; kb++) put(c * kb, 60);
-        for (long m = 0; m <= 600; m++) put(m, 2400);
-        VBX_HIP(ctx, hipMalloc((void **)&ctx->spectral_tab, h.size() * sizeof(double)));
-        VBX_HIP(ctx, hipMemcpy(ctx->spectral_tab, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+// twiddles of the fused spectral kernels (k_spectral.hip, k_spectral_pow2.hip), one table per plan
+int get_spectral_tab(vbx_ctx *ctx, int plan, const double **out) {
+    if (!ctx->spectral_tab[plan]) {
+        std::vector<double> h(2 * (size_t)spectral_tab_complex(plan));
+        spectral_fill_tab(plan, h.data());
+        VBX_HIP(ctx, hipMalloc((void **)&ctx->spectral_tab[plan], h.size() * sizeof(double)));
+        VBX_HIP(ctx, hipMemcpy(ctx->spectral_tab[plan], h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
     }
-    *out = ctx->spectral_tab;
+    *out = ctx->spectral_tab[plan];
     return VBX_SUCCESS;
 }
 
@@ -483,7 +475,7 @@ void vbx_ctx_destroy(vbx_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < vbx_ctx::WS_N; i++) if (ctx->ws[i]) hipFree(ctx->ws[i]);
     if (ctx->pitch_work) hipFree(ctx->pitch_work);
-    if (ctx->spectral_tab) hipFree(ctx->spectral_tab);
+    for (double *t : ctx->spectral_tab) if (t) hipFree(t);
     for (auto &kv : ctx->windows) hipFree(kv.second);
     for (auto &kv : ctx->goertzel) hipFree(kv.second);
     for (auto &kv : ctx->dct_tables) hipFree(kv.second);
@@ -716,7 +708,7 @@ static int launch_spectral(vbx_ctx *ctx, hipStream_t st, spectral_launch_t &L, c
     {
         Prof p(ctx, "pitch_direct_fallback", st);
         const int grid = ctx->cu_count > 0 ? ctx->cu_count * 4 : 1024;
-        launch_pitch_list(st, L.unsure_list, L.unsure_count, grid, L.x, SPECTRAL_N, L.stride, L.window, L.lag_window,
+        launch_pitch_list(st, L.unsure_list, L.unsure_count, grid, L.x, L.n, L.stride, L.window, L.lag_window,
                           L.sample_rate, L.threshold, L.fmin, L.fmax, L.kmax, L.out_cand, L.cand_ld, L.out_count,
                           L.pitch_status, L.work);
     }
@@ -743,9 +735,10 @@ static int run_pitch(vbx_ctx *ctx, hipStream_t st, const double *x, size_t n_fra
     if (!ctx->pitch_force_mfma && spectral_supported((int)frame_len, 0, 0, 0, 0)) {
         // autocorrelation by one real FFT of the frame (k_spectral.hip) instead of the O(N^2) lag sums
         const double *tab = nullptr;
-        rc = get_spectral_tab(ctx, &tab);
-        if (rc != VBX_SUCCESS) return rc;
         spectral_launch_t L{};
+        L.plan = spectral_plan((int)frame_len); L.n = (int)frame_len;
+        rc = get_spectral_tab(ctx, L.plan, &tab);
+        if (rc != VBX_SUCCESS) return rc;
         L.x = x; L.F = (long)n_frames; L.stride = (long)stride; L.window = window; L.lag_window = lagw; L.tab = tab;
         L.sample_rate = sample_rate; L.threshold = threshold; L.fmin = fmin; L.fmax = fmax; L.kmax = (int)kmax;
         L.out_cand = (pitch_t *)out_cand; L.cand_ld = (long)cand_ld; L.out_count = out_count; L.pitch_status = status;
@@ -1247,8 +1240,15 @@ int vbx_analyze_frames_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_
         if (rc != VBX_SUCCESS) return rc;
         nb = hb.back() - hb.front();
     }
-    const bool fused = !ctx->pitch_force_mfma && !bad_bins &&
-                       spectral_supported((int)frame_len, (int)h_p->lpc_order, nb, h_p->mfcc_coeffs ? hb.front() : 0, (int)h_p->mfcc_coeffs);
+    // (MFCC joins the fused kernel only when the frame fills the transform: n = 1024, 1200, 2048)
+    const bool fused_mfcc = !ctx->pitch_force_mfma && !bad_bins && h_p->mfcc_coeffs &&
+                            spectral_supported((int)frame_len, (int)h_p->lpc_order, nb, hb.front(), (int)h_p->mfcc_coeffs);
+    const bool fused = fused_mfcc || (!ctx->pitch_force_mfma && spectral_supported((int)frame_len, (int)h_p->lpc_order, 0, 0, 0));
+    if (fused && h_p->mfcc_coeffs && !fused_mfcc) {
+        rc = run_mfcc(ctx, ctx->side, x, n_frames, frame_len, stride, hann, h_p->mfcc_coeffs, h_p->mfcc_lo_hz, h_p->mfcc_hi_hz,
+                      h_p->sample_rate, out_records + c_mfcc, record_ld, st_mfcc);
+        if (rc != VBX_SUCCESS) return rc;
+    }
     if (!fused) {
         if (h_p->lpc_order) {
             rc = run_autocorr_lpc(ctx, ctx->side, x, n_frames, frame_len, stride, hann, h_p->lpc_order, 0, nullptr,
@@ -1266,8 +1266,8 @@ int vbx_analyze_frames_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_
     if (fused) {
         const double *lagw = nullptr, *tab = nullptr;
         rc = get_window_dev(ctx, VBX_WINDOW_HANNING_LAG, frame_len, &lagw); if (rc != VBX_SUCCESS) return rc;
-        rc = get_spectral_tab(ctx, &tab); if (rc != VBX_SUCCESS) return rc;
-        if (h_p->mfcc_coeffs) {
+        rc = get_spectral_tab(ctx, spectral_plan((int)frame_len), &tab); if (rc != VBX_SUCCESS) return rc;
+        if (fused_mfcc) {
             rc = get_dct_dev(ctx, h_p->mfcc_coeffs, &dct); if (rc != VBX_SUCCESS) return rc;
             rc = get_slopes_dev(ctx, frame_len, h_p->mfcc_coeffs, h_p->mfcc_lo_hz, h_p->mfcc_hi_hz, h_p->sample_rate, hb, &slopes);
             if (rc != VBX_SUCCESS) return rc;
@@ -1278,13 +1278,14 @@ int vbx_analyze_frames_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_
             VBX_HIP(ctx, hipMemsetAsync(ctx->pitch_work, 0, wb, ctx->stream));
         }
         spectral_launch_t L{};
+        L.plan = spectral_plan((int)frame_len); L.n = (int)frame_len;
         L.x = x; L.F = (long)n_frames; L.stride = (long)stride; L.window = hann; L.lag_window = lagw; L.tab = tab;
         L.sample_rate = h_p->sample_rate; L.threshold = h_p->pitch_threshold; L.fmin = h_p->pitch_fmin; L.fmax = h_p->pitch_fmax;
         L.kmax = 1;
         L.out_cand = (pitch_t *)out_records; L.cand_ld = (long)record_ld; L.out_count = nullptr; L.pitch_status = st_pitch;
         L.work = ctx->prof ? ctx->pitch_work : nullptr;
         if (h_p->lpc_order) { L.out_lpc = out_records + c_lpc; L.lpc_ld = (long)record_ld; }
-        if (h_p->mfcc_coeffs) {
+        if (fused_mfcc) {
             L.out_mfcc = out_records + c_mfcc; L.mfcc_ld = (long)record_ld; L.mfcc_status = st_mfcc;
             L.bins = d_bins; L.slopes = slopes; L.dct = dct; L.num_coeffs = (int)h_p->mfcc_coeffs; L.nb = nb;
         }

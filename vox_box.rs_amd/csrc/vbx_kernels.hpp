@@ -87,11 +87,23 @@ void launch_extremum_points(hipStream_t s, const double *y, int ylen, long offse
                             long depth, double *out_xy, int32_t *status, int interp = 2 /* 0 None, 1 Parabolic, 2 Sinc */,
                             int is_max = 1);
 
-// k_spectral.hip: pitch + LPC + MFCC from one FFT of the frame (frame length 1200)
+// k_spectral.hip, k_spectral_pow2.hip: pitch + LPC + MFCC from one real FFT of the zero-padded frame.  Three transform
+// sizes ("plans"), named by the complex FFT length Nc (the real transform has 2 Nc points, the frame at most Nc samples):
+// 1200 (25 ms at 48 kHz, and 1025..1199, e.g. 25 ms at 44.1 kHz), 1024 (512..1024) and 2048 (1201..2048): the reference's
+// own test and example shapes (tests/lib.rs:56, examples/pitch_detection.rs:23) and the lengths below them.
 constexpr int SPECTRAL_N = 1200;
 constexpr int SPECTRAL_LPC_ORDER = 12;
 constexpr int SPECTRAL_TAB_COMPLEX = 60 * 20 + 3 * 20 + 601;    // W_1200^(n' ka) | W_60^(c kb) | W_2400^m
+enum { SPECTRAL_PLAN_NONE = 0, SPECTRAL_PLAN_1200 = 1, SPECTRAL_PLAN_1024 = 2, SPECTRAL_PLAN_2048 = 3 };
+constexpr int SPECTRAL_MIN_N = 512;                             // shorter frames: the direct lag sums are as fast (measured)
+int spectral_plan(int n);                                       // the plan that serves frame length n, or SPECTRAL_PLAN_NONE
+int spectral_plan_nc(int plan);                                 // its complex FFT length
+int spectral_tab_complex(int plan);                             // complex entries of its twiddle table
+void spectral_fill_tab(int plan, double *h_out);                // the table, host side: [2 * spectral_tab_complex(plan)]
+int spectral_pow2_tab_complex(int plan);
+void spectral_pow2_fill_tab(int plan, double *h_out);
 struct spectral_launch_t {
+    int plan; int n;                                             // spectral_plan(n), frame length
     const double *x; long F; long stride; const double *window; const double *lag_window; const double *tab;
     double sample_rate, threshold, fmin, fmax; int kmax;
     pitch_t *out_cand; long cand_ld; int32_t *out_count; int32_t *pitch_status; unsigned long long *work;

@@ -1,0 +1,65 @@
+// vbx_spectral.hpp -- what the FFT-based analysis kernels share (k_spectral.hip: complex length 1200 = 20 * 20 * 3;
+// k_spectral_pow2.hip: complex length 1024 = 16 * 16 * 4 and 2048 = 16 * 16 * 8): the kernel arguments, the radix-4
+// butterfly and the register Levinson recursion.
+#pragma once
+
+#include "vbx_device.hpp"
+#include "vbx_kernels.hpp"
+#include "vbx_pitch_refine.hpp"
+
+namespace vbx {
+
+constexpr double SP_UNC_EPS = 6.0 * 400.0 * 2.220446049250313e-16;   // 1 / min w_lag * margin * eps
+
+// ---- small DFTs on separate re / im registers (forward: e^{-i...}) -------------------------------------------------
+__device__ __forceinline__ void dft4(double &r0, double &i0, double &r1, double &i1, double &r2, double &i2,
+                                     double &r3, double &i3) {
+    const double t0r = r0 + r2, t0i = i0 + i2, t1r = r0 - r2, t1i = i0 - i2;
+    const double t2r = r1 + r3, t2i = i1 + i3, t3r = r1 - r3, t3i = i1 - i3;
+    r0 = t0r + t2r; i0 = t0i + t2i;
+    r2 = t0r - t2r; i2 = t0i - t2i;
+    r1 = t1r + t3i; i1 = t1i - t3r;          // t1 - i t3
+    r3 = t1r - t3i; i3 = t1i + t3r;          // t1 + i t3
+}
+
+struct spectral_args_t {
+    const double *frames; long n_frames; long stride; const double *window; const double *lag_window;
+    const double2 *tab;
+    int n;                                                   // frame length (<= the plan's complex FFT length)
+    pitch_params_t pp;
+    double *out_cand; long cand_ld; int32_t *out_count; int32_t *pitch_status; unsigned long long *work;
+    double *out_lpc; long lpc_ld;
+    double *out_mfcc; long mfcc_ld; int32_t *mfcc_status;
+    const int32_t *bins; const double *slopes; const double *dct; int num_coeffs; int nb;
+    int32_t *unsure_list; int32_t *unsure_count;
+};
+
+// Levinson-Durbin on r[0..P] (src/spectrum.rs:63-84), every lane on the same (uniform) values
+template <int P>
+__device__ __forceinline__ void levinson_regs(const double (&r)[P + 1], double (&ac)[P + 1]) {
+    double tmp[P + 1];
+    double err = r[0];
+    ac[0] = 1.0;
+#pragma unroll
+    for (int i = 1; i <= P; i++) ac[i] = 0.0;
+#pragma unroll
+    for (int i = 1; i <= P; i++) {
+        double acc = r[i];
+#pragma unroll
+        for (int j = 1; j < i; j++) acc = acc + ac[j] * r[i - j];
+        const double k = -acc / err;
+        ac[i] = k;
+#pragma unroll
+        for (int j = 0; j < P; j++) tmp[j] = ac[j];
+#pragma unroll
+        for (int j = 1; j < i; j++) ac[j] = ac[j] + k * tmp[i - j];
+        err = err * (1.0 - k * k);
+    }
+}
+
+constexpr int SP_LPC_P = SPECTRAL_LPC_ORDER;
+
+// k_spectral_pow2.hip
+void launch_analyze_pow2(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a);
+
+}  // namespace vbx
