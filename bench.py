@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--hours", type=float, default=12.5, help="hours of 48 kHz audio PER GPU (pipeline / config3)")
     ap.add_argument("--frames", type=int, default=1_000_000, help="dense frames per GPU (config2 / config4)")
+    ap.add_argument("--frame-len", type=int, default=N48, help="pipeline / config3: samples per frame (default: BASELINE's 25 ms "
+                    "at 48 kHz; 2048 with --hop 1024 is the shape of the reference's examples/pitch_detection.rs)")
+    ap.add_argument("--hop", type=int, default=H48, help="pipeline / config3: samples between frames")
     ap.add_argument("--workload", default="pipeline", choices=["pipeline", "config2", "config3", "config4", "frontend"])
     ap.add_argument("--kmax", type=int, default=1, help="pitch candidates kept per frame (1 = PitchExtractor output; "
                     "64 = the head of the reference's sorted list, which disables the exact top-k pruning)")
@@ -114,7 +117,7 @@ def launch_ranks(args):
 # ------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle (kind "port") on a bounded sample of the same workload, natively threaded
 # ------------------------------------------------------------------------------------------------
-def cpu_baseline(workload, budget_s):
+def cpu_baseline(workload, budget_s, frame_len=N48, hop=H48):
     import importlib
     o = graft.load_oracle()
     graft.load_package()
@@ -156,9 +159,9 @@ def cpu_baseline(workload, budget_s):
     except OSError:
         physical = None
     if workload in ("pipeline", "config3"):
-        frame_len, hop = N48, H48
-        audio = synth.synth_speech(10 * 48000 + N48, sample_offset=0)       # 10 s: 2 of 10 seconds unvoiced
-        what = "frames of the 48 kHz / 25 ms / 10 ms view of 10 s of the same synthetic audio (2 of 10 s unvoiced), scrambled order"
+        audio = synth.synth_speech(10 * 48000 + frame_len, sample_offset=0)  # 10 s: 2 of 10 seconds unvoiced
+        what = (f"frames of the 48 kHz / {frame_len}-sample / {hop}-sample-hop view of 10 s of the same synthetic audio "
+                "(2 of 10 s unvoiced), scrambled order")
     else:
         frame_len, hop = 512, 480
         audio = synth.synth_speech(40 * 48000 + 512, sample_offset=0)
@@ -174,18 +177,19 @@ def cpu_baseline(workload, budget_s):
                       "crate itself is single-threaded and cannot be built here"}
 
 
-def flop_model():
+def flop_model(frame_len=N48, hop=H48):
     """Algorithmic FP64 flops per frame of the pitch path, counted by instrumenting the oracle on a
     10 s sample: 2 * autocorrelation MACs + 13 * sinc terms."""
     import importlib
     o = graft.load_oracle()
     synth = importlib.import_module(graft.PKG_NAME + ".synth")
-    audio = synth.synth_speech(10 * 48000 + N48, sample_offset=0)
-    w = o.window("hanning", N48)
-    idx = list(range(0, 1000, 50))
+    audio = synth.synth_speech(10 * 48000 + frame_len, sample_offset=0)
+    w = o.window("hanning", frame_len)
+    n_fr = (10 * 48000) // hop
+    idx = list(range(0, n_fr, max(1, n_fr // 20)))
     o.counters_reset()
     for t in idx:
-        o.pitch(audio[t * H48:t * H48 + N48] * w, SR, 0.2, 75.0, 600.0, cap=4)
+        o.pitch(audio[t * hop:t * hop + frame_len] * w, SR, 0.2, 75.0, 600.0, cap=4)
     c = o.counters()
     n = len(idx)
     return {"autocorr_macs": c["autocorr_macs"] / n, "sinc_terms": c["sinc_terms"] / n,
@@ -319,20 +323,22 @@ def run_rank(args):
 
     est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
     if wl in ("pipeline", "config3"):
-        total_frames_per_gpu = int(round(args.hours * 3600 * 100))            # 100 frames per second
+        N, H = args.frame_len, args.hop
+        total_frames_per_gpu = int(round(args.hours * 3600 * SR / H))         # 100 frames per second at the default hop
         total_frames_per_gpu -= total_frames_per_gpu % SEG_FRAMES             # whole utterances per rank
         F = max(total_frames_per_gpu, SEG_FRAMES)
         # weak scaling: the recording is world * F frames long and splits by contiguous ranges at utterance boundaries
         seg_all = np.arange(0, world * F, SEG_FRAMES, dtype=np.int64)
         lo, hi = pkg.shard_range(world * F, world, rank, seg_all)
         assert hi - lo == F
-        s0, s1 = pkg.shard_samples(lo, hi, N48, H48)                          # includes the 720-sample halo
+        s0, s1 = pkg.shard_samples(lo, hi, N, H)                              # includes the frame_len - hop halo
         audio = torch.empty(s1 - s0, dtype=f64, device=dev)
         vb.synth_speech(s1 - s0, sample_offset=s0, sample_rate=SR, out=audio)
-        frame_len, stride = N48, H48
-        win = vb.window(pkg.WINDOW_HANNING, N48)
+        frame_len, stride = N, H
+        win = vb.window(pkg.WINDOW_HANNING, N)
         desc = (f"{'full pitch+LPC+formants+MFCC pipeline' if wl == 'pipeline' else 'Boersma pitch path'}, "
-                f"{args.hours:g} h/GPU synthetic 48 kHz, 25 ms / 10 ms hop")
+                f"{args.hours:g} h/GPU synthetic 48 kHz, " +
+                ("25 ms / 10 ms hop" if (N, H) == (N48, H48) else f"{N}-sample frames / {H}-sample hop"))
     else:
         F = args.frames
         audio = torch.empty(F * 512, dtype=f64, device=dev)
@@ -426,10 +432,12 @@ def run_rank(args):
         dom_ms = kernels[dom]["ms_avg"]
         bytes_per_frame = ALG_BYTES.get(dom, lambda n, hop, p: hop * 8)(frame_len, stride, P)
         ach = Fl * bytes_per_frame / (dom_ms * 1e-3) / 1e9
-        tkey = {"config2": "autocorr_lpc_512", "config4": dom + "_512"}.get(wl, dom)
+        default_shape = wl not in ("pipeline", "config3") or (frame_len, stride) == (N48, H48)
+        tkey = {"config2": "autocorr_lpc_512", "config4": dom + "_512"}.get(wl, dom if default_shape else f"{dom}_{frame_len}")
         traffic, tsrc = measured_traffic(tkey, Fl)
         out = {
-            "metric": METRIC if wl == "pipeline" else f"frames/sec ({wl})",
+            "metric": METRIC if wl == "pipeline" and default_shape else
+                      f"frames/sec ({wl})" if default_shape else f"frames/sec ({wl}, {frame_len}-sample frames / {stride}-sample hop)",
             "value": total / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
@@ -456,16 +464,20 @@ def run_rank(args):
             # The kernel is bound by vector-instruction ISSUE (SQ counters under profiles/: VALU busy ~90-100 %), most of
             # which is not FMA work (Brent scalars, selects, address arithmetic): the executed fraction is small by
             # construction and the algorithmic one says how the kernel compares with running the reference's sums at peak.
-            fm = flop_model()
+            fm = flop_model(frame_len, stride)
             frames_w, cand_w, evals_w, terms_w = vb.profile_pitch_work()
             terms_pf = terms_w / max(frames_w, 1)
             flops_pf = 2.0 * fm["autocorr_macs"] + FLOPS_PER_SINC_TERM * terms_pf
             tf = F * flops_pf / (dom_ms * 1e-3) / 1e12
-            nfft = 2.0 * frame_len
-            fft_flops = 2.0 * 2.5 * nfft * np.log2(nfft) + 6.0 * nfft       # two real transforms (half the complex cost) + |X|^2, split
-            exec_pf = (fft_flops if frame_len == N48 else 2.0 * fm["autocorr_macs"]) + FLOPS_PER_SINC_TERM * terms_pf
+            # frame lengths 512..2048 have an FFT kernel: complex length 1024 (n <= 1024), 1200 (n <= 1200) or 2048
+            nc = 1024 if 512 <= frame_len <= 1024 else 1200 if 1024 < frame_len <= 1200 else 2048 if 1200 < frame_len <= 2048 else 0
+            nfft = 2.0 * nc
+            fft_flops = (2.0 * 2.5 * nfft * np.log2(nfft) + 6.0 * nfft) if nc else 0.0   # two real transforms (half the complex cost) + |X|^2, split
+            exec_pf = (fft_flops if nc else 2.0 * fm["autocorr_macs"]) + FLOPS_PER_SINC_TERM * terms_pf
             tfe = F * exec_pf / (dom_ms * 1e-3) / 1e12
             out["roofline_hbm"] = out["roofline"]
+            above = ("; a fraction above 1 means the kernel finishes sooner than the reference's lag sums could at the FP64 peak "
+                     "(the FFT does fewer flops)") if tf > FP64_PEAK_TFLOPS else ""
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": tf, "peak": FP64_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
                                "ms_avg": dom_ms,
@@ -474,12 +486,12 @@ def run_rank(args):
                                "candidates_per_frame": cand_w / max(frames_w, 1),
                                "reference_sinc_terms_per_frame": fm["sinc_terms"],
                                "executed": {"flops_per_frame": exec_pf, "achieved": tfe, "frac": tfe / FP64_PEAK_TFLOPS,
-                                            "model": "2 real FFTs of 2400 (5 N log2 N / 2 each) + power spectrum + 13 * sinc "
+                                            "model": f"2 real FFTs of {int(nfft)} (5 N log2 N / 2 each) + power spectrum + 13 * sinc "
                                                      "terms evaluated; the kernel is vector-issue bound, not FMA bound"},
                                "model": "algorithmic FP64 flops: 2*autocorr MACs of the reference's all-lag autocorrelation "
                                         "(oracle MAC counter) + 13*sinc terms the kernel evaluated (device counters; the "
                                         "reference evaluates reference_sinc_terms); peak = FP64 vector = FP64 matrix peak "
-                                        "(the kernel issues no MFMA: one FFT replaced the matrix-core autocorrelation)"}
+                                        "(the kernel issues no MFMA: one FFT replaced the matrix-core autocorrelation)" + above}
         # what "parity" means for this line: GPU == oracle is tested; oracle == reference is pinned
         # by the reference's own known-answer tests where it has any, and is NOT where it has none
         out["parity"] = {
@@ -500,7 +512,7 @@ def run_rank(args):
                                    "main_stream_ms": sum(v["ms_avg"] * v["launches"] for k, v in kernels.items() if k != "tracker") / args.steps,
                                    "tracker_ms_overlapped": kernels.get("tracker", {"ms_avg": 0, "launches": 0})["ms_avg"] * kernels.get("tracker", {"launches": 0})["launches"] / args.steps}
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds, frame_len, stride if wl in ("pipeline", "config3") else H48)
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()

@@ -15,6 +15,15 @@ run trace_pipeline --kernel-trace --stats --output-format csv -d $O/trace_pipeli
 run trace_config2 --kernel-trace --stats --output-format csv -d $O/trace_config2 -- python3 bench.py --workload config2 --steps 5 --warmup 2 --no-cpu
 run trace_config3 --kernel-trace --stats --output-format csv -d $O/trace_config3 -- python3 bench.py --workload config3 --hours 2 --steps 3 --warmup 1 --no-cpu
 run trace_config4 --kernel-trace --stats --output-format csv -d $O/trace_config4 -- python3 bench.py --workload config4 --steps 5 --warmup 2 --no-cpu
+# the reference's own frame shapes (examples/pitch_detection.rs:23: 2048 / 1024; tests/lib.rs:56-57: 1024 / 512)
+run trace_pipeline_2048 --kernel-trace --stats --output-format csv -d $O/trace_pipeline_2048 -- python3 bench.py --frame-len 2048 --hop 1024 --hours 2 --steps 3 --warmup 1 --no-cpu
+run trace_config3_2048 --kernel-trace --stats --output-format csv -d $O/trace_config3_2048 -- python3 bench.py --workload config3 --frame-len 2048 --hop 1024 --hours 2 --steps 3 --warmup 1 --no-cpu
+run trace_config3_1024 --kernel-trace --stats --output-format csv -d $O/trace_config3_1024 -- python3 bench.py --workload config3 --frame-len 1024 --hop 512 --hours 2 --steps 3 --warmup 1 --no-cpu
+for w in pipeline_2048:pipeline:2048:1024 config3_2048:config3:2048:1024 config3_1024:config3:1024:512; do
+  IFS=: read name wl fl hop <<< "$w"
+  run pmc_fetch_$name --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$name -- python3 bench.py --workload $wl --frame-len $fl --hop $hop --hours 0.5 --steps 1 --warmup 0 --no-cpu
+  run pmc_write_$name --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$name -- python3 bench.py --workload $wl --frame-len $fl --hop $hop --hours 0.5 --steps 1 --warmup 0 --no-cpu
+done
 # HBM traffic, one counter per pass
 for w in pipeline config3; do
   run pmc_fetch_$w --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$w -- python3 bench.py --workload $w --hours 0.5 --steps 1 --warmup 0 --no-cpu
