@@ -636,6 +636,21 @@ def test_pitch_other_frame_lengths(vb, oracle, audio, n):
     assert _check_pitch(vb, oracle, x, SR, 0.45, 60.0, 2000.0, 8) == 0
 
 
+@pytest.mark.parametrize("n,rect", [(513, False), (1103, False), (1103, True), (1199, False), (1601, False), (2047, True), (2049, False)])
+def test_pitch_odd_frame_lengths_read_the_last_lag(vb, oracle, audio, n, rect):
+    """An odd frame length makes improve_extremum's `ixmid >= nx` arm (src/periodic.rs:194) return y[n - 1], the LAST lag of
+    the curve, where the lag window is ~1e-17: candidates at the edge of the search range take their strength from it.
+    Unvoiced frames have such candidates (found by tools/soak_parity.py at n = 1103: the FFT kernels' rounding error,
+    divided by that window value, used to win the frame).  The FFT kernels compute the last lags as the reference does."""
+    hop = 211
+    F = (audio.size - n) // hop + 1
+    lo, hi = int(2.0 * 48000 / hop), int(3.0 * 48000 / hop)                   # the unvoiced second (4..5 s of the stream)
+    idx = list(range(lo, min(hi, F), 2)) + list(range(0, lo, 40))
+    w = np.ones(n) if rect else oracle.window("hanning", n)
+    x = _frames(audio, n, hop, idx) * w
+    assert _check_pitch(vb, oracle, x, SR, 0.2, 75.0, 600.0, 2, label=f"odd n = {n}") == 0
+
+
 @pytest.mark.parametrize("n", [4, 5, 6, 8, 13, 16, 31])
 def test_pitch_tiny_frames(vb, oracle, audio, n):
     """Frames of a few samples: the depth clips, the x > nx / x < 0 branches and the panics of the reference's

@@ -2,7 +2,9 @@
 """Parity at scale: the GPU's PitchExtractor output, candidate count and status, Burg coefficients, formant resonances and
 MFCC against the CPU oracle on tens of thousands of frames (the pytest suite compares hundreds).  The oracle runs on all
 the cores the process may use (ctypes releases the GIL).  Prints and writes a JSON summary of every disagreement class.
-usage (GPU box): python3 tools/soak_parity.py [n_frames=20000] [out.json]"""
+The pitch candidates come from vbx_pitch_f64 AND from the fused frame loop (vbx_analyze_frames_f64: pitch + LPC + MFCC from
+one FFT of the frame where the frame length has such a kernel), whose LPC and MFCC columns are checked too.
+usage (GPU box): python3 tools/soak_parity.py [n_frames=20000] [out.json] [frame_len=1200] [hop=480]"""
 import json
 import os
 import sys
@@ -14,12 +16,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g  # noqa: E402
 
-N, H, SR, P = 1200, 480, 48000.0, 12
+SR, P = 48000.0, 12
 
 
 def main():
     n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
     out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "soak_parity.json")
+    N = int(sys.argv[3]) if len(sys.argv) > 3 else 1200
+    H = int(sys.argv[4]) if len(sys.argv) > 4 else 480
     pkg, o = g.load_package(), g.load_oracle()
     vb = pkg.VoxBox(0)
     try:
@@ -41,6 +45,9 @@ def main():
     est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
     ff = vb.find_formants(audio_d, SR, P, est0, seg_start=np.arange(0, F_all, 1, dtype=np.int64), frame_len=N, stride=H, n_frames=F_all,
                           want=("res", "count", "status"))
+    params = pkg.AnalysisParams.make(SR, pitch=(0.2, 75.0, 600.0), lpc_order=P, formant_order=0, mfcc=(13, 100.0, 8000.0))
+    cols = params.columns()
+    rec_all, st_all = vb.analyze_frames(audio_d, params, frame_len=N, stride=H, n_frames=F_all)
     wh = o.window("hanning", N)
 
     def one(t):
@@ -66,20 +73,50 @@ def main():
                              not np.all(np.abs(ff["res"][t, :n_res, 0] - eres[:n_res, 0]) <= 1e-4 * np.abs(eres[:n_res, 0])))
         ms, em = o.mfcc(fr * wh, 13, 100.0, 8000.0, SR)
         rec["mfcc"] = int(ms != mst[t] or not np.all(np.abs(mf[t] - em) <= 1e-6 * np.maximum(np.abs(em), 1e-6 * np.max(np.abs(em)))))
+        # the fused frame loop's record of the same frame
+        c0, cn = cols["pitch"]; m0, mn = cols["mfcc"]; l0, ln = cols["lpc"]
+        fm = rec_all[t, m0:m0 + mn]
+        rec["fused_mfcc"] = int(ms != st_all[2, t] or not np.all(np.abs(fm - em) <= 1e-6 * np.maximum(np.abs(em), 1e-6 * np.max(np.abs(em)))))
+        el = o.lpc(o.autocorrelate(fr * wh, P + 1), P)
+        fl = rec_all[t, l0:l0 + ln]
+        rec["fused_lpc"] = int(not np.all(np.abs(fl - el) <= 1e-6 * np.maximum(np.abs(el), 1e-6 * np.max(np.abs(el)))))
+        rec["fused_lpc_beyond_oracle_rounding"] = 0
+        if rec["fused_lpc"]:
+            # a coefficient below 1e-6 of the largest one is held to an ABSOLUTE 1e-12: who is right?  The same recursion in
+            # long double on long-double lag sums, and both results' distance from it in the same metric
+            xl = (fr * wh).astype(np.longdouble)
+            rl = np.array([xl[0] + np.sum(xl[1:N - k] * xl[1 + k:N]) for k in range(P + 1)])
+            al = np.zeros(P + 1, dtype=np.longdouble); al[0] = 1; err = rl[0]
+            for i in range(1, P + 1):
+                kk = -(rl[i] + sum(al[j] * rl[i - j] for j in range(1, i))) / err
+                tl = al.copy(); al[i] = kk
+                for j in range(1, i):
+                    al[j] = tl[j] + kk * tl[i - j]
+                err = err * (1 - kk * kk)
+            dev = lambda v: float(np.max(np.abs(v - al) / np.maximum(np.abs(al), 1e-6 * np.max(np.abs(al)))))
+            rec["fused_lpc_beyond_oracle_rounding"] = int(dev(fl) > max(1e-6, 2.0 * dev(el)))
+        fp = rec_all[t, c0:c0 + 2]
+        rec["fused_pitch"] = int(es != st_all[0, t] or (es == 0 and not rec["top_swap"] and not (
+            abs(fp[0] - ec[0, 0]) <= 1e-4 * abs(ec[0, 0]) and abs(fp[1] - ec[0, 1]) <= 1e-4)))
         return rec
 
     with ThreadPoolExecutor(workers) as ex:
         recs = list(ex.map(one, idx))
     tot = {k: int(sum(r[k] for r in recs)) for k in recs[0]}
     voiced = int(np.sum(cand[idx, 0, 0] > 0))
-    summary = {"frames": n_frames, "voiced": voiced, "unvoiced": n_frames - voiced, "oracle_threads": workers,
+    summary = {"frame_len": N, "hop": H, "frames": n_frames, "voiced": voiced, "unvoiced": n_frames - voiced, "oracle_threads": workers,
                "disagreements": tot,
                "meaning": {"status": "pitch status differs", "count": "pitch candidate count differs",
                            "top_bad": "PitchExtractor output beyond 1e-4 and not a near tie",
                            "top_swap": "top two oracle strengths closer than 1e-3 and the GPU's top is the runner-up",
                            "vuv": "of the swaps: voiced/unvoiced flips outside a 1e-4 tie",
                            "burg": "Burg status or coefficients beyond 1e-6", "formant": "resonance count or Hz beyond 1e-4",
-                           "mfcc": "MFCC status or values beyond 1e-6"}}
+                           "mfcc": "MFCC status or values beyond 1e-6",
+                           "fused_pitch / fused_lpc / fused_mfcc": "the same checks on the columns of vbx_analyze_frames_f64 "
+                                                                   "(LPC: Levinson order 12 on autocorrelate(13), 1e-6)",
+                           "fused_lpc_beyond_oracle_rounding": "of the fused_lpc frames (a coefficient below 1e-6 of the largest one is "
+                                                               "held to an absolute 1e-12 there): those where the GPU is further from "
+                                                               "the long-double answer than 1e-6 AND than twice the oracle's own distance"}}
     print(json.dumps(summary))
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
     json.dump(summary, open(out_path, "w"), indent=1)

@@ -386,6 +386,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VBX_SPECTRAL
         }
     }
     if (lane < Y_PAD) ys[n + lane] = 0.0;
+#ifndef VBX_EXP_NO_EXACT_TAIL
+    if (!FULL) spectral_exact_tail(ys, n, xf, a.window, a.lag_window, x0, scale, lane);
+#endif
     wave_sync();
     // Rounding error of the two transforms: a few ulp of S[0] per lag (measured: < 8 eps S[0]); y = r * scale / w_lag
     // with w_lag >= 1/6 on the searched half.  SP_UNC_EPS bounds the error of a DIFFERENCE of two entries with a wide

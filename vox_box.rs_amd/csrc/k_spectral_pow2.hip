@@ -414,6 +414,9 @@ void analyze_pow2_kernel(const spectral_args_t a) {
         }
     }
     if (lane < Y_PAD) ys[n + lane] = 0.0;
+#ifndef VBX_EXP_NO_EXACT_TAIL
+    if (!FULL) spectral_exact_tail(ys, n, xf, a.window, a.lag_window, x0, scale, lane);
+#endif
     wave_sync();
     const double unc_tol = SP_UNC_EPS * fabs(s0) * scale;
     double2 *full = a.pp.full_off ? reinterpret_cast<double2 *>(reinterpret_cast<char *>(smem) + a.pp.full_off) : nullptr;

@@ -118,6 +118,17 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// reciprocal of a normal, well-scaled double: v_rcp_f64 (4.6e-8) + Newton steps
+__device__ __forceinline__ double rcp_nr1(double a) {       // ~2e-15 relative
+    double r = __builtin_amdgcn_rcp(a);
+    return fma(fma(-a, r, 1.0), r, r);
+}
+__device__ __forceinline__ double rcp_nr2(double a) {       // correctly rounded in practice
+    double r = __builtin_amdgcn_rcp(a);
+    r = fma(fma(-a, r, 1.0), r, r);
+    return fma(fma(-a, r, 1.0), r, r);
+}
+
 // ---- complex arithmetic (num-complex 0.2 formulas; FMA contraction allowed) -------
 // Generic over the scalar: Complex<f64> on the hot path, Complex<f32> for the f32 instantiation of Polynomial
 // (src/polynomial.rs:336-386).
@@ -137,9 +148,20 @@ template <typename T> __device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> b) {
 template <typename T> __device__ __forceinline__ cx<T> cmad(cx<T> a, cx<T> b, cx<T> c) {
     return cmk<T>(fma(a.re, b.re, fma(-a.im, b.im, c.re)), fma(a.re, b.im, fma(a.im, b.re, c.im)));
 }
+// 1 / ns of cdiv.  f64: where every lane's ns is a normal, well-scaled number (always, on polynomials of speech frames)
+// the reciprocal is v_rcp_f64 + two Newton steps instead of the IEEE division sequence (4 divisions per Laguerre
+// iteration were a quarter of the root kernel); any lane outside that range sends the whole wave through the division,
+// so zero / inf / NaN denominators keep their IEEE results.
+__device__ __forceinline__ double cdiv_recip(double ns) {
+#ifndef VBX_IEEE_CDIV
+    if (__all(ns > 1.0e-280 && ns < 1.0e280)) return rcp_nr2(ns);
+#endif
+    return 1.0 / ns;
+}
+__device__ __forceinline__ float cdiv_recip(float ns) { return 1.0f / ns; }
 template <typename T> __device__ __forceinline__ cx<T> cdiv(cx<T> a, cx<T> b) {
     T ns = b.re * b.re + b.im * b.im;
-    T inv = T(1) / ns;
+    T inv = cdiv_recip(ns);
     T re = a.re * b.re + a.im * b.im;
     T im = a.im * b.re - a.re * b.im;
     return cmk<T>(re * inv, im * inv);

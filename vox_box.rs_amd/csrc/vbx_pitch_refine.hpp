@@ -13,17 +13,6 @@
 namespace vbx {
 
 
-// reciprocal of a normal, well-scaled double: v_rcp_f64 (4.6e-8) + Newton steps
-__device__ __forceinline__ double rcp_nr1(double a) {       // ~2e-15 relative
-    double r = __builtin_amdgcn_rcp(a);
-    return fma(fma(-a, r, 1.0), r, r);
-}
-__device__ __forceinline__ double rcp_nr2(double a) {       // correctly rounded in practice
-    double r = __builtin_amdgcn_rcp(a);
-    r = fma(fma(-a, r, 1.0), r, r);
-    return fma(fma(-a, r, 1.0), r, r);
-}
-
 // sin(x), cos(x) for |x| <= pi/2 (a little beyond is fine): Taylor to x^21 / x^22 (< 2e-18 truncation)
 __device__ __forceinline__ double sin_poly(double x) {
     const double x2 = x * x;

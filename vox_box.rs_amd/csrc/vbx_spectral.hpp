@@ -34,6 +34,28 @@ struct spectral_args_t {
     int32_t *unsure_list; int32_t *unsure_count;
 };
 
+// The last SP_TAIL lags of the curve.  The lag window falls below 1e-8 there (1e-10 .. 1e-17 over the last twelve lags), so
+// the transforms' rounding error (~1e-16 S[0]) would be amplified into y by 1 / w_lag.  For an even frame length those
+// entries only enter sinc sums under a taper that vanishes with them, but an odd n reads y[n - 1] directly
+// (improve_extremum's ixmid >= nx arm, src/periodic.rs:194).  Those lags are sums of at most SP_TAIL products: lane l
+// computes lag n - 1 - l in the reference's fold order (seed x[0], Q1) and overwrites the entry.
+constexpr int SP_TAIL = 16;
+__device__ __forceinline__ void spectral_exact_tail(double *ys, int n, const double *__restrict__ xf, const double *__restrict__ window,
+                                                    const double *__restrict__ lag_window, double x0, double scale, int lane) {
+    wave_sync();                                             // after the transform's own stores of these entries
+    if (lane < SP_TAIL && lane < n) {
+#pragma clang fp contract(off)
+        const int L = n - 1 - lane;
+        double acc = x0;
+        for (int i = 1; i <= lane; i++) {
+            const double u = (window != nullptr) ? xf[i] * window[i] : xf[i];
+            const double v = (window != nullptr) ? xf[L + i] * window[L + i] : xf[L + i];
+            acc = acc + u * v;
+        }
+        ys[L] = (acc * scale) / lag_window[L];
+    }
+}
+
 // Levinson-Durbin on r[0..P] (src/spectrum.rs:63-84), every lane on the same (uniform) values
 template <int P>
 __device__ __forceinline__ void levinson_regs(const double (&r)[P + 1], double (&ac)[P + 1]) {
