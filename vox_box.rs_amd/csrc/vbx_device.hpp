@@ -148,20 +148,9 @@ template <typename T> __device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> b) {
 template <typename T> __device__ __forceinline__ cx<T> cmad(cx<T> a, cx<T> b, cx<T> c) {
     return cmk<T>(fma(a.re, b.re, fma(-a.im, b.im, c.re)), fma(a.re, b.im, fma(a.im, b.re, c.im)));
 }
-// 1 / ns of cdiv.  f64: where every lane's ns is a normal, well-scaled number (always, on polynomials of speech frames)
-// the reciprocal is v_rcp_f64 + two Newton steps instead of the IEEE division sequence (4 divisions per Laguerre
-// iteration were a quarter of the root kernel); any lane outside that range sends the whole wave through the division,
-// so zero / inf / NaN denominators keep their IEEE results.
-__device__ __forceinline__ double cdiv_recip(double ns) {
-#ifndef VBX_IEEE_CDIV
-    if (__all(ns > 1.0e-280 && ns < 1.0e280)) return rcp_nr2(ns);
-#endif
-    return 1.0 / ns;
-}
-__device__ __forceinline__ float cdiv_recip(float ns) { return 1.0f / ns; }
 template <typename T> __device__ __forceinline__ cx<T> cdiv(cx<T> a, cx<T> b) {
     T ns = b.re * b.re + b.im * b.im;
-    T inv = cdiv_recip(ns);
+    T inv = T(1) / ns;
     T re = a.re * b.re + a.im * b.im;
     T im = a.im * b.re - a.re * b.im;
     return cmk<T>(re * inv, im * inv);
