@@ -983,7 +983,8 @@ static int run_find_formants(vbx_ctx *ctx, hipStream_t stm, const double *x, siz
         for (size_t i = 0; i < n_segments && seg_len > 0; i++) if (h_seg_start[i] != (int64_t)i * seg_len) seg_len = 0;
         if (seg_len > 0 && ((long)(n_segments - 1) * seg_len >= F || seg_len < 64)) seg_len = 0;
     }
-    const int n_slices = seg_len > 0 ? 4 : 1;
+    static const int want_slices = [] { const char *e = getenv("VBX_FF_SLICES"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+    const int n_slices = seg_len > 0 ? want_slices : 1;
     if (n_slices == 1) {
         { Prof pr(ctx, "burg", stm); launch_burg(stm, x, F, (int)frame_len, (long)stride, hann, p, coeffs, st); }                 // :75
         { Prof pr(ctx, "formant_resonances", stm); launch_formant_resonances(stm, coeffs, F, p, sample_rate, res, cnt, st); }      // :80-110
