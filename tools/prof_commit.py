@@ -58,7 +58,8 @@ for key, (wl, kern) in KEYS.items():
     if not fe or not wr or not F:
         continue
     # sliced kernels run several launches per step: the counter averages are per launch, the frames too
-    per_step = {"burg_512": 4, "formant_resonances_512": 4, "tracker_512": 4, "burg": 4, "formant_resonances": 4, "tracker": 4}.get(key, 1)
+    SLICES = int(os.environ.get("VBX_FF_SLICES", "6"))                       # run_find_formants' default
+    per_step = SLICES if key.split("_")[0] in ("burg", "formant", "tracker") else 1
     F = F / per_step
     fetch_b, write_b = fe["avg"] * 1024.0 * 2.0, wr["avg"] * 1024.0
     traffic[key] = {"bytes_per_frame": (fetch_b + write_b) / F, "fetch_bytes_per_frame": fetch_b / F,

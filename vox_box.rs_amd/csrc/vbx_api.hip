@@ -983,8 +983,14 @@ static int run_find_formants(vbx_ctx *ctx, hipStream_t stm, const double *x, siz
         for (size_t i = 0; i < n_segments && seg_len > 0; i++) if (h_seg_start[i] != (int64_t)i * seg_len) seg_len = 0;
         if (seg_len > 0 && ((long)(n_segments - 1) * seg_len >= F || seg_len < 64)) seg_len = 0;
     }
-    static const int want_slices = [] { const char *e = getenv("VBX_FF_SLICES"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+    // Six slices (VBX_FF_SLICES overrides, 1..8).  With k equal slices the call ends about one slice's scan after the last
+    // resonance exists, so more slices shorten the exposed tail -- until a slice no longer fills the GPU: the root finder
+    // is a chain of dependent operations per lane and a launch takes one wavefront's run time (0.47 ms at order 12) however
+    // few wavefronts it has.  Measured, frames/s at 1 M x 512 for k = 4, 5, 6, 7, 8: 140, 144, 153, 142, 136 M; k = 6 is also
+    // the best or within 1 % of it at 0.3, 0.7, 1.3 and 2 M frames and in the 4.5 M-frame pipeline.
+    static const int want_slices = [] { const char *e = getenv("VBX_FF_SLICES"); const int v = e ? atoi(e) : 6; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
     const int n_slices = seg_len > 0 ? want_slices : 1;
+    const long tc = (seg_len + n_slices - 1) / n_slices;
     if (n_slices == 1) {
         { Prof pr(ctx, "burg", stm); launch_burg(stm, x, F, (int)frame_len, (long)stride, hann, p, coeffs, st); }                 // :75
         { Prof pr(ctx, "formant_resonances", stm); launch_formant_resonances(stm, coeffs, F, p, sample_rate, res, cnt, st); }      // :80-110
@@ -996,9 +1002,8 @@ static int run_find_formants(vbx_ctx *ctx, hipStream_t stm, const double *x, siz
         for (auto &e : ctx->ev_slice) VBX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         VBX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_trk, hipEventDisableTiming));
     }
-    const long tc = (seg_len + n_slices - 1) / n_slices;
-    for (int j = 0; j < n_slices; j++) {
-        const frame_map_t map{seg_len, j * tc, tc};
+    for (int j = 0; j < n_slices && j * tc < seg_len; j++) {
+        const frame_map_t map{seg_len, j * tc, (seg_len - j * tc < tc) ? seg_len - j * tc : tc};   // the last slice may be shorter
         { Prof pr(ctx, "burg", stm); launch_burg(stm, x, F, (int)frame_len, (long)stride, hann, p, coeffs, st, map); }
         { Prof pr(ctx, "formant_resonances", stm); launch_formant_resonances(stm, coeffs, F, p, sample_rate, res, cnt, st, map); }
         VBX_HIP(ctx, hipEventRecord(ctx->ev_slice[j], stm));
