@@ -43,12 +43,13 @@ def _oracle_records(oracle, pkg, audio, F, seg, N=N, H=H):
 
 
 # (1200, 480), (1024, 512), (2048, 1024): pitch + LPC + MFCC from one FFT of the frame; (1103, 441), (1600, 640): pitch + LPC
-# from the FFT (the frame is zero padded), MFCC by its own kernel; (512, 256): no fused kernel
-@pytest.mark.parametrize("N,H", [(1200, 480), (1024, 512), (2048, 1024), (1103, 441), (1600, 640), (512, 256)])
+# from the FFT (the frame is zero padded), MFCC by its own kernel; (4096, 2048): complex FFT of 4096; (256, 128): no fused kernel
+@pytest.mark.parametrize("N,H", [(1200, 480), (1024, 512), (2048, 1024), (1103, 441), (1600, 640), (512, 256), (4096, 2048), (256, 128)])
 def test_analyze_frames_matches_the_oracle_and_the_separate_entry_points(vb, pkg, oracle, audio_d, N, H):
     audio = audio_d.numpy()
     F = pkg.frame_count(audio.size, N, H)
-    seg = np.array([0, 150, 151, min(400, F - 10)], dtype=np.int64)
+    q = min(F // 4, 150)
+    seg = np.array([0, q, q + 1, min(400, F - 10)], dtype=np.int64)              # a one-frame utterance among them
     params = pkg.AnalysisParams.make(SR)
     assert params.columns() == {"pitch": (0, 2), "formants": (2, 8), "mfcc": (10, 13), "lpc": (23, 13)}
     rec, st = vb.analyze_frames(audio_d, params, seg_start=seg, frame_len=N, stride=H, n_frames=F)
@@ -66,7 +67,7 @@ def test_analyze_frames_matches_the_oracle_and_the_separate_entry_points(vb, pkg
     assert np.array_equal(rec[:, 2:10], ff["formants"].reshape(F, 8))        # same kernels, same stream order: bit-equal
     assert np.all(rel_close(rec[:, 10:23], mf)) and np.all(rel_close(rec[:, 23:36], a))
     # and the oracle on a subset (it takes ~10 ms per frame)
-    sub = 160 if N <= 1200 else 154
+    sub = 160 if N <= 1200 else min(154, F)
     orec, ost = _oracle_records(oracle, pkg, audio, sub, set(seg.tolist()), N, H)
     assert np.array_equal(st[:, :sub], ost)
     voiced_equal = (orec[:, 0] == 0.0) == (rec[:sub, 0] == 0.0)

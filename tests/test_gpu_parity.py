@@ -628,7 +628,7 @@ def test_pitch_work_counters(vb, oracle, audio, pkg):
     assert work[64][2] >= work[64][1]                                  # unpruned: every candidate is evaluated
 
 
-# 1280 / 1281: one / two autocorrelation passes of the direct kernel (VBX_PITCH_MFMA=1); 512..2048 take the FFT kernels
+# 1280 / 1281: one / two autocorrelation passes of the direct kernel (VBX_PITCH_MFMA=1); 512..4096 take the FFT kernels
 @pytest.mark.parametrize("n", [64, 100, 256, 511, 512, 513, 703, 704, 800, 1023, 1024, 1025, 1103, 1199, 1201, 1280, 1281, 1600, 2047, 2048,
                                2049, 4096])
 def test_pitch_other_frame_lengths(vb, oracle, audio, n):
@@ -636,7 +636,7 @@ def test_pitch_other_frame_lengths(vb, oracle, audio, n):
     assert _check_pitch(vb, oracle, x, SR, 0.45, 60.0, 2000.0, 8) == 0
 
 
-@pytest.mark.parametrize("n,rect", [(513, False), (1103, False), (1103, True), (1199, False), (1601, False), (2047, True), (2049, False)])
+@pytest.mark.parametrize("n,rect", [(513, False), (1103, False), (1103, True), (1199, False), (1601, False), (2047, True), (2049, False), (4095, False)])
 def test_pitch_odd_frame_lengths_read_the_last_lag(vb, oracle, audio, n, rect):
     """An odd frame length makes improve_extremum's `ixmid >= nx` arm (src/periodic.rs:194) return y[n - 1], the LAST lag of
     the curve, where the lag window is ~1e-17: candidates at the edge of the search range take their strength from it.
@@ -848,9 +848,10 @@ def test_zz_pitch_parity_report():
 @pytest.mark.parametrize("n,hop,rect", [(1200, 480, False), (1200, 480, True), (1024, 512, False), (1024, 512, True),
                                         (2048, 1024, False), (2048, 1024, True), (1103, 441, False), (1102, 441, True),
                                         (512, 256, True), (513, 200, False), (704, 300, False), (901, 333, True), (1025, 400, False), (1199, 480, True),
-                                        (1201, 480, False), (1600, 640, False), (2047, 900, True)])
+                                        (1201, 480, False), (1600, 640, False), (2047, 900, True), (2049, 900, False), (3000, 1024, True),
+                                        (4096, 2048, False), (4095, 2048, False)])
 def test_pitch_fft_path_and_direct_path_agree(pkg, oracle, audio, monkeypatch, n, hop, rect):
-    """Frame lengths 512..2048 take an FFT-based kernel (complex length 1024, 1200 or 2048, the frame zero padded);
+    """Frame lengths 512..4096 take an FFT-based kernel (complex length 1024, 1200, 2048 or 4096, the frame zero padded);
     VBX_PITCH_MFMA=1 keeps the direct-sum (matrix-core) kernel that also serves every other frame length and the FFT path's
     fallback list.  The two produce the lag curve in different arithmetic (errors ~1e-16 S[0]): statuses and candidate
     COUNTS must be identical (the peak decisions are guarded by the fallback), values within the pitch tolerance.

@@ -415,11 +415,13 @@ int spectral_plan(int n) {
     if (n <= 1024) return SPECTRAL_PLAN_1024;
     if (n <= SP_N) return SPECTRAL_PLAN_1200;
     if (n <= 2048) return SPECTRAL_PLAN_2048;
+    if (n <= 4096) return SPECTRAL_PLAN_4096;
     return SPECTRAL_PLAN_NONE;
 }
 
 int spectral_plan_nc(int plan) {
-    return plan == SPECTRAL_PLAN_1200 ? SP_N : plan == SPECTRAL_PLAN_1024 ? 1024 : plan == SPECTRAL_PLAN_2048 ? 2048 : 0;
+    return plan == SPECTRAL_PLAN_1200 ? SP_N : plan == SPECTRAL_PLAN_1024 ? 1024 : plan == SPECTRAL_PLAN_2048 ? 2048 :
+           plan == SPECTRAL_PLAN_4096 ? 4096 : 0;
 }
 
 int spectral_tab_complex(int plan) {

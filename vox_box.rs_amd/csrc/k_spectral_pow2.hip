@@ -3,10 +3,10 @@
 //
 // The same algebra as k_spectral.hip (see its header): ONE real FFT of the zero-padded windowed frame of length
 // M = 2 Nc >= 2 n gives every lag sum S[lag] (|X|^2 -> second transform), S[0..12] feed the register Levinson, and -- when
-// the frame fills the transform exactly (n == Nc) -- X[2k'] are the n-point DFT bins the mel filters read.  Nc is 1024
-// or 2048, the frame may be shorter (the padding is then longer than the frame; linear correlation needs M >= 2n - 1).
+// the frame fills the transform exactly (n == Nc) -- X[2k'] are the n-point DFT bins the mel filters read.  Nc is 1024,
+// 2048 or 4096, the frame may be shorter (the padding is then longer than the frame; linear correlation needs M >= 2n - 1).
 //
-// One wavefront per frame.  Complex FFT of length Nc = 16 * 16 * R (R = 4 or 8), decimation in frequency with
+// One wavefront per frame.  Complex FFT of length Nc = 16 * 16 * R (R = 4, 8 or 16), decimation in frequency with
 // n = 16R a + R b + c and k = ka + 16 kb + 256 kc:
 //   stage 1  unit n' = R b + c (16R units, U = R/4 per lane: n' = lane + 64 u): 16-point DFT over a, times W_Nc^(n' ka)
 //   stage 2  unit (ka, c):  16-point DFT over b, times W_16R^(c kb)
@@ -73,13 +73,17 @@ __device__ __forceinline__ void dft16(double (&re)[16], double (&im)[16]) {
         dft4(re[4 * k1], im[4 * k1], re[4 * k1 + 1], im[4 * k1 + 1], re[4 * k1 + 2], im[4 * k1 + 2], re[4 * k1 + 3], im[4 * k1 + 3]);
 }
 
-// R-point DFT of v[0..R) in natural order (R = 4: one butterfly; R = 8: radix 4 x 2)
+// R-point DFT of v[0..R) in natural order (R = 4: one butterfly; R = 8: radix 4 x 2; R = 16: radix 4 x 4)
 template <int R>
 __device__ __forceinline__ void dft_last(double (&vr)[R], double (&vi)[R], double (&xr)[R], double (&xi)[R]) {
     if constexpr (R == 4) {
         dft4(vr[0], vi[0], vr[1], vi[1], vr[2], vi[2], vr[3], vi[3]);
 #pragma unroll
         for (int k = 0; k < 4; k++) { xr[k] = vr[k]; xi[k] = vi[k]; }
+    } else if constexpr (R == 16) {
+        dft16(vr, vi);
+#pragma unroll
+        for (int k = 0; k < 16; k++) { xr[k] = vr[dft16_slot(k)]; xi[k] = vi[dft16_slot(k)]; }
     } else {
         constexpr double R2 = 0.70710678118654752440;
         // x[2 n1 + n2]: DFT over n1 for each n2 -> k1 in slot 2 k1 + n2
@@ -192,12 +196,14 @@ __device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16
     for (int t = 0; t < 4; t++) dft_last<R>(vr[t], vi[t], xr[t], xi[t]);
 }
 
-// Two wavefronts per SIMD.  U = 1 (Nc = 1024) needs ~210 registers.  U = 2 (Nc = 2048: 32 complex values per lane, 17
+// U = 4 (Nc = 4096: 64 complex values per lane): one wavefront per SIMD (512 registers); the frame state, 46 KB of LDS, admits
+// three frames per CU anyway.
+// U = 1, 2: two wavefronts per SIMD.  U = 1 (Nc = 1024) needs ~210 registers.  U = 2 (Nc = 2048: 32 complex values per lane, 17
 // spectrum pairs) needs ~290: at 256 a dozen to fifty of them spill, and the frame state (23 KB of LDS) admits six frames
 // per CU.  Measured at n = 2048: 25.2 M frames/s against 18.6 M with one wavefront per SIMD and no spills.
 // FULL: the frame fills the transform (n == Nc, the bounds tests fold away and MFCC can join); otherwise n < Nc.
 template <int U, bool LPC, bool MFCC, bool FULL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(U == 1 ? 2 : VBX_POW2_U2_WAVES, 2)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(U == 1 ? 2 : U == 2 ? VBX_POW2_U2_WAVES : 1, U == 4 ? 1 : 2)))
 void analyze_pow2_kernel(const spectral_args_t a) {
     using G = pow2_geom<U>;
     constexpr int R = G::R, NC = G::NC, TP = G::TP;
@@ -435,7 +441,9 @@ static size_t pow2_lds_bytes(int n, int nb) {
     return (need + 15) & ~(size_t)15;
 }
 
-int spectral_pow2_tab_complex(int plan) { return plan == SPECTRAL_PLAN_1024 ? pow2_geom<1>::TAB : pow2_geom<2>::TAB; }
+int spectral_pow2_tab_complex(int plan) {
+    return plan == SPECTRAL_PLAN_1024 ? pow2_geom<1>::TAB : plan == SPECTRAL_PLAN_2048 ? pow2_geom<2>::TAB : pow2_geom<4>::TAB;
+}
 
 // twiddles, evaluated in long double and rounded once: h_out[2 * spectral_pow2_tab_complex(plan)]
 template <int U>
@@ -452,7 +460,7 @@ static void fill_tab(double *h) {
     for (long m = 0; m <= G::NC / 2; m++) put(m, 2 * G::NC);
 }
 void spectral_pow2_fill_tab(int plan, double *h_out) {
-    if (plan == SPECTRAL_PLAN_1024) fill_tab<1>(h_out); else fill_tab<2>(h_out);
+    if (plan == SPECTRAL_PLAN_1024) fill_tab<1>(h_out); else if (plan == SPECTRAL_PLAN_2048) fill_tab<2>(h_out); else fill_tab<4>(h_out);
 }
 
 template <int U>
@@ -472,7 +480,7 @@ static void launch_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t 
 }
 
 void launch_analyze_pow2(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a) {
-    if (L.plan == SPECTRAL_PLAN_1024) launch_u<1>(s, L, a); else launch_u<2>(s, L, a);
+    if (L.plan == SPECTRAL_PLAN_1024) launch_u<1>(s, L, a); else if (L.plan == SPECTRAL_PLAN_2048) launch_u<2>(s, L, a); else launch_u<4>(s, L, a);
 }
 
 }  // namespace vbx

@@ -54,7 +54,7 @@ struct vbx_ctx {
     bool prof = false;
     std::vector<ProfRec> recs;
     std::map<std::string, std::pair<double, long>> prof_acc;
-    double *spectral_tab[4] = {nullptr, nullptr, nullptr, nullptr};   // twiddles of k_spectral*.hip, by plan
+    double *spectral_tab[SPECTRAL_PLANS] = {};             // twiddles of k_spectral*.hip, by plan
     bool pitch_force_mfma = false;                        // test hook: VBX_PITCH_MFMA=1 keeps the matrix-core pitch kernel on 1200-sample frames
     bool mfcc_force_goertzel = false;                     // test hooks: VBX_MFCC_GOERTZEL=1 / VBX_MFCC_DFT2=1 keep the
     bool mfcc_force_dft2 = false;                         //   fallback kernels covered on lengths the MFMA kernel takes

@@ -89,12 +89,13 @@ void launch_extremum_points(hipStream_t s, const double *y, int ylen, long offse
 
 // k_spectral.hip, k_spectral_pow2.hip: pitch + LPC + MFCC from one real FFT of the zero-padded frame.  Three transform
 // sizes ("plans"), named by the complex FFT length Nc (the real transform has 2 Nc points, the frame at most Nc samples):
-// 1200 (25 ms at 48 kHz, and 1025..1199, e.g. 25 ms at 44.1 kHz), 1024 (512..1024) and 2048 (1201..2048): the reference's
-// own test and example shapes (tests/lib.rs:56, examples/pitch_detection.rs:23) and the lengths below them.
+// 1200 (25 ms at 48 kHz, and 1025..1199, e.g. 25 ms at 44.1 kHz), 1024 (512..1024), 2048 (1201..2048) and 4096 (2049..4096):
+// the reference's own test and example shapes (tests/lib.rs:56, examples/pitch_detection.rs:23) and everything between.
 constexpr int SPECTRAL_N = 1200;
 constexpr int SPECTRAL_LPC_ORDER = 12;
 constexpr int SPECTRAL_TAB_COMPLEX = 60 * 20 + 3 * 20 + 601;    // W_1200^(n' ka) | W_60^(c kb) | W_2400^m
-enum { SPECTRAL_PLAN_NONE = 0, SPECTRAL_PLAN_1200 = 1, SPECTRAL_PLAN_1024 = 2, SPECTRAL_PLAN_2048 = 3 };
+enum { SPECTRAL_PLAN_NONE = 0, SPECTRAL_PLAN_1200 = 1, SPECTRAL_PLAN_1024 = 2, SPECTRAL_PLAN_2048 = 3, SPECTRAL_PLAN_4096 = 4,
+       SPECTRAL_PLANS = 5 };
 constexpr int SPECTRAL_MIN_N = 512;                             // shorter frames: the direct lag sums are as fast (measured)
 int spectral_plan(int n);                                       // the plan that serves frame length n, or SPECTRAL_PLAN_NONE
 int spectral_plan_nc(int plan);                                 // its complex FFT length
