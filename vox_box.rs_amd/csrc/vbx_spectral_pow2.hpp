@@ -1,0 +1,463 @@
+// vbx_spectral_pow2.hpp -- the spectral pass of k_spectral.hip for the frame lengths the reference itself uses: 2048
+// (examples/pitch_detection.rs:23, Windower::hanning(.., 2048, 1024)), 1024 (tests/lib.rs:56-57) and anything up to them.
+//
+// The same algebra as k_spectral.hip (see its header): ONE real FFT of the zero-padded windowed frame of length
+// M = 2 Nc >= 2 n gives every lag sum S[lag] (|X|^2 -> second transform), S[0..12] feed the register Levinson, and -- when
+// the frame fills the transform exactly (n == Nc) -- X[2k'] are the n-point DFT bins the mel filters read.  Nc is 1024,
+// 2048 or 4096, the frame may be shorter (the padding is then longer than the frame; linear correlation needs M >= 2n - 1).
+//
+// One wavefront per frame.  Complex FFT of length Nc = 16 * 16 * R (R = 4, 8 or 16), decimation in frequency with
+// n = 16R a + R b + c and k = ka + 16 kb + 256 kc:
+//   stage 1  unit n' = R b + c (16R units, U = R/4 per lane: n' = lane + 64 u): 16-point DFT over a, times W_Nc^(n' ka)
+//   stage 2  unit (ka, c):  16-point DFT over b, times W_16R^(c kb)
+//   stage 3  lane q = ka + 16 kb (4 per lane): R-point DFT over c -> X[q + 256 kc], natural order
+// between the stages the values change lanes through LDS, real and imaginary parts in two passes over one buffer that
+// later holds the lag curve y.
+#pragma once
+
+#include "vbx_device.hpp"
+#include "vbx_kernels.hpp"
+#include "vbx_mfcc_tail.hpp"
+#include "vbx_pitch_refine.hpp"
+#include "vbx_spectral.hpp"
+
+namespace vbx {
+
+#ifndef VBX_POW2_U2_WAVES
+#define VBX_POW2_U2_WAVES 2
+#endif
+
+template <int U>
+struct pow2_geom {
+    static constexpr int R = 4 * U;                    // radix of the last stage
+    static constexpr int NC = 256 * R;                 // complex FFT length
+    static constexpr int UNITS = 16 * R;               // 16-point DFTs per stage
+    static constexpr int S1 = 16 * R + 2;              // exchange 1 row stride [ka][n']: lane (ka, c) reads 2 ka + c mod 32
+    static constexpr int S2 = 256 + 16;                // exchange 2 row stride [c][ka + 16 kb]
+    static constexpr int T1 = 0;                       // twiddle table (complex entries): T1[16R][16] = W_Nc^(n' ka)
+    static constexpr int T2 = T1 + UNITS * 16;         //                                  T2[R][16]   = W_16R^(c kb)
+    static constexpr int TM = T2 + R * 16;             //                                  WM[Nc/2+1]  = W_2Nc^m
+    static constexpr int TAB = TM + NC / 2 + 1;
+    static constexpr int TP = NC / 128 + 1;            // pairs (m, Nc - m), m = lane + 64 t <= Nc / 2, per lane
+    static constexpr int EX = (16 * S1 > R * S2) ? 16 * S1 : R * S2;   // doubles of the exchange buffer
+};
+
+// 16-point DFT in place, radix 4 x 4.  Input index a sits in slot a; output index k is left in slot dft16_slot(k).
+__host__ __device__ constexpr int dft16_slot(int k) { return 4 * (k % 4) + k / 4; }
+
+__device__ __forceinline__ void rot(double &r, double &i, double wr, double wi) {      // (r + i i) * (wr + i wi)
+    const double a = r, b = i;
+    r = fma(a, wr, -(b * wi));
+    i = fma(a, wi, b * wr);
+}
+
+__device__ __forceinline__ void dft16(double (&re)[16], double (&im)[16]) {
+    constexpr double C1 = 0.92387953251128675613;    // cos(pi/8)
+    constexpr double S1 = 0.38268343236508977173;    // sin(pi/8)
+    constexpr double R2 = 0.70710678118654752440;    // sqrt(1/2)
+    // x[4 n1 + n2]: DFT over n1 for each n2 -> index k1 in slot 4 k1 + n2
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++)
+        dft4(re[n2], im[n2], re[4 + n2], im[4 + n2], re[8 + n2], im[8 + n2], re[12 + n2], im[12 + n2]);
+    // times W_16^(n2 k1)
+    rot(re[5], im[5], C1, -S1);                      // k1 = 1: W^1, W^2, W^3
+    { const double a = re[6], b = im[6]; re[6] = R2 * (a + b); im[6] = R2 * (b - a); }
+    rot(re[7], im[7], S1, -C1);
+    { const double a = re[9], b = im[9]; re[9] = R2 * (a + b); im[9] = R2 * (b - a); }   // k1 = 2: W^2, W^4, W^6
+    { const double a = re[10], b = im[10]; re[10] = b; im[10] = -a; }
+    { const double a = re[11], b = im[11]; re[11] = R2 * (b - a); im[11] = -(R2 * (a + b)); }
+    rot(re[13], im[13], S1, -C1);                    // k1 = 3: W^3, W^6, W^9
+    { const double a = re[14], b = im[14]; re[14] = R2 * (b - a); im[14] = -(R2 * (a + b)); }
+    rot(re[15], im[15], -C1, S1);
+    // DFT over n2 for each k1 -> index k2 in slot 4 k1 + k2, output k = k1 + 4 k2
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++)
+        dft4(re[4 * k1], im[4 * k1], re[4 * k1 + 1], im[4 * k1 + 1], re[4 * k1 + 2], im[4 * k1 + 2], re[4 * k1 + 3], im[4 * k1 + 3]);
+}
+
+// R-point DFT of v[0..R) in natural order (R = 4: one butterfly; R = 8: radix 4 x 2; R = 16: radix 4 x 4)
+template <int R>
+__device__ __forceinline__ void dft_last(double (&vr)[R], double (&vi)[R], double (&xr)[R], double (&xi)[R]) {
+    if constexpr (R == 4) {
+        dft4(vr[0], vi[0], vr[1], vi[1], vr[2], vi[2], vr[3], vi[3]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { xr[k] = vr[k]; xi[k] = vi[k]; }
+    } else if constexpr (R == 16) {
+        dft16(vr, vi);
+#pragma unroll
+        for (int k = 0; k < 16; k++) { xr[k] = vr[dft16_slot(k)]; xi[k] = vi[dft16_slot(k)]; }
+    } else {
+        constexpr double R2 = 0.70710678118654752440;
+        // x[2 n1 + n2]: DFT over n1 for each n2 -> k1 in slot 2 k1 + n2
+        dft4(vr[0], vi[0], vr[2], vi[2], vr[4], vi[4], vr[6], vi[6]);
+        dft4(vr[1], vi[1], vr[3], vi[3], vr[5], vi[5], vr[7], vi[7]);
+        // odd slots times W_8^k1
+        { const double a = vr[3], b = vi[3]; vr[3] = R2 * (a + b); vi[3] = R2 * (b - a); }
+        { const double a = vr[5], b = vi[5]; vr[5] = b; vi[5] = -a; }
+        { const double a = vr[7], b = vi[7]; vr[7] = R2 * (b - a); vi[7] = -(R2 * (a + b)); }
+#pragma unroll
+        for (int k1 = 0; k1 < 4; k1++) {
+            xr[k1] = vr[2 * k1] + vr[2 * k1 + 1]; xi[k1] = vi[2 * k1] + vi[2 * k1 + 1];
+            xr[k1 + 4] = vr[2 * k1] - vr[2 * k1 + 1]; xi[k1 + 4] = vi[2 * k1] - vi[2 * k1 + 1];
+        }
+    }
+}
+
+// Complex FFT of length Nc.  In: lane l holds z[16R a + l + 64 u] in (re[u][a], im[u][a]).  Out: lane l holds
+// X[l + 64 t + 256 kc] in (xr[t][kc], xi[t][kc]).  ex: LDS exchange buffer (pow2_geom<U>::EX doubles).
+template <int U>
+__device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16], double (&xr)[4][4 * U], double (&xi)[4][4 * U],
+                                         double *ex, const double2 *__restrict__ tab) {
+    using G = pow2_geom<U>;
+    constexpr int R = G::R;
+    const int lane = lane_id();
+    // stage 1
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        dft16(re[u], im[u]);
+        const double2 *tw = tab + G::T1 + (lane + 64 * u) * 16;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            double2 w[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) w[k] = tw[8 * h + k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (8 * h + k == 0) continue;
+                const int s = dft16_slot(8 * h + k);
+                rot(re[u][s], im[u][s], w[k].x, w[k].y);
+            }
+        }
+    }
+    // exchange 1: [ka][n'] -> unit (ka2, c2) reads n' = R b + c2
+    const int ka2 = lane & 15, c2 = lane >> 4;              // unit e = lane + 64 u: (ka2, c2 + 4 u)
+    double br[U][16], bi[U][16];
+    wave_sync();
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) ex[k * G::S1 + lane + 64 * u] = re[u][dft16_slot(k)];
+    wave_sync();
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int b = 0; b < 16; b++) br[u][b] = ex[ka2 * G::S1 + R * b + c2 + 4 * u];
+    wave_sync();
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) ex[k * G::S1 + lane + 64 * u] = im[u][dft16_slot(k)];
+    wave_sync();
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int b = 0; b < 16; b++) bi[u][b] = ex[ka2 * G::S1 + R * b + c2 + 4 * u];
+    // stage 2
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        dft16(br[u], bi[u]);
+        const double2 *tw = tab + G::T2 + (c2 + 4 * u) * 16;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            double2 w[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) w[k] = tw[8 * h + k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (8 * h + k == 0) continue;
+                const int s = dft16_slot(8 * h + k);
+                rot(br[u][s], bi[u][s], w[k].x, w[k].y);
+            }
+        }
+    }
+    // exchange 2: [c][ka + 16 kb] -> lane l reads q = l + 64 t for every c
+    double vr[4][R], vi[4][R];
+    wave_sync();
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) ex[(c2 + 4 * u) * G::S2 + ka2 + 16 * k] = br[u][dft16_slot(k)];
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int c = 0; c < R; c++) vr[t][c] = ex[c * G::S2 + lane + 64 * t];
+    wave_sync();
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) ex[(c2 + 4 * u) * G::S2 + ka2 + 16 * k] = bi[u][dft16_slot(k)];
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int c = 0; c < R; c++) vi[t][c] = ex[c * G::S2 + lane + 64 * t];
+    wave_sync();
+    // stage 3
+#pragma unroll
+    for (int t = 0; t < 4; t++) dft_last<R>(vr[t], vi[t], xr[t], xi[t]);
+}
+
+// U = 4 (Nc = 4096: 64 complex values per lane): one wavefront per SIMD (512 registers); the frame state, 46 KB of LDS, admits
+// three frames per CU anyway.
+// U = 1, 2: two wavefronts per SIMD.  U = 1 (Nc = 1024) needs ~210 registers.  U = 2 (Nc = 2048: 32 complex values per lane, 17
+// spectrum pairs) needs ~290: at 256 a dozen to fifty of them spill, and the frame state (23 KB of LDS) admits six frames
+// per CU.  Measured at n = 2048: 25.2 M frames/s against 18.6 M with one wavefront per SIMD and no spills.
+// FULL: the frame fills the transform (n == Nc, the bounds tests fold away and MFCC can join); otherwise n < Nc.
+template <int U, bool LPC, bool MFCC, bool FULL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(U == 1 ? 2 : U == 2 ? VBX_POW2_U2_WAVES : 1, U == 4 ? 1 : 2)))
+void analyze_pow2_kernel(const spectral_args_t a) {
+    using G = pow2_geom<U>;
+    constexpr int R = G::R, NC = G::NC, TP = G::TP;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const long f = xcd_item(blockIdx.x, a.n_frames);
+    if (f >= a.n_frames) return;
+    const int lane = lane_id();
+    const int n = FULL ? NC : a.n;                           // frame length, <= NC
+    double *ex = smem;                                       // exchange buffer, later the lag curve y
+    const double *xf = a.frames + f * a.stride;
+
+    // ---- load: z[16R a + n'] = (xw[32R a + 2 n'], xw[.. + 1]), a < 8 (the rest is the zero padding), 0 past the frame ----
+    double re[U][16], im[U][16];
+    {
+        const bool al = ((((uintptr_t)xf) | ((uintptr_t)a.window)) & 15) == 0;      // uniform
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            double2 xv[8], wv[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int i = 32 * R * q + 2 * (lane + 64 * u);
+                xv[q] = double2{0.0, 0.0}; wv[q] = double2{1.0, 1.0};
+                if (al && i + 1 < n) {
+                    xv[q] = *reinterpret_cast<const double2 *>(xf + i);
+                    if (a.window != nullptr) wv[q] = *reinterpret_cast<const double2 *>(a.window + i);
+                } else {
+                    if (i < n) { xv[q].x = xf[i]; if (a.window != nullptr) wv[q].x = a.window[i]; }
+                    if (i + 1 < n) { xv[q].y = xf[i + 1]; if (a.window != nullptr) wv[q].y = a.window[i + 1]; }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                re[u][q] = (a.window != nullptr) ? xv[q].x * wv[q].x : xv[q].x;
+                im[u][q] = (a.window != nullptr) ? xv[q].y * wv[q].y : xv[q].y;
+            }
+#pragma unroll
+            for (int q = 8; q < 16; q++) { re[u][q] = 0.0; im[u][q] = 0.0; }
+        }
+    }
+    const double x0 = readlane_f64(re[0][0], 0);            // x_w[0], for the fold seed (Q1)
+
+    // ---- forward transform of the packed frame ----
+    double xr[4][R], xi[4][R];
+    fft_pow2<U>(re, im, xr, xi, ex, a.tab);
+
+    // ---- exchange 3: natural order, then each lane takes the pairs (m, Nc - m), m = lane + 64 t <= Nc / 2 ----
+    double ar[TP], ai[TP], br[TP], bi[TP];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int kc = 0; kc < R; kc++) ex[lane + 64 * t + 256 * kc] = xr[t][kc];
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < TP; t++) {
+        const int m = lane + 64 * t;
+        const bool ok = m <= NC / 2;
+        ar[t] = ok ? ex[m] : 0.0;
+        br[t] = ok ? ex[(m == 0) ? 0 : NC - m] : 0.0;
+    }
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int kc = 0; kc < R; kc++) ex[lane + 64 * t + 256 * kc] = xi[t][kc];
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < TP; t++) {
+        const int m = lane + 64 * t;
+        const bool ok = m <= NC / 2;
+        ai[t] = ok ? ex[m] : 0.0;
+        bi[t] = ok ? ex[(m == 0) ? 0 : NC - m] : 0.0;
+    }
+    wave_sync();
+
+    // ---- spectrum of the real sequence, powers, the inverse transform's input (k_spectral.hip: same formulas) ----
+    const int b_lo = MFCC ? a.bins[0] : 0;
+    double pk[TP], pn[TP];                                   // P[m], P[Nc - m]
+#pragma unroll
+    for (int t = 0; t < TP; t++) {
+        const int m = lane + 64 * t;
+        const double2 w = a.tab[G::TM + ((m <= NC / 2) ? m : 0)];
+        const double er = 0.5 * (ar[t] + br[t]), ei = 0.5 * (ai[t] - bi[t]);
+        const double o_r = 0.5 * (ai[t] + bi[t]), o_i = -0.5 * (ar[t] - br[t]);
+        const double tr = fma(w.x, o_r, -(w.y * o_i)), ti = fma(w.x, o_i, w.y * o_r);
+        const double pr = er + tr, pi = ei + ti, qr = er - tr, qi = ei - ti;
+        pk[t] = fma(pr, pr, pi * pi);
+        pn[t] = fma(qr, qr, qi * qi);
+    }
+
+    // ---- exchange 4: G in natural order -> stage-1 layout of the second transform ----
+#pragma unroll
+    for (int t = 0; t < TP; t++) {
+        const int m = lane + 64 * t;
+        if (m <= NC / 2) {
+            const double2 w = a.tab[G::TM + m];
+            const double sm = pk[t] + pn[t], d = pk[t] - pn[t];
+            ex[m] = fma(d, w.y, sm);
+            if (m >= 1 && m < NC / 2) ex[NC - m] = fma(-d, w.y, sm);
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) re[u][q] = ex[16 * R * q + lane + 64 * u];
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < TP; t++) {
+        const int m = lane + 64 * t;
+        if (m <= NC / 2) {
+            const double2 w = a.tab[G::TM + m];
+            const double gi = -((pk[t] - pn[t]) * w.x);
+            ex[m] = gi;
+            if (m >= 1 && m < NC / 2) ex[NC - m] = gi;
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) im[u][q] = ex[16 * R * q + lane + 64 * u];
+    wave_sync();
+
+    // ---- MFCC::mfcc from the powers (n == Nc only): X_n[k'] = X_M[2 k'] ----
+    if (MFCC) {
+        const int nbp = (a.nb + 1) & ~1;
+        double *pu = ex, *pd = ex + nbp, *en = ex + 2 * nbp; // the exchange buffer is free between the two transforms
+#pragma unroll
+        for (int t = 0; t < TP; t++) {
+            const int m = lane + 64 * t;
+            if (m <= NC / 2 && (m & 1) == 0) {
+                const int b1 = (m >> 1) - b_lo, b2 = (NC / 2 - (m >> 1)) - b_lo;
+                if (b1 >= 0 && b1 < a.nb) {
+                    const double2 sl = *reinterpret_cast<const double2 *>(a.slopes + 2 * b1);
+                    pu[b1] = fabs(pk[t]) * sl.x;             // norm_sqr * multiplier (src/spectrum.rs:426-428)
+                    pd[b1] = fabs(sqrt(pk[t])) * sl.y;       // norm * multiplier (:432-434)
+                }
+                if (b2 >= 0 && b2 < a.nb && b2 != b1) {
+                    const double2 sl = *reinterpret_cast<const double2 *>(a.slopes + 2 * b2);
+                    pu[b2] = fabs(pn[t]) * sl.x;
+                    pd[b2] = fabs(sqrt(pn[t])) * sl.y;
+                }
+            }
+        }
+        wave_sync();
+        if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
+        else mfcc_tail_m(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
+        if (a.mfcc_status != nullptr && lane == 0) a.mfcc_status[f] = 0;
+        wave_sync();
+    }
+
+    // ---- second transform: Y = FFT(G);  S[2j] = Re Y[j] / M, S[2j+1] = -Im Y[j] / M, j = lane + 64 t + 256 kc < Nc / 2 ----
+    fft_pow2<U>(re, im, xr, xi, ex, a.tab);
+
+    constexpr int NS = 4 * (R / 2);                          // slots per lane: t < 4, kc < R / 2
+    constexpr double INV_M = 1.0 / (double)(2 * NC);
+    double r_e[NS], r_o[NS];
+    int jj[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const int t = s & 3, kc = s >> 2;
+        jj[s] = lane + 64 * t + 256 * kc;
+        r_e[s] = xr[t][kc] * INV_M;
+        r_o[s] = -(xi[t][kc] * INV_M);
+    }
+    const double s0 = readlane_f64(r_e[0], 0);               // S[0], the scale of the transform's rounding error
+    if (x0 != 0.0) {                                         // rectangular frames: the fold seed differs from S (uniform branch)
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const int i = 2 * jj[s];
+            if (i < n) {
+                const double xe = (a.window != nullptr) ? xf[i] * a.window[i] : xf[i];
+                r_e[s] = (r_e[s] - x0 * xe) + x0;
+            }
+            if (i + 1 < n) {
+                const double xo = (a.window != nullptr) ? xf[i + 1] * a.window[i + 1] : xf[i + 1];
+                r_o[s] = (r_o[s] - x0 * xo) + x0;
+            }
+        }
+    }
+    if (LPC) {                                               // LPC::lpc(12) on the raw autocorrelation r[0..12]
+        double rr[SP_LPC_P + 1], ac[SP_LPC_P + 1];
+#pragma unroll
+        for (int k = 0; k <= SP_LPC_P; k++) rr[k] = readlane_f64((k & 1) ? r_o[0] : r_e[0], k >> 1);
+        levinson_regs<SP_LPC_P>(rr, ac);
+        double mine = 0.0;
+#pragma unroll
+        for (int k = 0; k <= SP_LPC_P; k++) mine = (lane == k) ? ac[k] : mine;
+        if (lane <= SP_LPC_P) a.out_lpc[f * a.lpc_ld + lane] = mine;
+    }
+    double amax = -1.0;                                      // max_amplitude over the n lags (Q2; NaN never wins)
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const int i = 2 * jj[s];
+        const double ae = fabs(r_e[s]), ao = fabs(r_o[s]);
+        if (i < n) amax = (ae > amax) ? ae : amax;
+        if (i + 1 < n) amax = (ao > amax) ? ao : amax;
+    }
+    amax = wave_max(amax);
+    const double scale = 1.0 / amax;                         // normalize (:404), then / lag window (:406-408)
+    double *ys = smem;
+    wave_sync();                                             // every lane is done with the exchange buffer
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const int i = 2 * jj[s];
+        if (i + 1 < n) {
+            const double2 lw = *reinterpret_cast<const double2 *>(a.lag_window + i);
+            double2 y;
+            y.x = (r_e[s] * scale) / lw.x;
+            y.y = (r_o[s] * scale) / lw.y;
+            *reinterpret_cast<double2 *>(ys + i) = y;
+        } else if (i < n) {                                  // the last lag of an odd n
+            ys[i] = (r_e[s] * scale) / a.lag_window[i];
+        }
+    }
+    if (lane < Y_PAD) ys[n + lane] = 0.0;
+#ifndef VBX_EXP_NO_EXACT_TAIL
+    if (!FULL) spectral_exact_tail(ys, n, xf, a.window, a.lag_window, x0, scale, lane);
+#endif
+    wave_sync();
+    const double unc_tol = SP_UNC_EPS * fabs(s0) * scale;
+    double2 *full = a.pp.full_off ? reinterpret_cast<double2 *>(reinterpret_cast<char *>(smem) + a.pp.full_off) : nullptr;
+    if (!pitch_refine_store(ys, n, a.pp, f, a.out_cand, a.cand_ld, a.out_count, a.pitch_status, a.work, unc_tol, full)) {
+        if (lane == 0) a.unsure_list[atomicAdd(a.unsure_count, 1)] = (int32_t)f;
+    }
+}
+
+template <int U>
+inline size_t pow2_lds_bytes(int n, int nb) {
+    size_t need = (size_t)pitch_refine_lds_bytes(n);
+    const size_t exch = (size_t)pow2_geom<U>::EX * sizeof(double);
+    const size_t mel = (size_t)(2 * ((nb + 1) & ~1) + 64) * sizeof(double);
+    if (exch > need) need = exch;
+    if (mel > need) need = mel;
+    return (need + 15) & ~(size_t)15;
+}
+
+template <int U>
+void launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a) {
+    const dim3 grid((unsigned)L.F), block(64);
+    const size_t base = pow2_lds_bytes<U>(L.n, L.nb), extra = pitch_full_list_bytes(L.n, L.kmax);
+    a.pp.full_off = extra ? (int)base : 0;
+    const size_t lds = base + extra;
+    const bool lpc = L.out_lpc != nullptr, mf = L.out_mfcc != nullptr;
+    if (L.n != pow2_geom<U>::NC) {                           // spectral_supported(): no MFCC from a padded transform
+        if (lpc) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, false, false>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, false>), grid, block, lds, s, a);
+    } else if (lpc && mf) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, true, true>), grid, block, lds, s, a);
+    else if (lpc) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, false, true>), grid, block, lds, s, a);
+    else if (mf) hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, true>), grid, block, lds, s, a);
+}
+
+
+}  // namespace vbx
