@@ -469,8 +469,9 @@ def run_rank(args):
             terms_pf = terms_w / max(frames_w, 1)
             flops_pf = 2.0 * fm["autocorr_macs"] + FLOPS_PER_SINC_TERM * terms_pf
             tf = F * flops_pf / (dom_ms * 1e-3) / 1e12
-            # frame lengths 512..2048 have an FFT kernel: complex length 1024 (n <= 1024), 1200 (n <= 1200) or 2048
-            nc = 1024 if 512 <= frame_len <= 1024 else 1200 if 1024 < frame_len <= 1200 else 2048 if 1200 < frame_len <= 2048 else 0
+            # frame lengths 512..4096 have an FFT kernel: complex length 1024 (n <= 1024), 1200 (n <= 1200), 2048 or 4096
+            nc = (1024 if 512 <= frame_len <= 1024 else 1200 if 1024 < frame_len <= 1200 else 2048 if 1200 < frame_len <= 2048 else
+                  4096 if 2048 < frame_len <= 4096 else 0)
             nfft = 2.0 * nc
             fft_flops = (2.0 * 2.5 * nfft * np.log2(nfft) + 6.0 * nfft) if nc else 0.0   # two real transforms (half the complex cost) + |X|^2, split
             exec_pf = (fft_flops if nc else 2.0 * fm["autocorr_macs"]) + FLOPS_PER_SINC_TERM * terms_pf

@@ -18,6 +18,7 @@ run trace_config4 --kernel-trace --stats --output-format csv -d $O/trace_config4
 # the reference's own frame shapes (examples/pitch_detection.rs:23: 2048 / 1024; tests/lib.rs:56-57: 1024 / 512)
 run trace_pipeline_2048 --kernel-trace --stats --output-format csv -d $O/trace_pipeline_2048 -- python3 bench.py --frame-len 2048 --hop 1024 --hours 2 --steps 3 --warmup 1 --no-cpu
 run trace_config3_2048 --kernel-trace --stats --output-format csv -d $O/trace_config3_2048 -- python3 bench.py --workload config3 --frame-len 2048 --hop 1024 --hours 2 --steps 3 --warmup 1 --no-cpu
+run trace_config3_4096 --kernel-trace --stats --output-format csv -d $O/trace_config3_4096 -- python3 bench.py --workload config3 --frame-len 4096 --hop 2048 --hours 2 --steps 3 --warmup 1 --no-cpu
 run trace_config3_1024 --kernel-trace --stats --output-format csv -d $O/trace_config3_1024 -- python3 bench.py --workload config3 --frame-len 1024 --hop 512 --hours 2 --steps 3 --warmup 1 --no-cpu
 for w in pipeline_2048:pipeline:2048:1024 config3_2048:config3:2048:1024 config3_1024:config3:1024:512; do
   IFS=: read name wl fl hop <<< "$w"
