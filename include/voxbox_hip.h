@@ -248,7 +248,9 @@ int vbx_to_resonance_c64(vbx_ctx *ctx, const vbx_complex *roots, size_t n_rows, 
 
 /* EstimateFormants::estimate_formants carried frame to frame = FormantExtractor
  * (src/spectrum.rs:216-369).  The scan is sequential in the reference (the caller passes the
- * previous frame's estimates back in, tests/lib.rs:75-79); it is batched per utterance:
+ * previous frame's estimates back in, tests/lib.rs:75-79); here utterances of 384 frames or more are
+ * scanned in parallel chunks with exact repair (bit-identical rows, about a millisecond for any batch:
+ * utterance length is not a cost).  It is batched per utterance:
  * h_seg_start[n_segments] (HOST array) are the ascending frame indices at which the caller's
  * state is reset to est_init (h_seg_start[0] must be 0; NULL/0 = one segment).  res: [F, n_res]
  * resonance rows exactly as the reference passes them (zero padded); frame_status (optional):

@@ -46,8 +46,10 @@ KEYS = {   # bench.py profile name -> (workload, kernel-name prefix in the count
     "burg": ("pipeline", "void burg_kernel<64, 20, double>"),
     "formant_resonances_512": ("config4", "formant_resonances_kernel"),
     "formant_resonances": ("pipeline", "formant_resonances_kernel"),
-    "tracker_512": ("config4", "void tracker_kernel<4>"),
+    "tracker_512": ("config4", "void tracker_kernel<4>"),                 # VBX_TRACKER_CHUNKED=0 runs (time-sliced scan)
     "tracker": ("pipeline", "void tracker_kernel<4>"),
+    "tracker_chunked_512": ("config4", "void tracker_spec_kernel<4>"),    # the scan's first and longest kernel
+    "tracker_chunked": ("pipeline", "void tracker_spec_kernel<4>"),
     "autocorr_lpc_512": ("config2", "void autocorr_fewlags_kernel<8, 13>"),
 }
 traffic = {}
@@ -58,7 +60,8 @@ for key, (wl, kern) in KEYS.items():
     if not fe or not wr or not F:
         continue
     # sliced kernels run several launches per step: the counter averages are per launch, the frames too
-    SLICES = int(os.environ.get("VBX_FF_SLICES", "6"))                       # run_find_formants' default
+    # the time-sliced find_formants (VBX_TRACKER_CHUNKED=0) runs its kernels VBX_FF_SLICES (6) times per step
+    SLICES = int(os.environ.get("VBX_FF_SLICES", "6")) if os.environ.get("VBX_TRACKER_CHUNKED") == "0" else 1
     per_step = SLICES if key.split("_")[0] in ("burg", "formant", "tracker") else 1
     F = F / per_step
     fetch_b, write_b = fe["avg"] * 1024.0 * 2.0, wr["avg"] * 1024.0

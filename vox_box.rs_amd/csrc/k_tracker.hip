@@ -195,6 +195,256 @@ __global__ __launch_bounds__(64) void tracker_kernel(const res_t *__restrict__ r
     }
 }
 
+// ---- the scan of LONG utterances: speculative chunks with exact repair ------------------------------------------------
+// One lane per utterance is one chain of dependent steps, ~5 us each: an hour-long recording tracked as one utterance
+// (360,000 frames at a 10 ms hop, what a caller of the reference's find_formants loop over a whole file gets) would take
+// two seconds on a single lane.  But the tracker forgets: started from ANY estimates, its state after a few dozen frames is
+// bit for bit the state of the true scan (measured on the bench signal: 78 % after 16 frames, 90 % after 32, 100 % after 64
+// -- every estimate is overwritten by a resonance of the current frame as soon as that frame has enough of them).  So:
+//   A  tracker_spec_kernel    one lane per CHUNK of TRK_CHUNK frames: warm up over the TRK_WARM frames before the chunk
+//                             from the initial estimates (exact, not a guess, if an utterance starts inside the warm-up),
+//                             then scan the chunk; remember the state the chunk was entered with.
+//   B  tracker_check_kernel / tracker_repair_kernel (TRK_ROUNDS times)   every chunk whose remembered entry state is not
+//                             the row the previous chunk ended with is redone from that row, in parallel, until its
+//                             state meets the row it already holds (from there on the old rows are right).
+//   S  tracker_sweep_kernel   one wavefront per utterance walks the chunk boundaries in order and redoes whatever is still
+//                             inconsistent: this pass alone makes the result exact (== the sequential scan, bit for bit),
+//                             the rounds before it only leave it nothing to do.
+#ifndef VBX_TRK_CHUNK
+#define VBX_TRK_CHUNK 64
+#endif
+#ifndef VBX_TRK_WARM
+#define VBX_TRK_WARM 64
+#endif
+#ifndef VBX_TRK_ROUNDS
+#define VBX_TRK_ROUNDS 3
+#endif
+constexpr int TRK_CHUNK = VBX_TRK_CHUNK, TRK_WARM = VBX_TRK_WARM, TRK_ROUNDS = VBX_TRK_ROUNDS;
+
+struct trk_in_t {
+    const res_t *res; long n_frames; int n_res; const int32_t *res_count; const int64_t *seg_start; long n_seg;
+    const res_t *est_init; const int32_t *frame_status; double *out; long out_ld;
+};
+struct trk_spec_t {               // per chunk g
+    double *entry;                // [G][2 NS]: the state chunk g's rows were computed from
+    double *want;                 // [G][2 NS]: check -> repair: the row the previous chunk ends with
+    int32_t *exact;               // [G]: the entry state is not a guess
+    int32_t *redo;                // [G]: check -> repair
+    int64_t *stop;                // [G]: first utterance start inside the chunk (rows from there on are exact), or the chunk's end
+};
+
+__device__ __forceinline__ bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
+
+template <int NE>
+__device__ __forceinline__ void trk_init(const trk_in_t &in, double (&ef)[NS], double (&eb)[NS]) {
+#pragma unroll
+    for (int e = 0; e < NS; e++) { ef[e] = 0.0; eb[e] = 0.0; }
+#pragma unroll
+    for (int e = 0; e < NE; e++) { ef[e] = in.est_init[e].frequency; eb[e] = in.est_init[e].bandwidth; }
+}
+template <int NE>
+__device__ __forceinline__ void trk_load_row(const trk_in_t &in, long f, double (&ef)[NS], double (&eb)[NS]) {
+#pragma unroll
+    for (int e = 0; e < NS; e++) { ef[e] = 0.0; eb[e] = 0.0; }
+#pragma unroll
+    for (int e = 0; e < NE; e++) { const double2 p = *reinterpret_cast<const double2 *>(in.out + f * in.out_ld + 2 * e); ef[e] = p.x; eb[e] = p.y; }
+}
+template <int NE>
+__device__ __forceinline__ void trk_store_row(const trk_in_t &in, long f, const double (&ef)[NS], const double (&eb)[NS]) {
+#pragma unroll
+    for (int e = 0; e < NE; e++) { double2 o; o.x = ef[e]; o.y = eb[e]; *reinterpret_cast<double2 *>(in.out + f * in.out_ld + 2 * e) = o; }
+}
+template <int NE>
+__device__ __forceinline__ bool trk_row_is(const trk_in_t &in, long f, const double (&ef)[NS], const double (&eb)[NS]) {
+    bool same = true;
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+        const double2 p = *reinterpret_cast<const double2 *>(in.out + f * in.out_ld + 2 * e);
+        same = same && same_bits(p.x, ef[e]) && same_bits(p.y, eb[e]);
+    }
+    return same;
+}
+// one frame of the scan (a frame whose status is not 0 leaves the estimates untouched, src/lib.rs:75)
+template <int NE>
+__device__ __forceinline__ void trk_frame(const trk_in_t &in, long f, double (&ef)[NS], double (&eb)[NS]) {
+    const bool ok = (in.frame_status == nullptr) || in.frame_status[f] == 0;
+    if (!ok) return;
+    const int cnt = (in.res_count != nullptr) ? in.res_count[f] : in.n_res;
+    const res_t *row = in.res + f * (long)in.n_res;
+    res_t pre[TRK_PF];
+#pragma unroll
+    for (int i = 0; i < TRK_PF; i++) pre[i] = (i < in.n_res) ? row[i] : res_t{0.0, 0.0};
+    estimate_formants_step<NE>(ef, eb, pre, row, in.n_res, cnt);
+}
+// index of the utterance that holds frame f, and the frame at which the next one starts
+__device__ __forceinline__ long trk_segment_of(const trk_in_t &in, long f, long &next_start) {
+    if (in.seg_start == nullptr) { next_start = in.n_frames; return 0; }
+    long lo = 0, hi = in.n_seg - 1;                           // seg_start[0] == 0 <= f
+    while (lo < hi) { const long mid = (lo + hi + 1) >> 1; if (in.seg_start[mid] <= f) lo = mid; else hi = mid - 1; }
+    next_start = (lo + 1 < in.n_seg) ? in.seg_start[lo + 1] : in.n_frames;
+    return lo;
+}
+
+template <int NE>
+__global__ __launch_bounds__(64) void tracker_spec_kernel(const trk_in_t in, const trk_spec_t sp, long n_chunks) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_chunks) return;
+    const long f_begin = g * TRK_CHUNK;
+    const long f_end = (f_begin + TRK_CHUNK < in.n_frames) ? f_begin + TRK_CHUNK : in.n_frames;
+    const long w_begin = (f_begin > TRK_WARM) ? f_begin - TRK_WARM : 0;
+    long next_start;
+    long sg = trk_segment_of(in, w_begin, next_start);
+    const long seg_begin = (in.seg_start != nullptr) ? in.seg_start[sg] : 0;
+    bool exact = (w_begin == seg_begin);
+    long stop = f_end;
+    double ef[NS], eb[NS];
+    trk_init<NE>(in, ef, eb);
+    for (long f = w_begin; f < f_end; f++) {
+        if (f == next_start) {                                 // an utterance starts here: the state is known
+            trk_init<NE>(in, ef, eb);
+            exact = true;
+            if (f > f_begin && stop == f_end) stop = f;
+            sg++;
+            next_start = (sg + 1 < in.n_seg) ? in.seg_start[sg + 1] : in.n_frames;
+        }
+        if (f == f_begin) {
+#pragma unroll
+            for (int e = 0; e < NS; e++) { sp.entry[g * 2 * NS + 2 * e] = ef[e]; sp.entry[g * 2 * NS + 2 * e + 1] = eb[e]; }
+            sp.exact[g] = exact ? 1 : 0;
+        }
+        trk_frame<NE>(in, f, ef, eb);
+        if (f >= f_begin) trk_store_row<NE>(in, f, ef, eb);
+    }
+    sp.stop[g] = stop;
+}
+
+// does chunk g's entry state equal the row the previous chunk ends with?  (reads rows only: no lane writes here)
+template <int NE>
+__global__ __launch_bounds__(64) void tracker_check_kernel(const trk_in_t in, const trk_spec_t sp, long n_chunks) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_chunks) return;
+    int redo = 0;
+    if (g > 0 && !sp.exact[g]) {
+        double tf[NS], tb[NS];
+        trk_load_row<NE>(in, g * TRK_CHUNK - 1, tf, tb);
+        bool same = true;
+#pragma unroll
+        for (int e = 0; e < NE; e++) same = same && same_bits(tf[e], sp.entry[g * 2 * NS + 2 * e]) && same_bits(tb[e], sp.entry[g * 2 * NS + 2 * e + 1]);
+        if (!same) {
+            redo = 1;
+#pragma unroll
+            for (int e = 0; e < NS; e++) { sp.want[g * 2 * NS + 2 * e] = tf[e]; sp.want[g * 2 * NS + 2 * e + 1] = tb[e]; }
+        }
+    }
+    sp.redo[g] = redo;
+}
+
+// redo the flagged chunks from the state the check saw, each inside its own rows
+template <int NE>
+__global__ __launch_bounds__(64) void tracker_repair_kernel(const trk_in_t in, const trk_spec_t sp, long n_chunks) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_chunks || !sp.redo[g]) return;
+    double ef[NS], eb[NS];
+#pragma unroll
+    for (int e = 0; e < NS; e++) {
+        ef[e] = sp.want[g * 2 * NS + 2 * e]; eb[e] = sp.want[g * 2 * NS + 2 * e + 1];
+        sp.entry[g * 2 * NS + 2 * e] = ef[e]; sp.entry[g * 2 * NS + 2 * e + 1] = eb[e];      // what the rows now follow from
+    }
+    const long stop = sp.stop[g];
+    for (long f = g * TRK_CHUNK; f < stop; f++) {
+        trk_frame<NE>(in, f, ef, eb);
+        if (trk_row_is<NE>(in, f, ef, eb)) break;              // met the old scan: its remaining rows stand
+        trk_store_row<NE>(in, f, ef, eb);
+    }
+}
+
+// the guarantee: utterance by utterance, chunk boundary by chunk boundary, in order.  One WAVEFRONT per utterance: the lanes
+// read 64 of the check kernel's flags at a time (a 10-hour utterance has 56,000 chunks); lane 0 redoes a flagged chunk from
+// the row before it until its state meets rows that follow from it.  Rows past that point, and therefore the flags of the
+// chunks past it, are unchanged; the boundaries the redo crosses are compared on the way.
+template <int NE>
+__global__ __launch_bounds__(64) void tracker_sweep_kernel(const trk_in_t in, const trk_spec_t sp) {
+    const long sg = (long)blockIdx.x;
+    const int lane = (int)threadIdx.x;
+    const long s0 = (in.seg_start != nullptr) ? in.seg_start[sg] : 0;
+    const long s1 = (in.seg_start != nullptr && sg + 1 < in.n_seg) ? in.seg_start[sg + 1] : in.n_frames;
+    const long g_end = (s1 + TRK_CHUNK - 1) / TRK_CHUNK;       // chunks g with g * TRK_CHUNK < s1
+    long g = s0 / TRK_CHUNK + 1;                               // the first chunk that starts inside the utterance
+    while (g < g_end) {
+        const long mine = g + lane;
+        const unsigned long long mask = __ballot(mine < g_end && sp.redo[mine] != 0);
+        if (mask == 0ull) { g += 64; continue; }
+        const long first = g + __builtin_ctzll(mask);
+        long f = first * TRK_CHUNK;
+        if (lane == 0) {
+            double ef[NS], eb[NS];
+            trk_load_row<NE>(in, f - 1, ef, eb);
+            bool redo = false;
+#pragma unroll
+            for (int e = 0; e < NE; e++) redo = redo || !same_bits(ef[e], sp.entry[first * 2 * NS + 2 * e]) || !same_bits(eb[e], sp.entry[first * 2 * NS + 2 * e + 1]);
+            if (redo) {
+                while (f < s1) {
+                    if (f > first * TRK_CHUNK && f % TRK_CHUNK == 0) {   // entering the next chunk: its rows follow from sp.entry
+                        const long g2 = f / TRK_CHUNK;
+                        bool same = true;
+#pragma unroll
+                        for (int e = 0; e < NE; e++) same = same && same_bits(ef[e], sp.entry[g2 * 2 * NS + 2 * e]) && same_bits(eb[e], sp.entry[g2 * 2 * NS + 2 * e + 1]);
+                        if (same) break;
+                    }
+                    trk_frame<NE>(in, f, ef, eb);
+                    if (trk_row_is<NE>(in, f, ef, eb)) { f++; break; }
+                    trk_store_row<NE>(in, f, ef, eb);
+                    f++;
+                }
+            }
+        }
+        f = __shfl(f, 0, 64);
+        const long after = (f + TRK_CHUNK - 1) / TRK_CHUNK;     // the first boundary at or after the frame the redo ended on
+        g = (after > first + 1) ? after : first + 1;            // (a boundary the redo stopped ON was accepted there)
+    }
+}
+
+size_t tracker_chunked_workspace_bytes(long F) {
+    const size_t G = (size_t)((F + TRK_CHUNK - 1) / TRK_CHUNK);
+    return G * (2 * 2 * NS * sizeof(double) + 2 * sizeof(int32_t) + sizeof(int64_t)) + 64;
+}
+
+// The same result as launch_tracker (whole segments), for batches with long utterances.  ws: tracker_chunked_workspace_bytes(F).
+void launch_tracker_chunked(hipStream_t s, const res_t *res, long F, int n_res, const int32_t *res_count,
+                            const int64_t *seg_start, long n_seg, const res_t *est_init, int n_est,
+                            const int32_t *frame_status, res_t *out, long out_ld, void *ws) {
+    const long G = (F + TRK_CHUNK - 1) / TRK_CHUNK;
+    trk_in_t in{res, F, n_res, res_count, seg_start, seg_start != nullptr ? n_seg : 1, est_init, frame_status,
+                reinterpret_cast<double *>(out), out_ld};
+    trk_spec_t sp;
+    char *w = reinterpret_cast<char *>(ws);
+    sp.entry = reinterpret_cast<double *>(w); w += (size_t)G * 2 * NS * sizeof(double);
+    sp.want = reinterpret_cast<double *>(w); w += (size_t)G * 2 * NS * sizeof(double);
+    sp.stop = reinterpret_cast<int64_t *>(w); w += (size_t)G * sizeof(int64_t);
+    sp.exact = reinterpret_cast<int32_t *>(w); w += (size_t)G * sizeof(int32_t);
+    sp.redo = reinterpret_cast<int32_t *>(w);
+    const dim3 block(64), grid_c((unsigned)((G + 63) / 64)), grid_s((unsigned)in.n_seg);
+#define VBX_TRK_CH(NE)                                                                             \
+    do {                                                                                           \
+        hipLaunchKernelGGL(tracker_spec_kernel<NE>, grid_c, block, 0, s, in, sp, G);               \
+        for (int r = 0; r < TRK_ROUNDS; r++) {                                                     \
+            hipLaunchKernelGGL(tracker_check_kernel<NE>, grid_c, block, 0, s, in, sp, G);          \
+            hipLaunchKernelGGL(tracker_repair_kernel<NE>, grid_c, block, 0, s, in, sp, G);         \
+        }                                                                                          \
+        hipLaunchKernelGGL(tracker_check_kernel<NE>, grid_c, block, 0, s, in, sp, G);              \
+        hipLaunchKernelGGL(tracker_sweep_kernel<NE>, grid_s, block, 0, s, in, sp);                 \
+    } while (0)
+    switch (n_est) {
+        case 1: VBX_TRK_CH(1); break;
+        case 2: VBX_TRK_CH(2); break;
+        case 3: VBX_TRK_CH(3); break;
+        case 4: VBX_TRK_CH(4); break;
+        case 5: VBX_TRK_CH(5); break;
+        default: VBX_TRK_CH(6); break;
+    }
+#undef VBX_TRK_CH
+}
+
 void launch_tracker(hipStream_t s, const res_t *res, long F, int n_res, const int32_t *res_count,
                     const int64_t *seg_start, long n_seg, const res_t *est_init, int n_est,
                     const int32_t *frame_status, res_t *out, long out_ld, long t0, long tc) {

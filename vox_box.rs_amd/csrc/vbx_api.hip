@@ -37,7 +37,7 @@ struct vbx_ctx {
     std::string arch;
     int cu_count = 0;
     // workspaces (grown on demand, never shrunk)
-    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_UNSURE, WS_F32_IN, WS_F32_OUT, WS_N };
+    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_UNSURE, WS_F32_IN, WS_F32_OUT, WS_TRK, WS_N };
     void *ws[WS_N] = {nullptr};
     size_t ws_bytes[WS_N] = {0};
     // cached device tables
@@ -922,6 +922,38 @@ int vbx_to_resonance_c64(vbx_ctx *ctx, const vbx_complex *roots, size_t n_rows, 
     return check_launch(ctx, __func__);
 }
 
+// Utterances of a few hundred frames or more take the chunked scan (k_tracker.hip: speculative chunks + exact repair, the
+// same rows bit for bit, ~1 ms whatever the lengths): one lane per utterance costs ~5.4 us per frame of the LONGEST
+// utterance.  VBX_TRACKER_CHUNKED=1 / 0 forces / forbids it (tests, A/B runs).
+static bool tracker_wants_chunks(const int64_t *h_seg_start, size_t n_segments, size_t n_frames) {
+    const char *env = getenv("VBX_TRACKER_CHUNKED");          // read per call: tests switch it
+    const int forced = env ? atoi(env) : -1;
+    if (forced >= 0) return forced != 0;
+    long longest = 0;
+    if (h_seg_start == nullptr || n_segments == 0) longest = (long)n_frames;
+    else for (size_t i = 0; i < n_segments; i++) {
+        const long end = (i + 1 < n_segments) ? (long)h_seg_start[i + 1] : (long)n_frames;
+        if (end - (long)h_seg_start[i] > longest) longest = end - (long)h_seg_start[i];
+    }
+    return longest >= 384;                                     // 2 ms of scan on one lane; the chunked scan takes about 1
+}
+
+static int run_tracker(vbx_ctx *ctx, hipStream_t st, bool chunked, const res_t *res, long F, int n_res, const int32_t *res_count,
+                       const int64_t *d_seg, long nseg, const res_t *d_est, int n_est, const int32_t *frame_status,
+                       res_t *out, long out_ld) {
+    if (!chunked) {
+        Prof p(ctx, "tracker", st);
+        launch_tracker(st, res, F, n_res, res_count, d_seg, nseg, d_est, n_est, frame_status, out, out_ld);
+        return VBX_SUCCESS;
+    }
+    void *w = nullptr;
+    int rc = ws_get(ctx, vbx_ctx::WS_TRK, tracker_chunked_workspace_bytes(F), &w);
+    if (rc != VBX_SUCCESS) return rc;
+    Prof p(ctx, "tracker_chunked", st);
+    launch_tracker_chunked(st, res, F, n_res, res_count, d_seg, nseg, d_est, n_est, frame_status, out, out_ld, w);
+    return VBX_SUCCESS;
+}
+
 int vbx_estimate_formants_f64(vbx_ctx *ctx, const vbx_resonance *res, size_t n_frames, size_t n_res,
                               const int64_t *h_seg_start, size_t n_segments,
                               const vbx_resonance *h_est_init, size_t n_est,
@@ -937,11 +969,9 @@ int vbx_estimate_formants_f64(vbx_ctx *ctx, const vbx_resonance *res, size_t n_f
     if (rc != VBX_SUCCESS) return rc;
     rc = upload_estimates(ctx, ctx->stream, h_est_init, n_est, &d_est);
     if (rc != VBX_SUCCESS) return rc;
-    {
-        Prof p(ctx, "tracker");
-        launch_tracker(ctx->stream, (const res_t *)res, (long)n_frames, (int)n_res, nullptr, d_seg, (long)nseg, d_est,
-                       (int)n_est, frame_status, (res_t *)out, 2 * (long)n_est);
-    }
+    rc = run_tracker(ctx, ctx->stream, tracker_wants_chunks(h_seg_start, n_segments, n_frames), (const res_t *)res, (long)n_frames,
+                     (int)n_res, nullptr, d_seg, (long)nseg, d_est, (int)n_est, frame_status, (res_t *)out, 2 * (long)n_est);
+    if (rc != VBX_SUCCESS) return rc;
     return check_launch(ctx, __func__);
 }
 
@@ -974,11 +1004,14 @@ static int run_find_formants(vbx_ctx *ctx, hipStream_t stm, const double *x, siz
     if (rc != VBX_SUCCESS) return rc;
     rc = upload_estimates(ctx, stm, h_est_init, n_est, &d_est);
     if (rc != VBX_SUCCESS) return rc;
-    // The tracker is a chain of dependent steps per utterance (~5 us per frame, whatever the batch size), so on a large
-    // batch of equal-length utterances the work is cut into time slices: while the tracker walks frames [t0, t0 + tc) of
-    // every utterance on its own stream, Burg and the root finder already produce the next slice.
+    // The tracker is a chain of dependent steps per utterance (~5 us per frame, whatever the batch size).  Utterances long
+    // enough for that to matter take the chunked scan after Burg and the root finder (run_tracker).  The alternative kept
+    // behind VBX_TRACKER_CHUNKED=0 -- round 2's first answer, for batches of equal-length utterances: the work is cut into
+    // time slices, and while the tracker walks frames [t0, t0 + tc) of every utterance on its own stream, Burg and the root
+    // finder already produce the next slice (config 4: 152 M frames/s against the chunked scan's 156 M).
     long seg_len = 0;
-    if (h_seg_start != nullptr && n_segments >= 64 && F >= 65536) {
+    const bool chunked = tracker_wants_chunks(h_seg_start, n_segments, n_frames);   // long utterances: the chunked scan instead
+    if (!chunked && h_seg_start != nullptr && n_segments >= 64 && F >= 65536) {
         seg_len = (n_segments > 1) ? (long)h_seg_start[1] : 0;
         for (size_t i = 0; i < n_segments && seg_len > 0; i++) if (h_seg_start[i] != (int64_t)i * seg_len) seg_len = 0;
         if (seg_len > 0 && ((long)(n_segments - 1) * seg_len >= F || seg_len < 64)) seg_len = 0;
@@ -994,7 +1027,9 @@ static int run_find_formants(vbx_ctx *ctx, hipStream_t stm, const double *x, siz
     if (n_slices == 1) {
         { Prof pr(ctx, "burg", stm); launch_burg(stm, x, F, (int)frame_len, (long)stride, hann, p, coeffs, st); }                 // :75
         { Prof pr(ctx, "formant_resonances", stm); launch_formant_resonances(stm, coeffs, F, p, sample_rate, res, cnt, st); }      // :80-110
-        { Prof pr(ctx, "tracker", stm); launch_tracker(stm, res, F, VBX_MAX_RESONANCES, cnt, d_seg, (long)nseg, d_est, (int)n_est, st, (res_t *)out_formants, (long)formants_ld); }  // :114
+        rc = run_tracker(ctx, stm, chunked, res, F, VBX_MAX_RESONANCES, cnt, d_seg, (long)nseg, d_est, (int)n_est, st,
+                         (res_t *)out_formants, (long)formants_ld);                                                                    // :114
+        if (rc != VBX_SUCCESS) return rc;
         return check_launch(ctx, "vbx_find_formants_f64");
     }
     if (!ctx->trk) {

@@ -63,6 +63,12 @@ void launch_tracker(hipStream_t s, const res_t *res, long F, int n_res, const in
                     const int32_t *frame_status, res_t *out, long out_ld /* doubles per output row, >= 2*n_est */,
                     long t0 = 0 /* first frame of every segment's slice */, long tc = 0x7fffffffffffffffL /* frames per slice */);
 
+// the same scan for batches with long utterances: speculative chunks + exact repair (k_tracker.hip)
+size_t tracker_chunked_workspace_bytes(long F);
+void launch_tracker_chunked(hipStream_t s, const res_t *res, long F, int n_res, const int32_t *res_count,
+                            const int64_t *seg_start, long n_seg, const res_t *est_init, int n_est,
+                            const int32_t *frame_status, res_t *out, long out_ld, void *ws);
+
 // k_pitch.hip
 size_t pitch_lds_bytes(int n);
 // the sorted candidate list lives one entry per lane up to this many entries; a larger kmax parks the whole
