@@ -31,12 +31,31 @@ __global__ __launch_bounds__(64) void burg_kernel(
     const T *xf = x + (have ? f : 0) * stride;
 
     double b1[EPL], b2[EPL];
+    // A lane's EPL samples are contiguous: 16-byte loads where the lane lies inside the frame and the rows are aligned
+    // (one double at a time, the 64 lanes of an instruction touch 64 different cache lines EPL times over: the address
+    // path, not the arithmetic, then bounds the kernel -- measured 2.72 -> 1.84 ms per million 512-sample frames).
+    bool vec = false;
+    if constexpr (sizeof(T) == 8 && EPL % 2 == 0) {
+        vec = have && (lig + 1) * EPL <= n && ((((uintptr_t)xf) | ((uintptr_t)window)) & 15) == 0;
+        if (vec) {
+            const double2 *xv = reinterpret_cast<const double2 *>(xf + lig * EPL);
+            const double2 *wv = reinterpret_cast<const double2 *>(window != nullptr ? window + lig * EPL : xf + lig * EPL);
 #pragma unroll
-    for (int e = 0; e < EPL; e++) {
-        const int j = lig * EPL + e;
-        double v = (have && j < n) ? (double)xf[j] : 0.0;
-        if (window != nullptr && j < n) v = (double)(T)(v * (double)window[j]);
-        b1[e] = v;
+            for (int e = 0; e < EPL; e += 2) {
+                const double2 v = xv[e / 2];
+                if (window != nullptr) { const double2 w = wv[e / 2]; b1[e] = v.x * w.x; b1[e + 1] = v.y * w.y; }
+                else { b1[e] = v.x; b1[e + 1] = v.y; }
+            }
+        }
+    }
+    if (!vec) {
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const int j = lig * EPL + e;
+            double v = (have && j < n) ? (double)xf[j] : 0.0;
+            if (window != nullptr && j < n) v = (double)(T)(v * (double)window[j]);
+            b1[e] = v;
+        }
     }
     const bool last_lane = (lig == G - 1);          // its "next lane" belongs to another frame
     // b2[j] = x[j+1]  (zero past the frame);  b1[j] = x[j] for j <= n-2  (src/spectrum.rs:108-114)
@@ -58,13 +77,20 @@ __global__ __launch_bounds__(64) void burg_kernel(
     double aa = 0.0, co = 0.0;                       // lane t of the group: aa[t], coeffs[t]  (src/spectrum.rs:116-139)
     const int gbase = lane - lig;
     for (int i = 1; i <= p; i++) {
-        double num = 0.0, den = 0.0;
+        // six independent accumulators (even / odd slots; b1^2 and b2^2 apart): one chain of 3 EPL dependent FMAs was the
+        // latency of the whole order
+        double num0 = 0.0, num1 = 0.0, da0 = 0.0, da1 = 0.0, db0 = 0.0, db1 = 0.0;
 #pragma unroll
-        for (int e = 0; e < EPL; e++) {
-            num = fma(b1[e], b2[e], num);
-            den = fma(b1[e], b1[e], den);
-            den = fma(b2[e], b2[e], den);
+        for (int e = 0; e + 1 < EPL; e += 2) {
+            num0 = fma(b1[e], b2[e], num0);
+            num1 = fma(b1[e + 1], b2[e + 1], num1);
+            da0 = fma(b1[e], b1[e], da0);
+            da1 = fma(b1[e + 1], b1[e + 1], da1);
+            db0 = fma(b2[e], b2[e], db0);
+            db1 = fma(b2[e + 1], b2[e + 1], db1);
         }
+        if (EPL & 1) { num0 = fma(b1[EPL - 1], b2[EPL - 1], num0); da0 = fma(b1[EPL - 1], b1[EPL - 1], da0); db0 = fma(b2[EPL - 1], b2[EPL - 1], db0); }
+        double num = num0 + num1, den = (da0 + da1) + (db0 + db1);
         num = group_sum<G>(num);
         den = group_sum<G>(den);
         if (st == 0 && den <= 0.0) st = 1;           // Err(LPC), src/spectrum.rs:123-125 (NaN falls through)

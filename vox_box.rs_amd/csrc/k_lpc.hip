@@ -72,9 +72,16 @@ __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
         wreg[e] = (i < n) ? ((window != nullptr) ? (double)window[i] : 1.0) : 0.0;
     }
     const bool full = (n == 64 * EPL);               // uniform: unguarded, mergeable loads
+    // 16-byte loads where every row is 16-byte aligned: a lane's EPL samples are contiguous, and with one double per
+    // instruction the 64 lanes touch 64 cache lines EPL times over
+    const bool vec16 = full && sizeof(T) == 8 && EPL % 2 == 0 && (((uintptr_t)x) & 15) == 0 && (stride & 1) == 0;
     auto load_frame = [&](int g, double (&dst)[EPL]) {
         const T *xf = x + (f0 + g) * stride + lane * EPL;
-        if (full) {
+        if (vec16) {
+            const double2 *xv = reinterpret_cast<const double2 *>(xf);
+#pragma unroll
+            for (int e = 0; e < EPL; e += 2) { const double2 v = xv[e / 2]; dst[e] = v.x; if (e + 1 < EPL) dst[e + 1] = v.y; }
+        } else if (full) {
 #pragma unroll
             for (int e = 0; e < EPL; e++) dst[e] = (double)xf[e];
         } else {
