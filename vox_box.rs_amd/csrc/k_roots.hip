@@ -16,6 +16,7 @@ namespace vbx {
 
 constexpr int ROOTS_BLOCK = 64;
 
+
 template <typename T>
 struct lds_poly_t {
     cx<T> *base;   // element j of this lane at base[j * ROOTS_BLOCK]
@@ -50,14 +51,31 @@ __device__ __forceinline__ cx<T> laguerre(const lds_poly_t<T> &p, int len, cx<T>
     cx<T> z = start;
     bool done = false;
     if (top < 0 || top > n) top = n;
+    // the highest degree in the wave, as a scalar: entries above a lane's own degree are zeros, and a chain that starts
+    // above it runs through 0 * z + 0 (see above)
+    for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(top, o, 64); top = other > top ? other : top; }
+    const int top_u = __builtin_amdgcn_readfirstlane(top);
     for (int it = 0; it < 20; it++) {
         const bool zfin = (z.re - z.re == T(0)) && (z.im - z.im == T(0));
-        const int hi = __all(zfin || done) ? top : n;
-        cx<T> a0 = p.get(hi), a1 = cmk<T>(T(0), T(0)), a2 = cmk<T>(T(0), T(0));
-        for (int j = hi - 1; j >= 0; j--) {
-            a2 = cmad(a2, z, a1);
-            a1 = cmad(a1, z, a0);
-            a0 = cmad(a0, z, p.get(j));
+        cx<T> a0, a1 = cmk<T>(T(0), T(0)), a2 = cmk<T>(T(0), T(0));
+        if (__all(zfin || done)) {
+            // the usual case: the chain starts at the wave's highest degree, a scalar -- the loop runs on scalar control
+            // (unrolled by two: the three accumulators rotate through the same registers without copies)
+            const int hi = top_u;
+            a0 = p.get(hi);
+#pragma unroll 2
+            for (int j = hi - 1; j >= 0; j--) {
+                a2 = cmad(a2, z, a1);
+                a1 = cmad(a1, z, a0);
+                a0 = cmad(a0, z, p.get(j));
+            }
+        } else {
+            a0 = p.get(n);                                   // a non-finite z somewhere: every lane's full chain
+            for (int j = n - 1; j >= 0; j--) {
+                a2 = cmad(a2, z, a1);
+                a1 = cmad(a1, z, a0);
+                a0 = cmad(a0, z, p.get(j));
+            }
         }
         // |p(z)| <= 1e-16  (compared on squared norms)
         const T n0 = a0.re * a0.re + a0.im * a0.im;
