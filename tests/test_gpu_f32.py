@@ -113,12 +113,12 @@ def test_mfcc_f32(vb, oracle, audio, n):
     assert np.all(stb == 4) and np.all(bad == 0.0)
 
 
-def test_pitch_f32(vb, oracle, audio):
+@pytest.mark.parametrize("n,hop", [(1200, 480), (1024, 512), (2048, 1024), (1103, 441)])     # one per FFT plan, and a padded odd length
+def test_pitch_f32(vb, oracle, audio, n, hop):
     """Pitched<f32, f32>::pitch: identity with the f64 path on the widened frames (rounded once), and against the f32
     restatement -- whose lag curve carries the rounding of 1200 f32 folds, so candidate COUNTS may differ on peaks of
-    that size (counted, bounded); the top candidate of voiced frames agrees within 1e-4 / 1e-3."""
-    n, hop = 1200, 480
-    F = 60
+    that size (counted, bounded: more of them the longer the frame); the top candidate of voiced frames agrees within 1e-4 / 1e-3."""
+    F = min(60, (audio.size - n) // hop + 1)
     x = _frames32(audio, n, hop, F, oracle.window("hanning", n))
     cand, cnt, st = vb.pitch_f32(x, SR, 0.2, 75.0, 600.0, kmax=4)
     assert cand.dtype == np.float32 and np.all(st == 0)
@@ -134,4 +134,4 @@ def test_pitch_f32(vb, oracle, audio):
             assert abs(cand[f, 0, 0] - ec[0, 0]) <= 1e-4 * ec[0, 0] and abs(cand[f, 0, 1] - ec[0, 1]) <= 1e-3, (f, cand[f, 0], ec[0])
     print("\npitch_f32: %d clearly voiced frames compared, candidate count differs from the f32 restatement in %d of %d frames"
           % (n_voiced, n_count_diff, F))
-    assert n_voiced >= 20 and n_count_diff <= F // 4
+    assert n_voiced >= F // 3 and n_count_diff <= F // 4
