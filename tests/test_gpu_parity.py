@@ -738,7 +738,10 @@ def test_mfcc_not_nan(vb):
                                           (509, 13, 100.0, 8000.0, 22050.0),      # prime length: Goertzel kernel
                                           (1155, 13, 50.0, 11000.0, 22050.0),     # odd factors (3*5*7*11)
                                           (1000, 40, 0.0, 8000.0, 16000.0),       # every bin up to n/2 needed
-                                          (2400, 13, 100.0, 8000.0, 96000.0), (94, 5, 300.0, 3000.0, 8000.0)])
+                                          (2400, 13, 100.0, 8000.0, 96000.0), (94, 5, 300.0, 3000.0, 8000.0),
+                                          (2048, 13, 100.0, 8000.0, 48000.0), (2048, 40, 0.0, 24000.0, 48000.0),   # FFT kernels: every bin
+                                          (4096, 26, 50.0, 16000.0, 44100.0), (1024, 64, 0.0, 11025.0, 22050.0),
+                                          (1200, 40, 0.0, 24000.0, 48000.0)])
 def test_mfcc(vb, oracle, audio, n, k, lo, hi, sr):
     x = _frames(audio, n, 977, range(0, 60, 4)) * oracle.window("hanning", n) * 40.0
     m, st = vb.mfcc(x, k, (lo, hi), sr)
@@ -748,13 +751,14 @@ def test_mfcc(vb, oracle, audio, n, k, lo, hi, sr):
         assert np.all(rel_close(m[f], em, 1e-6)), (f, np.max(np.abs(m[f] - em)))
 
 
-def test_mfcc_three_kernels_agree(pkg, oracle, audio, monkeypatch):
-    """N = 1200 takes the matrix-core kernel; VBX_MFCC_DFT2=1 forces the vector two-stage kernel (lengths whose
-    factorisation does not fit the MFMA tiles) and VBX_MFCC_GOERTZEL=1 the Goertzel kernel (prime lengths).  The
-    three must agree with each other far inside the oracle tolerance, and differ in the last bits (three kernels ran)."""
+def test_mfcc_four_kernels_agree(pkg, oracle, audio, monkeypatch):
+    """N = 1200 takes the FFT kernel (the forward half of the fused spectral kernel: 1024, 1200, 2048, 4096); VBX_MFCC_MFMA=1
+    keeps the matrix-core two-stage DFT (other composite lengths), VBX_MFCC_DFT2=1 forces the vector two-stage kernel (lengths
+    whose factorisation does not fit the MFMA tiles) and VBX_MFCC_GOERTZEL=1 the Goertzel kernel (prime lengths).  The four
+    must agree with each other far inside the oracle tolerance, and differ in the last bits (four kernels ran)."""
     x = _frames(audio, N48, 977, range(0, 60, 4)) * oracle.window("hanning", N48) * 40.0
     res = {}
-    for name, var in (("mfma", None), ("dft2", "VBX_MFCC_DFT2"), ("goertzel", "VBX_MFCC_GOERTZEL")):
+    for name, var in (("fft", None), ("mfma", "VBX_MFCC_MFMA"), ("dft2", "VBX_MFCC_DFT2"), ("goertzel", "VBX_MFCC_GOERTZEL")):
         if var:
             monkeypatch.setenv(var, "1")
         v = pkg.VoxBox(0)
@@ -764,10 +768,10 @@ def test_mfcc_three_kernels_agree(pkg, oracle, audio, monkeypatch):
             res[name] = v.mfcc(x, 13, (100.0, 8000.0), SR)
         finally:
             v.close()
-    for a in ("dft2", "goertzel"):
+    for a in ("fft", "dft2", "goertzel"):
         assert np.array_equal(res["mfma"][1], res[a][1]) and not np.array_equal(res["mfma"][0], res[a][0])
         assert np.all(rel_close(res["mfma"][0], res[a][0], 1e-9)), a
-    assert not np.array_equal(res["dft2"][0], res["goertzel"][0])
+    assert not np.array_equal(res["dft2"][0], res["goertzel"][0]) and not np.array_equal(res["fft"][0], res["dft2"][0])
 
 
 def test_mfcc_and_formants_odd_signals(vb, oracle):

@@ -173,8 +173,11 @@ __device__ __forceinline__ void fft1200(double (&re)[20], double (&im)[20], doub
 #define VBX_SPECTRAL_WAVES 2
 #endif
 // FULL: the frame fills the transform (n == 1200, the bounds tests fold away); otherwise 1025 <= n < 1200, zero padded.
-template <bool LPC, bool MFCC, bool FULL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VBX_SPECTRAL_WAVES, VBX_SPECTRAL_WAVES))) void analyze_kernel(const spectral_args_t a) {
+// PITCH = false: MFCC::mfcc alone (vbx_mfcc_f64 on a full frame) -- the forward transform and the mel / DCT tail, nothing
+// after them; the registers of one transform let more wavefronts in.
+template <bool LPC, bool MFCC, bool FULL, bool PITCH = true>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PITCH ? VBX_SPECTRAL_WAVES : 2, PITCH ? VBX_SPECTRAL_WAVES : 4))) void analyze_kernel(const spectral_args_t a) {
+    static_assert(PITCH || (MFCC && FULL && !LPC), "the MFCC-only form needs the full frame and has no lag sums");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const long f = xcd_item(blockIdx.x, a.n_frames);            // neighbouring frames on the same XCD: their overlap hits its L2
     if (f >= a.n_frames) return;
@@ -261,35 +264,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VBX_SPECTRAL
         pn[t] = fma(qr, qr, qi * qi);
     }
 
-    // ---- exchange 4: G in natural order -> stage-1 layout of the second transform ----
-#pragma unroll
-    for (int t = 0; t < 10; t++) {
-        const int m = lane + 64 * t;
-        if (m <= 600) {
-            const double2 w = a.tab[SP_TM + m];
-            const double sm = pk[t] + pn[t], d = pk[t] - pn[t];
-            ex[m] = fma(d, w.y, sm);
-            if (m >= 1 && m < 600) ex[SP_N - m] = fma(-d, w.y, sm);
+    if constexpr (PITCH) {
+        // ---- exchange 4: G in natural order -> stage-1 layout of the second transform ----
+    #pragma unroll
+        for (int t = 0; t < 10; t++) {
+            const int m = lane + 64 * t;
+            if (m <= 600) {
+                const double2 w = a.tab[SP_TM + m];
+                const double sm = pk[t] + pn[t], d = pk[t] - pn[t];
+                ex[m] = fma(d, w.y, sm);
+                if (m >= 1 && m < 600) ex[SP_N - m] = fma(-d, w.y, sm);
+            }
         }
-    }
-    wave_sync();
-#pragma unroll
-    for (int q = 0; q < 20; q++) re[q] = ex[60 * q + np];
-    wave_sync();
-#pragma unroll
-    for (int t = 0; t < 10; t++) {
-        const int m = lane + 64 * t;
-        if (m <= 600) {
-            const double2 w = a.tab[SP_TM + m];
-            const double gi = -((pk[t] - pn[t]) * w.x);
-            ex[m] = gi;
-            if (m >= 1 && m < 600) ex[SP_N - m] = gi;
+        wave_sync();
+    #pragma unroll
+        for (int q = 0; q < 20; q++) re[q] = ex[60 * q + np];
+        wave_sync();
+    #pragma unroll
+        for (int t = 0; t < 10; t++) {
+            const int m = lane + 64 * t;
+            if (m <= 600) {
+                const double2 w = a.tab[SP_TM + m];
+                const double gi = -((pk[t] - pn[t]) * w.x);
+                ex[m] = gi;
+                if (m >= 1 && m < 600) ex[SP_N - m] = gi;
+            }
         }
+        wave_sync();
+    #pragma unroll
+        for (int q = 0; q < 20; q++) im[q] = ex[60 * q + np];
+        wave_sync();
     }
-    wave_sync();
-#pragma unroll
-    for (int q = 0; q < 20; q++) im[q] = ex[60 * q + np];
-    wave_sync();
 
     // ---- MFCC::mfcc from the powers: X_N[k'] = X_M[2 k'], i.e. bin m/2 from P[m] and bin 600 - m/2 from P[N - m] ----
     if (MFCC) {
@@ -318,6 +323,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VBX_SPECTRAL
         if (a.mfcc_status != nullptr && lane == 0) a.mfcc_status[f] = 0;
         wave_sync();
     }
+
+    if constexpr (!PITCH) return;
 
     // ---- second transform: Y = FFT(G);  S[2j] = Re Y[j] / M, S[2j+1] = -Im Y[j] / M, j < 600 only ----
     fft1200<2>(re, im, xr, xi, ex, a.tab);
@@ -470,6 +477,10 @@ void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
     a.pp.full_off = extra ? (int)base : 0;
     const size_t lds = base + extra;
     const bool lpc = L.out_lpc != nullptr, mf = L.out_mfcc != nullptr;
+    if (L.mfcc_only) {                                       // spectral_supported(): n == SP_N
+        hipLaunchKernelGGL((analyze_kernel<false, true, true, false>), grid, block, spectral_lds_bytes(0), s, a);
+        return;
+    }
     if (L.n != SP_N) {                                       // spectral_supported(): no MFCC from a padded transform
         if (lpc) hipLaunchKernelGGL((analyze_kernel<true, false, false>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((analyze_kernel<false, false, false>), grid, block, lds, s, a);

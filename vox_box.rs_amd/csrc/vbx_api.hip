@@ -58,6 +58,7 @@ struct vbx_ctx {
     bool pitch_force_mfma = false;                        // test hook: VBX_PITCH_MFMA=1 keeps the matrix-core pitch kernel on 1200-sample frames
     bool mfcc_force_goertzel = false;                     // test hooks: VBX_MFCC_GOERTZEL=1 / VBX_MFCC_DFT2=1 keep the
     bool mfcc_force_dft2 = false;                         //   fallback kernels covered on lengths the MFMA kernel takes
+    bool mfcc_force_mfma = false;                         //   VBX_MFCC_MFMA=1: no FFT kernel for 1024 / 1200 / 2048 / 4096 (k_spectral*.hip)
     unsigned long long *pitch_work = nullptr;             // [PITCH_WORK_SLOTS][4], counted while profiling
     // second stream of vbx_analyze_frames_f64 (the formant chain runs beside the pitch kernel) + fork/join events
     hipStream_t side = nullptr;
@@ -456,6 +457,7 @@ int vbx_ctx_create(vbx_ctx **out, int device, void *hip_stream) {
     ctx->cu_count = prop.multiProcessorCount;
     { const char *e = std::getenv("VBX_MFCC_GOERTZEL"); ctx->mfcc_force_goertzel = e && e[0] == '1'; }
     { const char *e = std::getenv("VBX_MFCC_DFT2"); ctx->mfcc_force_dft2 = e && e[0] == '1'; }
+    { const char *e = std::getenv("VBX_MFCC_MFMA"); ctx->mfcc_force_mfma = e && e[0] == '1'; }
     { const char *e = std::getenv("VBX_PITCH_MFMA"); ctx->pitch_force_mfma = e && e[0] == '1'; }
     if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->owns_stream = false; }
     else {
@@ -1082,6 +1084,23 @@ static int run_mfcc(vbx_ctx *ctx, hipStream_t stm, const double *x, size_t n_fra
     const double *dct = nullptr, *slopes = nullptr;
     rc = get_dct_dev(ctx, num_coeffs, &dct); if (rc != VBX_SUCCESS) return rc;
     rc = get_slopes_dev(ctx, frame_len, num_coeffs, lo_hz, hi_hz, sample_rate, hb, &slopes); if (rc != VBX_SUCCESS) return rc;
+    // frames that fill one of the FFT kernels' transforms (1024, 1200, 2048, 4096): the forward half of the fused spectral
+    // kernel -- one real FFT of the zero-padded frame, whose even bins are the n-point DFT the mel filters read
+    {
+        const int plan = spectral_plan((int)frame_len);
+        if (!ctx->mfcc_force_goertzel && !ctx->mfcc_force_dft2 && !ctx->mfcc_force_mfma && plan != SPECTRAL_PLAN_NONE &&
+            (int)frame_len == spectral_plan_nc(plan) && spectral_supported((int)frame_len, 0, nb, hb.front(), (int)num_coeffs)) {
+            const double *tab = nullptr;
+            rc = get_spectral_tab(ctx, plan, &tab); if (rc != VBX_SUCCESS) return rc;
+            spectral_launch_t L{};
+            L.plan = plan; L.n = (int)frame_len; L.mfcc_only = true;
+            L.x = x; L.F = (long)n_frames; L.stride = (long)stride; L.window = window; L.tab = tab;
+            L.out_mfcc = out; L.mfcc_ld = (long)out_ld; L.mfcc_status = status;
+            L.bins = d_bins; L.slopes = slopes; L.dct = dct; L.num_coeffs = (int)num_coeffs; L.nb = nb;
+            { Prof p(ctx, "mfcc", stm); launch_analyze(stm, L); }
+            return check_launch(ctx, "vbx_mfcc_f64");
+        }
+    }
     // composite frame lengths: two-stage DFT of the needed bins, on the matrix cores when the factorisation fits
     // the MFMA kernel's tiles, else on the vector ALU; otherwise (prime-ish lengths) Goertzel.  Every kernel writes
     // status 0 itself (no separate memset queued behind whatever the stream is running).

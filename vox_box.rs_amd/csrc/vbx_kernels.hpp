@@ -118,6 +118,7 @@ struct spectral_launch_t {
     double *out_mfcc; long mfcc_ld; int32_t *mfcc_status;        // NULL: no MFCC
     const int32_t *bins; const double *slopes; const double *dct; int num_coeffs; int nb;
     int32_t *unsure_list; int32_t *unsure_count;                 // frames handed to launch_pitch_list
+    bool mfcc_only;                                              // MFCC::mfcc alone (n == the plan's Nc): no pitch, no LPC
 };
 bool spectral_supported(int n, int lpc_order, int mfcc_nb, int mfcc_b_lo, int num_coeffs);
 void launch_analyze(hipStream_t s, const spectral_launch_t &L);

@@ -204,8 +204,10 @@ __device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16
 // spectrum pairs) needs ~290: at 256 a dozen to fifty of them spill, and the frame state (23 KB of LDS) admits six frames
 // per CU.  Measured at n = 2048: 25.2 M frames/s against 18.6 M with one wavefront per SIMD and no spills.
 // FULL: the frame fills the transform (n == Nc, the bounds tests fold away and MFCC can join); otherwise n < Nc.
-template <int U, bool LPC, bool MFCC, bool FULL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(U == 1 ? 2 : U == 2 ? VBX_POW2_U2_WAVES : 1, U == 4 ? 1 : 2)))
+// PITCH = false: MFCC::mfcc alone (vbx_mfcc_f64 on a full frame): the forward transform and the mel / DCT tail only.
+template <int U, bool LPC, bool MFCC, bool FULL, bool PITCH = true>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(U == 4 ? 1 : (U == 2 && PITCH) ? VBX_POW2_U2_WAVES : 2,
+                                                                     U == 4 ? (PITCH ? 1 : 2) : PITCH ? 2 : 4)))
 void analyze_pow2_kernel(const spectral_args_t a) {
     using G = pow2_geom<U>;
     constexpr int R = G::R, NC = G::NC, TP = G::TP;
@@ -295,39 +297,41 @@ void analyze_pow2_kernel(const spectral_args_t a) {
         pn[t] = fma(qr, qr, qi * qi);
     }
 
-    // ---- exchange 4: G in natural order -> stage-1 layout of the second transform ----
-#pragma unroll
-    for (int t = 0; t < TP; t++) {
-        const int m = lane + 64 * t;
-        if (m <= NC / 2) {
-            const double2 w = a.tab[G::TM + m];
-            const double sm = pk[t] + pn[t], d = pk[t] - pn[t];
-            ex[m] = fma(d, w.y, sm);
-            if (m >= 1 && m < NC / 2) ex[NC - m] = fma(-d, w.y, sm);
+    if constexpr (PITCH) {
+        // ---- exchange 4: G in natural order -> stage-1 layout of the second transform ----
+    #pragma unroll
+        for (int t = 0; t < TP; t++) {
+            const int m = lane + 64 * t;
+            if (m <= NC / 2) {
+                const double2 w = a.tab[G::TM + m];
+                const double sm = pk[t] + pn[t], d = pk[t] - pn[t];
+                ex[m] = fma(d, w.y, sm);
+                if (m >= 1 && m < NC / 2) ex[NC - m] = fma(-d, w.y, sm);
+            }
         }
-    }
-    wave_sync();
-#pragma unroll
-    for (int u = 0; u < U; u++)
-#pragma unroll
-        for (int q = 0; q < 16; q++) re[u][q] = ex[16 * R * q + lane + 64 * u];
-    wave_sync();
-#pragma unroll
-    for (int t = 0; t < TP; t++) {
-        const int m = lane + 64 * t;
-        if (m <= NC / 2) {
-            const double2 w = a.tab[G::TM + m];
-            const double gi = -((pk[t] - pn[t]) * w.x);
-            ex[m] = gi;
-            if (m >= 1 && m < NC / 2) ex[NC - m] = gi;
+        wave_sync();
+    #pragma unroll
+        for (int u = 0; u < U; u++)
+    #pragma unroll
+            for (int q = 0; q < 16; q++) re[u][q] = ex[16 * R * q + lane + 64 * u];
+        wave_sync();
+    #pragma unroll
+        for (int t = 0; t < TP; t++) {
+            const int m = lane + 64 * t;
+            if (m <= NC / 2) {
+                const double2 w = a.tab[G::TM + m];
+                const double gi = -((pk[t] - pn[t]) * w.x);
+                ex[m] = gi;
+                if (m >= 1 && m < NC / 2) ex[NC - m] = gi;
+            }
         }
+        wave_sync();
+    #pragma unroll
+        for (int u = 0; u < U; u++)
+    #pragma unroll
+            for (int q = 0; q < 16; q++) im[u][q] = ex[16 * R * q + lane + 64 * u];
+        wave_sync();
     }
-    wave_sync();
-#pragma unroll
-    for (int u = 0; u < U; u++)
-#pragma unroll
-        for (int q = 0; q < 16; q++) im[u][q] = ex[16 * R * q + lane + 64 * u];
-    wave_sync();
 
     // ---- MFCC::mfcc from the powers (n == Nc only): X_n[k'] = X_M[2 k'] ----
     if (MFCC) {
@@ -356,6 +360,8 @@ void analyze_pow2_kernel(const spectral_args_t a) {
         if (a.mfcc_status != nullptr && lane == 0) a.mfcc_status[f] = 0;
         wave_sync();
     }
+
+    if constexpr (!PITCH) return;
 
     // ---- second transform: Y = FFT(G);  S[2j] = Re Y[j] / M, S[2j+1] = -Im Y[j] / M, j = lane + 64 t + 256 kc < Nc / 2 ----
     fft_pow2<U>(re, im, xr, xi, ex, a.tab);
@@ -450,6 +456,10 @@ void launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a
     a.pp.full_off = extra ? (int)base : 0;
     const size_t lds = base + extra;
     const bool lpc = L.out_lpc != nullptr, mf = L.out_mfcc != nullptr;
+    if (L.mfcc_only) {                                       // spectral_supported(): n == Nc
+        hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, true, false>), grid, block, pow2_lds_bytes<U>(0, L.nb), s, a);
+        return;
+    }
     if (L.n != pow2_geom<U>::NC) {                           // spectral_supported(): no MFCC from a padded transform
         if (lpc) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, false, false>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, false>), grid, block, lds, s, a);
