@@ -71,7 +71,10 @@ def test_synth_matches_host_statement(vb, pkg, audio):
 
 @pytest.mark.parametrize("n,lags", [(512, 13), (512, 1), (16, 16), (100, 7), (1200, 13), (1200, 1200),
                                     (333, 333), (2048, 17), (4096, 40), (640, 321), (64, 64), (5, 5),
-                                    (1300, 1290), (4096, 4096), (1280, 257)])     # several matrix-core passes / partial tiles
+                                    (1300, 1290), (4096, 4096), (1280, 257),      # several matrix-core passes / partial tiles
+                                    # 64 lags or more of a 512..4096-sample frame: one FFT of the zero-padded frame
+                                    (512, 64), (512, 511), (1024, 1024), (1103, 1103), (1200, 65), (2047, 1001), (2048, 2048),
+                                    (3000, 64), (640, 63), (1024, 18), (2048, 40)])
 def test_autocorrelate(vb, oracle, n, lags):
     rng = np.random.default_rng(n * 1000 + lags)
     x = rng.uniform(-1, 1, (9, n))          # rectangular frames: x[0] != 0 exercises the Q1 seed
@@ -79,6 +82,29 @@ def test_autocorrelate(vb, oracle, n, lags):
     for f in range(x.shape[0]):
         exp = oracle.autocorrelate(x[f], lags)
         assert np.all(rel_close(got[f], exp)), (f, np.max(np.abs(got[f] - exp)))
+
+
+@pytest.mark.parametrize("n,lags", [(1200, 1200), (1024, 100), (2048, 2047), (777, 300), (4096, 4096)])
+def test_autocorrelate_fft_and_direct_kernels_agree(pkg, oracle, audio, monkeypatch, n, lags):
+    """Many lags of a long frame come from one FFT; VBX_PITCH_MFMA=1 keeps the direct (matrix-core) lag sums.  Windowed speech
+    frames: the sums at the far lags are 1e-13 of r[0] -- the FFT's rounding error must stay under the tolerance's floor."""
+    F = (audio.size - n) // 997 + 1
+    x = _frames(audio, n, 997, range(0, F, max(1, F // 40))) * oracle.window("hanning", n)
+    res = {}
+    for name, var in (("fft", None), ("direct", "VBX_PITCH_MFMA")):
+        if var:
+            monkeypatch.setenv(var, "1")
+        v = pkg.VoxBox(0)
+        if var:
+            monkeypatch.delenv(var)
+        try:
+            res[name] = v.autocorrelate(x, lags)
+        finally:
+            v.close()
+    assert not np.array_equal(res["fft"], res["direct"])                       # two kernels really ran
+    for f in range(x.shape[0]):
+        assert np.all(rel_close(res["fft"][f], res["direct"][f])), f
+        assert np.all(rel_close(res["fft"][f], oracle.autocorrelate(x[f], lags))), f
 
 
 def test_autocorrelate_strided_windowed(vb, oracle, pkg, audio):

@@ -173,11 +173,14 @@ __device__ __forceinline__ void fft1200(double (&re)[20], double (&im)[20], doub
 #define VBX_SPECTRAL_WAVES 2
 #endif
 // FULL: the frame fills the transform (n == 1200, the bounds tests fold away); otherwise 1025 <= n < 1200, zero padded.
-// PITCH = false: MFCC::mfcc alone (vbx_mfcc_f64 on a full frame) -- the forward transform and the mel / DCT tail, nothing
-// after them; the registers of one transform let more wavefronts in.
-template <bool LPC, bool MFCC, bool FULL, bool PITCH = true>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PITCH ? VBX_SPECTRAL_WAVES : 2, PITCH ? VBX_SPECTRAL_WAVES : 4))) void analyze_kernel(const spectral_args_t a) {
-    static_assert(PITCH || (MFCC && FULL && !LPC), "the MFCC-only form needs the full frame and has no lag sums");
+// MODE: SP_ANALYZE the fused analysis; SP_MFCC_ONLY MFCC::mfcc alone (vbx_mfcc_f64 on a full frame): the forward transform and
+// the mel / DCT tail, nothing after them; SP_AC_ONLY Autocorrelate::autocorrelate alone (vbx_autocorrelate_f64 with many lags):
+// both transforms, the fold seed, the lag sums stored.
+template <bool LPC, bool MFCC, bool FULL, int MODE = SP_ANALYZE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_MFCC_ONLY ? 2 : VBX_SPECTRAL_WAVES, MODE == SP_MFCC_ONLY ? 4 : VBX_SPECTRAL_WAVES))) void analyze_kernel(const spectral_args_t a) {
+    static_assert(MODE != SP_MFCC_ONLY || (MFCC && FULL && !LPC), "the MFCC-only form needs the full frame and has no lag sums");
+    static_assert(MODE != SP_AC_ONLY || (!MFCC && !LPC), "the autocorrelation-only form");
+    constexpr bool PITCH = MODE != SP_MFCC_ONLY;             // the second transform runs
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const long f = xcd_item(blockIdx.x, a.n_frames);            // neighbouring frames on the same XCD: their overlap hits its L2
     if (f >= a.n_frames) return;
@@ -357,6 +360,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PITCH ? VBX_
             }
         }
     }
+    if constexpr (MODE == SP_AC_ONLY) {                      // autocorrelate(n_lags): the lag sums and nothing else
+        double *row = a.out_r + f * (long)a.n_lags;
+        const bool al = ((((uintptr_t)a.out_r) & 15) == 0) && (a.n_lags & 1) == 0;      // uniform: every row 16-byte aligned
+#pragma unroll
+        for (int s = 0; s < 11; s++) {
+            const int i = 2 * jj[s];
+            if (jj[s] >= 0 && i + 1 < a.n_lags && al) *reinterpret_cast<double2 *>(row + i) = double2{r_e[s], r_o[s]};
+            else {
+                if (jj[s] >= 0 && i < a.n_lags) row[i] = r_e[s];
+                if (jj[s] >= 0 && i + 1 < a.n_lags) row[i + 1] = r_o[s];
+            }
+        }
+        return;
+    }
     if (LPC) {                                               // LPC::lpc(12) on the raw autocorrelation r[0..12]
         double rr[SP_LPC_P + 1], ac[SP_LPC_P + 1];
 #pragma unroll
@@ -471,6 +488,7 @@ void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
     a.out_mfcc = L.out_mfcc; a.mfcc_ld = L.mfcc_ld; a.mfcc_status = L.mfcc_status;
     a.bins = L.bins; a.slopes = L.slopes; a.dct = L.dct; a.num_coeffs = L.num_coeffs; a.nb = L.nb;
     a.unsure_list = L.unsure_list; a.unsure_count = L.unsure_count;
+    a.out_r = L.out_r; a.n_lags = L.n_lags;
     if (L.plan != SPECTRAL_PLAN_1200) { launch_analyze_pow2(s, L, a); return; }
     const dim3 grid((unsigned)L.F), block(64);
     const size_t base = spectral_lds_bytes(L.n), extra = pitch_full_list_bytes(L.n, L.kmax);
@@ -478,7 +496,12 @@ void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
     const size_t lds = base + extra;
     const bool lpc = L.out_lpc != nullptr, mf = L.out_mfcc != nullptr;
     if (L.mfcc_only) {                                       // spectral_supported(): n == SP_N
-        hipLaunchKernelGGL((analyze_kernel<false, true, true, false>), grid, block, spectral_lds_bytes(0), s, a);
+        hipLaunchKernelGGL((analyze_kernel<false, true, true, SP_MFCC_ONLY>), grid, block, spectral_lds_bytes(0), s, a);
+        return;
+    }
+    if (L.out_r != nullptr) {                                // autocorrelate(n_lags) alone
+        if (L.n == SP_N) hipLaunchKernelGGL((analyze_kernel<false, false, true, SP_AC_ONLY>), grid, block, spectral_lds_bytes(0), s, a);
+        else hipLaunchKernelGGL((analyze_kernel<false, false, false, SP_AC_ONLY>), grid, block, spectral_lds_bytes(0), s, a);
         return;
     }
     if (L.n != SP_N) {                                       // spectral_supported(): no MFCC from a padded transform

@@ -650,6 +650,19 @@ int vbx_autocorrelate_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t
     if (fewlags_supported((int)frame_len, (int)n_lags, false)) {
         Prof p(ctx, "autocorr_fewlags");
         launch_autocorr_fewlags(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_lags, 0, out, nullptr);
+    } else if (!ctx->pitch_force_mfma && spectral_plan((int)frame_len) != SPECTRAL_PLAN_NONE &&
+               (n_lags >= SPECTRAL_AC_MIN_LAGS || frame_len >= 1024)) {
+        // many lags of a 512..4096-sample frame: every lag sum from one real FFT of the zero-padded frame (k_spectral*.hip)
+        // instead of lags x frame_len products; the rounding error, ~1e-16 r[0] per lag, is a thousandth of the tolerance's floor
+        const double *tab = nullptr;
+        spectral_launch_t L{};
+        L.plan = spectral_plan((int)frame_len); L.n = (int)frame_len;
+        rc = get_spectral_tab(ctx, L.plan, &tab);
+        if (rc != VBX_SUCCESS) return rc;
+        L.x = x; L.F = (long)n_frames; L.stride = (long)stride; L.window = window; L.tab = tab;
+        L.out_r = out; L.n_lags = (int)n_lags;
+        Prof p(ctx, "autocorr_fft");
+        launch_analyze(ctx->stream, L);
     } else {
         Prof p(ctx, "autocorr_tiles");
         launch_autocorr_tiles(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_lags, out);
@@ -1381,6 +1394,20 @@ int vbx_autocorrelate_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t 
     VBX_REQUIRE(ctx, out != nullptr, "null output");
     VBX_REQUIRE(ctx, n_lags >= 1 && n_lags <= frame_len, "n_lags must be in [1, frame_len] (the reference panics beyond)");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
+    if (!fewlags_supported((int)frame_len, (int)n_lags, false) && !ctx->pitch_force_mfma &&
+        spectral_plan((int)frame_len) != SPECTRAL_PLAN_NONE && (n_lags >= SPECTRAL_AC_MIN_LAGS || frame_len >= 1024)) {
+        // many lags: widen (the windowed product rounded to f32 first), the f64 FFT path, one rounding to f32
+        void *wi = nullptr, *wo = nullptr;
+        rc = ws_get(ctx, vbx_ctx::WS_F32_IN, n_frames * frame_len * sizeof(double), &wi);
+        if (rc != VBX_SUCCESS) return rc;
+        rc = ws_get(ctx, vbx_ctx::WS_F32_OUT, n_frames * n_lags * sizeof(double), &wo);
+        if (rc != VBX_SUCCESS) return rc;
+        { Prof p(ctx, "widen_frames"); launch_widen_frames(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, (double *)wi); }
+        rc = vbx_autocorrelate_f64(ctx, (const double *)wi, n_frames, frame_len, frame_len, nullptr, n_lags, (double *)wo);
+        if (rc != VBX_SUCCESS) return rc;
+        { Prof p(ctx, "narrow"); launch_narrow(ctx->stream, (const double *)wo, (long)(n_frames * n_lags), out); }
+        return check_launch(ctx, __func__);
+    }
     if (fewlags_supported((int)frame_len, (int)n_lags, false)) {
         Prof p(ctx, "autocorr_fewlags_f32");
         launch_autocorr_fewlags_f32(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_lags, 0, out, nullptr);

@@ -102,6 +102,8 @@ constexpr int SPECTRAL_LPC_ORDER = 12;
 constexpr int SPECTRAL_TAB_COMPLEX = 60 * 20 + 3 * 20 + 601;    // W_1200^(n' ka) | W_60^(c kb) | W_2400^m
 enum { SPECTRAL_PLAN_NONE = 0, SPECTRAL_PLAN_1200 = 1, SPECTRAL_PLAN_1024 = 2, SPECTRAL_PLAN_2048 = 3, SPECTRAL_PLAN_4096 = 4,
        SPECTRAL_PLANS = 5 };
+constexpr int SPECTRAL_AC_MIN_LAGS = 64;                        // vbx_autocorrelate_f64 below 1024 samples: fewer lags -> the direct kernel
+                                                                // (from 1024 samples on the FFT wins wherever the few-lag kernel does not apply)
 constexpr int SPECTRAL_MIN_N = 512;                             // shorter frames: the direct lag sums are as fast (measured)
 int spectral_plan(int n);                                       // the plan that serves frame length n, or SPECTRAL_PLAN_NONE
 int spectral_plan_nc(int plan);                                 // its complex FFT length
@@ -119,6 +121,7 @@ struct spectral_launch_t {
     const int32_t *bins; const double *slopes; const double *dct; int num_coeffs; int nb;
     int32_t *unsure_list; int32_t *unsure_count;                 // frames handed to launch_pitch_list
     bool mfcc_only;                                              // MFCC::mfcc alone (n == the plan's Nc): no pitch, no LPC
+    double *out_r; int n_lags;                                   // non-NULL: Autocorrelate::autocorrelate(n_lags) alone, [F, n_lags]
 };
 bool spectral_supported(int n, int lpc_order, int mfcc_nb, int mfcc_b_lo, int num_coeffs);
 void launch_analyze(hipStream_t s, const spectral_launch_t &L);

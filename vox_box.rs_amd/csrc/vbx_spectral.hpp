@@ -9,6 +9,8 @@
 
 namespace vbx {
 
+enum { SP_ANALYZE = 0, SP_MFCC_ONLY = 1, SP_AC_ONLY = 2 };   // what a spectral kernel instantiation computes
+
 constexpr double SP_UNC_EPS = 6.0 * 400.0 * 2.220446049250313e-16;   // 1 / min w_lag * margin * eps
 
 // ---- small DFTs on separate re / im registers (forward: e^{-i...}) -------------------------------------------------
@@ -32,6 +34,7 @@ struct spectral_args_t {
     double *out_mfcc; long mfcc_ld; int32_t *mfcc_status;
     const int32_t *bins; const double *slopes; const double *dct; int num_coeffs; int nb;
     int32_t *unsure_list; int32_t *unsure_count;
+    double *out_r; int n_lags;                               // SP_AC_ONLY: [F, n_lags] lag sums
 };
 
 // The last SP_TAIL lags of the curve.  The lag window falls below 1e-8 there (1e-10 .. 1e-17 over the last twelve lags), so

@@ -204,11 +204,15 @@ __device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16
 // spectrum pairs) needs ~290: at 256 a dozen to fifty of them spill, and the frame state (23 KB of LDS) admits six frames
 // per CU.  Measured at n = 2048: 25.2 M frames/s against 18.6 M with one wavefront per SIMD and no spills.
 // FULL: the frame fills the transform (n == Nc, the bounds tests fold away and MFCC can join); otherwise n < Nc.
-// PITCH = false: MFCC::mfcc alone (vbx_mfcc_f64 on a full frame): the forward transform and the mel / DCT tail only.
-template <int U, bool LPC, bool MFCC, bool FULL, bool PITCH = true>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(U == 4 ? 1 : (U == 2 && PITCH) ? VBX_POW2_U2_WAVES : 2,
-                                                                     U == 4 ? (PITCH ? 1 : 2) : PITCH ? 2 : 4)))
+// MODE (vbx_spectral.hpp): SP_ANALYZE the fused analysis; SP_MFCC_ONLY MFCC::mfcc alone (the forward transform and the mel / DCT
+// tail only); SP_AC_ONLY Autocorrelate::autocorrelate alone (both transforms, the fold seed, the lag sums stored).
+template <int U, bool LPC, bool MFCC, bool FULL, int MODE = SP_ANALYZE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(U == 4 ? 1 : (U == 2 && MODE != SP_MFCC_ONLY) ? VBX_POW2_U2_WAVES : 2,
+                                                                     U == 4 ? (MODE != SP_MFCC_ONLY ? 1 : 2) : MODE != SP_MFCC_ONLY ? 2 : 4)))
 void analyze_pow2_kernel(const spectral_args_t a) {
+    static_assert(MODE != SP_MFCC_ONLY || (MFCC && FULL && !LPC), "the MFCC-only form needs the full frame and has no lag sums");
+    static_assert(MODE != SP_AC_ONLY || (!MFCC && !LPC), "the autocorrelation-only form");
+    constexpr bool PITCH = MODE != SP_MFCC_ONLY;             // the second transform runs
     using G = pow2_geom<U>;
     constexpr int R = G::R, NC = G::NC, TP = G::TP;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -392,6 +396,20 @@ void analyze_pow2_kernel(const spectral_args_t a) {
             }
         }
     }
+    if constexpr (MODE == SP_AC_ONLY) {                      // autocorrelate(n_lags): the lag sums and nothing else
+        double *row = a.out_r + f * (long)a.n_lags;
+        const bool al = ((((uintptr_t)a.out_r) & 15) == 0) && (a.n_lags & 1) == 0;      // uniform: every row 16-byte aligned
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const int i = 2 * jj[s];
+            if (i + 1 < a.n_lags && al) *reinterpret_cast<double2 *>(row + i) = double2{r_e[s], r_o[s]};
+            else {
+                if (i < a.n_lags) row[i] = r_e[s];
+                if (i + 1 < a.n_lags) row[i + 1] = r_o[s];
+            }
+        }
+        return;
+    }
     if (LPC) {                                               // LPC::lpc(12) on the raw autocorrelation r[0..12]
         double rr[SP_LPC_P + 1], ac[SP_LPC_P + 1];
 #pragma unroll
@@ -457,7 +475,12 @@ void launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a
     const size_t lds = base + extra;
     const bool lpc = L.out_lpc != nullptr, mf = L.out_mfcc != nullptr;
     if (L.mfcc_only) {                                       // spectral_supported(): n == Nc
-        hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, true, false>), grid, block, pow2_lds_bytes<U>(0, L.nb), s, a);
+        hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, true, SP_MFCC_ONLY>), grid, block, pow2_lds_bytes<U>(0, L.nb), s, a);
+        return;
+    }
+    if (L.out_r != nullptr) {                                // autocorrelate(n_lags) alone
+        if (L.n == pow2_geom<U>::NC) hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, true, SP_AC_ONLY>), grid, block, pow2_lds_bytes<U>(0, 0), s, a);
+        else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, false, SP_AC_ONLY>), grid, block, pow2_lds_bytes<U>(0, 0), s, a);
         return;
     }
     if (L.n != pow2_geom<U>::NC) {                           // spectral_supported(): no MFCC from a padded transform
