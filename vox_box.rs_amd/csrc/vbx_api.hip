@@ -640,6 +640,33 @@ size_t vbx_find_formants_complex_work_size(size_t n_coeffs) { return n_coeffs * 
 
 // ---- periodic.rs --------------------------------------------------------------------------
 
+// Autocorrelate::autocorrelate(n_lags) of every frame on stream st: the few-lag register kernel, one FFT of the zero-padded
+// frame (many lags of a 512..4096-sample frame), or the matrix-core tiles.
+static int run_autocorrelate(vbx_ctx *ctx, hipStream_t st, const double *x, size_t n_frames, size_t frame_len, size_t stride,
+                             const double *window, size_t n_lags, double *out) {
+    if (fewlags_supported((int)frame_len, (int)n_lags, false)) {
+        Prof p(ctx, "autocorr_fewlags", st);
+        launch_autocorr_fewlags(st, x, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_lags, 0, out, nullptr);
+    } else if (!ctx->pitch_force_mfma && spectral_plan((int)frame_len) != SPECTRAL_PLAN_NONE &&
+               (n_lags >= SPECTRAL_AC_MIN_LAGS || frame_len >= 1024)) {
+        // every lag sum from one real FFT of the zero-padded frame (k_spectral*.hip) instead of lags x frame_len products;
+        // the rounding error, ~1e-16 r[0] per lag, is a thousandth of the tolerance's floor
+        const double *tab = nullptr;
+        spectral_launch_t L{};
+        L.plan = spectral_plan((int)frame_len); L.n = (int)frame_len;
+        int rc = get_spectral_tab(ctx, L.plan, &tab);
+        if (rc != VBX_SUCCESS) return rc;
+        L.x = x; L.F = (long)n_frames; L.stride = (long)stride; L.window = window; L.tab = tab;
+        L.out_r = out; L.n_lags = (int)n_lags;
+        Prof p(ctx, "autocorr_fft", st);
+        launch_analyze(st, L);
+    } else {
+        Prof p(ctx, "autocorr_tiles", st);
+        launch_autocorr_tiles(st, x, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_lags, out);
+    }
+    return VBX_SUCCESS;
+}
+
 int vbx_autocorrelate_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
                           size_t stride, const double *window, size_t n_lags, double *out) {
     int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
@@ -647,26 +674,8 @@ int vbx_autocorrelate_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t
     VBX_REQUIRE(ctx, out != nullptr, "null output");
     VBX_REQUIRE(ctx, n_lags >= 1 && n_lags <= frame_len, "n_lags must be in [1, frame_len] (the reference panics beyond)");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
-    if (fewlags_supported((int)frame_len, (int)n_lags, false)) {
-        Prof p(ctx, "autocorr_fewlags");
-        launch_autocorr_fewlags(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_lags, 0, out, nullptr);
-    } else if (!ctx->pitch_force_mfma && spectral_plan((int)frame_len) != SPECTRAL_PLAN_NONE &&
-               (n_lags >= SPECTRAL_AC_MIN_LAGS || frame_len >= 1024)) {
-        // many lags of a 512..4096-sample frame: every lag sum from one real FFT of the zero-padded frame (k_spectral*.hip)
-        // instead of lags x frame_len products; the rounding error, ~1e-16 r[0] per lag, is a thousandth of the tolerance's floor
-        const double *tab = nullptr;
-        spectral_launch_t L{};
-        L.plan = spectral_plan((int)frame_len); L.n = (int)frame_len;
-        rc = get_spectral_tab(ctx, L.plan, &tab);
-        if (rc != VBX_SUCCESS) return rc;
-        L.x = x; L.F = (long)n_frames; L.stride = (long)stride; L.window = window; L.tab = tab;
-        L.out_r = out; L.n_lags = (int)n_lags;
-        Prof p(ctx, "autocorr_fft");
-        launch_analyze(ctx->stream, L);
-    } else {
-        Prof p(ctx, "autocorr_tiles");
-        launch_autocorr_tiles(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_lags, out);
-    }
+    rc = run_autocorrelate(ctx, ctx->stream, x, n_frames, frame_len, stride, window, n_lags, out);
+    if (rc != VBX_SUCCESS) return rc;
     return check_launch(ctx, __func__);
 }
 
@@ -818,13 +827,8 @@ static int run_autocorr_lpc(vbx_ctx *ctx, hipStream_t st, const double *x, size_
         if (rc != VBX_SUCCESS) return rc;
         r = (double *)w;
     }
-    if (fewlags_supported((int)frame_len, n_lags, false)) {
-        Prof p(ctx, "autocorr_fewlags", st);
-        launch_autocorr_fewlags(st, x, (long)n_frames, (int)frame_len, (long)stride, window, n_lags, 0, r, nullptr);
-    } else {
-        Prof p(ctx, "autocorr_tiles", st);
-        launch_autocorr_tiles(st, x, (long)n_frames, (int)frame_len, (long)stride, window, n_lags, r);
-    }
+    rc = run_autocorrelate(ctx, st, x, n_frames, frame_len, stride, window, (size_t)n_lags, r);
+    if (rc != VBX_SUCCESS) return rc;
     if (normalize) { Prof p(ctx, "normalize_rows", st); launch_normalize_rows(st, r, (long)n_frames, n_lags); }
     if (out_lpc) { Prof p(ctx, "levinson_rows", st); launch_levinson_rows(st, r, (long)n_frames, n_lags, (int)n_coeffs, out_lpc, (long)lpc_ld); }
     return check_launch(ctx, "vbx_autocorr_lpc_f64");
