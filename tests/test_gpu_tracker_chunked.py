@@ -92,3 +92,24 @@ def test_find_formants_long_utterance_takes_the_chunked_scan(vb, pkg, oracle, mo
             assert np.all(np.abs(default["formants"][t, :, 0] - est[:, 0]) <= 1e-4 * np.abs(est[:, 0])), t
     finally:
         audio_d.free()
+
+
+def test_time_sliced_find_formants_equals_chunked(vb, pkg, monkeypatch):
+    """VBX_TRACKER_CHUNKED=0 on a large batch of equal-length utterances takes round 2's first answer, the time-sliced
+    find_formants (six slices, the sequential tracker on its own stream): same tracks, bit for bit, as the default path."""
+    n_seg, seg_len = 160, 512
+    F = n_seg * seg_len                                                   # 81,920 frames: above the slicing threshold
+    audio_d = vb.synth_speech(F * 256 + N, sample_offset=48000)
+    est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+    seg = np.arange(0, F, seg_len, dtype=np.int64)
+    try:
+        seq, chk = _both(vb, monkeypatch, lambda: vb.find_formants(audio_d, SR, P, est0, seg_start=seg, frame_len=N, stride=256, n_frames=F,
+                                                               want=("formants", "status")))
+        assert np.array_equal(seq["status"], chk["status"])
+        assert np.array_equal(seq["formants"].view(np.uint64), chk["formants"].view(np.uint64))
+        # the state really is reset at every utterance start: the first frame's estimates do not depend on the utterance before
+        one = vb.find_formants(audio_d, SR, P, est0, frame_len=N, stride=256, n_frames=F, want=("formants",))
+        assert not np.array_equal(one["formants"], chk["formants"])
+    finally:
+        audio_d.free()
+
