@@ -48,7 +48,10 @@ __global__ __launch_bounds__(64) void burg_kernel(
             }
         }
     }
-    if (!vec) {
+    if (!vec && (!have || lig * EPL >= n)) {                 // a lane past the frame (or without one): zeros, no loads
+#pragma unroll
+        for (int e = 0; e < EPL; e++) b1[e] = 0.0;
+    } else if (!vec) {                                       // a lane that straddles the frame's end, unaligned rows, floats
 #pragma unroll
         for (int e = 0; e < EPL; e++) {
             const int j = lig * EPL + e;
