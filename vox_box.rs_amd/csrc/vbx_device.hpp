@@ -148,9 +148,21 @@ template <typename T> __device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> b) {
 template <typename T> __device__ __forceinline__ cx<T> cmad(cx<T> a, cx<T> b, cx<T> c) {
     return cmk<T>(fma(a.re, b.re, fma(-a.im, b.im, c.re)), fma(a.re, b.im, fma(a.im, b.re, c.im)));
 }
+// 1 / |b|^2 of cdiv.  f64: v_rcp_f64 + two Newton steps (correctly rounded in practice) instead of the IEEE division
+// sequence -- 7 instructions fewer, three times per Laguerre iteration of a vector-issue-bound kernel.  The two differ only
+// where |b|^2 is 0, inf or denormal (NaN instead of inf / a huge number): there the reference's own iterate is already
+// non-finite or frozen (a converged lane ignores the step), and no resonance comes out of such a root either way.
+__device__ __forceinline__ double cdiv_recip(double ns) {
+#ifdef VBX_IEEE_CDIV
+    return 1.0 / ns;
+#else
+    return rcp_nr2(ns);
+#endif
+}
+__device__ __forceinline__ float cdiv_recip(float ns) { return 1.0f / ns; }
 template <typename T> __device__ __forceinline__ cx<T> cdiv(cx<T> a, cx<T> b) {
     T ns = b.re * b.re + b.im * b.im;
-    T inv = T(1) / ns;
+    T inv = cdiv_recip(ns);
     T re = a.re * b.re + a.im * b.im;
     T im = a.im * b.re - a.re * b.im;
     return cmk<T>(re * inv, im * inv);
