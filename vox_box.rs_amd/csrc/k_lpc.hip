@@ -36,7 +36,10 @@ __device__ __forceinline__ void levinson_uniform(const double (&r)[P + 1], doubl
     }
 }
 
-constexpr int AC_FPW = 16;   // frames per wavefront: short enough that the last round of waves is a small tail
+#ifndef VBX_AC_FPW
+#define VBX_AC_FPW 16
+#endif
+constexpr int AC_FPW = VBX_AC_FPW;   // frames per wavefront: short enough that the last round of waves is a small tail
 
 // EPL: samples per lane (frame_len <= 64*EPL).  NL: number of lags computed (n_lags <= NL).
 //
