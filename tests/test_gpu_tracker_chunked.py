@@ -1,4 +1,4 @@
-"""The tracker scan of long utterances (k_tracker.hip: speculative chunks of 64 frames, warm-up, parallel repair rounds and a
+"""The tracker scan of long utterances (k_tracker.hip: speculative chunks of 32 frames, warm-up, parallel repair rounds and a
 final in-order sweep) must return the sequential scan's rows BIT FOR BIT, whatever the resonances look like: frames that
 overwrite every estimate (the state is forgotten within a chunk: nothing to repair), frames with too few resonances (the
 state persists: most chunks are redone), utterance boundaries anywhere relative to the chunk grid, skipped frames.

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(const res_t *__restrict__ r
 // One lane per utterance is one chain of dependent steps, ~5 us each: an hour-long recording tracked as one utterance
 // (360,000 frames at a 10 ms hop, what a caller of the reference's find_formants loop over a whole file gets) would take
 // two seconds on a single lane.  But the tracker forgets: started from ANY estimates, its state after a few dozen frames is
-// bit for bit the state of the true scan (measured on the bench signal: 78 % after 16 frames, 90 % after 32, 100 % after 64
+// bit for bit the state of the true scan (measured on the bench signal: 78 % after 16 frames, 90 % after 32, all after 64
 // -- every estimate is overwritten by a resonance of the current frame as soon as that frame has enough of them).  So:
 //   A  tracker_spec_kernel    one lane per CHUNK of TRK_CHUNK frames: warm up over the TRK_WARM frames before the chunk
 //                             from the initial estimates (exact, not a guess, if an utterance starts inside the warm-up),
@@ -211,10 +211,10 @@ __global__ __launch_bounds__(64) void tracker_kernel(const res_t *__restrict__ r
 //                             inconsistent: this pass alone makes the result exact (== the sequential scan, bit for bit),
 //                             the rounds before it only leave it nothing to do.
 #ifndef VBX_TRK_CHUNK
-#define VBX_TRK_CHUNK 64
+#define VBX_TRK_CHUNK 32
 #endif
 #ifndef VBX_TRK_WARM
-#define VBX_TRK_WARM 64
+#define VBX_TRK_WARM 32
 #endif
 #ifndef VBX_TRK_ROUNDS
 #define VBX_TRK_ROUNDS 3
