@@ -107,13 +107,11 @@ __device__ __forceinline__ int find_roots_emit(const lds_poly_t<T> &co, int len,
     int zi = 0;
     for (int k = m; k >= 3; k--) {                      // (3..m+1).rev()
         // the lanes of a wave hold different polynomials: the chain starts at the highest degree among them
-        int top = poly_degree(co, clen);
-        for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(top, o, 64); top = other > top ? other : top; }
-        const cx<T> z = laguerre(co, clen, cmk<T>(T(-2), T(-2)), top);
+        const int ns = poly_degree(co, clen);          // this lane's degree (the division below starts from it)
+        const cx<T> z = laguerre(co, clen, cmk<T>(T(-2), T(-2)), ns);   // laguerre() takes the wave's maximum of it
         emit(zi++, z);
         if (ciszero(z)) return 2;                       // div by zero -> Err, :123,:192
         // divide by (x - z): other = -z; q[i] = c[i+1] - q[i+1]*other
-        const int ns = poly_degree(co, clen);
         cx<T> t = co.get(ns);
         for (int i = ns - 1; i >= 0; i--) {
             const cx<T> old = co.get(i);
