@@ -49,6 +49,11 @@ def main():
     cols = params.columns()
     rec_all, st_all = vb.analyze_frames(audio_d, params, frame_len=N, stride=H, n_frames=F_all)
     wh = o.window("hanning", N)
+    # every lag of every 8th visited frame (vbx_autocorrelate_f64 with n_lags = N: the FFT kernels from 512 samples on)
+    ac_idx = idx[::8]
+    ac_frames = np.stack([audio_d.numpy_slice(int(t) * H, N) for t in ac_idx])
+    ac_gpu = vb.autocorrelate(ac_frames * wh, N)
+    ac_pos = {int(t): k for k, t in enumerate(ac_idx)}
 
     def one(t):
         fr = audio_d.numpy_slice(int(t) * H, N)
@@ -95,6 +100,11 @@ def main():
                 err = err * (1 - kk * kk)
             dev = lambda v: float(np.max(np.abs(v - al) / np.maximum(np.abs(al), 1e-6 * np.max(np.abs(al)))))
             rec["fused_lpc_beyond_oracle_rounding"] = int(dev(fl) > max(1e-6, 2.0 * dev(el)))
+        rec["autocorr_all_lags"] = 0
+        if int(t) in ac_pos:
+            ea = o.autocorrelate(fr * wh, N)
+            ga = ac_gpu[ac_pos[int(t)]]
+            rec["autocorr_all_lags"] = int(not np.all(np.abs(ga - ea) <= 1e-6 * np.maximum(np.abs(ea), 1e-6 * np.max(np.abs(ea)))))
         fp = rec_all[t, c0:c0 + 2]
         rec["fused_pitch"] = int(es != st_all[0, t] or (es == 0 and not rec["top_swap"] and not (
             abs(fp[0] - ec[0, 0]) <= 1e-4 * abs(ec[0, 0]) and abs(fp[1] - ec[0, 1]) <= 1e-4)))
@@ -112,6 +122,7 @@ def main():
                            "vuv": "of the swaps: voiced/unvoiced flips outside a 1e-4 tie",
                            "burg": "Burg status or coefficients beyond 1e-6", "formant": "resonance count or Hz beyond 1e-4",
                            "mfcc": "MFCC status or values beyond 1e-6",
+                           "autocorr_all_lags": "autocorrelate(N) of every 8th frame beyond 1e-6 (floor 1e-6 of the row's largest)",
                            "fused_pitch / fused_lpc / fused_mfcc": "the same checks on the columns of vbx_analyze_frames_f64 "
                                                                    "(LPC: Levinson order 12 on autocorrelate(13), 1e-6)",
                            "fused_lpc_beyond_oracle_rounding": "of the fused_lpc frames (a coefficient below 1e-6 of the largest one is "
