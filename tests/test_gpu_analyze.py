@@ -80,6 +80,29 @@ def test_analyze_frames_matches_the_oracle_and_the_separate_entry_points(vb, pkg
         assert np.all(rel_close(rec[t, 23:36], orec[t, 23:36])), t
 
 
+@pytest.mark.parametrize("order", [8, 10, 16, 20])
+def test_analyze_frames_other_lpc_orders(vb, pkg, oracle, audio_d, order):
+    """The fused kernel's register Levinson is built for order 12; another order runs from the LPC kernels beside the fused
+    pitch + MFCC pass: same pitch and MFCC columns as the default call, LPC columns equal to the stand-alone entry point and
+    within 1e-6 of the oracle."""
+    F = 96
+    base, _ = vb.analyze_frames(audio_d, pkg.AnalysisParams.make(SR), frame_len=N, stride=H, n_frames=F)
+    params = pkg.AnalysisParams.make(SR, lpc_order=order)
+    cols = params.columns()
+    rec, st = vb.analyze_frames(audio_d, params, frame_len=N, stride=H, n_frames=F)
+    assert rec.shape == (F, cols["lpc"][0] + order + 1) and np.all(st == 0)
+    assert np.array_equal(rec[:, 0:2], base[:, 0:2]) and np.array_equal(rec[:, 2:23], base[:, 2:23])      # pitch, formants, MFCC
+    han = vb.window(pkg.WINDOW_HANNING, N)
+    _, a = vb.autocorr_lpc(audio_d, order, frame_len=N, stride=H, n_frames=F, window=han)
+    l0 = cols["lpc"][0]
+    assert np.array_equal(rec[:, l0:l0 + order + 1], a)
+    audio = audio_d.numpy()
+    w = oracle.window("hanning", N)
+    for t in range(0, F, 7):
+        exp = oracle.lpc(oracle.autocorrelate(audio[t * H:t * H + N] * w, order + 1), order)
+        assert np.all(rel_close(rec[t, l0:l0 + order + 1], exp)), t
+
+
 def test_analyze_frames_parts_can_be_skipped_and_rows_can_be_padded(vb, pkg, audio_d):
     F = 64
     full = pkg.AnalysisParams.make(SR)

@@ -1317,10 +1317,17 @@ int vbx_analyze_frames_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_
         if (rc != VBX_SUCCESS) return rc;
         nb = hb.back() - hb.front();
     }
-    // (MFCC joins the fused kernel only when the frame fills the transform: n = 1024, 1200, 2048)
-    const bool fused_mfcc = !ctx->pitch_force_mfma && !bad_bins && h_p->mfcc_coeffs &&
-                            spectral_supported((int)frame_len, (int)h_p->lpc_order, nb, hb.front(), (int)h_p->mfcc_coeffs);
-    const bool fused = fused_mfcc || (!ctx->pitch_force_mfma && spectral_supported((int)frame_len, (int)h_p->lpc_order, 0, 0, 0));
+    // (MFCC joins the fused kernel only when the frame fills the transform: n = 1024, 1200, 2048, 4096; LPC only at the order
+    // the kernel's register Levinson is built for -- what cannot join runs from its own kernel on the side stream)
+    const bool fused = !ctx->pitch_force_mfma && spectral_supported((int)frame_len, 0, 0, 0, 0);
+    const bool fused_lpc = fused && h_p->lpc_order == SPECTRAL_LPC_ORDER;
+    const bool fused_mfcc = fused && !bad_bins && h_p->mfcc_coeffs &&
+                            spectral_supported((int)frame_len, 0, nb, hb.front(), (int)h_p->mfcc_coeffs);
+    if (fused && h_p->lpc_order && !fused_lpc) {
+        rc = run_autocorr_lpc(ctx, ctx->side, x, n_frames, frame_len, stride, hann, h_p->lpc_order, 0, nullptr,
+                              out_records + c_lpc, record_ld);
+        if (rc != VBX_SUCCESS) return rc;
+    }
     if (fused && h_p->mfcc_coeffs && !fused_mfcc) {
         rc = run_mfcc(ctx, ctx->side, x, n_frames, frame_len, stride, hann, h_p->mfcc_coeffs, h_p->mfcc_lo_hz, h_p->mfcc_hi_hz,
                       h_p->sample_rate, out_records + c_mfcc, record_ld, st_mfcc);
@@ -1361,7 +1368,7 @@ int vbx_analyze_frames_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_
         L.kmax = 1;
         L.out_cand = (pitch_t *)out_records; L.cand_ld = (long)record_ld; L.out_count = nullptr; L.pitch_status = st_pitch;
         L.work = ctx->prof ? ctx->pitch_work : nullptr;
-        if (h_p->lpc_order) { L.out_lpc = out_records + c_lpc; L.lpc_ld = (long)record_ld; }
+        if (fused_lpc) { L.out_lpc = out_records + c_lpc; L.lpc_ld = (long)record_ld; }
         if (fused_mfcc) {
             L.out_mfcc = out_records + c_mfcc; L.mfcc_ld = (long)record_ld; L.mfcc_status = st_mfcc;
             L.bins = d_bins; L.slopes = slopes; L.dct = dct; L.num_coeffs = (int)h_p->mfcc_coeffs; L.nb = nb;
