@@ -96,6 +96,33 @@ __device__ __forceinline__ void estimate_formants_step(double (&ef)[NS], double 
         }
     }
 
+    // The usual frame, in every lane of the wave: each estimate kept its own resonance.  Slots 0..NE-1 are Some, the rest
+    // None: Step 4 has nothing to place, the stable sort of :312-324 puts the Nones first and orders the NE resonances by
+    // frequency (adjacent exchanges on strict '>': the same permutation as the six-slot sort below), and the winners are
+    // read off in that order.  A third of the step's instructions were the six-slot sort's flag logic.
+    if (!__any(has_unassigned)) {
+        double sf[NE], sb[NE];
+#pragma unroll
+        for (int i = 0; i < NE; i++) { sf[i] = s[i].f; sb[i] = s[i].bw; }
+#pragma unroll
+        for (int pass = 0; pass < NE - 1; pass++) {
+#pragma unroll
+            for (int i = 0; i + 1 < NE - pass; i++) {
+                if (sf[i] > sf[i + 1]) { const double tf = sf[i], tb = sb[i]; sf[i] = sf[i + 1]; sb[i] = sb[i + 1]; sf[i + 1] = tf; sb[i + 1] = tb; }
+            }
+        }
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < NE; i++) {
+            if (sf[i] > 0.0) {                                // e < n_est holds: at most NE winners
+#pragma unroll
+                for (int q = 0; q < NE; q++) if (q == e) { ef[q] = sf[i]; eb[q] = sb[i]; }
+                e++;
+            }
+        }
+        return;
+    }
+
     // Step 4 (:274-310).  For j >= 6 no branch of the reference can place a peak, so j stops at 6.
     if (has_unassigned) {
 #pragma unroll
