@@ -4,7 +4,9 @@ MFCC against the CPU oracle on tens of thousands of frames (the pytest suite com
 the cores the process may use (ctypes releases the GIL).  Prints and writes a JSON summary of every disagreement class.
 The pitch candidates come from vbx_pitch_f64 AND from the fused frame loop (vbx_analyze_frames_f64: pitch + LPC + MFCC from
 one FFT of the frame where the frame length has such a kernel), whose LPC and MFCC columns are checked too.
-usage (GPU box): python3 tools/soak_parity.py [n_frames=20000] [out.json] [frame_len=1200] [hop=480]"""
+usage (GPU box): python3 tools/soak_parity.py [n_frames=20000] [out.json] [frame_len=1200] [hop=480] [visit_step=7] [first_frame=0]
+visit_step = 1 checks EVERY frame of a stretch of the recording (first_frame .. first_frame + n_frames): a whole bench shard can be
+walked in pieces (tools/soak_shard.sh)."""
 import json
 import os
 import sys
@@ -24,6 +26,8 @@ def main():
     out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "soak_parity.json")
     N = int(sys.argv[3]) if len(sys.argv) > 3 else 1200
     H = int(sys.argv[4]) if len(sys.argv) > 4 else 480
+    step = int(sys.argv[5]) if len(sys.argv) > 5 else 7
+    first = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     pkg, o = g.load_package(), g.load_oracle()
     vb = pkg.VoxBox(0)
     try:
@@ -34,11 +38,11 @@ def main():
     except (OSError, ValueError, AttributeError):
         workers = os.cpu_count() or 1
     # frames: the bench's synthetic recording, visited with a stride coprime to the 5 s voiced/unvoiced pattern
-    ns = (n_frames * 7 - 1) * H + N
-    audio_d = vb.synth_speech(ns, sample_offset=5 * 48000)
+    ns = (n_frames * step - 1) * H + N
+    audio_d = vb.synth_speech(ns, sample_offset=5 * 48000 + first * H)
     han = vb.window(pkg.WINDOW_HANNING, N)
     F_all = pkg.frame_count(ns, N, H)
-    idx = (np.arange(n_frames) * 7) % F_all
+    idx = (np.arange(n_frames) * step) % F_all
     cand, cnt, st = vb.pitch(audio_d, SR, 0.2, 75.0, 600.0, kmax=1, frame_len=N, stride=H, n_frames=F_all, window=han)
     co, cst = vb.lpc_praat(audio_d, P, frame_len=N, stride=H, n_frames=F_all, window=vb.window(pkg.WINDOW_HANNING_PERIODIC, N))
     mf, mst = vb.mfcc(audio_d, 13, (100.0, 8000.0), SR, frame_len=N, stride=H, n_frames=F_all, window=han)
@@ -114,7 +118,7 @@ def main():
         recs = list(ex.map(one, idx))
     tot = {k: int(sum(r[k] for r in recs)) for k in recs[0]}
     voiced = int(np.sum(cand[idx, 0, 0] > 0))
-    summary = {"frame_len": N, "hop": H, "frames": n_frames, "voiced": voiced, "unvoiced": n_frames - voiced, "oracle_threads": workers,
+    summary = {"frame_len": N, "hop": H, "visit_step": step, "first_frame": first, "frames": n_frames, "voiced": voiced, "unvoiced": n_frames - voiced, "oracle_threads": workers,
                "disagreements": tot,
                "meaning": {"status": "pitch status differs", "count": "pitch candidate count differs",
                            "top_bad": "PitchExtractor output beyond 1e-4 and not a near tie",
