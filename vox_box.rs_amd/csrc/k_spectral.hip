@@ -1,4 +1,7 @@
-// k_spectral.hip -- one spectral pass per frame feeding pitch, LPC and MFCC (frame length 1200 = 25 ms at 48 kHz).
+// k_spectral.hip -- one spectral pass per frame feeding pitch, LPC and MFCC: the transform of 2400 real points, for frames of
+// 1200 samples (25 ms at 48 kHz) and, zero padded, of 1025..1199 (k_spectral_pow2*.hip hold the 1024 / 2048 / 4096 forms).
+// The same kernel also serves MFCC::mfcc alone and Autocorrelate::autocorrelate with many lags (MODE), and this file holds
+// the host side shared by all forms: which transform serves a frame length (spectral_plan), the twiddle tables, the launch.
 //
 // Reference rows served: A1-A3 (autocorrelate, normalize, lag window), A4-A9 (pitch, through
 // vbx_pitch_refine.hpp), A10 (lpc on r[0..12]), A14 (mfcc).  What the reference computes with an O(N^2) fold per lag

@@ -1,6 +1,7 @@
 // vbx_spectral.hpp -- what the FFT-based analysis kernels share (k_spectral.hip: complex length 1200 = 20 * 20 * 3;
-// k_spectral_pow2.hip: complex length 1024 = 16 * 16 * 4 and 2048 = 16 * 16 * 8): the kernel arguments, the radix-4
-// butterfly and the register Levinson recursion.
+// vbx_spectral_pow2.hpp: 1024 = 16 * 16 * 4, 2048 = 16 * 16 * 8 and 4096 = 16 * 16 * 16): the kernel arguments, what an
+// instantiation computes (MODE), the radix-4 butterfly, the exact tail of a padded frame's lag curve and the register
+// Levinson recursion.
 #pragma once
 
 #include "vbx_device.hpp"
