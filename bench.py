@@ -25,7 +25,8 @@ Rank 0 prints ONE JSON line with the contract fields plus
   roofline_hbm  the pitch kernel against the HBM roof, as north_star asks (tiny by construction)
   cpu_baseline  the CPU oracle (C restatement of the reference path) timed natively (oracle/vbx_cpu_bench.c) on
                 1 core and on all the cores the process may use (affinity mask capped by the cgroup CPU quota)
-Other workloads (--workload config2|config3|config4|frontend) time a single BASELINE config.
+Other workloads (--workload config2|config3|config4|frontend) time a single BASELINE config; --frame-len / --hop move the
+pipeline and config3 to another frame shape (2048 / 1024 is the reference example's), under its own metric name.
 """
 import argparse
 import json
