@@ -37,11 +37,11 @@ def frames_of(run):
         return None
 
 KEYS = {   # bench.py profile name -> (workload, kernel-name prefix in the counter files)
-    "analyze": ("pipeline", "void analyze_kernel<true, true, true>"),
-    "pitch": ("config3", "void analyze_kernel<false, false, true>"),
-    "analyze_2048": ("pipeline_2048", "void analyze_pow2_kernel<2, true, true, true>"),     # bench.py --frame-len 2048 --hop 1024
-    "pitch_2048": ("config3_2048", "void analyze_pow2_kernel<2, false, false, true>"),
-    "pitch_1024": ("config3_1024", "void analyze_pow2_kernel<1, false, false, true>"),
+    "analyze": ("pipeline", "void analyze_kernel<true, true, true, 0>"),
+    "pitch": ("config3", "void analyze_kernel<false, false, true, 0>"),
+    "analyze_2048": ("pipeline_2048", "void analyze_pow2_kernel<2, true, true, true, 0>"),     # bench.py --frame-len 2048 --hop 1024
+    "pitch_2048": ("config3_2048", "void analyze_pow2_kernel<2, false, false, true, 0>"),
+    "pitch_1024": ("config3_1024", "void analyze_pow2_kernel<1, false, false, true, 0>"),
     "burg_512": ("config4", "void burg_kernel<16, 32, double>"),
     "burg": ("pipeline", "void burg_kernel<64, 20, double>"),
     "formant_resonances_512": ("config4", "formant_resonances_kernel"),
