@@ -1104,9 +1104,12 @@ static int run_mfcc(vbx_ctx *ctx, hipStream_t stm, const double *x, size_t n_fra
     // frames that fill one of the FFT kernels' transforms (1024, 1200, 2048, 4096): the forward half of the fused spectral
     // kernel -- one real FFT of the zero-padded frame, whose even bins are the n-point DFT the mel filters read
     {
-        const int plan = spectral_plan((int)frame_len);
+        int plan = spectral_plan((int)frame_len);
+        // 2048 and 4096 samples: the frame as the real sequence of the half-size transform (complex 1024 / 2048), no padding
+        if (frame_len == 2048) plan = SPECTRAL_PLAN_1024; else if (frame_len == 4096) plan = SPECTRAL_PLAN_2048;
         if (!ctx->mfcc_force_goertzel && !ctx->mfcc_force_dft2 && !ctx->mfcc_force_mfma && plan != SPECTRAL_PLAN_NONE &&
-            (int)frame_len == spectral_plan_nc(plan) && spectral_supported((int)frame_len, 0, nb, hb.front(), (int)num_coeffs)) {
+            ((int)frame_len == spectral_plan_nc(plan) || (int)frame_len == 2 * spectral_plan_nc(plan)) &&
+            num_coeffs <= 64 && nb >= 1 && hb.front() >= 0 && hb.front() + nb <= (int)frame_len / 2) {
             const double *tab = nullptr;
             rc = get_spectral_tab(ctx, plan, &tab); if (rc != VBX_SUCCESS) return rc;
             spectral_launch_t L{};

@@ -10,7 +10,9 @@
 
 namespace vbx {
 
-enum { SP_ANALYZE = 0, SP_MFCC_ONLY = 1, SP_AC_ONLY = 2 };   // what a spectral kernel instantiation computes
+// what a spectral kernel instantiation computes.  SP_MFCC_HALF (power-of-two kernels): MFCC::mfcc of a frame of 2 Nc samples --
+// the frame itself is the real sequence of the transform (no padding), its bins are the transform's bins
+enum { SP_ANALYZE = 0, SP_MFCC_ONLY = 1, SP_AC_ONLY = 2, SP_MFCC_HALF = 3 };
 
 constexpr double SP_UNC_EPS = 6.0 * 400.0 * 2.220446049250313e-16;   // 1 / min w_lag * margin * eps
 

@@ -207,19 +207,20 @@ __device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16
 // MODE (vbx_spectral.hpp): SP_ANALYZE the fused analysis; SP_MFCC_ONLY MFCC::mfcc alone (the forward transform and the mel / DCT
 // tail only); SP_AC_ONLY Autocorrelate::autocorrelate alone (both transforms, the fold seed, the lag sums stored).
 template <int U, bool LPC, bool MFCC, bool FULL, int MODE = SP_ANALYZE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(U == 4 ? 1 : (U == 2 && MODE != SP_MFCC_ONLY) ? VBX_POW2_U2_WAVES : 2,
-                                                                     U == 4 ? (MODE != SP_MFCC_ONLY ? 1 : 2) : MODE != SP_MFCC_ONLY ? 2 : 4)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(U == 4 ? 1 : (U == 2 && MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? VBX_POW2_U2_WAVES : 2,
+                                                                     U == 4 ? ((MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? 1 : 2) : (MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? 2 : 4)))
 void analyze_pow2_kernel(const spectral_args_t a) {
-    static_assert(MODE != SP_MFCC_ONLY || (MFCC && FULL && !LPC), "the MFCC-only form needs the full frame and has no lag sums");
+    static_assert((MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) || (MFCC && FULL && !LPC), "the MFCC-only forms need the full frame and have no lag sums");
     static_assert(MODE != SP_AC_ONLY || (!MFCC && !LPC), "the autocorrelation-only form");
-    constexpr bool PITCH = MODE != SP_MFCC_ONLY;             // the second transform runs
+    constexpr bool PITCH = MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF;   // the second transform runs
+    constexpr bool HALF = MODE == SP_MFCC_HALF;              // the frame has 2 Nc samples: every slot of the transform is data
     using G = pow2_geom<U>;
     constexpr int R = G::R, NC = G::NC, TP = G::TP;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const long f = xcd_item(blockIdx.x, a.n_frames);
     if (f >= a.n_frames) return;
     const int lane = lane_id();
-    const int n = FULL ? NC : a.n;                           // frame length, <= NC
+    const int n = HALF ? 2 * NC : FULL ? NC : a.n;           // frame length, <= NC (SP_MFCC_HALF: 2 NC)
     double *ex = smem;                                       // exchange buffer, later the lag curve y
     const double *xf = a.frames + f * a.stride;
 
@@ -229,9 +230,10 @@ void analyze_pow2_kernel(const spectral_args_t a) {
         const bool al = ((((uintptr_t)xf) | ((uintptr_t)a.window)) & 15) == 0;      // uniform
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            double2 xv[8], wv[8];
+            constexpr int NQ = HALF ? 16 : 8;               // slots that hold samples (the rest is the zero padding)
+            double2 xv[NQ], wv[NQ];
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
+            for (int q = 0; q < NQ; q++) {
                 const int i = 32 * R * q + 2 * (lane + 64 * u);
                 xv[q] = double2{0.0, 0.0}; wv[q] = double2{1.0, 1.0};
                 if (al && i + 1 < n) {
@@ -243,12 +245,12 @@ void analyze_pow2_kernel(const spectral_args_t a) {
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
+            for (int q = 0; q < NQ; q++) {
                 re[u][q] = (a.window != nullptr) ? xv[q].x * wv[q].x : xv[q].x;
                 im[u][q] = (a.window != nullptr) ? xv[q].y * wv[q].y : xv[q].y;
             }
 #pragma unroll
-            for (int q = 8; q < 16; q++) { re[u][q] = 0.0; im[u][q] = 0.0; }
+            for (int q = NQ; q < 16; q++) { re[u][q] = 0.0; im[u][q] = 0.0; }
         }
     }
     const double x0 = readlane_f64(re[0][0], 0);            // x_w[0], for the fold seed (Q1)
@@ -344,8 +346,9 @@ void analyze_pow2_kernel(const spectral_args_t a) {
 #pragma unroll
         for (int t = 0; t < TP; t++) {
             const int m = lane + 64 * t;
-            if (m <= NC / 2 && (m & 1) == 0) {
-                const int b1 = (m >> 1) - b_lo, b2 = (NC / 2 - (m >> 1)) - b_lo;
+            if (m <= NC / 2 && (HALF || (m & 1) == 0)) {
+                // padded frame of Nc samples: its DFT bin k' is the transform's bin 2 k'; frame of 2 Nc samples: bin m itself
+                const int b1 = (HALF ? m : (m >> 1)) - b_lo, b2 = (HALF ? NC - m : NC / 2 - (m >> 1)) - b_lo;
                 if (b1 >= 0 && b1 < a.nb) {
                     const double2 sl = *reinterpret_cast<const double2 *>(a.slopes + 2 * b1);
                     pu[b1] = fabs(pk[t]) * sl.x;             // norm_sqr * multiplier (src/spectrum.rs:426-428)
@@ -474,8 +477,10 @@ void launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a
     a.pp.full_off = extra ? (int)base : 0;
     const size_t lds = base + extra;
     const bool lpc = L.out_lpc != nullptr, mf = L.out_mfcc != nullptr;
-    if (L.mfcc_only) {                                       // spectral_supported(): n == Nc
-        hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, true, SP_MFCC_ONLY>), grid, block, pow2_lds_bytes<U>(0, L.nb), s, a);
+    if (L.mfcc_only) {                                       // n == Nc, or (L.n == 2 Nc) the unpadded form
+        if (L.n == 2 * pow2_geom<U>::NC) {
+            if constexpr (U <= 2) hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, true, SP_MFCC_HALF>), grid, block, pow2_lds_bytes<U>(0, L.nb), s, a);
+        } else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, true, SP_MFCC_ONLY>), grid, block, pow2_lds_bytes<U>(0, L.nb), s, a);
         return;
     }
     if (L.out_r != nullptr) {                                // autocorrelate(n_lags) alone
