@@ -1,0 +1,47 @@
+"""The line bench.py prints, end to end on the GPU (a short run): exactly one JSON line on stdout with the contract's fields,
+`roofline` with measured traffic, `cpu_baseline` with both legs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_default_workload_line():
+    d = _bench("--hours", "0.25", "--steps", "2", "--warmup", "1", "--cpu-seconds", "4")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "frames/s" and d["dtype"] == "f64"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and d["config"]["frame_len"] == 1200 and d["config"]["hop"] == 480
+    assert d["value"] > 1e6
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["kernel"] == "analyze" and 0.0 < r["frac"] < 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] is not None and r["traffic"] > 0.9 * 4064 * d["config"]["frames_per_gpu"]     # at least the algorithmic bytes
+    assert 0.0 < r["executed"]["frac"] < r["frac"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["one_core"]["cores"] == 1 and c["sample"]
+
+
+def test_config_workloads_pick_the_measured_dominant_kernel():
+    d = _bench("--workload", "config4", "--frames", "200000", "--steps", "3", "--warmup", "1", "--no-cpu")
+    assert d["metric"].startswith("frames/sec (config4") and d["roofline"]["kernel"] in d["kernels_ms"]
+    assert d["roofline"]["kernel"] == max(d["kernels_ms"], key=lambda k: d["kernels_ms"][k])
+    assert "whole_config" in d and d["whole_config"]["fp64_frac"] > 0
+    d = _bench("--workload", "config3", "--frame-len", "2048", "--hop", "1024", "--hours", "0.25", "--steps", "2", "--warmup", "1", "--no-cpu")
+    assert "2048-sample frames" in d["metric"] and d["config"]["frame_len"] == 2048 and d["roofline"]["kernel"] == "pitch"
