@@ -49,7 +49,8 @@ def test_chunked_scan_equals_sequential_scan(vb, pkg, monkeypatch, n_est, kind):
     cuts |= set(rng.integers(9100, 14000, 40).tolist())
     seg = np.array(sorted(cuts), dtype=np.int64)
     status = (rng.random(F) < 0.02).astype(np.int32) * 2
-    for segs, fs in ((None, None), (seg, None), (seg, status), (np.array([0], dtype=np.int64), status)):
+    dup = np.sort(np.concatenate([seg, seg[5:25], [F]]))                   # empty utterances among them, one that starts at F
+    for segs, fs in ((None, None), (seg, None), (seg, status), (np.array([0], dtype=np.int64), status), (dup, status)):
         a, b = _both(vb, monkeypatch, lambda: vb.estimate_formants(res, est0, seg_start=segs, frame_status=fs))
         assert a.shape == (F, n_est, 2)
         assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (kind, n_est, segs is None, fs is None,
@@ -66,6 +67,7 @@ def test_chunked_scan_short_batches_and_edges(vb, pkg, monkeypatch):
         if F > 3:
             segs.append(np.arange(0, F, 1, dtype=np.int64))                     # every frame its own utterance
             segs.append(np.array(sorted({0, F // 2, F - 1}), dtype=np.int64))
+            segs.append(np.array([0, 0, F // 3, F // 3, F // 3, F - 2, F - 2, F], dtype=np.int64))   # empty utterances, a start at F
         for s in segs:
             a, b = _both(vb, monkeypatch, lambda: vb.estimate_formants(res, est0, seg_start=s))
             assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (F, None if s is None else s.size)

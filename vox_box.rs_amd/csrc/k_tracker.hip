@@ -331,8 +331,10 @@ __global__ __launch_bounds__(64) void tracker_spec_kernel(const trk_in_t in, con
             trk_init<NE>(in, ef, eb);
             exact = true;
             if (f > f_begin && stop == f_end) stop = f;
-            sg++;
-            next_start = (sg + 1 < in.n_seg) ? in.seg_start[sg + 1] : in.n_frames;
+            do {                                               // (empty utterances: several starts on one frame)
+                sg++;
+                next_start = (sg + 1 < in.n_seg) ? in.seg_start[sg + 1] : in.n_frames;
+            } while (next_start == f);
         }
         if (f == f_begin) {
 #pragma unroll
