@@ -17,7 +17,7 @@ MAX_RESONANCES = 32
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("vbx_oracle.c", "vbx_oracle_f32.c", "vbx_cpu_bench.c", "vbx_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("vbx_oracle.c", "vbx_oracle_f32.c", "vbx_cpu_bench.c", "vbx_soak.c", "vbx_oracle.h")]
     if force or not os.path.exists(_SO) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_SO) for s in src
     ):
@@ -403,3 +403,71 @@ def cpu_bench(workload, audio, frame_len, hop, order, sample_rate, n_threads, se
     if rc != 0:
         raise ValueError("vbxo_cpu_bench: bad argument")
     return int(done.value), float(dt.value)
+
+
+def usable_cores():
+    """Threads worth starting: the affinity mask capped by the cgroup CPU quota (a container with 256 logical CPUs and a
+    16-CPU quota runs 256 threads at 1/16 speed each)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+SOAK_PITCH, SOAK_LPC, SOAK_MFCC, SOAK_FORMANTS = 1, 2, 4, 8
+
+
+def soak(audio, frame_len, hop, first, count, order, sample_rate, what, n_threads=None, pitch=(0.2, 75.0, 600.0),
+         mfcc=(13, 100.0, 8000.0)):
+    """vbx_soak.c: frames [first, first + count) of the hop-strided view through the oracle on native threads; every
+    per-frame result of the parts selected by `what` (SOAK_* bits) as numpy arrays."""
+    a = _f64(audio)
+    n_threads = n_threads or usable_cores()
+    p, k = order, mfcc[0]
+    out = {}
+    i32 = lambda *sh: np.zeros(sh, dtype=np.int32)
+    f64 = lambda *sh: np.zeros(sh, dtype=np.float64)
+    if what & SOAK_PITCH:
+        out.update(pitch_status=i32(count), pitch_count=i32(count), pitch_top=f64(count, 3, 2))
+    if what & SOAK_LPC:
+        out.update(r=f64(count, p + 1), a=f64(count, p + 1))
+    if what & SOAK_MFCC:
+        out.update(mfcc=f64(count, k), mfcc_status=i32(count))
+    if what & SOAK_FORMANTS:
+        out.update(burg=f64(count, p), ff_status=i32(count), res=f64(count, MAX_RESONANCES, 2), res_count=i32(count))
+    g = lambda name: _p(out[name]) if name in out else None
+    fn = lib().vbxo_soak
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.c_int, C.c_int,
+                   C.c_double, C.c_double, C.c_double, C.c_size_t, C.c_double, C.c_double] + [C.c_void_p] * 11
+    rc = fn(_p(a), a.size, frame_len, hop, first, count, order, sample_rate, what, n_threads,
+            pitch[0], pitch[1], pitch[2], k, mfcc[1], mfcc[2],
+            g("pitch_status"), g("pitch_count"), g("pitch_top"), g("r"), g("a"), g("mfcc"), g("mfcc_status"),
+            g("burg"), g("ff_status"), g("res"), g("res_count"))
+    if rc != 0:
+        raise ValueError("vbxo_soak: bad argument")
+    return out
+
+
+def soak_track(res, ff_status, est_init, seg_start=None):
+    """vbx_soak.c: the sequential formant tracker over resonance rows [F, 32, 2] (restarts at seg_start entries)."""
+    res = _f64(res)
+    st = np.ascontiguousarray(ff_status, dtype=np.int32)
+    est = _f64(est_init)
+    seg = None if seg_start is None else np.ascontiguousarray(seg_start, dtype=np.int64)
+    out = np.zeros((res.shape[0], est.shape[0], 2), dtype=np.float64)
+    fn = lib().vbxo_soak_track
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    rc = fn(_p(res), st.ctypes.data, res.shape[0], None if seg is None else seg.ctypes.data, 0 if seg is None else seg.size,
+            _p(est), est.shape[0], _p(out))
+    if rc != 0:
+        raise ValueError("vbxo_soak_track: bad argument")
+    return out

@@ -517,12 +517,17 @@ def _check_pitch(vb, oracle, frames_windowed, sr, thr, fmin, fmax, kmax, stats=N
     compared within BASELINE's tolerance: every frequency within 1e-4 relative, strengths within 1e-4.
     Everything that is NOT an exact agreement is COUNTED and bounded:
       n_flip      candidates whose refinement ended on the other side of the integer-lag discontinuity (same
-                  frequency, strength off by more than 1e-4): at most 1 % of the candidates compared
+                  frequency, strength off by more than 1e-4)
       n_top_swap  frames whose top candidate (the PitchExtractor output) differs because the oracle's two best
-                  strengths are closer than 1e-3 AND the GPU's top is the oracle's runner-up: at most 0.5 % of frames
+                  strengths are closer than 1e-3 AND the GPU's top is the oracle's runner-up
       n_vuv_flip  of those, swaps between a voiced candidate and the unvoiced one (a voiced/unvoiced decision
                   change): allowed only inside a 1e-4 tie, i.e. inside the tolerance itself
-      n_top_bad   any other top-candidate disagreement: zero."""
+      n_top_bad   any other top-candidate disagreement: zero.
+    Bounds = what is observed plus a stated margin.  Observed on the whole corpus of this file (rounds 2 and 3: ~700 frames,
+    ~2,400 fully compared candidates; gpurun_out/pitch_parity_stats.json): n_flip = n_top_swap = 0.  Margin: one event per
+    call (a single candidate whose chaotic tail lands elsewhere after a change of summation order must not turn the suite
+    red), and test_zz_pitch_parity_report bounds the TOTALS at 0.2 % of the frames / 0.1 % of the candidates -- a fifth
+    and a tenth of the round-2 bounds."""
     cand, cnt, st = vb.pitch(frames_windowed, sr, thr, fmin, fmax, kmax=kmax)
     F = frames_windowed.shape[0]
     n_cand = n_flip = n_top_bad = n_top_swap = n_vuv_flip = n_vuv_outside = 0
@@ -565,8 +570,8 @@ def _check_pitch(vb, oracle, frames_windowed, sr, thr, fmin, fmax, kmax, stats=N
         stats.update(rec)
     assert n_top_bad == 0, rec
     assert n_vuv_outside == 0, rec
-    assert n_top_swap <= max(1, F // 200), rec
-    assert n_flip <= max(1, n_cand // 100), rec
+    assert n_top_swap <= 1, rec
+    assert n_flip <= max(1, n_cand // 1000), rec
     return 0
 
 
@@ -873,6 +878,8 @@ def test_zz_pitch_parity_report():
         with open(os.path.join(out, "pitch_parity_stats.json"), "w") as fh:
             json.dump({"total": tot, "calls": PITCH_STATS}, fh, indent=1)
     assert tot["n_top_bad"] == 0 and tot["n_vuv_outside_tol"] == 0
+    assert tot["n_top_swap"] <= max(1, tot["frames"] // 500), tot      # observed: 0
+    assert tot["n_flip"] <= max(1, tot["n_cand"] // 1000), tot         # observed: 0
 
 
 @pytest.mark.parametrize("n,hop,rect", [(1200, 480, False), (1200, 480, True), (1024, 512, False), (1024, 512, True),

@@ -51,10 +51,13 @@ __device__ __forceinline__ cx<T> laguerre(const lds_poly_t<T> &p, int len, cx<T>
     cx<T> z = start;
     bool done = false;
     if (top < 0 || top > n) top = n;
-    // the highest degree in the wave, as a scalar: entries above a lane's own degree are zeros, and a chain that starts
-    // above it runs through 0 * z + 0 (see above)
-    for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(top, o, 64); top = other > top ? other : top; }
-    const int top_u = __builtin_amdgcn_readfirstlane(top);
+    // the highest degree among the ACTIVE lanes, as a scalar: entries above a lane's own degree are zeros, and a chain
+    // that starts above it runs through 0 * z + 0 (see above).  The callers reach this point diverged (find_roots_emit's
+    // early returns and its per-lane trip count), so the maximum is built bit by bit from ballots, which only ever see
+    // the active lanes -- a shuffle butterfly would read inactive lanes' registers.
+    int top_u = 0;
+    for (int bit = 64; bit > 0; bit >>= 1)                   // top <= n <= 64 (len <= 65 by the API's bound)
+        if (__any(top >= (top_u | bit))) top_u |= bit;
     for (int it = 0; it < 20; it++) {
         const bool zfin = (z.re - z.re == T(0)) && (z.im - z.im == T(0));
         cx<T> a0, a1 = cmk<T>(T(0), T(0)), a2 = cmk<T>(T(0), T(0));

@@ -1033,7 +1033,9 @@ static int run_find_formants(vbx_ctx *ctx, hipStream_t stm, const double *x, siz
     if (!chunked && h_seg_start != nullptr && n_segments >= 64 && F >= 65536) {
         seg_len = (n_segments > 1) ? (long)h_seg_start[1] : 0;
         for (size_t i = 0; i < n_segments && seg_len > 0; i++) if (h_seg_start[i] != (int64_t)i * seg_len) seg_len = 0;
-        if (seg_len > 0 && ((long)(n_segments - 1) * seg_len >= F || seg_len < 64)) seg_len = 0;
+        // the slices cover t in [0, seg_len) of every utterance: a LAST utterance longer than the others (its end is
+        // n_frames, not a seg_start entry) would keep rows past seg_len that no slice tracks -> the unsliced path
+        if (seg_len > 0 && ((long)(n_segments - 1) * seg_len >= F || (long)n_segments * seg_len < F || seg_len < 64)) seg_len = 0;
     }
     // Six slices (VBX_FF_SLICES overrides, 1..8).  With k equal slices the call ends about one slice's scan after the last
     // resonance exists, so more slices shorten the exposed tail -- until a slice no longer fills the GPU: the root finder
