@@ -5,26 +5,33 @@
 
 N > 1: when no RANK is in the environment this process only LAUNCHES N fresh rank processes (before it makes any
 GPU call itself), relays rank 0's JSON line and exits with their status; under torch.distributed.run (RANK set)
-it is one of the ranks.  One process per GPU; torch.distributed (backend nccl = RCCL) carries the barrier and the
-max-over-ranks of the timing, the data path's only exchange -- the gather of per-frame records to rank 0 -- is the
-library's own grouped ncclSend/ncclRecv (vbx_gather_records_f64).
+it is one of the ranks.  One process per GPU.  The CONTROL plane (rendezvous, the broadcast of the RCCL id, the
+barrier, the max-over-ranks of the timing) runs over torch.distributed's gloo backend on CPU tensors; the DATA plane
+-- the path's only exchange, the gather of per-frame records to rank 0 -- is the library's own grouped
+ncclSend/ncclRecv (vbx_gather_records_f64): exactly ONE RCCL communicator per process, and no other transport exists
+in the timed region (if the library's communicator does not come up on every rank the bench fails, it never falls back).
 
 A "step" is one pass of the whole per-frame path over this rank's shard of a long synthetic 48 kHz recording
 (25 ms window = 1200 samples, 10 ms hop = 480 samples): vbx_analyze_frames_f64 = Boersma pitch candidates,
 autocorrelation + Levinson LPC(12) and MFCC(13) from one FFT of each frame (analyze_kernel), find_formants (Burg(12) ->
-Laguerre roots -> resonances -> formant tracker) beside it, written as one fixed-size record per frame; at N > 1 the step ends by queueing the gather of the records
-to rank 0 (it overlaps the next step's kernels; every gather is complete when the timed region ends).  The audio is
-generated on the device before the timed region (inputs resident in HBM); frames are range-split over ranks (weak
-scaling: --hours is per GPU; the default 12.5 h/GPU is BASELINE config 5's 100 h over 8 GPUs).
+Laguerre roots -> resonances -> formant tracker) beside it, written as one fixed-size record per frame; at N > 1 the
+step ends by queueing the gather of the records to rank 0 (it overlaps the next step's kernels; every gather is complete
+when the timed region ends).  The audio is generated on the device before the timed region (inputs resident in HBM);
+frames are range-split over ranks (weak scaling: --hours is per GPU; the default 12.5 h/GPU is BASELINE config 5's 100 h
+over 8 GPUs).
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline      the kernel with the largest measured time against the roof that binds it: pitch / analyze -> FP64 vector
-                (= matrix) peak, algorithmic flops in `frac` and executed flops in `executed`; everything else -> HBM
-                (algorithmic bytes).  `traffic` = measured HBM bytes per launch from the PMC passes committed under
-                profiles/ (profiles/pmc_traffic.json), scaled to this launch's frames.
-  roofline_hbm  the pitch kernel against the HBM roof, as north_star asks (tiny by construction)
-  cpu_baseline  the CPU oracle (C restatement of the reference path) timed natively (oracle/vbx_cpu_bench.c) on
-                1 core and on all the cores the process may use (affinity mask capped by the cgroup CPU quota)
+  roofline        the kernel with the largest measured time against the roof that binds it.  pitch / analyze -> FP64
+                  vector peak with the flops the kernel EXECUTES (`frac`), `issue_frac` = the share of SIMD time the vector
+                  ALU is issuing (SQ counters of the committed PMC pass) and, under `reference_sums_at_peak`, how the kernel
+                  compares with running the reference's O(N^2) lag sums at peak (a speed-up statement, not a roofline);
+                  everything else -> HBM, algorithmic bytes.  `traffic` = measured HBM bytes per launch from the PMC passes
+                  committed under profiles/ (profiles/pmc_traffic.json), scaled to this launch's frames.
+  roofline_hbm    the pitch kernel against the HBM roof, as north_star asks (tiny by construction)
+  cpu_baseline    the CPU oracle (C restatement of the reference path) timed natively (oracle/vbx_cpu_bench.c) on
+                  1 core and on all the cores the process may use, at the GPU leg's frame geometry
+  sub_benchmarks  (default run, N = 1) BASELINE configs 2, 3 (kmax 1 / 8 / the whole candidate Vec) and 4, a few steps
+                  each outside the headline's timed region, each with its own roofline
 Other workloads (--workload config2|config3|config4|frontend) time a single BASELINE config; --frame-len / --hop move the
 pipeline and config3 to another frame shape (2048 / 1024 is the reference example's), under its own metric name.
 """
@@ -48,6 +55,7 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6           # FP64 vector peak (= FP64 matrix peak on gfx950)
 FLOPS_PER_SINC_TERM = 13.0        # reference formula per term: sin, cos, 2 div, 9 mul/add (each counted once)
 METRIC = "frames/sec (pitch+LPC+formants), 48 kHz 25 ms/10 ms hop, 1→8 MI355X"   # BASELINE.json "metric", verbatim
+CONFIG3_FRAMES = 3_599_998        # 10 h at 48 kHz / 1200 / 480
 
 # algorithmic HBM bytes per frame of each kernel, keyed by the profile name
 ALG_BYTES = {
@@ -78,6 +86,7 @@ def parse():
                     "64 = the head of the reference's sorted list, which disables the exact top-k pruning)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="wall budget of the CPU baseline leg (both legs together)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-sub", action="store_true", help="skip the sub_benchmarks of the default run (configs 2, 3, 4)")
     return ap.parse_args()
 
 
@@ -120,32 +129,21 @@ def launch_ranks(args):
 # CPU baseline: the oracle (kind "port") on a bounded sample of the same workload, natively threaded
 # ------------------------------------------------------------------------------------------------
 def cpu_baseline(workload, budget_s, frame_len=N48, hop=H48):
+    """`hop` is the GPU leg's stride: 480 for the Windower view of the pipeline / config 3, 512 (dense frames) for
+    configs 2 and 4."""
     import importlib
     o = graft.load_oracle()
     graft.load_package()
     synth = importlib.import_module(graft.PKG_NAME + ".synth")
     logical = os.cpu_count() or 1
-    try:
-        usable = len(os.sched_getaffinity(0))
-    except AttributeError:
-        usable = logical
-    # a container's CPU quota (cgroup) caps what the threads can use, whatever the affinity mask says: 256 logical
-    # CPUs with an 8-CPU quota run 256 threads at 1/32 speed each (measured on the GPU box: 8x the 1-thread rate)
+    usable = o.usable_cores()          # affinity mask capped by the cgroup CPU quota
     quota = None
     try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                    # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
         if q != "max":
             quota = float(q) / float(per)
     except (OSError, ValueError):
-        try:
-            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())              # cgroup v1
-            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                quota = q / per
-        except (OSError, ValueError):
-            pass
-    if quota is not None:
-        usable = max(1, min(usable, int(quota + 0.5)))
+        pass
     try:    # physical cores: distinct (package, core) pairs
         pairs, phys, core = set(), None, None
         for line in open("/proc/cpuinfo"):
@@ -165,9 +163,8 @@ def cpu_baseline(workload, budget_s, frame_len=N48, hop=H48):
         what = (f"frames of the 48 kHz / {frame_len}-sample / {hop}-sample-hop view of 10 s of the same synthetic audio "
                 "(2 of 10 s unvoiced), scrambled order")
     else:
-        frame_len, hop = 512, 480
-        audio = synth.synth_speech(40 * 48000 + 512, sample_offset=0)
-        what = "512-sample frames (hop 480) of 40 s of the same synthetic audio, scrambled order"
+        audio = synth.synth_speech(40 * 48000 + frame_len, sample_offset=0)
+        what = f"{frame_len}-sample frames (hop {hop}, the GPU leg's stride) of 40 s of the same synthetic audio, scrambled order"
     leg = max(budget_s / 2.0, 1.0)
     n1, t1 = o.cpu_bench(workload, audio, frame_len, hop, P, SR, 1, leg)
     na, ta = o.cpu_bench(workload, audio, frame_len, hop, P, SR, usable, leg)
@@ -179,11 +176,17 @@ def cpu_baseline(workload, budget_s, frame_len=N48, hop=H48):
                       "crate itself is single-threaded and cannot be built here"}
 
 
+_FLOP_MODEL = {}
+
+
 def flop_model(frame_len=N48, hop=H48):
-    """Algorithmic FP64 flops per frame of the pitch path, counted by instrumenting the oracle on a
+    """FP64 flops per frame of the reference's pitch path, counted by instrumenting the oracle on a
     10 s sample: 2 * autocorrelation MACs + 13 * sinc terms."""
+    if (frame_len, hop) in _FLOP_MODEL:
+        return _FLOP_MODEL[(frame_len, hop)]
     import importlib
     o = graft.load_oracle()
+    graft.load_package()
     synth = importlib.import_module(graft.PKG_NAME + ".synth")
     audio = synth.synth_speech(10 * 48000 + frame_len, sample_offset=0)
     w = o.window("hanning", frame_len)
@@ -194,23 +197,141 @@ def flop_model(frame_len=N48, hop=H48):
         o.pitch(audio[t * hop:t * hop + frame_len] * w, SR, 0.2, 75.0, 600.0, cap=4)
     c = o.counters()
     n = len(idx)
-    return {"autocorr_macs": c["autocorr_macs"] / n, "sinc_terms": c["sinc_terms"] / n,
-            "sinc_evals": c["sinc_evals"] / n, "candidates": c["candidates"] / n,
-            "flops": (2.0 * c["autocorr_macs"] + FLOPS_PER_SINC_TERM * c["sinc_terms"]) / n}
+    m = {"autocorr_macs": c["autocorr_macs"] / n, "sinc_terms": c["sinc_terms"] / n,
+         "sinc_evals": c["sinc_evals"] / n, "candidates": c["candidates"] / n,
+         "flops": (2.0 * c["autocorr_macs"] + FLOPS_PER_SINC_TERM * c["sinc_terms"]) / n}
+    _FLOP_MODEL[(frame_len, hop)] = m
+    return m
+
+
+_PMC = None
+
+
+def pmc_entry(kernel):
+    """One kernel's entry of profiles/pmc_traffic.json (committed PMC passes: HBM bytes per frame = FETCH_SIZE x2 per the
+    guide's gfx950 correction + WRITE_SIZE; SQ counters per frame where a pass collected them), or None."""
+    global _PMC
+    if _PMC is None:
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                _PMC = json.load(f)
+        except (OSError, ValueError):
+            _PMC = {}
+    return _PMC.get(kernel)
 
 
 def measured_traffic(kernel, frames):
-    """HBM bytes of one launch from the committed PMC passes (profiles/pmc_traffic.json: bytes per frame of each
-    kernel, FETCH_SIZE x2 per the guide's gfx950 correction + WRITE_SIZE, with the commit and the raw file)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            tab = json.load(f)
-    except (OSError, ValueError):
-        return None, None
-    e = tab.get(kernel)
+    e = pmc_entry(kernel)
     if not e:
         return None, None
     return e["bytes_per_frame"] * frames, {k: e[k] for k in ("bytes_per_frame", "source", "commit") if k in e}
+
+
+def traffic_key(wl, dom, frame_len, stride):
+    """profiles/pmc_traffic.json key of the dominant kernel of a workload (tests/test_bench_contract.py walks every key this
+    function can return for the shapes the bench documents)."""
+    if wl == "config2":
+        return "autocorr_lpc_512"
+    if wl == "config4":
+        return dom + "_512"
+    if wl == "frontend":
+        return "pcm16"
+    return dom if (frame_len, stride) == (N48, H48) else f"{dom}_{frame_len}"
+
+
+# ------------------------------------------------------------------------------------------------
+# one timed workload: K steps bracketed by a fence, HIP events around every kernel launch
+# ------------------------------------------------------------------------------------------------
+def timed(vb, torch, step, warmup, steps, barrier=None):
+    def fence():
+        torch.cuda.synchronize()                                              # every stream of the device, the transfers included
+        if barrier is not None:
+            barrier()
+    for i in range(warmup):
+        step(i)
+    fence()
+    vb.profile_reset()
+    vb.profile(True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if barrier is not None:
+        barrier()
+    prof = dict(vb.profile_report())
+    work = vb.profile_pitch_work()
+    vb.profile(False)
+    return dt, prof, work
+
+
+def roofline_for(wl, prof, work, F, frame_len, stride, steps):
+    """The dominant kernel (largest measured time) against its roof.  Returns (roofline, roofline_hbm or None, kernels_ms)."""
+    kernels = {k: {"ms_avg": ms / max(c, 1), "launches": c} for k, (ms, c) in prof.items()}
+    dom = max(kernels, key=lambda k: kernels[k]["ms_avg"] * kernels[k]["launches"])   # by measured time
+    # a kernel may run in several launches per step (the time slices of find_formants): per-launch figures
+    per_step = max(kernels[dom]["launches"] // max(steps, 1), 1)
+    Fl = F / per_step                                                    # frames per launch
+    dom_ms = kernels[dom]["ms_avg"]
+    bytes_per_frame = ALG_BYTES.get(dom, lambda n, hop, p: hop * 8)(frame_len, stride, P)
+    ach = Fl * bytes_per_frame / (dom_ms * 1e-3) / 1e9
+    tkey = traffic_key(wl, dom, frame_len, stride)
+    traffic, tsrc = measured_traffic(tkey, Fl)
+    hbm = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+           "algorithmic_bytes_per_frame": bytes_per_frame, "ms_avg": dom_ms, "frames_per_launch": Fl,
+           "launches_per_step": per_step,
+           "note": "dominant kernel = largest measured time; ms_avg from HIP events on the stream the kernel runs on"}
+    kms = {k: round(v["ms_avg"], 3) for k, v in kernels.items()}
+    if dom not in ("pitch", "analyze"):
+        return hbm, None, kms, kernels
+    # FP64 roof (vector peak = matrix peak on gfx950: 78.6 TFLOP/s).
+    #   `achieved` / `frac` (the headline): the arithmetic the kernel EXECUTES -- the autocorrelation is two real FFTs of
+    #     the zero-padded frame (5 N log2 N / 2 flops each, + the power spectrum), not N^2 MACs -- plus 13 flops for every
+    #     sinc term it evaluated (device counters; the exact top-k pruning skips most of the reference's refinements and
+    #     pruned work is not credited).  Small by construction: the kernel is bound by vector-instruction ISSUE, most of
+    #     which is not FMA work (Brent scalars, selects, address arithmetic) -- `issue_frac` says how busy the issue port is.
+    #   `reference_sums_at_peak`: the same kernel time against what the REFERENCE's algorithm would need at the FP64 peak
+    #     (2 * the MACs of its O(N^2) all-lag autocorrelation + the same sinc terms).  Above 1 it means the kernel finishes
+    #     sooner than the reference's lag sums could at peak; it is a speed-up statement, not a roofline fraction.
+    fm = flop_model(frame_len, stride)
+    frames_w, cand_w, evals_w, terms_w = work
+    terms_pf = terms_w / max(frames_w, 1)
+    nc = (1024 if 512 <= frame_len <= 1024 else 1200 if 1024 < frame_len <= 1200 else 2048 if 1200 < frame_len <= 2048 else
+          4096 if 2048 < frame_len <= 4096 else 0)                      # complex FFT length of the frame's plan
+    nfft = 2.0 * nc
+    fft_flops = (2.0 * 2.5 * nfft * np.log2(nfft) + 6.0 * nfft) if nc else 0.0   # two real transforms (half the complex cost) + |X|^2, split
+    exec_pf = (fft_flops if nc else 2.0 * fm["autocorr_macs"]) + FLOPS_PER_SINC_TERM * terms_pf
+    tfe = Fl * exec_pf / (dom_ms * 1e-3) / 1e12
+    ref_pf = 2.0 * fm["autocorr_macs"] + FLOPS_PER_SINC_TERM * terms_pf
+    tfr = Fl * ref_pf / (dom_ms * 1e-3) / 1e12
+    e = pmc_entry(tkey) or {}
+    roof = {"bound": "mfma", "kernel": dom, "achieved": tfe, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": tfe / FP64_PEAK_TFLOPS,
+            "issue_frac": e.get("valu_busy"), "issue_frac_source": e.get("sq_source"),
+            "traffic": traffic, "traffic_source": tsrc, "ms_avg": dom_ms, "frames_per_launch": Fl,
+            "flops_per_frame": exec_pf, "sinc_terms_per_frame": terms_pf, "sinc_evals_per_frame": evals_w / max(frames_w, 1),
+            "candidates_per_frame": cand_w / max(frames_w, 1), "reference_sinc_terms_per_frame": fm["sinc_terms"],
+            "model": (f"executed FP64 flops: 2 real FFTs of {int(nfft)} points (5 N log2 N / 2 each) + power spectrum + 13 * sinc "
+                      "terms evaluated (device counters); peak = FP64 vector = FP64 matrix peak (78.6 TFLOP/s; the kernel issues "
+                      "no MFMA); the kernel is vector-ISSUE bound, not FMA bound: see issue_frac") if nc else
+                     "executed FP64 flops: 2 * the all-lag autocorrelation MACs (matrix-core tiles) + 13 * sinc terms evaluated",
+            "reference_sums_at_peak": {"flops_per_frame": ref_pf, "autocorr_macs_per_frame": fm["autocorr_macs"], "achieved": tfr,
+                                       "ratio": tfr / FP64_PEAK_TFLOPS,
+                                       "meaning": "kernel time against running the reference's O(N^2) lag sums (+ the same sinc terms) "
+                                                  "at the FP64 peak; > 1 = faster than that; NOT a roofline fraction"}}
+    return roof, hbm, kms, kernels
+
+
+PARITY_NOTE = {
+    "checked_against": "oracle/vbx_oracle.c (C restatement of the reference, pinned by its 26 inline known-answer tests "
+                       "and both WAV fixtures: tests/test_oracle_kat.py), through the C ABI in tests/ -m gpu; "
+                       "tests/test_gpu_soak.py holds 50,000 consecutive frames of this workload (and 20,000 each of configs 2 "
+                       "and 4) to the oracle on every run of the suite",
+    "unpinned_by_the_reference": ["MFCC values (rustfft un-vendored; the reference asserts finiteness only)",
+                                  "find_formants end to end (the reference's test prints)",
+                                  "sinc / Brent values beyond the one 150 Hz vector (1e-2 Hz)",
+                                  "sample 0.10 window phase recurrence and the linear resampler (crate un-vendored)"]}
 
 
 def bench_frontend(args, torch, dev, vb, pkg):
@@ -225,20 +346,11 @@ def bench_frontend(args, torch, dev, vb, pkg):
     pe = torch.empty((Fp, N48), dtype=torch.float64, device=dev)
     win = vb.window(pkg.WINDOW_HANNING, N48)
 
-    def step():
+    def step(i):
         vb.pcm16_to_f64(pcm, out=audio)
         vb.L.vbx_rms_f64(vb.ctx, audio.data_ptr(), F, N48, H48, win.ptr, rms.data_ptr())
         vb.preemphasis(audio, 0.1, frame_len=N48, stride=H48, n_frames=Fp, out=pe)
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    vb.profile_reset(); vb.profile(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof = vb.profile_report(); vb.profile(False)
+    dt, prof, _ = timed(vb, torch, step, args.warmup, args.steps)
     k = {name: ms / max(c, 1) for name, (ms, c) in prof.items()}
     ach = n * 10 / (k["pcm16"] * 1e-3) / 1e9
     traffic, tsrc = measured_traffic("pcm16", n)
@@ -246,7 +358,8 @@ def bench_frontend(args, torch, dev, vb, pkg):
            "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
-           "config": {"workload": f"frontend, {hours:g} h 48 kHz int16 PCM -> f64, rms over {F} frames, preemphasis over {Fp}"},
+           "config": {"workload": f"frontend, {hours:g} h 48 kHz int16 PCM -> f64, rms over {F} frames, preemphasis over {Fp}",
+                      "samples": n, "frames_per_gpu": F},
            "roofline": {"bound": "hbm", "kernel": "pcm16", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                         "algorithmic_bytes_per_sample": 10, "ms_avg": k["pcm16"]},
@@ -258,22 +371,122 @@ def bench_frontend(args, torch, dev, vb, pkg):
 
 
 # ------------------------------------------------------------------------------------------------
+# sub-benchmarks of the default run: BASELINE configs 2, 3 and 4, a few steps each, outside the headline's timed region
+# ------------------------------------------------------------------------------------------------
+def sub_benchmarks(vb, torch, dev, pkg, audio48, F48):
+    """audio48: the pipeline's resident recording (F48 frames at 1200 / 480).  Returns a list of compact bench records."""
+    f64, i32 = torch.float64, torch.int32
+    out = []
+    est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+
+    def record(name, wl, desc, F, frame_len, stride, step, steps, warmup, kmax=None, extra=None):
+        dt, prof, work = timed(vb, torch, step, warmup, steps)
+        roof, hbm, kms, kernels = roofline_for(wl, prof, work, F, frame_len, stride, steps)
+        r = {"name": name, "workload": desc, "value": F * steps / dt, "unit": "frames/s", "steps": steps, "warmup": warmup,
+             "ms_per_step": dt / steps * 1e3, "frames": F, "frame_len": frame_len, "hop": stride, "roofline": roof, "kernels_ms": kms}
+        if kmax is not None:
+            r["pitch_kmax"] = kmax
+        if hbm is not None:
+            r["roofline_hbm"] = {k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes_per_frame")}
+        if extra:
+            r.update(extra(dt, kernels, steps))
+        out.append(r)
+
+    # ---- config 3: Boersma pitch path, 10 h (3,599,998 frames) of the resident recording ----------------------------
+    win = vb.window(pkg.WINDOW_HANNING, N48)
+    F3 = min(CONFIG3_FRAMES, F48)
+    for kmax, Fk, steps in ((1, F3, 2), (8, min(F3, 720_000), 2), (pkg.pitch_max_candidates(N48), min(F3, 360_000), 1)):
+        cand = torch.empty((Fk, kmax, 2), dtype=f64, device=dev)
+        cnt = torch.empty(Fk, dtype=i32, device=dev)
+        pst = torch.empty(Fk, dtype=i32, device=dev)
+
+        def step3(i, kmax=kmax, Fk=Fk, cand=cand, cnt=cnt, pst=pst):
+            vb.pitch(audio48, SR, 0.2, 75.0, 600.0, kmax=kmax, frame_len=N48, stride=H48, n_frames=Fk, window=win, out=(cand, cnt, pst))
+        what = "PitchExtractor output" if kmax == 1 else f"first {kmax} of the sorted candidate Vec" if kmax == 8 else "the WHOLE candidate Vec"
+        record(f"config3_kmax{kmax}", "config3", f"Boersma pitch path, {Fk} frames of the synthetic 48 kHz recording, 25 ms / 10 ms hop, "
+               f"kmax = {kmax} ({what})", Fk, N48, H48, step3, steps, 1, kmax=kmax)
+        del cand, cnt, pst
+
+    # ---- configs 2 and 4: dense [1,000,000, 512] f64 frames -------------------------------------------------------
+    Fd = 1_000_000
+    dense = torch.empty(Fd * 512, dtype=f64, device=dev)
+    vb.synth_speech(Fd * 512, sample_offset=0, sample_rate=SR, out=dense)
+    win512 = vb.window(pkg.WINDOW_HANNING, 512)
+    o_r = torch.empty((Fd, P + 1), dtype=f64, device=dev)
+    o_a = torch.empty((Fd, P + 1), dtype=f64, device=dev)
+    record("config2", "config2", f"batched autocorrelation(13) + LPC order-12, {Fd} x 512-sample f64 frames",
+           Fd, 512, 512, lambda i: vb.autocorr_lpc(dense, P, frame_len=512, stride=512, n_frames=Fd, window=win512, out=(o_r, o_a)), 5, 2)
+    del o_r, o_a
+    seg = np.arange(0, Fd, SEG_FRAMES, dtype=np.int64)
+    ff = {"formants": torch.empty((Fd, 4, 2), dtype=f64, device=dev), "res": None, "count": None, "coeffs": None,
+          "status": torch.empty(Fd, dtype=i32, device=dev)}
+
+    def whole4(dt, kernels, steps):
+        step_s = dt / steps
+        return {"whole_config": {"bytes_per_frame": 4264, "GBps": Fd * 4264 / step_s / 1e9, "hbm_frac": Fd * 4264 / step_s / 1e9 / HBM_PEAK_GBS,
+                                 "flops_per_frame": 135e3, "TFLOPs": Fd * 135e3 / step_s / 1e12,
+                                 "fp64_frac": Fd * 135e3 / step_s / 1e12 / FP64_PEAK_TFLOPS,
+                                 "kernels_ms_per_step": {k: round(v["ms_avg"] * v["launches"] / steps, 3) for k, v in kernels.items()}}}
+    record("config4", "config4", f"LPC(Burg)->Laguerre roots->formant track, {Fd} x 512-sample f64 frames, utterances of {SEG_FRAMES}",
+           Fd, 512, 512, lambda i: vb.find_formants(dense, SR, P, est0, seg_start=seg, frame_len=512, stride=512, n_frames=Fd, out=ff), 5, 2,
+           extra=whole4)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 def run_rank(args):
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    dry = bool(os.environ.get("VBX_BENCH_DRY_RUN"))      # tests/test_shard_cpu.py: the launcher's plumbing without a GPU
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if os.environ.get("VBX_BENCH_DRY_RUN"):    # tests/test_shard_cpu.py: the launcher's plumbing without a GPU
+        # control plane: gloo on CPU tensors.  torch never brings up RCCL in this process; the library's communicator
+        # (below) is the only RCCL instance.
         dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    pkg = graft.load_package()
+    N, H = args.frame_len, args.hop
+    wl = args.workload
+    # shard geometry (host arithmetic only: also what the dry run reports)
+    if wl in ("pipeline", "config3"):
+        total_frames_per_gpu = int(round(args.hours * 3600 * SR / H))         # 100 frames per second at the default hop
+        total_frames_per_gpu -= total_frames_per_gpu % SEG_FRAMES             # whole utterances per rank
+        F = max(total_frames_per_gpu, SEG_FRAMES)
+        # weak scaling: the recording is world * F frames long and splits by contiguous ranges at utterance boundaries
+        seg_all = np.arange(0, world * F, SEG_FRAMES, dtype=np.int64)
+        lo, hi = pkg.shard_range(world * F, world, rank, seg_all)
+        assert hi - lo == F
+        s0, s1 = pkg.shard_samples(lo, hi, N, H)                              # includes the frame_len - hop halo
+    else:
+        F = args.frames
+    counts = [F] * world
+    gather_desc = ("library (vbx_gather_records_f64: grouped ncclSend/ncclRecv on the communicator's own stream, one direct "
+                   "xGMI link per peer; control plane = torch.distributed gloo)") if world > 1 else None
+    if dry:
+        REC = 36
+        off, cnt, op = pkg.gather_plan(counts, rank, 0, REC)
         seen = [None] * world
-        dist.all_gather_object(seen, (rank, local, os.environ.get("MASTER_PORT")))
+        mine = (rank, local, os.environ.get("MASTER_PORT"), [int(x) for x in op], [int(x) for x in off])
+        if world > 1:
+            dist.all_gather_object(seen, mine)
+        else:
+            seen = [mine]
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": seen, "gpus_arg": args.gpus}), flush=True)
-        dist.destroy_process_group()
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": [list(s[:3]) for s in seen], "gpus_arg": args.gpus,
+                              "control_plane": dist.get_backend() if world > 1 else None, "data_plane": gather_desc,
+                              "rccl_comms_per_rank_planned": 1 if world > 1 else 0, "torch_nccl_process_groups": 0,
+                              "gather_plan": {"rows": counts, "record_doubles": REC, "ops_by_rank": [s[3] for s in seen],
+                                              "offsets": seen[0][4]}}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
         return 0
     if os.environ.get("VBX_BENCH_ONE_GPU"):     # test hook: every rank on GPU 0 (whether RCCL accepts that is up to RCCL)
         local = 0
@@ -283,57 +496,46 @@ def run_rank(args):
         raise SystemExit(f"bench.py: rank {rank} wants GPU {local} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    pkg = graft.load_package()
     # one explicit HIP stream shared by torch (allocation) and the library's kernels; the library adds its own side
-    # stream (formant chain, MFCC beside the pitch kernel) and the communicator's transfer stream
+    # stream (formant chain beside the pitch kernel) and the communicator's transfer stream
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     vb = pkg.VoxBox(local, tstream.cuda_stream)
 
-    wl = args.workload
     f64 = torch.float64
     if wl == "frontend":
         return bench_frontend(args, torch, dev, vb, pkg)
     comm = None
-    gather_via = "library (vbx_gather_records_f64: grouped ncclSend/ncclRecv on the communicator's own stream)"
     if world > 1:
-        # the library's own RCCL communicator for the record gather; the 128-byte id travels over torch.distributed.
-        # Should the library's communicator fail to come up on any rank (it is a second RCCL instance in a process that
-        # already runs torch's), every rank falls back to the same grouped send/recv through torch.distributed.
-        ok = 1
-        try:
-            ids = [pkg.comm_unique_id() if rank == 0 else None]
-        except pkg.VoxBoxError as e:
-            sys.stderr.write(f"bench.py rank {rank}: {e}\n"); ids = [None]; ok = 0
-        dist.broadcast_object_list(ids, src=0, device=dev)
-        if ids[0] is None:
-            ok = 0
-        else:
+        # the library's RCCL communicator for the record gather; the 128-byte id travels over the gloo control plane.
+        # Every rank learns whether every other rank's communicator came up; if not, the bench FAILS: there is no other
+        # transport for the records.
+        ids = [None]
+        err = ""
+        if rank == 0:
+            try:
+                ids = [pkg.comm_unique_id()]
+            except pkg.VoxBoxError as e:
+                err = str(e)
+        dist.broadcast_object_list(ids, src=0)
+        ok = 0
+        if ids[0] is not None:
             try:
                 comm = pkg.Comm(vb, ids[0], world, rank)
+                ok = 1
             except pkg.VoxBoxError as e:
-                sys.stderr.write(f"bench.py rank {rank}: {e}\n"); ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                err = str(e)
+        flag = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             if comm is not None:
                 comm.close()
-            comm = None
-            gather_via = "torch.distributed batch_isend_irecv (fallback: the library's communicator did not come up)"
+            raise SystemExit(f"bench.py rank {rank}: the library's RCCL communicator did not come up on every rank "
+                             f"({err or 'another rank failed'}); the record gather has no fallback transport")
+        assert pkg.comm_live_count() == 1
 
     est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
     if wl in ("pipeline", "config3"):
-        N, H = args.frame_len, args.hop
-        total_frames_per_gpu = int(round(args.hours * 3600 * SR / H))         # 100 frames per second at the default hop
-        total_frames_per_gpu -= total_frames_per_gpu % SEG_FRAMES             # whole utterances per rank
-        F = max(total_frames_per_gpu, SEG_FRAMES)
-        # weak scaling: the recording is world * F frames long and splits by contiguous ranges at utterance boundaries
-        seg_all = np.arange(0, world * F, SEG_FRAMES, dtype=np.int64)
-        lo, hi = pkg.shard_range(world * F, world, rank, seg_all)
-        assert hi - lo == F
-        s0, s1 = pkg.shard_samples(lo, hi, N, H)                              # includes the frame_len - hop halo
         audio = torch.empty(s1 - s0, dtype=f64, device=dev)
         vb.synth_speech(s1 - s0, sample_offset=s0, sample_rate=SR, out=audio)
         frame_len, stride = N, H
@@ -342,7 +544,6 @@ def run_rank(args):
                 f"{args.hours:g} h/GPU synthetic 48 kHz, " +
                 ("25 ms / 10 ms hop" if (N, H) == (N48, H48) else f"{N}-sample frames / {H}-sample hop"))
     else:
-        F = args.frames
         audio = torch.empty(F * 512, dtype=f64, device=dev)
         vb.synth_speech(F * 512, sample_offset=rank * F * 512, sample_rate=SR, out=audio)
         frame_len, stride = 512, 512
@@ -350,7 +551,6 @@ def run_rank(args):
         desc = ("batched autocorrelation + LPC order-12" if wl == "config2" else
                 "LPC(Burg)->Laguerre roots->formant track") + f", {F} x 512-sample f64 frames/GPU"
     seg = np.arange(0, F, SEG_FRAMES, dtype=np.int64)
-    counts = [F] * world
 
     # outputs (torch owns the device memory; the C ABI gets raw pointers).  The pipeline writes one record per frame
     # straight into the buffer the gather sends (rank 0: straight into the gathered array), double-buffered so that
@@ -385,15 +585,8 @@ def run_rank(args):
                 comm.wait(b)                                                  # device-side: buffer b's last transfer is done
             vb.analyze_frames(audio, params, seg_start=seg, frame_len=frame_len, stride=stride, n_frames=F,
                               out=rec[b], record_ld=REC, status=st3)
-            if comm is not None:   # per-frame records to rank 0 over RCCL/xGMI (no other collective on the path)
+            if comm is not None:   # per-frame records to rank 0 over RCCL/xGMI (the path's only exchange)
                 comm.gather_records(rec[b], counts, REC, 0, out=gathered[b], slot=b)
-            elif world > 1:
-                if rank == 0:
-                    ops = [dist.P2POp(dist.irecv, gathered[b][r * F:(r + 1) * F], r) for r in range(1, world)]
-                else:
-                    ops = [dist.P2POp(dist.isend, rec[b], 0)]
-                for w_ in dist.batch_isend_irecv(ops):
-                    w_.wait()
         elif wl == "config4":
             vb.find_formants(audio, SR, P, est0, seg_start=seg, frame_len=frame_len, stride=stride, n_frames=F, out=ff)
         elif wl == "config2":
@@ -402,41 +595,16 @@ def run_rank(args):
             vb.pitch(audio, SR, 0.2, 75.0, 600.0, kmax=args.kmax, frame_len=frame_len, stride=stride, n_frames=F, window=win,
                      out=(o_cand, o_cnt, o_pst))
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()                                              # every stream of the device, the transfers included
-
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    vb.profile_reset()
-    vb.profile(True)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
-    prof = dict(vb.profile_report())
-    vb.profile(False)
+    dt, prof, work = timed(vb, torch, step, args.warmup, args.steps, barrier if world > 1 else None)
     if world > 1:
-        tt = torch.tensor([dt], dtype=f64, device=dev)
+        tt = torch.tensor([dt], dtype=f64)                                   # CPU tensor: gloo
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     if rank == 0:
         total = F * world * args.steps
-        kernels = {k: {"ms_avg": ms / max(c, 1), "launches": c} for k, (ms, c) in prof.items()}
-        dom = max(kernels, key=lambda k: kernels[k]["ms_avg"] * kernels[k]["launches"])   # by measured time
-        # a kernel may run in several launches per step (the time slices of find_formants): per-launch figures
-        per_step = max(kernels[dom]["launches"] // max(args.steps, 1), 1)
-        Fl = F / per_step                                                    # frames per launch
-        dom_ms = kernels[dom]["ms_avg"]
-        bytes_per_frame = ALG_BYTES.get(dom, lambda n, hop, p: hop * 8)(frame_len, stride, P)
-        ach = Fl * bytes_per_frame / (dom_ms * 1e-3) / 1e9
         default_shape = wl not in ("pipeline", "config3") or (frame_len, stride) == (N48, H48)
-        tkey = {"config2": "autocorr_lpc_512", "config4": dom + "_512"}.get(wl, dom if default_shape else f"{dom}_{frame_len}")
-        traffic, tsrc = measured_traffic(tkey, Fl)
+        roof, hbm, kms, kernels = roofline_for(wl, prof, work, F, frame_len, stride, args.steps)
         out = {
             "metric": METRIC if wl == "pipeline" and default_shape else
                       f"frames/sec ({wl})" if default_shape else f"frames/sec ({wl}, {frame_len}-sample frames / {stride}-sample hop)",
@@ -447,63 +615,16 @@ def run_rank(args):
                        "lpc_order": P, "mfcc": 13, "pitch_kmax": args.kmax if wl != "pipeline" else 1,
                        "record_bytes": REC * 8,
                        "parallelism": f"frame-range split x{world}, one process per GPU, RCCL gather of the records to rank 0",
-                       "gather": gather_via if world > 1 else None},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
-                         "algorithmic_bytes_per_frame": bytes_per_frame, "ms_avg": dom_ms, "frames_per_launch": Fl,
-                         "launches_per_step": per_step,
-                         "note": "dominant kernel = largest measured time; ms_avg from HIP events on the stream the kernel runs on"},
-            "kernels_ms": {k: round(v["ms_avg"], 3) for k, v in kernels.items()},
+                       "gather": gather_desc, "control_plane": "gloo (CPU tensors)" if world > 1 else None,
+                       "rccl_comms_per_rank": pkg.comm_live_count(), "torch_nccl_process_groups": 0},
+            "roofline": roof,
+            "kernels_ms": kms,
         }
-        if dom in ("pitch", "analyze"):
-            # FP64 roof (vector peak = matrix peak on gfx950: 78.6 TFLOP/s).  Two flop models, both stated:
-            #   ALGORITHMIC (`achieved`, `frac`): what the reference's algorithm does per frame for the parts this kernel
-            #     replaces -- 2 * the MACs of its O(N^2) all-lag autocorrelation (oracle counter) + 13 * the sinc terms the
-            #     kernel actually evaluated (device counters; the exact top-k pruning skips most of the reference's
-            #     refinements and pruned work is not credited).
-            #   EXECUTED (`executed`): the arithmetic the kernel issues -- the autocorrelation is two real FFTs of length
-            #     2400 (5 N log2 N flops each, + the power spectrum), not N^2 MACs -- plus the same sinc terms.
-            # The kernel is bound by vector-instruction ISSUE (SQ counters under profiles/: VALU busy ~90-100 %), most of
-            # which is not FMA work (Brent scalars, selects, address arithmetic): the executed fraction is small by
-            # construction and the algorithmic one says how the kernel compares with running the reference's sums at peak.
-            fm = flop_model(frame_len, stride)
-            frames_w, cand_w, evals_w, terms_w = vb.profile_pitch_work()
-            terms_pf = terms_w / max(frames_w, 1)
-            flops_pf = 2.0 * fm["autocorr_macs"] + FLOPS_PER_SINC_TERM * terms_pf
-            tf = F * flops_pf / (dom_ms * 1e-3) / 1e12
-            # frame lengths 512..4096 have an FFT kernel: complex length 1024 (n <= 1024), 1200 (n <= 1200), 2048 or 4096
-            nc = (1024 if 512 <= frame_len <= 1024 else 1200 if 1024 < frame_len <= 1200 else 2048 if 1200 < frame_len <= 2048 else
-                  4096 if 2048 < frame_len <= 4096 else 0)
-            nfft = 2.0 * nc
-            fft_flops = (2.0 * 2.5 * nfft * np.log2(nfft) + 6.0 * nfft) if nc else 0.0   # two real transforms (half the complex cost) + |X|^2, split
-            exec_pf = (fft_flops if nc else 2.0 * fm["autocorr_macs"]) + FLOPS_PER_SINC_TERM * terms_pf
-            tfe = F * exec_pf / (dom_ms * 1e-3) / 1e12
-            out["roofline_hbm"] = out["roofline"]
-            above = ("; a fraction above 1 means the kernel finishes sooner than the reference's lag sums could at the FP64 peak "
-                     "(the FFT does fewer flops)") if tf > FP64_PEAK_TFLOPS else ""
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": tf, "peak": FP64_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
-                               "ms_avg": dom_ms,
-                               "flops_per_frame": flops_pf, "autocorr_macs_per_frame": fm["autocorr_macs"],
-                               "sinc_terms_per_frame": terms_pf, "sinc_evals_per_frame": evals_w / max(frames_w, 1),
-                               "candidates_per_frame": cand_w / max(frames_w, 1),
-                               "reference_sinc_terms_per_frame": fm["sinc_terms"],
-                               "executed": {"flops_per_frame": exec_pf, "achieved": tfe, "frac": tfe / FP64_PEAK_TFLOPS,
-                                            "model": f"2 real FFTs of {int(nfft)} (5 N log2 N / 2 each) + power spectrum + 13 * sinc "
-                                                     "terms evaluated; the kernel is vector-issue bound, not FMA bound"},
-                               "model": "algorithmic FP64 flops: 2*autocorr MACs of the reference's all-lag autocorrelation "
-                                        "(oracle MAC counter) + 13*sinc terms the kernel evaluated (device counters; the "
-                                        "reference evaluates reference_sinc_terms); peak = FP64 vector = FP64 matrix peak "
-                                        "(the kernel issues no MFMA: one FFT replaced the matrix-core autocorrelation)" + above}
+        if hbm is not None:
+            out["roofline_hbm"] = hbm
         # what "parity" means for this line: GPU == oracle is tested; oracle == reference is pinned
         # by the reference's own known-answer tests where it has any, and is NOT where it has none
-        out["parity"] = {
-            "checked_against": "oracle/vbx_oracle.c (C restatement of the reference, pinned by its 26 inline known-answer tests "
-                               "and both WAV fixtures: tests/test_oracle_kat.py), through the C ABI in tests/ -m gpu",
-            "unpinned_by_the_reference": ["MFCC values (rustfft un-vendored; the reference asserts finiteness only)",
-                                          "find_formants end to end (the reference's test prints)",
-                                          "sinc / Brent values beyond the one 150 Hz vector (1e-2 Hz)",
-                                          "sample 0.10 window phase recurrence and the linear resampler (crate un-vendored)"]}
+        out["parity"] = PARITY_NOTE
         if wl == "config4":
             # three kernels in sequence -- Burg, the root finder, the chunked tracker scan (four launches + a sweep, timed as
             # one) -- so besides the dominant kernel's line: the whole config against both roofs (4264 B and
@@ -513,8 +634,11 @@ def run_rank(args):
                                    "flops_per_frame": 135e3, "TFLOPs": F * 135e3 / step_s / 1e12,
                                    "fp64_frac": F * 135e3 / step_s / 1e12 / FP64_PEAK_TFLOPS,
                                    "kernels_ms_per_step": {k: round(v["ms_avg"] * v["launches"] / args.steps, 3) for k, v in kernels.items()}}
-        if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds, frame_len, stride if wl in ("pipeline", "config3") else H48)
+        if wl == "pipeline" and default_shape and world == 1 and not args.no_sub:
+            del rec, gathered                                                 # the records' HBM back before the dense batches
+            out["sub_benchmarks"] = sub_benchmarks(vb, torch, dev, pkg, audio, F)
+        if not args.no_cpu:          # rank 0, outside the timed region, at every N
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds, frame_len, stride)
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()

@@ -406,6 +406,17 @@ void vbx_comm_destroy(vbx_comm *comm);
  * batch overlaps it; `slot` in [0, VBX_COMM_SLOTS) names the buffer being sent for vbx_comm_wait. */
 int vbx_gather_records_f64(vbx_ctx *ctx, vbx_comm *comm, const double *local, const int64_t *h_rows,
                            size_t row_doubles, int dst, double *out, int slot);
+/* The transfer list of that gather as one rank sees it, on the host (no GPU, no RCCL: what vbx_gather_records_f64 posts,
+ * exposed so that a caller -- and the CPU tests -- can check the layout for any world size and uneven h_rows):
+ * for every rank r, h_offset[r] = element offset (doubles) of rank r's rows in `out`, h_count[r] = doubles rank r
+ * contributes; h_op[r] = what THIS rank does for peer r: VBX_GATHER_NONE, VBX_GATHER_RECV (this rank is dst and r sends),
+ * VBX_GATHER_SEND (r == dst and this rank has rows), VBX_GATHER_COPY (r == rank == dst: device copy unless in place).
+ * Arrays of `world` entries; any of the three may be NULL. */
+enum { VBX_GATHER_NONE = 0, VBX_GATHER_RECV = 1, VBX_GATHER_SEND = 2, VBX_GATHER_COPY = 3 };
+int vbx_gather_plan(const int64_t *h_rows, int world, int rank, int dst, size_t row_doubles,
+                    int64_t *h_offset, int64_t *h_count, int32_t *h_op);
+/* Live communicators of this process (the bench prints it: exactly one RCCL instance per rank). */
+int vbx_comm_live_count(void);
 /* Makes the context's stream wait (on the device, not the host) until the gather that used `slot` has finished:
  * call before overwriting that buffer. */
 int vbx_comm_wait(vbx_ctx *ctx, vbx_comm *comm, int slot);

@@ -144,6 +144,47 @@ def test_library_shard_helpers_match_the_python_ones(pkg):
     assert pkg.shard_samples(5, 5, N, H) == sh.sample_range(5, 5, N, H)
 
 
+def test_gather_plan_for_uneven_shards(pkg):
+    """vbx_gather_plan = the transfer list vbx_gather_records_f64 posts (one grouped ncclRecv per sending peer on dst, one
+    ncclSend on every peer with rows), checked on the host for world 2 / 3 / 8 with uneven and empty shards: the offsets
+    tile the gathered array in rank order, every byte is received exactly once, and sends pair with receives."""
+    REC = 36
+    for rows in ([5, 3], [0, 4], [4, 0], [7, 0, 2], [1000, 1000, 999], [3, 1, 4, 1, 5, 9, 2, 6], [0, 0, 0, 0, 0, 0, 0, 8]):
+        world = len(rows)
+        for dst in (0, world - 1):
+            plans = [pkg.gather_plan(rows, r, dst, REC) for r in range(world)]
+            off_d, cnt_d, op_d = plans[dst]
+            assert off_d[0] == 0 and np.array_equal(off_d[1:], np.cumsum(np.array(rows) * REC)[:-1])
+            assert np.array_equal(cnt_d, np.array(rows) * REC)
+            covered = np.zeros(sum(rows) * REC, dtype=np.int32)
+            for r in range(world):
+                off, cnt, op = plans[r]
+                assert np.array_equal(off, off_d) and np.array_equal(cnt, cnt_d)      # every rank agrees on the layout
+                if r == dst:
+                    for q in range(world):
+                        exp = pkg.GATHER_NONE if rows[q] == 0 else (pkg.GATHER_COPY if q == dst else pkg.GATHER_RECV)
+                        assert op[q] == exp, (rows, dst, q)
+                        if op[q] != pkg.GATHER_NONE:
+                            covered[off[q]:off[q] + cnt[q]] += 1
+                else:
+                    sends = [q for q in range(world) if op[q] == pkg.GATHER_SEND]
+                    assert sends == ([dst] if rows[r] > 0 else []), (rows, dst, r)
+                    assert all(op[q] == pkg.GATHER_NONE for q in range(world) if q != dst)
+                    # the matching receive exists on dst with the same element count
+                    assert (op_d[r] == pkg.GATHER_RECV) == (rows[r] > 0) and cnt_d[r] == rows[r] * REC
+            assert np.all(covered == 1)
+    # the bench's shards: utterance-aligned ranges of an uneven recording
+    seg = np.arange(0, 10_500, 1000)
+    for world in (2, 3, 8):
+        rr = [pkg.shard_range(10_500, world, r, seg) for r in range(world)]
+        rows = [b - a for a, b in rr]
+        off, cnt, _ = pkg.gather_plan(rows, 0, 0, REC)
+        assert [int(o) // REC for o in off] == [a for a, _ in rr] and int(off[-1] + cnt[-1]) == 10_500 * REC
+    with pytest.raises(pkg.VoxBoxError):
+        pkg.gather_plan([1, -1], 0, 0, REC)
+    assert pkg.comm_live_count() == 0
+
+
 def test_bench_gpus_n_launches_n_ranks_itself():
     """`python bench.py --gpus 2` with no RANK in the environment starts 2 rank processes before touching the GPU,
     relays rank 0's JSON line and returns their status (dry run: the ranks only rendezvous over gloo)."""
@@ -158,6 +199,13 @@ def test_bench_gpus_n_launches_n_ranks_itself():
     assert line["dry_run"] and line["n_gpus"] == 2 and line["gpus_arg"] == 2
     assert sorted(x[0] for x in line["ranks"]) == [0, 1] and sorted(x[1] for x in line["ranks"]) == [0, 1]
     assert len({x[2] for x in line["ranks"]}) == 1
+    # control plane over gloo, ONE RCCL communicator per rank (the library's), no torch nccl process group, and the
+    # gather's transfer list: rank 0 keeps its rows in place and receives rank 1's, rank 1 sends to rank 0
+    assert line["control_plane"] == "gloo" and line["rccl_comms_per_rank_planned"] == 1 and line["torch_nccl_process_groups"] == 0
+    gp = line["gather_plan"]
+    assert gp["ops_by_rank"] == [[3, 1], [2, 0]] and gp["offsets"] == [0, gp["rows"][0] * gp["record_doubles"]]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "init_process_group(\"nccl\"" not in src and "batch_isend_irecv" not in src      # no second RCCL instance, no fallback transport
     # a failing rank makes the launcher fail (no GPU here: the ranks refuse to run)
     env.pop("VBX_BENCH_DRY_RUN")
     import torch

@@ -16,7 +16,8 @@ from .voxbox import (  # noqa: F401
     WINDOW_HANNING, WINDOW_HANNING_LAG, WINDOW_HANNING_PERIODIC, WINDOW_RECTANGLE,
     MALE_FORMANT_ESTIMATES, FEMALE_FORMANT_ESTIMATES,
     FRAME_OK, FRAME_ERR_LPC, FRAME_ERR_POLYNOMIAL, FRAME_ERR_NAN, FRAME_ERR_PANIC,
-    AnalysisParams, Comm, comm_unique_id, shard_range, shard_samples,
+    AnalysisParams, Comm, comm_unique_id, comm_live_count, gather_plan, shard_range, shard_samples,
+    GATHER_NONE, GATHER_RECV, GATHER_SEND, GATHER_COPY,
     MAX_PITCH_CANDIDATES, pitch_max_candidates,
 )
 from . import shard  # noqa: F401

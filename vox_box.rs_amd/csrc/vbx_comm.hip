@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -40,9 +41,34 @@ int fail(vbx_ctx *ctx, int code, const std::string &msg) { return vbx_internal_f
         if (r_ != ncclSuccess) return fail(ctx, VBX_E_RUNTIME, std::string(#expr) + ": " + ncclGetErrorString(r_)); \
     } while (0)
 
+std::atomic<int> g_live_comms{0};
+
 }  // namespace
 
 extern "C" {
+
+int vbx_comm_live_count(void) { return g_live_comms.load(); }
+
+int vbx_gather_plan(const int64_t *h_rows, int world, int rank, int dst, size_t row_doubles,
+                    int64_t *h_offset, int64_t *h_count, int32_t *h_op) {
+    if (!h_rows || world < 1 || rank < 0 || rank >= world || dst < 0 || dst >= world || row_doubles < 1)
+        return fail(nullptr, VBX_E_INVALID, "vbx_gather_plan: bad argument");
+    int64_t off = 0;
+    for (int r = 0; r < world; r++) {
+        if (h_rows[r] < 0) return fail(nullptr, VBX_E_INVALID, "vbx_gather_plan: negative row count");
+        const int64_t cnt = h_rows[r] * (int64_t)row_doubles;
+        if (h_offset) h_offset[r] = off;
+        if (h_count) h_count[r] = cnt;
+        if (h_op) {
+            int32_t op = VBX_GATHER_NONE;
+            if (rank == dst) { if (cnt > 0) op = (r == dst) ? VBX_GATHER_COPY : VBX_GATHER_RECV; }
+            else if (r == dst && h_rows[rank] > 0) op = VBX_GATHER_SEND;       // whatever dst itself contributes
+            h_op[r] = op;
+        }
+        off += cnt;
+    }
+    return VBX_SUCCESS;
+}
 
 int vbx_shard_range(size_t n_frames, int world, int rank, const int64_t *h_seg_start, size_t n_segments,
                     size_t *lo, size_t *hi) {
@@ -100,11 +126,13 @@ int vbx_comm_create(vbx_ctx *ctx, const void *h_id, int world, int rank, vbx_com
     for (int s = 0; s < VBX_COMM_SLOTS && e == hipSuccess; s++) e = hipEventCreateWithFlags(&c->done[s], hipEventDisableTiming);
     if (e != hipSuccess) { vbx_comm_destroy(c); return fail(ctx, VBX_E_RUNTIME, std::string("vbx_comm_create: ") + hipGetErrorString(e)); }
     *out = c;
+    g_live_comms++;
     return VBX_SUCCESS;
 }
 
 void vbx_comm_destroy(vbx_comm *c) {
     if (!c) return;
+    if (c->nccl && c->done[VBX_COMM_SLOTS - 1]) g_live_comms--;      // fully constructed communicators only
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->nccl) ncclCommDestroy(c->nccl);
@@ -128,28 +156,21 @@ int vbx_gather_records_f64(vbx_ctx *ctx, vbx_comm *c, const double *local, const
     // the transfer starts when everything queued on the context's stream so far (the kernels writing `local`) is done
     VBXC_HIP(ctx, hipEventRecord(c->ready, main));
     VBXC_HIP(ctx, hipStreamWaitEvent(c->stream, c->ready, 0));
-    if (c->rank == dst) {
-        size_t off = 0;
-        for (int r = 0; r < dst; r++) off += (size_t)h_rows[r];
-        double *own = out + off * row_doubles;
-        if (mine > 0 && own != local)
-            VBXC_HIP(ctx, hipMemcpyAsync(own, local, mine * row_doubles * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    }
+    // the transfer list (vbx_gather_plan: the same function the CPU tests drive for world 2 / 3 / 8 with uneven rows)
+    std::vector<int64_t> off(c->world), cnt(c->world);
+    std::vector<int32_t> op(c->world);
+    if (vbx_gather_plan(h_rows, c->world, c->rank, dst, row_doubles, off.data(), cnt.data(), op.data()) != VBX_SUCCESS)
+        return fail(ctx, VBX_E_INVALID, "vbx_gather_records_f64: bad row counts");
+    if (op[c->rank] == VBX_GATHER_COPY && out + off[c->rank] != local)
+        VBXC_HIP(ctx, hipMemcpyAsync(out + off[c->rank], local, (size_t)cnt[c->rank] * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     if (c->world > 1) {
         // one group: every peer -> dst transfer is posted together and runs concurrently, each over the direct
         // xGMI link between that peer and dst
         VBXC_NCCL(ctx, ncclGroupStart());
         ncclResult_t res = ncclSuccess;
-        if (c->rank == dst) {
-            size_t off = 0;
-            for (int r = 0; r < c->world && res == ncclSuccess; r++) {
-                const size_t rows = (size_t)h_rows[r];
-                if (r != dst && rows > 0)
-                    res = ncclRecv(out + off * row_doubles, rows * row_doubles, ncclDouble, r, c->nccl, c->stream);
-                off += rows;
-            }
-        } else if (mine > 0) {
-            res = ncclSend(local, mine * row_doubles, ncclDouble, dst, c->nccl, c->stream);
+        for (int r = 0; r < c->world && res == ncclSuccess; r++) {
+            if (op[r] == VBX_GATHER_RECV) res = ncclRecv(out + off[r], (size_t)cnt[r], ncclDouble, r, c->nccl, c->stream);
+            else if (op[r] == VBX_GATHER_SEND) res = ncclSend(local, (size_t)cnt[c->rank], ncclDouble, dst, c->nccl, c->stream);
         }
         ncclResult_t end = ncclGroupEnd();
         if (res != ncclSuccess) return fail(ctx, VBX_E_RUNTIME, std::string("ncclSend/ncclRecv: ") + ncclGetErrorString(res));

@@ -175,6 +175,8 @@ def load_library():
         "vbx_comm_create": (C.c_int, [vp, vp, i32, i32, C.POINTER(vp)]),
         "vbx_comm_destroy": (None, [vp]),
         "vbx_gather_records_f64": (C.c_int, [vp, vp, vp, vp, sz, i32, vp, i32]),
+        "vbx_gather_plan": (C.c_int, [vp, i32, i32, i32, sz, vp, vp, vp]),
+        "vbx_comm_live_count": (C.c_int, []),
         "vbx_comm_wait": (C.c_int, [vp, vp, i32]),
         "vbx_comm_sync": (C.c_int, [vp]),
         "vbx_comm_selftest": (C.c_int, [vp, vp, sz]),
@@ -237,6 +239,23 @@ def shard_samples(lo, hi, frame_len, hop):
     if load_library().vbx_shard_samples(lo, hi, frame_len, hop, C.byref(s0), C.byref(s1)) != 0:
         raise VoxBoxError("vbx_shard_samples: bad argument")
     return s0.value, s1.value
+
+
+GATHER_NONE, GATHER_RECV, GATHER_SEND, GATHER_COPY = 0, 1, 2, 3
+
+
+def gather_plan(rows, rank, dst, row_doubles):
+    """vbx_gather_plan: (offset[world], count[world], op[world]) of the record gather as `rank` sees it (host only)."""
+    r = np.ascontiguousarray(rows, dtype=np.int64)
+    off, cnt, op = np.zeros(r.size, np.int64), np.zeros(r.size, np.int64), np.zeros(r.size, np.int32)
+    rc = load_library().vbx_gather_plan(r.ctypes.data, r.size, rank, dst, row_doubles, off.ctypes.data, cnt.ctypes.data, op.ctypes.data)
+    if rc != 0:
+        raise VoxBoxError("vbx_gather_plan: bad argument")
+    return off, cnt, op
+
+
+def comm_live_count():
+    return int(load_library().vbx_comm_live_count())
 
 
 def comm_unique_id():
