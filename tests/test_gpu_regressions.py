@@ -44,13 +44,13 @@ def test_find_formants_time_sliced_uneven_last_utterance(vb, oracle, pkg, monkey
             assert np.array_equal(a["formants"][t], est), (s, t)
 
 
-def _mixed_degree_polys(rng, n, length=13):
+def _mixed_degree_polys(rng, n, length=13, deg_even=8, deg_odd=12):
     """One wave's worth (and a ragged second wave) of polynomials whose degrees interleave: lane 0 holds a LOW degree,
     lane 1 a constant (Err), even lanes degree 8, odd lanes degree 12 -- the wave's maximum is never in lane 0."""
     P = np.zeros((n, length), dtype=np.complex128)
     for f in range(n):
         lane = f % 64
-        deg = 3 if lane == 0 else 0 if lane == 1 else 8 if lane % 2 == 0 else 12
+        deg = 3 if lane == 0 else 0 if lane == 1 else deg_even if lane % 2 == 0 else deg_odd
         if lane == 5:
             deg = 2                                          # closed-form tail only: leaves the k loop at once
         if lane == 7:
@@ -82,7 +82,7 @@ def test_find_roots_mixed_degrees_in_one_wave(vb, oracle):
 
 def test_find_roots_f32_mixed_degrees_in_one_wave(vb, oracle):
     rng = np.random.default_rng(32)
-    P = _mixed_degree_polys(rng, 64, length=10).astype(np.complex64)
+    P = _mixed_degree_polys(rng, 64, length=10, deg_even=6, deg_odd=9).astype(np.complex64)
     P[P.real != 0] = np.clip(P[P.real != 0].real, -1.0, 1.0)
     for f in range(64):                                      # keep the leading coefficients at 1 after clipping
         nz = np.nonzero(P[f])[0]

@@ -14,7 +14,10 @@ tests/test_oracle_soak.py).  What is held to it:
 Tolerances are north_star's: autocorrelation / LPC / MFCC / Burg 1e-6 relative (floor 1e-6 of the row's largest entry),
 pitch and formant Hz 1e-4 relative, statuses and counts exact.
 
-The one class with a non-zero allowance: TOP-CANDIDATE TIE SWAPS.  The reference's Brent iteration is chaotic below its
+Two classes have a non-zero allowance.  (1) LEVINSON ROWS: order-12 Levinson on a 48 kHz frame is ill-conditioned; a handful
+of rows (observed: 4 of 50,000, 1 of 20,000) differ from the oracle by more than 1e-6 on one tiny coefficient.  Each such row
+is adjudicated against the same recursion in long double: zero rows may be further from it than 1e-6 AND twice the oracle's
+own distance (`*_beyond_oracle_rounding`), and the rows themselves are bounded at 1 per 5,000.  (2) TOP-CANDIDATE TIE SWAPS.  The reference's Brent iteration is chaotic below its
 own stopping width, so two candidates whose oracle strengths differ by less than 1e-3 may come out
 in the other order (top against runner-up, or runner-up against third at kmax = 2).  Allowed: 1 per 10,000 frames per
 class, and none of them may flip voiced <-> unvoiced outside a 1e-4 tie; the counts observed on the GPU are written to
@@ -42,6 +45,33 @@ def _rows_bad(got, exp, rtol=1e-6):
     scale = np.max(np.abs(exp), axis=1, keepdims=True)
     ok = np.abs(got - exp) <= rtol * np.maximum(np.abs(exp), 1e-6 * scale) + 1e-300
     return np.nonzero(~np.all(ok, axis=1))[0]
+
+
+def _lpc_adjudicate(frames_windowed, got, exp, rows):
+    """Rows where the GPU's Levinson coefficients and the oracle's differ by more than 1e-6 in the parity metric: who is
+    right?  Order-12 Levinson on the autocorrelation of a 48 kHz speech frame is ill-conditioned (the recursion divides by
+    the prediction error, ~1e-5 of r[0] here), so BOTH f64 results carry rounding of their own lag sums amplified by 1e5 and
+    more, and a coefficient that happens to be tiny against the row's largest is held to an absolute 1e-12 by the metric.
+    The same recursion in long double (x87 80-bit) on long-double lag sums of the same frame is the arbiter: a row counts
+    as a GPU error only if the GPU is further from it than 1e-6 AND than twice the oracle's own distance.
+    Returns (rows beyond the oracle's own rounding, worst GPU distance / worst oracle distance over the rows)."""
+    beyond, worst_g, worst_o = 0, 0.0, 0.0
+    for t in rows:
+        xl = frames_windowed(t).astype(np.longdouble)
+        n, p = xl.size, got.shape[1] - 1
+        rl = np.array([xl[0] + np.sum(xl[1:n - k] * xl[1 + k:n]) for k in range(p + 1)])     # src/periodic.rs:284: seeded with x[0]
+        al = np.zeros(p + 1, dtype=np.longdouble); al[0] = 1; err = rl[0]
+        for i in range(1, p + 1):                                                              # src/spectrum.rs:63-84
+            kk = -(rl[i] + sum(al[j] * rl[i - j] for j in range(1, i))) / err
+            tl = al.copy(); al[i] = kk
+            for j in range(1, i):
+                al[j] = tl[j] + kk * tl[i - j]
+            err = err * (1 - kk * kk)
+        dev = lambda v: float(np.max(np.abs(v - al) / np.maximum(np.abs(al), 1e-6 * np.max(np.abs(al)))))
+        dg, do = dev(got[t]), dev(exp[t])
+        worst_g, worst_o = max(worst_g, dg), max(worst_o, do)
+        beyond += int(dg > max(1e-6, 2.0 * do))
+    return beyond, worst_g, worst_o
 
 
 def _formant_classes(oracle, gpu, s, est0, seg):
@@ -121,7 +151,12 @@ def test_soak_pipeline_shard(vb, oracle, pkg):
 
     # ---- LPC and MFCC columns of the fused loop ------------------------------------------------------------------
     l0, ln = cols["lpc"]; m0, mn = cols["mfcc"]
-    cls["fused_lpc_1e-6"] = int(_rows_bad(rec[:, l0:l0 + ln], s["a"]).size)
+    lpc_rows = _rows_bad(rec[:, l0:l0 + ln], s["a"])
+    wh = oracle.window("hanning", N48)
+    beyond, wg, wo = _lpc_adjudicate(lambda t: audio[t * H48:t * H48 + N48] * wh, rec[:, l0:l0 + ln], s["a"], lpc_rows)
+    cls["fused_lpc_vs_oracle_1e-6"] = int(lpc_rows.size)         # both sides' own rounding (see _lpc_adjudicate): bounded below
+    cls["fused_lpc_beyond_oracle_rounding"] = beyond
+    lpc_note = {"rows": [int(t) for t in lpc_rows[:8]], "worst_gpu_vs_long_double": wg, "worst_oracle_vs_long_double": wo}
     cls["mfcc_status"] = int(np.sum(st3[2] != s["mfcc_status"]))
     cls["fused_mfcc_1e-6"] = int(_rows_bad(rec[:, m0:m0 + mn], s["mfcc"]).size)
 
@@ -134,13 +169,14 @@ def test_soak_pipeline_shard(vb, oracle, pkg):
 
     voiced = int(np.sum(e_top[:, 0] > 0))
     REPORT["pipeline"] = {"frames": F, "voiced": voiced, "unvoiced": F - voiced, "oracle_seconds": round(wall, 1),
-                          "oracle_threads": oracle.usable_cores(), "disagreements": cls}
+                          "oracle_threads": oracle.usable_cores(), "disagreements": cls, "lpc_ill_conditioned_rows": lpc_note}
     print("\nsoak pipeline:", REPORT["pipeline"])
     # the runner-up of an unvoiced frame is a noise candidate: <= 0.5 % of those refinements end on the other side of the
     # lag discontinuity (same frequency, another strength) -- _check_pitch in test_gpu_parity.py
     # classifies them candidate by candidate, here they are only bounded (1 % of the frames)
     allowed = {"pitch_top_tie_swap": F // 10000, "fused_pitch_top_tie_swap": F // 10000,
-               "pitch_runner_up_tie_swap": F // 1000, "pitch_runner_up_bad": F // 100}
+               "pitch_runner_up_tie_swap": F // 1000, "pitch_runner_up_bad": F // 100,
+               "fused_lpc_vs_oracle_1e-6": F // 5000}      # observed 4 of 50,000, none of them beyond the oracle's own rounding
     bad = {k: v for k, v in cls.items() if v > allowed.get(k, 0)}
     assert not bad, f"disagreements with the oracle over {F} consecutive frames: {bad} (all classes: {cls})"
     assert voiced > F // 2 and F - voiced > F // 10           # the stretch holds both kinds of frame
@@ -156,10 +192,15 @@ def test_soak_config2(vb, oracle, pkg):
     r, a = vb.autocorr_lpc(audio_d, P, frame_len=512, stride=512, n_frames=F, window=han)
     audio_d.free()
     s = oracle.soak(audio, 512, 512, 0, F, P, SR, oracle.SOAK_LPC)
-    cls = {"autocorr_1e-6": int(_rows_bad(r, s["r"]).size), "lpc_1e-6": int(_rows_bad(a, s["a"]).size)}
-    REPORT["config2"] = {"frames": F, "disagreements": cls}
+    rows = _rows_bad(a, s["a"])
+    wh = oracle.window("hanning", 512)
+    beyond, wg, wo = _lpc_adjudicate(lambda t: audio[t * 512:(t + 1) * 512] * wh, a, s["a"], rows)
+    cls = {"autocorr_1e-6": int(_rows_bad(r, s["r"]).size), "lpc_vs_oracle_1e-6": int(rows.size), "lpc_beyond_oracle_rounding": beyond}
+    REPORT["config2"] = {"frames": F, "disagreements": cls,
+                         "lpc_ill_conditioned_rows": {"rows": [int(t) for t in rows[:8]], "worst_gpu_vs_long_double": wg,
+                                                      "worst_oracle_vs_long_double": wo}}
     print("\nsoak config2:", REPORT["config2"])
-    assert not any(cls.values()), cls
+    assert cls["autocorr_1e-6"] == 0 and cls["lpc_beyond_oracle_rounding"] == 0 and cls["lpc_vs_oracle_1e-6"] <= F // 5000, cls
 
 
 def test_soak_config4(vb, oracle, pkg):

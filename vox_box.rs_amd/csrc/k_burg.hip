@@ -9,6 +9,21 @@
 // lane permute: no LDS, no serial loop), one fused update sweep.
 // The shrinking valid range [0, N-i) is kept by zeroing exactly the element that drops out.
 // Short frames use small groups so that the per-order overhead is shared by several frames.
+//
+// The denominator.  The reference sums b1^2 + b2^2 over the valid range at every order (:118-121).  With mu = 2 num / den
+// the updated arrays satisfy, exactly in real arithmetic,
+//     den' = (1 - mu^2) den - (b1[last] - mu b2[last])^2 - (b2[0] - mu b1[0])^2
+// (the two elements that leave the range: `last` = the one the update zeroes, and the one the shift drops at the front),
+// which costs two broadcasts instead of 2 EPL FMAs and a group reduction per order -- a quarter of the kernel's vector
+// instructions, and the kernel is vector-issue bound.  Its rounding differs from the direct sums' by ~eps / (1 - mu^2)
+// per order (relative), so it is used only while that stays far inside the 1e-6 coefficient tolerance: after an order with
+// 1 - mu^2 < 2^-20, or once den' has fallen below 2^-24 of the first order's den (absolute errors ~eps * den_1 would show),
+// the next order sums directly again.  The status test `den <= 0` (:123-125) can only fire on a directly summed
+// denominator: a recursion value that small has already handed over to the direct sums.  Only the one-frame-per-wavefront
+// form (G = 64: frames of more than 1024 samples) does this: there the choice is a scalar branch that depends on the frame
+// alone (a frame's result must not depend on which frames share its wavefront), and that is where it pays (measured:
+// Burg at N = 1200 23.4 -> 19.5 ms per 4.5 M frames; at N = 512 with four frames per wavefront the permutes cost what the
+// FMAs save).
 #include "vbx_device.hpp"
 #include "vbx_kernels.hpp"
 
@@ -79,23 +94,34 @@ __global__ __launch_bounds__(64) void burg_kernel(
     int st = 0;
     double aa = 0.0, co = 0.0;                       // lane t of the group: aa[t], coeffs[t]  (src/spectrum.rs:116-139)
     const int gbase = lane - lig;
+    constexpr bool DEN_RECURSION = (G == 64);
+    bool den_known = false;                          // den of this order follows from the previous order (wave-uniform)
+    double den_next = 0.0, den_first = 0.0;
     for (int i = 1; i <= p; i++) {
-        // six independent accumulators (even / odd slots; b1^2 and b2^2 apart): one chain of 3 EPL dependent FMAs was the
+        // independent accumulators (even / odd slots; b1^2 and b2^2 apart): one chain of 3 EPL dependent FMAs was the
         // latency of the whole order
-        double num0 = 0.0, num1 = 0.0, da0 = 0.0, da1 = 0.0, db0 = 0.0, db1 = 0.0;
+        double num0 = 0.0, num1 = 0.0;
 #pragma unroll
         for (int e = 0; e + 1 < EPL; e += 2) {
             num0 = fma(b1[e], b2[e], num0);
             num1 = fma(b1[e + 1], b2[e + 1], num1);
-            da0 = fma(b1[e], b1[e], da0);
-            da1 = fma(b1[e + 1], b1[e + 1], da1);
-            db0 = fma(b2[e], b2[e], db0);
-            db1 = fma(b2[e + 1], b2[e + 1], db1);
         }
-        if (EPL & 1) { num0 = fma(b1[EPL - 1], b2[EPL - 1], num0); da0 = fma(b1[EPL - 1], b1[EPL - 1], da0); db0 = fma(b2[EPL - 1], b2[EPL - 1], db0); }
-        double num = num0 + num1, den = (da0 + da1) + (db0 + db1);
-        num = group_sum<G>(num);
-        den = group_sum<G>(den);
+        if (EPL & 1) num0 = fma(b1[EPL - 1], b2[EPL - 1], num0);
+        double num = group_sum<G>(num0 + num1), den;
+        if (den_known) den = den_next;
+        else {
+            double da0 = 0.0, da1 = 0.0, db0 = 0.0, db1 = 0.0;
+#pragma unroll
+            for (int e = 0; e + 1 < EPL; e += 2) {
+                da0 = fma(b1[e], b1[e], da0);
+                da1 = fma(b1[e + 1], b1[e + 1], da1);
+                db0 = fma(b2[e], b2[e], db0);
+                db1 = fma(b2[e + 1], b2[e + 1], db1);
+            }
+            if (EPL & 1) { da0 = fma(b1[EPL - 1], b1[EPL - 1], da0); db0 = fma(b2[EPL - 1], b2[EPL - 1], db0); }
+            den = group_sum<G>((da0 + da1) + (db0 + db1));
+            if (i == 1) den_first = den;
+        }
         if (st == 0 && den <= 0.0) st = 1;           // Err(LPC), src/spectrum.rs:123-125 (NaN falls through)
         const double c = 2.0 * num / den;
         {   // coeffs[i-1] = c;  coeffs[j-1] = aa[j-1] - c * aa[i-j-1], j = 1..i-1   (t = j-1 <-> lane t)
@@ -111,6 +137,7 @@ __global__ __launch_bounds__(64) void burg_kernel(
             const double f1 = from_next_lane(b1[0]), f2 = from_next_lane(b2[0]);
             const double nb1 = last_lane ? 0.0 : f1;
             const double nb2 = last_lane ? 0.0 : f2;
+            const double e_front = fma(-a, b1[0], b2[0]);    // lane 0 of the group: the element the shift drops, b2[0] - mu b1[0]
 #pragma unroll
             for (int e = 0; e < EPL; e++) {
                 const double b1n = (e + 1 < EPL) ? b1[e + 1] : nb1;   // old b1[j+1]
@@ -122,11 +149,22 @@ __global__ __launch_bounds__(64) void burg_kernel(
             }
             // element n-i-1 leaves the valid range (the update loop runs j-1 < n-i-1)
             const int drop = n - i - 1;
+            den_known = false;
             if (drop >= 0) {
                 const int kb = __builtin_amdgcn_readfirstlane(drop % EPL), lb = drop / EPL;
+                double e_back = 0.0;                 // lane lb of the group: b1[last] - mu b2[last], just computed
 #pragma unroll
                 for (int e = 0; e < EPL; e++)
-                    if (e == kb) { asm volatile("" : "+v"(b1[e]), "+v"(b2[e])); if (lig == lb) { b1[e] = 0.0; b2[e] = 0.0; } }
+                    if (e == kb) { asm volatile("" : "+v"(b1[e]), "+v"(b2[e])); e_back = b1[e]; if (lig == lb) { b1[e] = 0.0; b2[e] = 0.0; } }
+                if constexpr (DEN_RECURSION) {
+                    // the next order's denominator from this one (header comment); the two dropped elements by one
+                    // lane broadcast each (lb is a scalar)
+                    const double eb = readlane_f64(e_back, __builtin_amdgcn_readfirstlane(lb)), ef = readlane_f64(e_front, 0);
+                    const double omm = fma(-a, a, 1.0);
+                    den_next = fma(-ef, ef, fma(-eb, eb, omm * den));
+                    const bool fine = omm > 0x1p-20 && den_next > den_first * 0x1p-24;     // NaN: not fine
+                    den_known = __builtin_amdgcn_readfirstlane((int)fine) != 0;            // identical in every lane
+                }
             }
         }
     }

@@ -44,9 +44,17 @@ __device__ __forceinline__ double from_next_lane(double v) { return dpp_f64<DPP_
 // value of lane-1 (lane 0 receives 0)
 __device__ __forceinline__ double from_prev_lane(double v) { return dpp_f64<DPP_WAVE_SHR1>(v); }
 
+// A value the compiler must treat as computed: stops FP contraction from fusing the multiplication that produced it into
+// a following addition.  A product that feeds a cross-lane sum must be ROUNDED before the exchange -- fused as
+// fma(a_i, k_i, dpp(round(a_j k_j))) in lane i and fma(a_j, k_j, dpp(round(a_i k_i))) in lane j, the two partners of a
+// butterfly step end up an ulp apart, and the "bit-identical in every lane of the group" property of group_sum is gone
+// (whether the compiler fuses depends on the inlining context: the same source gave different bits in two kernels).
+__device__ __forceinline__ double rounded(double v) { asm volatile("" : "+v"(v)); return v; }
+
 // Sum over the 64 lanes; the result is bit-identical in every lane (it is broadcast from
 // scalar registers), which keeps data-dependent control flow wave-uniform.
 __device__ __forceinline__ double wave_sum(double v) {
+    v = rounded(v);
     // all-reduce inside each 16-lane row by rotations (full-rate DPP moves)
     v += dpp_f64<DPP_ROW_ROR8>(v);
     v += dpp_f64<DPP_ROW_ROR4>(v);
@@ -99,6 +107,7 @@ constexpr int DPP_ROW_MIRROR = 0x140;       // i <-> 15-i inside each 16 lanes
 template <int G>
 __device__ __forceinline__ double group_sum(double v) {
     static_assert(G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "group size");
+    v = rounded(v);                              // a product that arrives here is rounded before the first exchange
     v += dpp_f64<DPP_QUAD_XOR1>(v);
     v += dpp_f64<DPP_QUAD_REV>(v);
     if (G >= 8) v += dpp_f64<DPP_ROW_HALF_MIRROR>(v);

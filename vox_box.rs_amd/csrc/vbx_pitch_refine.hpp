@@ -148,7 +148,7 @@ __device__ __forceinline__ double sinc_terms_fast(const double *y, int ibase_l, 
     }
     const double k = s0 * (0.5 * 0.31830988618379067154);     // sin(pi*ph) / pi, and the 0.5 of the taper
     const double acc = acc0 + acc1;
-    return ((n0 & 1) ? -acc : acc) * k;
+    return rounded(((n0 & 1) ? -acc : acc) * k);       // rounded before the cross-lane sum (vbx_device.hpp)
 }
 
 // interpolate_sinc (src/periodic.rs:29-87), cooperative over groups of G lanes; the arguments are
@@ -321,6 +321,88 @@ __device__ __forceinline__ void improve_extremum_sinc(const double *y, int nvali
         }
     }
     if (run) { xmid = x; ymid = fx; }
+}
+
+// The same refinement when the whole wavefront works on ONE candidate (G = 64, every lane active, every argument identical
+// in all lanes) and the bracket is trusted (sinc_bracket_trusted): every value of the Brent iteration is then identical
+// in all lanes, so every decision is taken ONCE, as a scalar branch (__any of a uniform condition is the condition), instead
+// of being if-converted into per-lane selects whose both sides execute: the parabolic step with its IEEE division runs only
+// when it is taken (a quarter of the steps), the bookkeeping of (a, b, v, w, x, fv, fw, fx) becomes register moves on the
+// taken path.  Same operations on the same values in the same order as improve_extremum_sinc<64>: bit-identical results
+// (tests/test_gpu_parity.py::test_improve_extremum_points compares the two forms).  Returns false when the bracket is not
+// trusted or an early-out applies (the caller then takes the general form).
+__device__ __forceinline__ bool improve_extremum_sinc_wave(const double *y, int nvalid, int ylen, int offset, int nx,
+                                                           double ixmid, int depth, double &xmid, double &ymid,
+                                                           unsigned &terms, unsigned &evals, double bar, bool &pruned) {
+#pragma clang fp contract(off)   // keep the scalar iteration bit-identical to the unfused CPU arithmetic
+    const double golden = 1. - 0.6180339887498948482045868343656381177203091798057628621;
+    const double sqrt_epsilon = 1.4901161193847656e-08;   // sqrt(f64::EPSILON)
+    const double eps = 2.220446049250313e-16;
+    const double tol = 1e-10;
+    if (__any(ixmid == 0. || ixmid >= (double)nx || !(ixmid - 1. < ixmid + 1.))) return false;   // :193-194, :113
+    double a = ixmid - 1., b = ixmid + 1.;
+    if (!__any(sinc_bracket_trusted(a, b, nvalid, ylen, offset, nx, depth))) return false;
+    // one evaluation of the interpolant at a trusted abscissa (sinc_interp<64>'s trusted arm, decisions as scalar branches)
+    auto eval = [&](double x) -> double {
+        const double fl = floor(x);
+        const int nl = (int)fl, nr = nl + 1;
+        const double phil = x - fl, phir = 1.0 - phil;
+        if (__any(fabs(x - (double)nl) < 1.0e-10)) return y[offset + nl];                        // :41
+        if (__any(fabs(x - (double)nr) < 1.0e-10)) return y[offset + nr];                        // :42
+        int md = depth;
+        if ((offset + nr) < md) md = offset + nr;                                                // :46-52 (offset + nr >= 1 here)
+        if ((offset + nl + md) >= nx) md = nx - offset + nl - 1;                                 // :55-57
+        terms += 2u * (unsigned)(md + 1);
+        return group_sum<64>(sinc_terms_fast<64>(y, offset + nr, offset + nl, phil, phir, md));
+    };
+    double v = a + golden * (b - a);
+    double fv = eval(v);
+    evals += 1u;
+    double x = v, w = v, fx = fv, fw = fv;
+    // a >= -offset: every abscissa of the bracket has its left neighbour at index >= 0, so none of the evaluations a
+    // pruned candidate skips could have been an out-of-bounds panic of the reference
+    const bool prunable = __any(a >= (double)(-offset));
+    pruned = false;
+    if (prunable && __any(((fv <= 1.) ? fv : 1.) < bar)) { pruned = true; return true; }          // f(v0) already caps the strength
+    for (int it = 1; it <= 60; it++) {
+        const double range = b - a;
+        const double middle_range = (a + b) * 0.5;
+        const double tol_act = sqrt_epsilon * fabs(x) + tol / 3.;
+        if (__any(fabs(x - middle_range) + range * 0.5 <= 2. * tol_act)) break;
+        double new_step = __any(x < middle_range) ? golden * (b - x) : golden * (a - x);
+        if (__any(fabs(x - w) >= tol_act)) {
+            const double t = (x - w) * (fx - fv);
+            double q = (x - v) * (fx - fw);
+            double p = (x - v) * q - (x - w) * t;
+            q = 2. * q - t;
+            if (__any(q > 0.)) p = -p; else q = -q;
+            if (__any(fabs(p) < fabs(new_step * q) && p > q * (a - x + 2. * tol_act) && p < q * (b - x - 2. * tol_act)))
+                new_step = p / q;
+        }
+        if (__any(fabs(new_step) < tol_act)) new_step = __any(new_step > 0.) ? tol_act : -tol_act;
+        const double t = x + new_step;
+        const double ft = eval(t);
+        evals += 1u;
+        if (__any(ft <= fx)) {
+            if (__any(t < x)) b = x; else a = x;
+            v = w; w = x; x = t;
+            fv = fw; fw = fx; fx = ft;
+        } else {
+            if (__any(t < x)) a = t; else b = t;
+            if (__any(ft <= fw || fabs(w - x) < eps)) {
+                v = w; w = t;
+                fv = fw; fw = ft;
+            } else if (__any(ft <= fv || fabs(v - x) < eps || fabs(v - w) < eps)) {
+                v = t;
+                fv = ft;
+            }
+        }
+        // brent_maximize only ever replaces fx by a smaller value (:162): the final strength is <= the current fx
+        // (<= 1 here, so the reflection of :446 does not apply).  Strictly below the bar it cannot be returned.
+        if (prunable && __any(fx < bar)) { pruned = true; return true; }
+    }
+    xmid = x; ymid = fx;
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -664,7 +746,10 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
             double freq, nn, xmid, ymid;
             cand_from_peak(ys, cand_list[c], sample_rate, offset, freq, nn);
             bool dropped = false;
-            improve_extremum_sinc<64>(ys, nvalid, ylen, offset, nx, nn, 1200, true, xmid, ymid, st, &cterms, &cevals, bar, &dropped);
+#ifndef VBX_EXP_NO_WAVE_BRENT
+            if (!improve_extremum_sinc_wave(ys, nvalid, ylen, offset, nx, nn, 1200, xmid, ymid, cterms, cevals, bar, dropped))
+#endif
+                improve_extremum_sinc<64>(ys, nvalid, ylen, offset, nx, nn, 1200, true, xmid, ymid, st, &cterms, &cevals, bar, &dropped);
             if (dropped) continue;
             double xm, ym;
             {
