@@ -603,10 +603,14 @@ def test_pitch_whole_vec(vb, oracle, audio, pkg):
     assert np.array_equal(cnt1, cnt) and np.array_equal(st1, st)
     again, cnt2, _ = vb.pitch(x, SR, 0.2, 75.0, 600.0, kmax=int(cnt1.max()))
     assert np.array_equal(again, full[:, :int(cnt1.max())]) and np.array_equal(cnt2, cnt)
-    # the lane-resident lists (kmax <= 64, pruned) are bit for bit the head of the whole Vec
-    for kmax in (1, 8, 64):
+    # the lane-resident lists (4 <= kmax <= 64, pruned) are bit for bit the head of the whole Vec; kmax = 1 (the other
+    # class of kmax, see test_pitch_topk_is_the_prefix_of_the_full_list) within the Brent iteration's scatter
+    for kmax in (4, 8, 64):
         head, c, s_ = vb.pitch(x, SR, 0.2, 75.0, 600.0, kmax=kmax)
         assert np.array_equal(head, full[:, :kmax]) and np.array_equal(c, cnt) and np.array_equal(s_, st), kmax
+    head, c, s_ = vb.pitch(x, SR, 0.2, 75.0, 600.0, kmax=1)
+    assert np.array_equal(c, cnt) and np.array_equal(s_, st)
+    assert np.all(np.abs(head[:, 0, 0] - full[:, 0, 0]) <= 1e-6 * np.abs(full[:, 0, 0])) and np.all(np.abs(head[:, 0, 1] - full[:, 0, 1]) <= 1e-5)
     # a kmax between 64 and the count: still the head of the same list
     mid, _, _ = vb.pitch(x, SR, 0.2, 75.0, 600.0, kmax=100)
     assert np.array_equal(mid, full[:, :100])
@@ -627,18 +631,38 @@ def test_pitch_whole_vec_other_lengths(vb, oracle, audio, pkg, n):
 @pytest.mark.parametrize("thr", [0.0, 0.2, 0.6, 0.999, 5.0])
 def test_pitch_topk_is_the_prefix_of_the_full_list(vb, oracle, audio, pkg, thr):
     """The refine kernel skips candidates that provably cannot reach the first kmax entries (DESIGN.md
-    "exact top-k pruning").  What is returned must be, bit for bit, the prefix of the unpruned list
-    (a list that never fills, kmax >= count, disables the bound), and count/status must not change."""
+    "exact top-k pruning").  What is returned must be the prefix of the unpruned list (a list that never fills,
+    kmax >= count, disables the bound), and count/status must not change.  BIT FOR BIT inside each of the two classes of
+    kmax -- {1, 2, 3} and {4, ...}: from kmax = 4 on, frames with few candidates refine them four at a time with 16 lanes each
+    instead of one at a time with 64, which changes the last bits of a candidate's sinc sums and with them where the
+    chaotic tail of its Brent iteration lands.  ACROSS the classes: the same candidates in the same order within the Brent
+    iteration's own scatter (1e-6 relative in Hz, 1e-5 in strength: a hundred times inside the parity tolerance), except where
+    two neighbours in the list are closer than that in strength (they may swap)."""
     F = pkg.frame_count(audio.size, N48, H48)
     x = _frames(audio, N48, H48, list(range(0, F, 7))) * oracle.window("hanning", N48)
     full, cnt_full, st_full = vb.pitch(x, SR, thr, 75.0, 600.0, kmax=64)
     assert cnt_full.min() < 64 < cnt_full.max()       # both unpruned and pruned frames in the 64-deep run
-    for kmax in (1, 2, 3, 8):
+    for kmax in (4, 8, 15, 16, 33):
         cand, cnt, st = vb.pitch(x, SR, thr, 75.0, 600.0, kmax=kmax)
         assert np.array_equal(cnt, cnt_full) and np.array_equal(st, st_full)
         assert np.array_equal(cand, full[:, :kmax]), kmax
+    c3, cnt, st = vb.pitch(x, SR, thr, 75.0, 600.0, kmax=3)
+    assert np.array_equal(cnt, cnt_full) and np.array_equal(st, st_full)
+    for kmax in (1, 2):
+        cand, cnt, st = vb.pitch(x, SR, thr, 75.0, 600.0, kmax=kmax)
+        assert np.array_equal(cnt, cnt_full) and np.array_equal(st, st_full)
+        assert np.array_equal(cand, c3[:, :kmax]), kmax
+    # across the classes
+    a, b = c3, full[:, :3]
+    close = (np.abs(a[:, :, 0] - b[:, :, 0]) <= 1e-6 * np.abs(b[:, :, 0])) & (np.abs(a[:, :, 1] - b[:, :, 1]) <= 1e-5)
+    rows = np.nonzero(~np.all(close, axis=1))[0]
+    for f in rows:                                    # a swap of two entries whose strengths are closer than the scatter
+        sa, sb = np.sort(a[f, :, 1]), np.sort(b[f, :, 1])
+        assert np.all(np.abs(sa - sb) <= 1e-5) and np.min(np.abs(np.diff(full[f, :4, 1]))) <= 2e-5, (f, a[f], b[f])
+    assert rows.size <= max(1, x.shape[0] // 100), rows.size
     # and the prefix agrees with the oracle's sorted Vec
     assert _check_pitch(vb, oracle, x[::5], SR, thr, 75.0, 600.0, 1) == 0
+    assert _check_pitch(vb, oracle, x[::9], SR, thr, 75.0, 600.0, 8) == 0
 
 
 def test_pitch_work_counters(vb, oracle, audio, pkg):
@@ -715,10 +739,13 @@ def test_pitch_odd_signals(vb, oracle):
             lambda: np.sin(2 * np.pi * 120 * t) * (1 + 0.5 * np.sin(2 * np.pi * 7 * t)) + 0.2 * rng.standard_normal(N),
             lambda: np.clip(3 * np.sin(2 * np.pi * rng.uniform(75, 600) * t), -1, 1)]
     X = np.array([gens[i % len(gens)]() * w for i in range(200)])
-    res = {k: vb.pitch(X, SR, 0.2, 75.0, 600.0, kmax=k) for k in (1, 3, 64)}
-    for k in (1, 3):
+    res = {k: vb.pitch(X, SR, 0.2, 75.0, 600.0, kmax=k) for k in (1, 3, 8, 64)}
+    for k in (1, 3, 8):
         assert np.array_equal(res[k][1], res[64][1]) and np.array_equal(res[k][2], res[64][2])
-        assert np.array_equal(res[k][0], res[64][0][:, :k]), k
+    # bit for bit inside a class of kmax ({1, 2, 3} and {4, ...}: test_pitch_topk_is_the_prefix_of_the_full_list)
+    assert np.array_equal(res[1][0], res[3][0][:, :1]) and np.array_equal(res[8][0], res[64][0][:, :8])
+    # (the head of the kmax = 64 list is held to the oracle below, through _check_pitch at kmax = 8)
+    assert _check_pitch(vb, oracle, X[::4], SR, 0.2, 75.0, 600.0, 8, label="odd signals, kmax 8") == 0
     # the head of the list against the oracle, every disagreement counted (see _check_pitch)
     assert _check_pitch(vb, oracle, X, SR, 0.2, 75.0, 600.0, 1, label="odd signals") == 0
 

@@ -179,8 +179,12 @@ __device__ __forceinline__ void fft1200(double (&re)[20], double (&im)[20], doub
 // MODE: SP_ANALYZE the fused analysis; SP_MFCC_ONLY MFCC::mfcc alone (vbx_mfcc_f64 on a full frame): the forward transform and
 // the mel / DCT tail, nothing after them; SP_AC_ONLY Autocorrelate::autocorrelate alone (vbx_autocorrelate_f64 with many lags):
 // both transforms, the fold seed, the lag sums stored.
-template <bool LPC, bool MFCC, bool FULL, int MODE = SP_ANALYZE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_MFCC_ONLY ? 2 : VBX_SPECTRAL_WAVES, MODE == SP_MFCC_ONLY ? 4 : VBX_SPECTRAL_WAVES))) void analyze_kernel(const spectral_args_t a) {
+// WAVES: wavefronts per SIMD the kernel is compiled for.  2 (the default: no spills) for kmax = 1, where the two transforms
+// are a third of the kernel; 3 for 2 <= kmax <= 64, where the kernel is almost all refinement -- chains of dependent FP64
+// operations that two wavefronts do not cover (measured at kmax = 2 / 8 / 64: 12.1 -> 13.6, 4.55 -> 5.65, 2.2 -> 2.7 M
+// frames/s; kmax = 1: 32.5 -> 31.7, hence the split).  The transforms then spill ~55 registers, which the refinement hides.
+template <bool LPC, bool MFCC, bool FULL, int MODE = SP_ANALYZE, int WAVES = VBX_SPECTRAL_WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_MFCC_ONLY ? 2 : WAVES, MODE == SP_MFCC_ONLY ? 4 : WAVES))) void analyze_kernel(const spectral_args_t a) {
     static_assert(MODE != SP_MFCC_ONLY || (MFCC && FULL && !LPC), "the MFCC-only form needs the full frame and has no lag sums");
     static_assert(MODE != SP_AC_ONLY || (!MFCC && !LPC), "the autocorrelation-only form");
     constexpr bool PITCH = MODE != SP_MFCC_ONLY;             // the second transform runs
@@ -507,12 +511,17 @@ void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
         else hipLaunchKernelGGL((analyze_kernel<false, false, false, SP_AC_ONLY>), grid, block, spectral_lds_bytes(0), s, a);
         return;
     }
+    // several candidates per frame and no full-list region in LDS (12 wavefronts of 13.5 KB fit the CU): the form compiled
+    // for three wavefronts per SIMD (pitch alone; the fused frame loop keeps kmax = 1)
+    const bool w3 = !lpc && !mf && L.kmax >= 2 && extra == 0 && 12 * lds <= 160 * 1024;
     if (L.n != SP_N) {                                       // spectral_supported(): no MFCC from a padded transform
         if (lpc) hipLaunchKernelGGL((analyze_kernel<true, false, false>), grid, block, lds, s, a);
+        else if (w3) hipLaunchKernelGGL((analyze_kernel<false, false, false, SP_ANALYZE, 3>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((analyze_kernel<false, false, false>), grid, block, lds, s, a);
     } else if (lpc && mf) hipLaunchKernelGGL((analyze_kernel<true, true, true>), grid, block, lds, s, a);
     else if (lpc) hipLaunchKernelGGL((analyze_kernel<true, false, true>), grid, block, lds, s, a);
     else if (mf) hipLaunchKernelGGL((analyze_kernel<false, true, true>), grid, block, lds, s, a);
+    else if (w3) hipLaunchKernelGGL((analyze_kernel<false, false, true, SP_ANALYZE, 3>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((analyze_kernel<false, false, true>), grid, block, lds, s, a);
 }
 

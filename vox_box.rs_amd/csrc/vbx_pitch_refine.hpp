@@ -419,6 +419,13 @@ typedef unsigned short cand_t;                  // candidate lags (< 2048)
 constexpr int PG = 16;                          // lanes per query point (sinc_points / extremum_points kernels)
 constexpr int PNG = 64 / PG;                    // points per wavefront
 constexpr int GROUP_PATH_MIN_CAND = 32;         // pitch frames with more candidates refine them 4 at a time, 16 lanes each
+#ifndef VBX_EXP_RG
+#define VBX_EXP_RG 16
+#endif
+#ifndef VBX_EXP_GROUP_KMAX
+#define VBX_EXP_GROUP_KMAX 4                    // kmax from which frames with few candidates take the group path too
+#endif
+constexpr int RG = VBX_EXP_RG;                  // lanes per candidate on the group path of pitch_refine_store
 
 __device__ __forceinline__ void cand_from_peak(const double *ys, int kk, double sample_rate, int offset,
                                                double &freq, double &nn) {
@@ -734,11 +741,15 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
     // other candidate without an evaluation.  Finished candidates enter the lane-resident list ordered by
     // (strength desc, candidate index asc) == the reference's stable sort (:453).
     // Frames with many candidates (noise-like frames: short lags, little work per evaluation) use four groups of 16
-    // lanes instead, each refining one candidate and taking the next-best as soon as its own has converged.  Which of
-    // the two paths a frame takes depends on its candidate count only, never on kmax: a candidate's result does not
-    // depend on which others are refined, and the returned list is the same head of the same full list.
+    // lanes instead, each refining one candidate and taking the next-best as soon as its own has converged.  So do frames
+    // with at least four candidates when the caller keeps four or more (kmax >= 4): several candidates have to be refined
+    // to the end whatever the bar does, and four at a time share the per-evaluation overhead (+9 % at kmax = 8, +8 % at 64).
+    // A candidate's result does not depend on which others are refined, but its last bits depend on which path summed its
+    // sinc terms (64 or 16 lanes): lists returned for kmax in {1, 2, 3} are bit for bit the head of one another, and so are
+    // the lists for every kmax >= 4; between the two classes a candidate agrees within the Brent iteration's own scatter
+    // (~1e-7 relative in Hz), counts and statuses exactly (tests/test_gpu_parity.py::test_pitch_topk_is_the_prefix...).
     unsigned nterms = 0, nevals = 0;                // group path: work executed (group leaders' counts are summed)
-    if (ncand <= GROUP_PATH_MIN_CAND) {
+    if (ncand <= GROUP_PATH_MIN_CAND && !(kmax >= VBX_EXP_GROUP_KMAX && ncand >= 4)) {
         for (;;) {
             const double bar = VBX_BAR();
             const int c = pick_best(keys, ncand, bar, lane);
@@ -763,12 +774,12 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
         }
     } else {
         bool exhausted = false;
-        const int gid = lane / PG;
+        const int gid = lane / RG;
         int ci = -1, it = 0;
         bool special = false, safe = false, trusted = false;
         double ba = 0., bb = 0., v = 0., w = 0., x = 0., fv = 0., fw = 0., fx = 0., xmid = 0., ymid = 0.;
-        constexpr unsigned long long LEADERS = (PG == 16) ? 0x0001000100010001ull : (PG == 8) ? 0x0101010101010101ull
-                                             : (PG == 32) ? 0x0000000100000001ull : (PG == 4) ? 0x1111111111111111ull : 1ull;
+        constexpr unsigned long long LEADERS = (RG == 16) ? 0x0001000100010001ull : (RG == 8) ? 0x0101010101010101ull
+                                             : (RG == 32) ? 0x0000000100000001ull : (RG == 4) ? 0x1111111111111111ull : 1ull;
         for (;;) {
 #pragma clang fp contract(off)   // the scalar Brent arithmetic stays bit-identical to the unfused CPU arithmetic
             {   // hand the best remaining candidates to the idle groups, in group order
@@ -776,7 +787,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
                 while (im != 0ull && !exhausted) {
                     const int c = pick_best(keys, ncand, VBX_BAR(), lane);
                     if (c < 0) { exhausted = true; break; }
-                    const int g = __builtin_ctzll(im) / PG;
+                    const int g = __builtin_ctzll(im) / RG;
                     im &= im - 1ull;
                     if (gid == g) {
                         ci = c;
@@ -824,7 +835,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
                     }
                 }
             }
-            const double ft = sinc_interp<PG>(ys, nvalid, ylen, offset, nx, t, 1200, need, st, &nterms, trusted);
+            const double ft = sinc_interp<RG>(ys, nvalid, ylen, offset, nx, t, 1200, need, st, &nterms, trusted);
             nevals += need ? 1u : 0u;
             if (need) {
                 if (it == 0) {
@@ -900,7 +911,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
         if (status != nullptr) status[f] = code;
     }
     if (work != nullptr) {                          // profiling only: frames, candidates, sinc evaluations, sinc terms
-        const bool leader = (lane & (PG - 1)) == 0;
+        const bool leader = (lane & (RG - 1)) == 0;
         unsigned long long te = leader ? nterms : 0u, ev = leader ? nevals : 0u;
         for (int o = 32; o > 0; o >>= 1) { te += __shfl_xor(te, o, 64); ev += __shfl_xor(ev, o, 64); }
         if (lane == 0) {
