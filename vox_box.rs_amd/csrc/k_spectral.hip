@@ -425,7 +425,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
     // with w_lag >= 1/6 on the searched half.  SP_UNC_EPS bounds the error of a DIFFERENCE of two entries with a wide
     // margin; frames with a peak decision inside it go to the direct-sum kernel (launch_pitch_list).
     const double unc_tol = SP_UNC_EPS * fabs(s0) * scale;
-    double2 *full = a.pp.full_off ? reinterpret_cast<double2 *>(reinterpret_cast<char *>(smem) + a.pp.full_off) : nullptr;
+    double2 *full = a.pp.full_off > 0 ? reinterpret_cast<double2 *>(reinterpret_cast<char *>(smem) + a.pp.full_off)
+                  : a.pp.full_off < 0 ? reinterpret_cast<double2 *>(a.out_cand + f * a.cand_ld) : nullptr;
     if (!pitch_refine_store(ys, n, a.pp, f, a.out_cand, a.cand_ld, a.out_count, a.pitch_status, a.work, unc_tol, full)) {
         if (lane == 0) a.unsure_list[atomicAdd(a.unsure_count, 1)] = (int32_t)f;
     }
@@ -498,8 +499,13 @@ void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
     a.out_r = L.out_r; a.n_lags = L.n_lags;
     if (L.plan != SPECTRAL_PLAN_1200) { launch_analyze_pow2(s, L, a); return; }
     const dim3 grid((unsigned)L.F), block(64);
-    const size_t base = spectral_lds_bytes(L.n), extra = pitch_full_list_bytes(L.n, L.kmax);
+    const size_t base = spectral_lds_bytes(L.n);
+    size_t extra = pitch_full_list_bytes(L.n, L.kmax);
     a.pp.full_off = extra ? (int)base : 0;
+    // kmax = VBX_PITCH_MAX_CANDIDATES(frame_len) (the whole Vec of every frame fits its output row): the refined candidates
+    // are parked in the row itself instead of an extra LDS region, which keeps the frame state at 13.5 KB = twelve
+    // wavefronts per CU (the form compiled for three wavefronts per SIMD, below)
+    if (extra && L.kmax >= pitch_full_list_entries(L.n) && L.out_r == nullptr && !L.mfcc_only) { a.pp.full_off = -1; extra = 0; }
     const size_t lds = base + extra;
     const bool lpc = L.out_lpc != nullptr, mf = L.out_mfcc != nullptr;
     if (L.mfcc_only) {                                       // spectral_supported(): n == SP_N

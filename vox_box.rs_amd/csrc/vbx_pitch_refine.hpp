@@ -586,7 +586,8 @@ __host__ __device__ constexpr int pitch_refine_lds_bytes(int n) {
 
 struct pitch_params_t { double sample_rate, threshold, fmin, fmax; int kmax; int full_off; };   // full_off: byte offset of
                                                                                                 // the full-list region in the
-                                                                                                // dynamic LDS, 0 = none
+                                                                                                // dynamic LDS, 0 = none, < 0 =
+                                                                                                // the frame's output row
 // entries of the full-list region: at most n/4 strict local maxima in [0, n/2) plus the unvoiced candidate
 __host__ __device__ constexpr int pitch_full_list_entries(int n) { return n / 4 + 2; }
 
@@ -886,6 +887,16 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
     if (st & 4) code = 4; else if (st & 8) code = 3;
     if (fullm) {
         wave_sync();
+        if (pp.full_off < 0) {
+            // the candidates were parked in the frame's own output row (global memory; the launch guarantees that the
+            // row holds the whole Vec): bring them into LDS, over the lag curve that nobody reads any more, and sort there
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            double2 *lds_list = reinterpret_cast<double2 *>(ys);
+            for (int i = lane; i < total_cand; i += 64) lds_list[i] = full[i];
+            full = lds_list;
+            wave_sync();
+        }
         double *row = out_cand + f * cand_ld;
         const int total = (code == 0) ? total_cand : 0;
         for (int i0 = 0; i0 < total; i0 += 64) {
