@@ -87,6 +87,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="wall budget of the CPU baseline leg (both legs together)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-sub", action="store_true", help="skip the sub_benchmarks of the default run (configs 2, 3, 4)")
+    ap.add_argument("--host-fed", action="store_true", help="pipeline only: the recording starts in pinned HOST memory as 16-bit PCM "
+                    "and crosses PCIe inside the timed region, in chunks, double-buffered against the kernels (vbx_analyze_frames_pcm16); "
+                    "reported under its own metric name, never as the headline `value`")
+    ap.add_argument("--chunk-frames", type=int, default=500_000, help="--host-fed: frames per H2D chunk (whole utterances)")
     return ap.parse_args()
 
 
@@ -371,6 +375,89 @@ def bench_frontend(args, torch, dev, vb, pkg):
 
 
 # ------------------------------------------------------------------------------------------------
+# host-fed operation: 16-bit PCM in pinned host memory -> PCIe -> the fused frame loop, chunked and double-buffered
+# ------------------------------------------------------------------------------------------------
+def bench_host_fed(args, torch, dev, vb, pkg):
+    """What a deployment that does not keep the audio on the device pays: the PCIe-inclusive rate.  The recording sits in
+    pinned host memory as 16-bit PCM (960 B of new samples per frame: 63 GB/s of link carry 66 M frames/s, above what the
+    GPU analyses); chunk c+1's copy runs on a copy stream while chunk c is analysed (vbx_analyze_frames_pcm16, which
+    widens in registers), two device buffers.  Records stay on the device (as in the resident bench)."""
+    N, H = N48, H48
+    C = max(SEG_FRAMES, args.chunk_frames - args.chunk_frames % SEG_FRAMES)
+    F = int(round(args.hours * 3600 * SR / H)); F -= F % C; F = max(F, C)
+    n_chunks = F // C
+    ns_chunk = (C - 1) * H + N
+    # build the PCM recording on the device (synthetic speech quantised to int16), park it in pinned host memory
+    host = torch.empty((F - 1) * H + N, dtype=torch.int16).pin_memory()
+    tmp = torch.empty(ns_chunk, dtype=torch.float64, device=dev)
+    for c in range(n_chunks):
+        vb.synth_speech(ns_chunk, sample_offset=c * C * H, sample_rate=SR, out=tmp)
+        torch.cuda.synchronize()
+        host[c * C * H:c * C * H + ns_chunk] = torch.clamp(torch.round(tmp * (0.9 * 32767.0 / 0.5)), -32768, 32767).to(torch.int16).cpu()
+    del tmp
+    est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+    params = pkg.AnalysisParams.make(SR, pitch=(0.2, 75.0, 600.0), lpc_order=P, formant_order=P, est_init=est0, mfcc=(13, 100.0, 8000.0))
+    REC = int(vb.L.vbx_record_doubles(params))
+    rec = torch.empty((F, REC), dtype=torch.float64, device=dev)
+    st3 = torch.empty((3, C), dtype=torch.int32, device=dev)
+    bufs = [torch.empty(ns_chunk, dtype=torch.int16, device=dev) for _ in range(2)]
+    seg = np.arange(0, C, SEG_FRAMES, dtype=np.int64)
+    main = torch.cuda.current_stream()
+    copy = torch.cuda.Stream(device=dev)
+    ready = [torch.cuda.Event() for _ in range(2)]          # chunk landed in bufs[b]
+    freed = [torch.cuda.Event() for _ in range(2)]          # the kernels are done with bufs[b]
+
+    def upload(c):
+        b = c % 2
+        with torch.cuda.stream(copy):
+            copy.wait_event(freed[b])
+            bufs[b].copy_(host[c * C * H:c * C * H + ns_chunk], non_blocking=True)
+            ready[b].record(copy)
+
+    def step(i):
+        for b in range(2):
+            freed[b].record(main)
+        upload(0)
+        for c in range(n_chunks):
+            b = c % 2
+            if c + 1 < n_chunks:
+                upload(c + 1)
+            main.wait_event(ready[b])
+            vb.analyze_frames_pcm16(bufs[b], params, seg_start=seg, frame_len=N, stride=H, n_frames=C,
+                                    out=rec[c * C:(c + 1) * C], record_ld=REC, status=st3)
+            freed[b].record(main)
+    dt, prof, work = timed(vb, torch, step, args.warmup, args.steps)
+    # the same chunks already resident (no copy in the loop): what the link costs
+    def step_resident(i):
+        for c in range(n_chunks):
+            vb.analyze_frames_pcm16(bufs[c % 2], params, seg_start=seg, frame_len=N, stride=H, n_frames=C,
+                                    out=rec[c * C:(c + 1) * C], record_ld=REC, status=st3)
+    dt_res, _, _ = timed(vb, torch, step_resident, 1, args.steps)
+    # the copies alone
+    t0 = time.perf_counter()
+    for c in range(n_chunks):
+        bufs[c % 2].copy_(host[c * C * H:c * C * H + ns_chunk], non_blocking=True)
+    torch.cuda.synchronize()
+    dt_copy = time.perf_counter() - t0
+    kms = {k: round(ms / max(c, 1), 3) for k, (ms, c) in prof.items()}
+    out = {"metric": "frames/sec (host-fed: 16-bit PCM in pinned host memory -> PCIe -> pitch+LPC+formants+MFCC), 48 kHz 25 ms/10 ms hop",
+           "value": F * args.steps / dt, "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"host-fed pipeline, {F} frames ({F * H / SR / 3600:.2f} h) as int16 PCM in pinned host memory, "
+                                  f"chunks of {C} frames, two device buffers, copy stream beside the kernels",
+                      "frames_per_gpu": F, "frame_len": N, "hop": H, "chunk_frames": C, "pcm_bytes_per_frame": 2 * H},
+           "pcie": {"bytes_per_step": int(2 * ns_chunk * n_chunks), "copy_alone_GBps": 2 * ns_chunk * n_chunks / dt_copy / 1e9,
+                    "link_peak_GBps": 63.0, "inclusive_GBps": 2 * ns_chunk * n_chunks * args.steps / dt / 1e9},
+           "same_chunks_resident_frames_per_s": F * args.steps / dt_res,
+           "pcie_inclusive_over_resident": dt_res / dt,
+           "kernels_ms_per_chunk": kms}
+    print(json.dumps(out), flush=True)
+    vb.close()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
 # sub-benchmarks of the default run: BASELINE configs 2, 3 and 4, a few steps each, outside the headline's timed region
 # ------------------------------------------------------------------------------------------------
 def sub_benchmarks(vb, torch, dev, pkg, audio48, F48):
@@ -505,6 +592,10 @@ def run_rank(args):
     f64 = torch.float64
     if wl == "frontend":
         return bench_frontend(args, torch, dev, vb, pkg)
+    if args.host_fed:
+        if wl != "pipeline" or world != 1 or (N, H) != (N48, H48):
+            raise SystemExit("bench.py --host-fed: the default pipeline shape on one GPU only")
+        return bench_host_fed(args, torch, dev, vb, pkg)
     comm = None
     if world > 1:
         # the library's RCCL communicator for the record gather; the 128-byte id travels over the gloo control plane.

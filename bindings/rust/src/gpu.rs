@@ -805,3 +805,360 @@ pub fn find_formants(frames: &FrameBatch, sample_rate: f64, resample_ratio: f64,
     }
     Ok((track, status))
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// spectrum.rs: EstimateFormants / FormantExtractor over resonance rows on the device
+// ---------------------------------------------------------------------------------------------------------------
+
+/// Resonance rows `[F, n_res]` on the device (zero padded, sorted by frequency: what `find_formants` builds at
+/// src/lib.rs:94-110, or whatever the caller uploads).  The receiver of the batched `EstimateFormants`.
+pub struct ResonanceRows<'g> {
+    gpu: &'g Gpu,
+    rows: DeviceBuf<'g, Resonance<f64>>,
+    n_frames: usize,
+    n_res: usize,
+}
+
+impl<'g> ResonanceRows<'g> {
+    /// `rows`: `n_frames * n_res` resonances, row-major.
+    pub fn new(gpu: &'g Gpu, rows: &[Resonance<f64>], n_res: usize) -> GpuResult<ResonanceRows<'g>> {
+        assert!(n_res >= 1 && rows.len() % n_res == 0, "rows must hold whole rows of n_res resonances");
+        Ok(ResonanceRows { gpu, rows: gpu.upload(rows)?, n_frames: rows.len() / n_res, n_res })
+    }
+
+    pub fn n_frames(&self) -> usize {
+        self.n_frames
+    }
+
+    /// `EstimateFormants::estimate_formants` (src/spectrum.rs:232-333) applied frame after frame, the estimates carried
+    /// from each frame to the next exactly as `FormantExtractor::next` does (src/spectrum.rs:357-369): returns the
+    /// estimates after every frame, `[F, estimates.len()]`, and leaves the state after the last frame in `estimates`.
+    /// `seg_start`: frames at which the state restarts from the incoming estimates (`&[]` = one utterance);
+    /// `frame_status`: frames whose status is not `Ok` leave the state untouched (src/lib.rs:75 `?`).
+    /// Utterances of a few hundred frames or more take the library's chunked scan (bit-identical to the sequential one).
+    pub fn estimate_formants_all(&self, estimates: &mut [Resonance<f64>], seg_start: &[i64], frame_status: Option<&[i32]>) -> GpuResult<Vec<Resonance<f64>>> {
+        let gpu = self.gpu;
+        let n_est = estimates.len();
+        let out = gpu.alloc::<Resonance<f64>>(self.n_frames * n_est)?;
+        let st_dev = match frame_status {
+            Some(s) => {
+                assert_eq!(s.len(), self.n_frames);
+                Some(gpu.upload(s)?)
+            }
+            None => None,
+        };
+        let (seg_ptr, n_seg) = if seg_start.is_empty() { (ptr::null(), 0) } else { (seg_start.as_ptr(), seg_start.len()) };
+        gpu.check(unsafe {
+            ffi::vbx_estimate_formants_f64(
+                gpu.raw, self.rows.as_ptr() as *const ffi::VbxResonance, self.n_frames, self.n_res, seg_ptr, n_seg,
+                estimates.as_ptr() as *const ffi::VbxResonance, n_est, st_dev.as_ref().map_or(ptr::null(), |d| d.as_ptr()),
+                out.as_mut_ptr() as *mut ffi::VbxResonance,
+            )
+        })?;
+        let track = out.to_vec()?;
+        if self.n_frames > 0 {
+            estimates.copy_from_slice(&track[(self.n_frames - 1) * n_est..self.n_frames * n_est]);
+        }
+        Ok(track)
+    }
+
+    /// The reference's `FormantExtractor::new(num_formants, resonances, starting_estimates)` (src/spectrum.rs:343-355)
+    /// with the whole scan done up front on the device: an iterator over the per-frame estimate Vecs.
+    pub fn formant_extractor(&self, num_formants: usize, starting_estimates: Vec<Resonance<f64>>) -> GpuResult<FormantExtractor> {
+        assert_eq!(num_formants, starting_estimates.len(), "one starting estimate per formant");
+        let mut est = starting_estimates;
+        let track = self.estimate_formants_all(&mut est, &[], None)?;
+        Ok(FormantExtractor { estimates: est, num_formants, track, next: 0 })
+    }
+}
+
+/// `vox_box::spectrum::FormantExtractor` (src/spectrum.rs:336-369) over a scan the device has already done:
+/// `next()` yields the estimates after each frame; `estimates` holds the state after the last one.
+pub struct FormantExtractor {
+    pub estimates: Vec<Resonance<f64>>,
+    num_formants: usize,
+    track: Vec<Resonance<f64>>,
+    next: usize,
+}
+
+impl Iterator for FormantExtractor {
+    type Item = Vec<Resonance<f64>>;
+
+    fn next(&mut self) -> Option<Vec<Resonance<f64>>> {
+        let n = self.num_formants;
+        if n == 0 || (self.next + 1) * n > self.track.len() {
+            return None;
+        }
+        let row = self.track[self.next * n..(self.next + 1) * n].to_vec();
+        self.next += 1;
+        Some(row)
+    }
+}
+
+/// One frame's `EstimateFormants<f64>` (src/spectrum.rs:216-219) through the library: `self` = the estimates (in/out),
+/// `resonances` = the frame's row.  For code that keeps the reference's per-frame loop; a batch should call
+/// [`ResonanceRows::estimate_formants_all`] once instead.
+pub struct GpuEstimates<'g> {
+    pub gpu: &'g Gpu,
+    pub estimates: Vec<Resonance<f64>>,
+}
+
+impl<'g> vox_box::spectrum::EstimateFormants<f64> for GpuEstimates<'g> {
+    type FormantSlots = [Option<Resonance<f64>>; 6];
+
+    fn estimate_formants(&mut self, resonances: &[Resonance<f64>]) {
+        let rows = expect_gpu(ResonanceRows::new(self.gpu, resonances, resonances.len().max(1)));
+        let mut est = self.estimates.clone();
+        expect_gpu(rows.estimate_formants_all(&mut est, &[], None));
+        self.estimates = est;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the user's frame loop, fused: vbx_analyze_frames_f64 / _pcm16
+// ---------------------------------------------------------------------------------------------------------------
+
+/// What one call of the fused frame loop computes per frame (`vbx_analysis_params`): the parts with order / count 0 are
+/// skipped.  `Default` = the bench's pipeline: pitch (0.2, 75..600 Hz), LPC(12), find_formants(12) from the male
+/// estimates (src/lib.rs:27), MFCC(13, 100..8000 Hz).
+#[derive(Clone, Debug)]
+pub struct AnalysisParams {
+    pub sample_rate: f64,
+    pub pitch: (f64, f64, f64),
+    pub lpc_order: usize,
+    pub formant_order: usize,
+    pub est_init: Vec<Resonance<f64>>,
+    pub mfcc: Option<(usize, f64, f64)>,
+}
+
+impl AnalysisParams {
+    pub fn new(sample_rate: f64) -> AnalysisParams {
+        let est_init = ffi_male_estimates();
+        AnalysisParams { sample_rate, pitch: (0.2, 75.0, 600.0), lpc_order: 12, formant_order: 12, est_init, mfcc: Some((13, 100.0, 8000.0)) }
+    }
+
+    fn to_ffi(&self) -> ffi::VbxAnalysisParams {
+        assert!(self.est_init.len() <= ffi::VBX_FORMANT_SLOTS, "at most 6 formant slots (src/spectrum.rs:228)");
+        let mut est = [ffi::VbxResonance { frequency: 0.0, bandwidth: 0.0 }; ffi::VBX_FORMANT_SLOTS];
+        for (slot, r) in est.iter_mut().zip(self.est_init.iter()) {
+            *slot = ffi::VbxResonance { frequency: r.frequency, bandwidth: r.bandwidth };
+        }
+        let (k, lo, hi) = self.mfcc.unwrap_or((0, 0.0, 0.0));
+        ffi::VbxAnalysisParams {
+            sample_rate: self.sample_rate,
+            pitch_threshold: self.pitch.0,
+            pitch_fmin: self.pitch.1,
+            pitch_fmax: self.pitch.2,
+            lpc_order: self.lpc_order,
+            formant_order: self.formant_order,
+            n_est: if self.formant_order > 0 { self.est_init.len() } else { 0 },
+            est_init: est,
+            mfcc_coeffs: k,
+            mfcc_lo_hz: lo,
+            mfcc_hi_hz: hi,
+        }
+    }
+
+    /// Doubles per record (`vbx_record_doubles`) and the first column of each part: (pitch, formants, mfcc, lpc).
+    pub fn layout(&self) -> (usize, usize, usize, usize, usize) {
+        let p = self.to_ffi();
+        let rec = unsafe { ffi::vbx_record_doubles(&p) };
+        let c_form = 2;
+        let c_mfcc = c_form + 2 * p.n_est;
+        let c_lpc = c_mfcc + p.mfcc_coeffs;
+        (rec, 0, c_form, c_mfcc, c_lpc)
+    }
+}
+
+fn ffi_male_estimates() -> Vec<Resonance<f64>> {
+    vox_box::MALE_FORMANT_ESTIMATES.iter().map(|&f| Resonance::new(f, 1.0)).collect()
+}
+
+/// The records of one fused call: `[F, record_ld]` doubles on the device (the buffer the multi-GPU gather sends) plus
+/// the three status rows.
+pub struct Records<'g> {
+    pub data: DeviceBuf<'g, f64>,
+    pub status3: DeviceBuf<'g, i32>,
+    pub n_frames: usize,
+    pub record_ld: usize,
+}
+
+impl<'g> Records<'g> {
+    /// `(records [F * record_ld], pitch status [F], formant status [F], mfcc status [F])` on the host.
+    pub fn to_host(&self) -> GpuResult<(Vec<f64>, Vec<FrameStatus>, Vec<FrameStatus>, Vec<FrameStatus>)> {
+        let st = self.status3.to_vec()?;
+        let f = self.n_frames;
+        let conv = |s: &[i32]| s.iter().map(|&c| FrameStatus::from_code(c)).collect::<Vec<_>>();
+        Ok((self.data.to_vec()?, conv(&st[0..f]), conv(&st[f..2 * f]), conv(&st[2 * f..3 * f])))
+    }
+}
+
+impl<'g> FrameBatch<'g> {
+    /// The user's whole frame loop in one call (`vbx_analyze_frames_f64`): per frame
+    /// `pitch::<Hanning>(..)[0]`, `autocorrelate(p + 1)` -> `lpc(p)`, `find_formants(..)` with the state carried per
+    /// utterance, `mfcc(..)` -- examples/pitch_detection.rs:23-30, tests/lib.rs:71-83 -- as one fixed-size record per
+    /// frame.  The batch must be a rectangular view (the library applies the Hanning window of the `Windower` and the
+    /// periodic Hanning of `find_formants` itself).
+    pub fn analyze(&self, params: &AnalysisParams, seg_start: &[i64]) -> GpuResult<Records<'g>> {
+        assert!(self.window.is_none(), "analyze applies the windows itself: pass a rectangular view (windower_rectangle)");
+        let gpu = self.gpu;
+        let p = params.to_ffi();
+        let rec = unsafe { ffi::vbx_record_doubles(&p) };
+        let ld = rec + (rec & 1);
+        let data = gpu.alloc::<f64>(self.n_frames * ld)?;
+        let status3 = gpu.alloc::<i32>(3 * self.n_frames)?;
+        let (seg_ptr, n_seg) = if seg_start.is_empty() { (ptr::null(), 0) } else { (seg_start.as_ptr(), seg_start.len()) };
+        gpu.check(unsafe {
+            ffi::vbx_analyze_frames_f64(gpu.raw, self.samples.as_ptr(), self.n_frames, self.frame_len, self.stride, &p, seg_ptr, n_seg,
+                                        data.as_mut_ptr(), ld, status3.as_mut_ptr())
+        })?;
+        Ok(Records { data, status3, n_frames: self.n_frames, record_ld: ld })
+    }
+}
+
+/// 16-bit PCM samples on the device with a `Windower` view over them: what a WAV reader hands the reference's callers
+/// before the `as f64 / 32767` of tests/lib.rs:17-19.  A quarter of the bytes of the f64 view: the form for host-fed
+/// operation.
+pub struct PcmBatch<'g> {
+    gpu: &'g Gpu,
+    samples: DeviceBuf<'g, i16>,
+    n_frames: usize,
+    frame_len: usize,
+    stride: usize,
+}
+
+impl<'g> PcmBatch<'g> {
+    /// `Windower::rectangle(samples, bin, hop)` semantics (frame t = samples[t*hop .. t*hop+bin] while bin <= remaining).
+    pub fn windower(gpu: &'g Gpu, samples: &[i16], bin: usize, hop: usize) -> GpuResult<PcmBatch<'g>> {
+        let n_frames = unsafe { ffi::vbx_frame_count(samples.len(), bin, hop) };
+        Ok(PcmBatch { gpu, samples: gpu.upload(samples)?, n_frames, frame_len: bin, stride: hop })
+    }
+
+    pub fn n_frames(&self) -> usize {
+        self.n_frames
+    }
+
+    /// `samples as f64 / 32767` for every sample, on the device (`vbx_pcm16_to_f64`): the f64 batch of the same view.
+    pub fn widen(&self) -> GpuResult<FrameBatch<'g>> {
+        let out = self.gpu.alloc::<f64>(self.samples.len())?;
+        self.gpu.check(unsafe { ffi::vbx_pcm16_to_f64(self.gpu.raw, self.samples.as_ptr(), self.samples.len(), out.as_mut_ptr()) })?;
+        Ok(FrameBatch::new(self.gpu, out, None, self.n_frames, self.frame_len, self.stride))
+    }
+
+    /// [`FrameBatch::analyze`] reading the PCM directly (`vbx_analyze_frames_pcm16`): bit-identical records to
+    /// `self.widen()?.analyze(..)`.
+    pub fn analyze(&self, params: &AnalysisParams, seg_start: &[i64]) -> GpuResult<Records<'g>> {
+        let gpu = self.gpu;
+        let p = params.to_ffi();
+        let rec = unsafe { ffi::vbx_record_doubles(&p) };
+        let ld = rec + (rec & 1);
+        let data = gpu.alloc::<f64>(self.n_frames * ld)?;
+        let status3 = gpu.alloc::<i32>(3 * self.n_frames)?;
+        let (seg_ptr, n_seg) = if seg_start.is_empty() { (ptr::null(), 0) } else { (seg_start.as_ptr(), seg_start.len()) };
+        gpu.check(unsafe {
+            ffi::vbx_analyze_frames_pcm16(gpu.raw, self.samples.as_ptr(), self.n_frames, self.frame_len, self.stride, &p, seg_ptr, n_seg,
+                                          data.as_mut_ptr(), ld, status3.as_mut_ptr())
+        })?;
+        Ok(Records { data, status3, n_frames: self.n_frames, record_ld: ld })
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// multi-GPU: frame-range sharding and the record gather (one process per GPU, RCCL inside the library)
+// ---------------------------------------------------------------------------------------------------------------
+
+/// Frames `[lo, hi)` of `rank` out of `world` (`vbx_shard_range`): contiguous ranges, cut at utterance boundaries when
+/// `seg_start` is given so that no tracker segment straddles two ranks.
+pub fn shard_range(n_frames: usize, world: i32, rank: i32, seg_start: &[i64]) -> GpuResult<(usize, usize)> {
+    let (mut lo, mut hi) = (0usize, 0usize);
+    let (seg_ptr, n_seg) = if seg_start.is_empty() { (ptr::null(), 0) } else { (seg_start.as_ptr(), seg_start.len()) };
+    let rc = unsafe { ffi::vbx_shard_range(n_frames, world, rank, seg_ptr, n_seg, &mut lo, &mut hi) };
+    if rc != ffi::VBX_SUCCESS {
+        return Err(GpuError { code: rc, message: last_error(ptr::null()) });
+    }
+    Ok((lo, hi))
+}
+
+/// Samples `[s0, s1)` the frames `[lo, hi)` read, including the `frame_len - hop` halo (`vbx_shard_samples`).
+pub fn shard_samples(lo: usize, hi: usize, frame_len: usize, hop: usize) -> GpuResult<(usize, usize)> {
+    let (mut s0, mut s1) = (0usize, 0usize);
+    let rc = unsafe { ffi::vbx_shard_samples(lo, hi, frame_len, hop, &mut s0, &mut s1) };
+    if rc != ffi::VBX_SUCCESS {
+        return Err(GpuError { code: rc, message: last_error(ptr::null()) });
+    }
+    Ok((s0, s1))
+}
+
+/// `(offset, count, op)` per rank of the record gather as `rank` sees it (`vbx_gather_plan`; host arithmetic only).
+pub fn gather_plan(rows: &[i64], rank: i32, dst: i32, row_doubles: usize) -> GpuResult<(Vec<i64>, Vec<i64>, Vec<i32>)> {
+    let w = rows.len();
+    let (mut off, mut cnt, mut op) = (vec![0i64; w], vec![0i64; w], vec![0i32; w]);
+    let rc = unsafe { ffi::vbx_gather_plan(rows.as_ptr(), w as i32, rank, dst, row_doubles, off.as_mut_ptr(), cnt.as_mut_ptr(), op.as_mut_ptr()) };
+    if rc != ffi::VBX_SUCCESS {
+        return Err(GpuError { code: rc, message: last_error(ptr::null()) });
+    }
+    Ok((off, cnt, op))
+}
+
+/// This rank's RCCL communicator for the record gather (`vbx_comm_*`): one per process.  The 128-byte id comes from
+/// [`Comm::unique_id`] on rank 0 and travels to the other ranks by whatever the application has (MPI, a TCP store, a file).
+pub struct Comm<'g> {
+    gpu: &'g Gpu,
+    raw: *mut ffi::VbxComm,
+    world: usize,
+}
+
+impl<'g> Comm<'g> {
+    pub fn unique_id() -> GpuResult<[u8; ffi::VBX_UNIQUE_ID_BYTES]> {
+        let mut id = [0u8; ffi::VBX_UNIQUE_ID_BYTES];
+        let rc = unsafe { ffi::vbx_comm_unique_id(id.as_mut_ptr() as *mut c_void) };
+        if rc != ffi::VBX_SUCCESS {
+            return Err(GpuError { code: rc, message: last_error(ptr::null()) });
+        }
+        Ok(id)
+    }
+
+    /// Collective: every rank calls it with the same id.
+    pub fn new(gpu: &'g Gpu, id: &[u8; ffi::VBX_UNIQUE_ID_BYTES], world: i32, rank: i32) -> GpuResult<Comm<'g>> {
+        let mut raw: *mut ffi::VbxComm = ptr::null_mut();
+        gpu.check(unsafe { ffi::vbx_comm_create(gpu.raw, id.as_ptr() as *const c_void, world, rank, &mut raw) })?;
+        Ok(Comm { gpu, raw, world: world as usize })
+    }
+
+    /// Live communicators of this process (`vbx_comm_live_count`): 1 while a `Comm` exists.
+    pub fn live_count() -> i32 {
+        unsafe { ffi::vbx_comm_live_count() }
+    }
+
+    /// Queues the gather of `records` (this rank's rows) to rank `dst` behind the kernels already queued on the context
+    /// (`vbx_gather_records_f64`); `rows[r]` = frames of rank r; on `dst`, `out` receives every rank's rows in rank order
+    /// (it may be the buffer `records` points into, at this rank's offset: no copy).  `slot` names the buffer for `wait`.
+    pub fn gather_records(&self, records: &Records, rows: &[i64], dst: i32, out: Option<&DeviceBuf<f64>>, slot: i32) -> GpuResult<()> {
+        assert_eq!(rows.len(), self.world);
+        self.gpu.check(unsafe {
+            ffi::vbx_gather_records_f64(self.gpu.raw, self.raw, records.data.as_ptr(), rows.as_ptr(), records.record_ld, dst,
+                                        out.map_or(ptr::null_mut(), |o| o.as_mut_ptr()), slot)
+        })
+    }
+
+    /// The context's stream waits (on the device) for the gather that used `slot`: call before overwriting that buffer.
+    pub fn wait(&self, slot: i32) -> GpuResult<()> {
+        self.gpu.check(unsafe { ffi::vbx_comm_wait(self.gpu.raw, self.raw, slot) })
+    }
+
+    /// The host waits for every queued gather.
+    pub fn sync(&self) -> GpuResult<()> {
+        self.gpu.check(unsafe { ffi::vbx_comm_sync(self.raw) })
+    }
+
+    /// Loopback self-test of the RCCL path on this GPU (`vbx_comm_selftest`).
+    pub fn selftest(&self, n_doubles: usize) -> GpuResult<()> {
+        self.gpu.check(unsafe { ffi::vbx_comm_selftest(self.gpu.raw, self.raw, n_doubles) })
+    }
+}
+
+impl<'g> Drop for Comm<'g> {
+    fn drop(&mut self) {
+        unsafe { ffi::vbx_comm_destroy(self.raw) };
+    }
+}

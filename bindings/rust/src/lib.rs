@@ -9,6 +9,11 @@
 //!
 //! * **batched** (`FrameBatch::autocorrelate_all`, `pitch_all`, `lpc_praat_all`, `mfcc_all`, `find_formants`):
 //!   one library call = the user's whole frame loop;
+//! * **fused** (`FrameBatch::analyze` / `PcmBatch::analyze`): pitch + LPC + find_formants + MFCC of every frame as one
+//!   record per frame from one call (`vbx_analyze_frames_f64` / `_pcm16`), the buffer [`gpu::Comm::gather_records`] sends
+//!   to rank 0 when the recording is sharded over the GPUs of a node ([`gpu::shard_range`], [`gpu::shard_samples`]);
+//! * **tracker** (`ResonanceRows::estimate_formants_all`, `ResonanceRows::formant_extractor`): `EstimateFormants` /
+//!   `FormantExtractor` (src/spectrum.rs:216-369) over resonance rows on the device;
 //! * **drop-in** (`FrameBatch::frames()` yields [`gpu::GpuFrame`] views that implement the crate's traits):
 //!   the user's loop stays as written, the first call of a method computes the whole batch on the GPU and the
 //!   per-frame calls read their row of the cached result.
@@ -21,4 +26,5 @@
 pub mod ffi;
 pub mod gpu;
 
-pub use gpu::{find_formants, DeviceBuf, FrameBatch, FrameStatus, Frames, Gpu, GpuError, GpuFrame, PolyBatch, RootRow, RootRows};
+pub use gpu::{find_formants, gather_plan, shard_range, shard_samples, AnalysisParams, Comm, DeviceBuf, FormantExtractor, FrameBatch, FrameStatus,
+              Frames, Gpu, GpuError, GpuEstimates, GpuFrame, PcmBatch, PolyBatch, Records, ResonanceRows, RootRow, RootRows};

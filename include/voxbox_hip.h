@@ -377,6 +377,17 @@ int vbx_analyze_frames_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_
                            const vbx_analysis_params *h_params, const int64_t *h_seg_start, size_t n_segments,
                            double *out_records, size_t record_ld, int32_t *status3);
 
+/* The same frame loop on 16-bit PCM: what a WAV reader hands the reference's callers before the `as f64 / 32767` of
+ * tests/lib.rs:17-19 and examples/formant_extraction/src/main.rs.  `pcm` holds the recording's samples (device memory);
+ * frame t is pcm[t*stride .. +frame_len), widened in registers exactly as vbx_pcm16_to_f64 would (s / 32767, correctly
+ * rounded), so the records are BIT-IDENTICAL to vbx_pcm16_to_f64 followed by vbx_analyze_frames_f64 -- at a quarter of
+ * the input bytes (960 instead of 3840 new bytes per 48 kHz / 10 ms frame): the form for host-fed operation, where the
+ * samples cross PCIe.  Full 1200-sample frames with lpc_order in {0, 12} read the PCM directly; other shapes are widened
+ * into a context-owned f64 copy of the view first. */
+int vbx_analyze_frames_pcm16(vbx_ctx *ctx, const int16_t *pcm, size_t n_frames, size_t frame_len, size_t stride,
+                             const vbx_analysis_params *h_params, const int64_t *h_seg_start, size_t n_segments,
+                             double *out_records, size_t record_ld, int32_t *status3);
+
 /* ------------------------------------------------------------------ multi-GPU: frame-range sharding */
 
 /* The reference has no distribution of any kind; frames are independent (the tracker per utterance), so a long

@@ -182,6 +182,18 @@ def test_rust_binding_is_complete_and_in_sync(pkg):
                          ("MFCC<f64> for GpuFrame", "vbx_mfcc_f64"), ("ToResonance<f64> for RootRow", "vbx_to_resonance_c64"),
                          ("pub fn find_formants", "vbx_find_formants_f64")):
         assert trait in gpu and entry in used, (trait, entry)
+    for trait, entry in (("EstimateFormants<f64> for GpuEstimates", "vbx_estimate_formants_f64"), ("impl Iterator for FormantExtractor", "vbx_estimate_formants_f64"),
+                         ("pub fn analyze", "vbx_analyze_frames_f64"), ("pub fn analyze", "vbx_analyze_frames_pcm16"),
+                         ("pub struct Comm", "vbx_gather_records_f64"), ("pub fn shard_range", "vbx_shard_range")):
+        assert trait in gpu and entry in used, (trait, entry)
+    # every entry point of the ABI that is not a context / memory / profiling utility or part of the f32 / c32 instantiation
+    # has a caller in the safe layer
+    utility = {n for n in declared if re.match(r"vbx_(abi_version|ctx_|sync|last_error|device_info|malloc|free|memcpy|memset|timer_|profile_|"
+                                               r"selftest|internal_|synth_speech|window_table_f32|degree_|off_low_|hz_to_mel|mel_to_hz|"
+                                               r"find_formants_(real|complex)_work_size|improve_extremum_ex|interpolate_sinc|improve_extremum_f64|"
+                                               r"ring_frames|preemphasis|dct_|lpc_f64$)", n) or n.endswith("_f32") or n.endswith("_c32")}
+    missing = declared - utility - used
+    assert not missing, f"ABI entry points without a caller in bindings/rust/src/gpu.rs: {sorted(missing)}"
     for stub in ("unimplemented!", "todo!", "unreachable!"):
         assert stub not in gpu and stub not in before, stub
     for f in ("Cargo.toml", "build.rs", os.path.join("src", "lib.rs"), os.path.join("examples", "pitch_detection.rs")):

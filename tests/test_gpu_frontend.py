@@ -134,3 +134,53 @@ def test_ring_buffer_view_autocorrelate(vb, oracle):
         assert np.all(rel_close(got[t], exp)), t
     with pytest.raises(Exception):
         vb.ring_frames(ring, head, 30, n, hop)               # 29*160 + 512 > 4096: longer than the deque can be
+
+
+def _speech_pcm(vb, n_samples, offset=0):
+    """The synthetic recording quantised to 16-bit PCM the way a WAV writer would (round to nearest, peak 0.9)."""
+    a = vb.synth_speech(n_samples, sample_offset=offset)
+    x = a.numpy()
+    a.free()
+    return np.clip(np.rint(x / np.max(np.abs(x)) * 0.9 * 32767.0), -32768, 32767).astype(np.int16)
+
+
+@pytest.mark.parametrize("N,H,odd_start", [(1200, 480, 0), (1200, 480, 1), (1200, 481, 0), (1024, 512, 0), (1103, 441, 0), (512, 256, 0)])
+def test_analyze_frames_pcm16_is_bit_identical_to_widening_first(vb, pkg, N, H, odd_start):
+    """vbx_analyze_frames_pcm16 (the fused frame loop reading 16-bit PCM, 960 B of new samples per frame instead of 3840) ==
+    vbx_pcm16_to_f64 followed by vbx_analyze_frames_f64, bit for bit: every record column and every status.  1200-sample
+    frames take the PCM forms of the fused spectral kernel and of Burg (4-byte loads where the frame starts on a 4-byte
+    boundary -- an odd first sample or an odd hop takes the 2-byte path); the other shapes are widened inside the library."""
+    F = 700
+    pcm = _speech_pcm(vb, (F - 1) * H + N + odd_start, offset=3 * 48000)[odd_start:]
+    params = pkg.AnalysisParams.make(48000.0)
+    seg = np.array([0, 250, 251], dtype=np.int64)
+    d16 = vb.to_device(np.concatenate([np.zeros(odd_start, np.int16), pcm]), np.int16)
+    ptr16 = d16.ptr + 2 * odd_start                              # a view that starts on an odd sample: 2-byte aligned only
+    rec, st = vb.empty((F, 36)), vb.empty((3, F), np.int32)
+    vb.analyze_frames_pcm16(ptr16, params, seg_start=seg, frame_len=N, stride=H, n_frames=F, out=rec, record_ld=36, status=st)
+    wide = vb.pcm16_to_f64(pcm)
+    assert np.array_equal(wide.numpy(), pcm.astype(np.float64) / 32767.0)
+    rec2, st2 = vb.analyze_frames(wide, params, seg_start=seg, frame_len=N, stride=H, n_frames=F)
+    R, S = rec.numpy(), st.numpy()
+    assert np.array_equal(S, st2)
+    bad = np.nonzero(np.any(R != rec2, axis=1))[0]
+    assert bad.size == 0, (bad[:5], R[bad[0]], rec2[bad[0]])
+    assert np.any(R[:, 0] > 0) and np.all(S == 0)                # voiced frames in there, every part ran
+    for d in (d16, rec, st, wide):
+        d.free()
+
+
+def test_analyze_frames_pcm16_rectangular_seed_and_other_params(vb, pkg):
+    """Parameter sets that leave the fused kernel's PCM form: LPC order 10 (its own kernel -> widened copy), no MFCC, no
+    formants; and silence (Burg's Err(LPC) status) -- all bit-identical to the widen-first path."""
+    N, H, F = 1200, 480, 300
+    pcm = _speech_pcm(vb, (F - 1) * H + N, offset=9 * 48000)
+    pcm[40 * H:43 * H + N] = 0                                   # a few all-zero frames
+    wide = vb.pcm16_to_f64(pcm)
+    for kw in (dict(lpc_order=10), dict(mfcc=None), dict(formant_order=0), dict(lpc_order=0, mfcc=(20, 50.0, 12000.0))):
+        params = pkg.AnalysisParams.make(48000.0, **kw)
+        a, sa = vb.analyze_frames_pcm16(pcm, params, frame_len=N, stride=H)
+        b, sb = vb.analyze_frames(wide, params, frame_len=N, stride=H, n_frames=F)
+        assert np.array_equal(sa, sb) and np.array_equal(a, b, equal_nan=True), kw     # silent frames: Levinson on zeros is NaN in both
+    assert np.any(sb[1] == 1)                                    # the silent frames: Err(LPC) from Burg
+    wide.free()

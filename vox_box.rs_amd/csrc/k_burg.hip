@@ -31,9 +31,10 @@ namespace vbx {
 
 // T: Sample type of the frames and of the coefficients (double; float = the f32 instantiation: widened on load, the
 // windowed product rounded to T first, the recursion in f64, one rounding to T on the store).
-template <int G, int EPL, typename T>
+// TIN: what the frames hold when it is not T: int16_t = 16-bit PCM (widened in registers, s / 32767; window and results f64).
+template <int G, int EPL, typename T, typename TIN = T>
 __global__ __launch_bounds__(64) void burg_kernel(
-    const T *__restrict__ x, long n_frames, int n, long stride, const T *__restrict__ window,
+    const TIN *__restrict__ x, long n_frames, int n, long stride, const T *__restrict__ window,
     int p, T *__restrict__ out, int32_t *__restrict__ status, const frame_map_t map) {
     constexpr int NG = 64 / G;
     static_assert(G >= VBX_MAX_LPC_ORDER_K || G == 16, "one coefficient per lane of the group");
@@ -43,14 +44,15 @@ __global__ __launch_bounds__(64) void burg_kernel(
     const long blk = (NG == 1) ? xcd_item(blockIdx.x, gridDim.x) : (long)blockIdx.x;
     const long f = frame_map(map, blk * NG + gid, n_frames);
     const bool have = f >= 0;
-    const T *xf = x + (have ? f : 0) * stride;
+    const TIN *xf = x + (have ? f : 0) * stride;
+    constexpr bool PCM = sizeof(TIN) == 2;
 
     double b1[EPL], b2[EPL];
     // A lane's EPL samples are contiguous: 16-byte loads where the lane lies inside the frame and the rows are aligned
     // (one double at a time, the 64 lanes of an instruction touch 64 different cache lines EPL times over: the address
     // path, not the arithmetic, then bounds the kernel -- measured 2.72 -> 1.84 ms per million 512-sample frames).
     bool vec = false;
-    if constexpr (sizeof(T) == 8 && EPL % 2 == 0) {
+    if constexpr (sizeof(T) == 8 && !PCM && EPL % 2 == 0) {
         vec = have && (lig + 1) * EPL <= n && ((((uintptr_t)xf) | ((uintptr_t)window)) & 15) == 0;
         if (vec) {
             const double2 *xv = reinterpret_cast<const double2 *>(xf + lig * EPL);
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(64) void burg_kernel(
 #pragma unroll
         for (int e = 0; e < EPL; e++) {
             const int j = lig * EPL + e;
-            double v = (have && j < n) ? (double)xf[j] : 0.0;
+            double v = (have && j < n) ? (PCM ? pcm16_value((int)xf[j]) : (double)xf[j]) : 0.0;
             if (window != nullptr && j < n) v = (double)(T)(v * (double)window[j]);
             b1[e] = v;
         }
@@ -203,6 +205,21 @@ static void launch_burg_t(hipStream_t s, const T *x, long F, int n, long stride,
 void launch_burg(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                  int p, double *out, int32_t *status, frame_map_t map) {
     launch_burg_t<double>(s, x, F, n, stride, window, p, out, status, map);
+}
+void launch_burg_pcm16(hipStream_t s, const int16_t *x, long F, int n, long stride, const double *window,
+                       int p, double *out, int32_t *status, frame_map_t map) {
+    dim3 b(64);
+    const long items = frame_map_items(map, F);
+#define VBX_BURG16(GG, E)                                                                                                  \
+    hipLaunchKernelGGL((burg_kernel<GG, E, double, int16_t>), dim3((unsigned)((items + (64 / GG) - 1) / (64 / GG))), b, 0, s, \
+                       x, F, n, stride, window, p, out, status, map)
+    const bool g16 = burg_small_groups_ok(p);
+    if (g16 && n <= 16 * 32) VBX_BURG16(16, 32);
+    else if (n <= 32 * 32) VBX_BURG16(32, 32);
+    else if (n <= 64 * 20) VBX_BURG16(64, 20);
+    else if (n <= 64 * 32) VBX_BURG16(64, 32);
+    else VBX_BURG16(64, 64);
+#undef VBX_BURG16
 }
 void launch_burg_f32(hipStream_t s, const float *x, long F, int n, long stride, const float *window,
                      int p, float *out, int32_t *status) {

@@ -8,15 +8,6 @@
 
 namespace vbx {
 
-// x / denom for |x| <= 32768: reciprocal multiply + one Markstein correction step.  Correctly rounded
-// (== true division, which is what the reference computes) -- checked exhaustively over all 65536
-// int16 values in tests/test_gpu_frontend.py.
-__device__ __forceinline__ double div_exact_small(double x, double denom, double r) {
-    const double q = x * r;
-    const double rem = fma(-q, denom, x);
-    return fma(rem, r, q);
-}
-
 // two samples per lane and step: one 4-B load, one 16-B store -- every wave instruction touches one
 // contiguous span (256 B in, 1 KiB out)
 __global__ void pcm16_kernel(const int16_t *__restrict__ pcm, size_t n, double denom, double *__restrict__ out) {

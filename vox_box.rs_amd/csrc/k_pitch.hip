@@ -39,7 +39,7 @@ __device__ __forceinline__ void pitch_frame_mfma(
     double *smem, const long f, const double *__restrict__ frames, int n, long stride, const double *__restrict__ window,
     const double *__restrict__ lag_window, double sample_rate, double threshold, double fmin, double fmax,
     int kmax, int full_off, double *__restrict__ out_cand, long cand_ld, int32_t *__restrict__ out_count,
-    int32_t *__restrict__ status, unsigned long long *__restrict__ work) {
+    int32_t *__restrict__ status, unsigned long long *__restrict__ work, const bool pcm = false) {
     const int lane = lane_id();
     double *zs = smem;                              // padded image of the windowed frame (vbx_autocorr.hpp)
     // refinement state (vbx_pitch_refine.hpp): y[n + Y_PAD] | p16 | keys | candidate list
@@ -48,6 +48,7 @@ __device__ __forceinline__ void pitch_frame_mfma(
         // all of the frame's loads are issued before the first LDS store (nothing else hides their latency here);
         // only the zero margins of the image are cleared, the pad double inside each 16 samples is never read
         const double *xf = frames + f * stride;
+        const int16_t *x16 = reinterpret_cast<const int16_t *>(frames) + f * stride;        // the frame when pcm
         constexpr int NB = 8;
         for (int p = lane; p < ac_mf_phys(0); p += 64) zs[p] = 0.0;
         for (int p = ac_mf_phys(n) + lane; p < ac_mf_lds_doubles(n); p += 64) zs[p] = 0.0;
@@ -56,7 +57,7 @@ __device__ __forceinline__ void pitch_frame_mfma(
 #pragma unroll
             for (int j = 0; j < NB; j++) {
                 const int i = i0 + 64 * j + lane;
-                xv[j] = (i < n) ? xf[i] : 0.0;
+                xv[j] = (i < n) ? (pcm ? pcm16_value(x16[i]) : xf[i]) : 0.0;
                 wv[j] = (window != nullptr && i < n) ? window[i] : 1.0;
             }
 #pragma unroll
@@ -130,12 +131,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const double *__restrict__ frames, int n, long stride, const double *__restrict__ window,
     const double *__restrict__ lag_window, double sample_rate, double threshold, double fmin, double fmax,
     int kmax, int full_off, double *__restrict__ out_cand, long cand_ld, int32_t *__restrict__ out_count,
-    int32_t *__restrict__ status, unsigned long long *__restrict__ work) {
+    int32_t *__restrict__ status, unsigned long long *__restrict__ work, int pcm) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int count = *list_count;
     for (int i = blockIdx.x; i < count; i += gridDim.x) {
         pitch_frame_mfma<ALIAS>(smem, (long)frame_list[i], frames, n, stride, window, lag_window, sample_rate, threshold,
-                                fmin, fmax, kmax, full_off, out_cand, cand_ld, out_count, status, work);
+                                fmin, fmax, kmax, full_off, out_cand, cand_ld, out_count, status, work, pcm != 0);
         wave_sync();
     }
 }
@@ -231,17 +232,17 @@ void launch_pitch_list(hipStream_t s, const int32_t *frame_list, const int32_t *
                        const double *x, int n, long stride, const double *window,
                        const double *lag_window, double sample_rate, double threshold, double fmin, double fmax,
                        int kmax, pitch_t *out_cand, long cand_ld, int32_t *out_count, int32_t *status,
-                       unsigned long long *work) {
+                       unsigned long long *work, bool pcm) {
     const size_t base = (pitch_lds_bytes(n) + 15) & ~(size_t)15, extra = pitch_full_list_bytes(n, kmax);
     const int full_off = extra ? (int)base : 0;
     if (n <= AC_MF_NT * AC_MF_TILE)
         hipLaunchKernelGGL((pitch_list_kernel<true>), dim3((unsigned)grid), dim3(64), base + extra, s,
                            frame_list, list_count, x, n, stride, window, lag_window, sample_rate, threshold, fmin, fmax, kmax,
-                           full_off, reinterpret_cast<double *>(out_cand), cand_ld, out_count, status, work);
+                           full_off, reinterpret_cast<double *>(out_cand), cand_ld, out_count, status, work, pcm ? 1 : 0);
     else
         hipLaunchKernelGGL((pitch_list_kernel<false>), dim3((unsigned)grid), dim3(64), base + extra, s,
                            frame_list, list_count, x, n, stride, window, lag_window, sample_rate, threshold, fmin, fmax, kmax,
-                           full_off, reinterpret_cast<double *>(out_cand), cand_ld, out_count, status, work);
+                           full_off, reinterpret_cast<double *>(out_cand), cand_ld, out_count, status, work, pcm ? 1 : 0);
 }
 
 void launch_sinc_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *xs, long m,

@@ -199,13 +199,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
 
     // ---- load: z[60 a + n'] = (xw[120 a + 2 n'], xw[120 a + 2 n' + 1]), a < 10 (the rest is the zero padding) ----
     double re[20], im[20];
+    const int16_t *x16 = reinterpret_cast<const int16_t *>(a.frames) + f * a.stride;       // the frame when a.pcm (FULL only)
     {
         const bool al = ((((uintptr_t)xf) | ((uintptr_t)a.window)) & 15) == 0;      // uniform
         double2 xv[10], wv[10];
 #pragma unroll
         for (int q = 0; q < 10; q++) {
             const int i = 120 * q + 2 * np;
-            if (al && i + 1 < n) {
+            if (FULL && a.pcm) {
+                // 16-bit PCM in: 960 B of new samples per frame instead of 3840 (the host-fed case: PCIe carries the PCM);
+                // widened here exactly as vbx_pcm16_to_f64 would have (bit-identical frames, tests/test_gpu_frontend.py)
+                int lo, hi;
+                if ((((uintptr_t)x16) & 3) == 0) { const int w = *reinterpret_cast<const int *>(x16 + i); lo = (short)(w & 0xffff); hi = w >> 16; }
+                else { lo = x16[i]; hi = x16[i + 1]; }
+                xv[q] = double2{pcm16_value(lo), pcm16_value(hi)};
+                wv[q] = (a.window != nullptr) ? (((uintptr_t)a.window & 15) == 0 ? *reinterpret_cast<const double2 *>(a.window + i)
+                                                                                  : double2{a.window[i], a.window[i + 1]}) : double2{1.0, 1.0};
+            } else if (al && i + 1 < n) {
                 xv[q] = *reinterpret_cast<const double2 *>(xf + i);
                 wv[q] = (a.window != nullptr) ? *reinterpret_cast<const double2 *>(a.window + i) : double2{1.0, 1.0};
             } else {
@@ -358,11 +368,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
         for (int s = 0; s < 11; s++) {
             const int i = 2 * jj[s];
             if (jj[s] >= 0 && i < n) {
-                const double xe = (a.window != nullptr) ? xf[i] * a.window[i] : xf[i];
+                const double xs = (FULL && a.pcm) ? pcm16_value(x16[i]) : xf[i];
+                const double xe = (a.window != nullptr) ? xs * a.window[i] : xs;
                 r_e[s] = (r_e[s] - x0 * xe) + x0;
             }
             if (jj[s] >= 0 && i + 1 < n) {
-                const double xo = (a.window != nullptr) ? xf[i + 1] * a.window[i + 1] : xf[i + 1];
+                const double xs = (FULL && a.pcm) ? pcm16_value(x16[i + 1]) : xf[i + 1];
+                const double xo = (a.window != nullptr) ? xs * a.window[i + 1] : xs;
                 r_o[s] = (r_o[s] - x0 * xo) + x0;
             }
         }
@@ -497,6 +509,7 @@ void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
     a.bins = L.bins; a.slopes = L.slopes; a.dct = L.dct; a.num_coeffs = L.num_coeffs; a.nb = L.nb;
     a.unsure_list = L.unsure_list; a.unsure_count = L.unsure_count;
     a.out_r = L.out_r; a.n_lags = L.n_lags;
+    a.pcm = (L.pcm && L.n == SP_N) ? 1 : 0;                  // the host side only asks for it on full 1200-sample frames
     if (L.plan != SPECTRAL_PLAN_1200) { launch_analyze_pow2(s, L, a); return; }
     const dim3 grid((unsigned)L.F), block(64);
     const size_t base = spectral_lds_bytes(L.n);

@@ -734,7 +734,7 @@ static int launch_spectral(vbx_ctx *ctx, hipStream_t st, spectral_launch_t &L, c
         const int grid = ctx->cu_count > 0 ? ctx->cu_count * 4 : 1024;
         launch_pitch_list(st, L.unsure_list, L.unsure_count, grid, L.x, L.n, L.stride, L.window, L.lag_window,
                           L.sample_rate, L.threshold, L.fmin, L.fmax, L.kmax, L.out_cand, L.cand_ld, L.out_count,
-                          L.pitch_status, L.work);
+                          L.pitch_status, L.work, L.pcm);
     }
     return check_launch(ctx, "launch_spectral");
 }
@@ -999,7 +999,7 @@ static int run_find_formants(vbx_ctx *ctx, hipStream_t stm, const double *x, siz
                              const int64_t *h_seg_start, size_t n_segments,
                              const vbx_resonance *h_est_init, size_t n_est,
                              vbx_resonance *out_formants, size_t formants_ld, vbx_resonance *out_res, int32_t *out_res_count,
-                             double *out_coeffs, int32_t *status) {
+                             double *out_coeffs, int32_t *status, const int16_t *pcm = nullptr /* the frames as 16-bit PCM instead of x */) {
     VBX_REQUIRE(ctx, h_est_init && out_formants, "null argument");
     VBX_REQUIRE(ctx, burg_supported((int)frame_len, (int)n_coeffs), "frame_len must be in [2, 4096], order in [1, 30]");
     VBX_REQUIRE(ctx, n_est >= 1 && n_est <= VBX_FORMANT_SLOTS, "n_est must be in [1, 6]");
@@ -1046,7 +1046,9 @@ static int run_find_formants(vbx_ctx *ctx, hipStream_t stm, const double *x, siz
     const int n_slices = seg_len > 0 ? want_slices : 1;
     const long tc = (seg_len + n_slices - 1) / n_slices;
     if (n_slices == 1) {
-        { Prof pr(ctx, "burg", stm); launch_burg(stm, x, F, (int)frame_len, (long)stride, hann, p, coeffs, st); }                 // :75
+        { Prof pr(ctx, "burg", stm);                                                                                              // :75
+          if (pcm) launch_burg_pcm16(stm, pcm, F, (int)frame_len, (long)stride, hann, p, coeffs, st);
+          else launch_burg(stm, x, F, (int)frame_len, (long)stride, hann, p, coeffs, st); }
         { Prof pr(ctx, "formant_resonances", stm); launch_formant_resonances(stm, coeffs, F, p, sample_rate, res, cnt, st); }      // :80-110
         rc = run_tracker(ctx, stm, chunked, res, F, VBX_MAX_RESONANCES, cnt, d_seg, (long)nseg, d_est, (int)n_est, st,
                          (res_t *)out_formants, (long)formants_ld);                                                                    // :114
@@ -1060,7 +1062,9 @@ static int run_find_formants(vbx_ctx *ctx, hipStream_t stm, const double *x, siz
     }
     for (int j = 0; j < n_slices && j * tc < seg_len; j++) {
         const frame_map_t map{seg_len, j * tc, (seg_len - j * tc < tc) ? seg_len - j * tc : tc};   // the last slice may be shorter
-        { Prof pr(ctx, "burg", stm); launch_burg(stm, x, F, (int)frame_len, (long)stride, hann, p, coeffs, st, map); }
+        { Prof pr(ctx, "burg", stm);
+          if (pcm) launch_burg_pcm16(stm, pcm, F, (int)frame_len, (long)stride, hann, p, coeffs, st, map);
+          else launch_burg(stm, x, F, (int)frame_len, (long)stride, hann, p, coeffs, st, map); }
         { Prof pr(ctx, "formant_resonances", stm); launch_formant_resonances(stm, coeffs, F, p, sample_rate, res, cnt, st, map); }
         VBX_HIP(ctx, hipEventRecord(ctx->ev_slice[j], stm));
         VBX_HIP(ctx, hipStreamWaitEvent(ctx->trk, ctx->ev_slice[j], 0));
@@ -1276,10 +1280,13 @@ size_t vbx_record_doubles(const vbx_analysis_params *h_p) {
     return n;
 }
 
-int vbx_analyze_frames_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
-                           const vbx_analysis_params *h_p, const int64_t *h_seg_start, size_t n_segments,
-                           double *out_records, size_t record_ld, int32_t *status3) {
-    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+// x: the frames as f64 samples, or -- pcm16 non-null -- as 16-bit PCM (the kernels that have a PCM form read it directly:
+// 1200-sample frames through the fused spectral kernel, Burg at every length; every other shape is widened into a
+// context-owned f64 copy of the view first and takes the f64 path)
+static int analyze_frames_impl(vbx_ctx *ctx, const char *fn, const double *x, const int16_t *pcm16, size_t n_frames, size_t frame_len,
+                               size_t stride, const vbx_analysis_params *h_p, const int64_t *h_seg_start, size_t n_segments,
+                               double *out_records, size_t record_ld, int32_t *status3) {
+    int rc = check_frames(ctx, fn, pcm16 ? (const void *)pcm16 : (const void *)x, n_frames, frame_len, stride);
     if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
     VBX_REQUIRE(ctx, h_p && out_records, "null argument");
     const size_t rec = vbx_record_doubles(h_p);
@@ -1289,28 +1296,6 @@ int vbx_analyze_frames_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     rc = ensure_side_stream(ctx);
     if (rc != VBX_SUCCESS) return rc;
-    const double *hann = nullptr;
-    rc = get_window_dev(ctx, VBX_WINDOW_HANNING, frame_len, &hann);        // Windower::hanning frames (examples/pitch_detection.rs:23)
-    if (rc != VBX_SUCCESS) return rc;
-    // record columns
-    const size_t c_form = 2, c_mfcc = c_form + (h_p->formant_order ? 2 * h_p->n_est : 0),
-                 c_lpc = c_mfcc + h_p->mfcc_coeffs;
-    int32_t *st_pitch = nullptr, *st_form = nullptr, *st_mfcc = nullptr;
-    if (status3) { st_pitch = status3; st_form = status3 + n_frames; st_mfcc = status3 + 2 * n_frames; }
-    // fork: the formant chain (Burg -> roots -> the latency-bound tracker scan) and the MFCC run on the side stream,
-    // beside the FP64-bound pitch kernel
-    VBX_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-    VBX_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-    if (h_p->formant_order) {
-        vbx_resonance est[VBX_FORMANT_SLOTS];
-        for (size_t e = 0; e < h_p->n_est; e++) est[e] = h_p->est_init[e];
-        rc = run_find_formants(ctx, ctx->side, x, n_frames, frame_len, stride, h_p->sample_rate, h_p->formant_order,
-                               h_seg_start, n_segments, est, h_p->n_est, (vbx_resonance *)(out_records + c_form), record_ld,
-                               nullptr, nullptr, nullptr, st_form);
-        if (rc != VBX_SUCCESS) return rc;
-    } else if (st_form) {
-        VBX_HIP(ctx, hipMemsetAsync(st_form, 0, n_frames * sizeof(int32_t), ctx->side));
-    }
     // One spectral pass for pitch + LPC + MFCC when the shape has a fused kernel (k_spectral.hip); otherwise the LPC
     // and MFCC kernels run on the side stream and the pitch kernel alone on the main one.
     std::vector<int32_t> hb; bool bad_bins = false; const int32_t *d_bins = nullptr;
@@ -1328,6 +1313,41 @@ int vbx_analyze_frames_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_
     const bool fused_lpc = fused && h_p->lpc_order == SPECTRAL_LPC_ORDER;
     const bool fused_mfcc = fused && !bad_bins && h_p->mfcc_coeffs &&
                             spectral_supported((int)frame_len, 0, nb, hb.front(), (int)h_p->mfcc_coeffs);
+    // 16-bit PCM frames: the fused kernel of full 1200-sample frames, the pitch fallback and Burg read them directly;
+    // anything that would send another kernel over the samples takes one widening pass into a context-owned f64 copy
+    const bool pcm_native = pcm16 != nullptr && fused && frame_len == (size_t)SPECTRAL_N &&
+                            (!h_p->lpc_order || fused_lpc) && (!h_p->mfcc_coeffs || fused_mfcc);
+    if (pcm16 != nullptr && !pcm_native) {
+        const size_t ns = (n_frames - 1) * stride + frame_len;
+        void *w = nullptr;
+        rc = ws_get(ctx, vbx_ctx::WS_F32_IN, ns * sizeof(double), &w);
+        if (rc != VBX_SUCCESS) return rc;
+        { Prof p(ctx, "pcm16"); launch_pcm16(ctx->stream, pcm16, ns, 32767.0, (double *)w); }
+        x = (const double *)w; pcm16 = nullptr;
+    }
+    if (pcm_native) x = reinterpret_cast<const double *>(pcm16);          // the PCM kernels take the pointer through the f64 slot
+    const double *hann = nullptr;
+    rc = get_window_dev(ctx, VBX_WINDOW_HANNING, frame_len, &hann);        // Windower::hanning frames (examples/pitch_detection.rs:23)
+    if (rc != VBX_SUCCESS) return rc;
+    // record columns
+    const size_t c_form = 2, c_mfcc = c_form + (h_p->formant_order ? 2 * h_p->n_est : 0),
+                 c_lpc = c_mfcc + h_p->mfcc_coeffs;
+    int32_t *st_pitch = nullptr, *st_form = nullptr, *st_mfcc = nullptr;
+    if (status3) { st_pitch = status3; st_form = status3 + n_frames; st_mfcc = status3 + 2 * n_frames; }
+    // fork: the formant chain (Burg -> roots -> the latency-bound tracker scan) and the MFCC run on the side stream,
+    // beside the FP64-bound pitch kernel
+    VBX_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    VBX_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    if (h_p->formant_order) {
+        vbx_resonance est[VBX_FORMANT_SLOTS];
+        for (size_t e = 0; e < h_p->n_est; e++) est[e] = h_p->est_init[e];
+        rc = run_find_formants(ctx, ctx->side, x, n_frames, frame_len, stride, h_p->sample_rate, h_p->formant_order,
+                               h_seg_start, n_segments, est, h_p->n_est, (vbx_resonance *)(out_records + c_form), record_ld,
+                               nullptr, nullptr, nullptr, st_form, pcm_native ? pcm16 : nullptr);
+        if (rc != VBX_SUCCESS) return rc;
+    } else if (st_form) {
+        VBX_HIP(ctx, hipMemsetAsync(st_form, 0, n_frames * sizeof(int32_t), ctx->side));
+    }
     if (fused && h_p->lpc_order && !fused_lpc) {
         rc = run_autocorr_lpc(ctx, ctx->side, x, n_frames, frame_len, stride, hann, h_p->lpc_order, 0, nullptr,
                               out_records + c_lpc, record_ld);
@@ -1371,6 +1391,7 @@ int vbx_analyze_frames_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_
         L.x = x; L.F = (long)n_frames; L.stride = (long)stride; L.window = hann; L.lag_window = lagw; L.tab = tab;
         L.sample_rate = h_p->sample_rate; L.threshold = h_p->pitch_threshold; L.fmin = h_p->pitch_fmin; L.fmax = h_p->pitch_fmax;
         L.kmax = 1;
+        L.pcm = pcm_native;
         L.out_cand = (pitch_t *)out_records; L.cand_ld = (long)record_ld; L.out_count = nullptr; L.pitch_status = st_pitch;
         L.work = ctx->prof ? ctx->pitch_work : nullptr;
         if (fused_lpc) { L.out_lpc = out_records + c_lpc; L.lpc_ld = (long)record_ld; }
@@ -1386,6 +1407,21 @@ int vbx_analyze_frames_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_
     if (rc != VBX_SUCCESS) return rc;
     VBX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));       // join: the records are complete on ctx's stream
     return VBX_SUCCESS;
+}
+
+int vbx_analyze_frames_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
+                           const vbx_analysis_params *h_p, const int64_t *h_seg_start, size_t n_segments,
+                           double *out_records, size_t record_ld, int32_t *status3) {
+    return analyze_frames_impl(ctx, __func__, x, nullptr, n_frames, frame_len, stride, h_p, h_seg_start, n_segments, out_records,
+                               record_ld, status3);
+}
+
+int vbx_analyze_frames_pcm16(vbx_ctx *ctx, const int16_t *pcm, size_t n_frames, size_t frame_len, size_t stride,
+                             const vbx_analysis_params *h_p, const int64_t *h_seg_start, size_t n_segments,
+                             double *out_records, size_t record_ld, int32_t *status3) {
+    if (n_frames != 0 && ctx && !pcm) return fail(ctx, VBX_E_INVALID, "vbx_analyze_frames_pcm16: null frame pointer");
+    return analyze_frames_impl(ctx, __func__, nullptr, pcm, n_frames, frame_len, stride, h_p, h_seg_start, n_segments, out_records,
+                               record_ld, status3);
 }
 
 // ---- Sample = f32 ----------------------------------------------------------

@@ -138,6 +138,18 @@ __device__ __forceinline__ double rcp_nr2(double a) {       // correctly rounded
     return fma(fma(-a, r, 1.0), r, r);
 }
 
+// x / denom for |x| <= 32768: reciprocal multiply + one Markstein correction step.  Correctly rounded
+// (== true division, which is what the reference computes) -- checked exhaustively over all 65536
+// int16 values in tests/test_gpu_frontend.py.
+__device__ __forceinline__ double div_exact_small(double x, double denom, double r) {
+    const double q = x * r;
+    const double rem = fma(-q, denom, x);
+    return fma(rem, r, q);
+}
+// 16-bit PCM sample -> f64 as the reference's callers ingest WAV data (hound: i16 as f64 / 32767, tests/lib.rs:17-19):
+// what vbx_pcm16_to_f64 writes, computed in registers by the kernels that take PCM frames directly
+__device__ __forceinline__ double pcm16_value(int s) { return div_exact_small((double)s, 32767.0, 1.0 / 32767.0); }
+
 // ---- complex arithmetic (num-complex 0.2 formulas; FMA contraction allowed) -------
 // Generic over the scalar: Complex<f64> on the hot path, Complex<f32> for the f32 instantiation of Polynomial
 // (src/polynomial.rs:336-386).

@@ -44,6 +44,9 @@ void launch_levinson_rows(hipStream_t s, const double *r, long rows, long r_stri
 bool burg_supported(int n, int p);
 void launch_burg(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                  int p, double *out, int32_t *status, frame_map_t map = frame_map_t{0, 0, 0});
+// the same on 16-bit PCM frames (samples widened in registers: s / 32767), f64 coefficients
+void launch_burg_pcm16(hipStream_t s, const int16_t *x, long F, int n, long stride, const double *window,
+                       int p, double *out, int32_t *status, frame_map_t map = frame_map_t{0, 0, 0});
 
 // k_roots.hip
 void launch_find_roots(hipStream_t s, cplx_t *polys, long F, int len, int32_t *status);
@@ -86,7 +89,7 @@ void launch_pitch_list(hipStream_t s, const int32_t *frame_list, const int32_t *
                        const double *x, int n, long stride, const double *window,
                        const double *lag_window, double sample_rate, double threshold, double fmin, double fmax,
                        int kmax, pitch_t *out_cand, long cand_ld, int32_t *out_count, int32_t *status,
-                       unsigned long long *work);
+                       unsigned long long *work, bool pcm = false /* x points to int16 PCM samples */);
 void launch_sinc_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *xs, long m,
                         long depth, double *out, int32_t *status);
 void launch_extremum_points(hipStream_t s, const double *y, int ylen, long offset, long nx, const double *ix, long m,
@@ -122,6 +125,7 @@ struct spectral_launch_t {
     int32_t *unsure_list; int32_t *unsure_count;                 // frames handed to launch_pitch_list
     bool mfcc_only;                                              // MFCC::mfcc alone (n == the plan's Nc): no pitch, no LPC
     double *out_r; int n_lags;                                   // non-NULL: Autocorrelate::autocorrelate(n_lags) alone, [F, n_lags]
+    bool pcm;                                                    // x points to int16 PCM samples (n == 1200 only)
 };
 bool spectral_supported(int n, int lpc_order, int mfcc_nb, int mfcc_b_lo, int num_coeffs);
 void launch_analyze(hipStream_t s, const spectral_launch_t &L);

@@ -169,6 +169,7 @@ def load_library():
         "vbx_internal_last_unsure_count": (C.c_int, [vp, vp]),
         "vbx_record_doubles": (sz, [C.POINTER(AnalysisParams)]),
         "vbx_analyze_frames_f64": (C.c_int, [vp, vp, sz, sz, sz, C.POINTER(AnalysisParams), vp, sz, vp, sz, vp]),
+        "vbx_analyze_frames_pcm16": (C.c_int, [vp, vp, sz, sz, sz, C.POINTER(AnalysisParams), vp, sz, vp, sz, vp]),
         "vbx_shard_range": (C.c_int, [sz, i32, i32, vp, sz, C.POINTER(sz), C.POINTER(sz)]),
         "vbx_shard_samples": (C.c_int, [sz, sz, sz, sz, C.POINTER(sz), C.POINTER(sz)]),
         "vbx_comm_unique_id": (C.c_int, [vp]),
@@ -799,6 +800,35 @@ class VoxBox:
         self._check(self.L.vbx_analyze_frames_f64(self.ctx, ptr, F, N, S, C.byref(params),
                                                   None if seg is None else seg.ctypes.data, 0 if seg is None else seg.size,
                                                   _ptr(o), ld, _ptr(st)))
+        if out is not None:
+            return None
+        res = (o.numpy(), st.numpy())
+        for d in (o, st, tmp):
+            if d is not None:
+                d.free()
+        return res
+
+    def analyze_frames_pcm16(self, pcm, params, seg_start=None, frame_len=None, stride=None, n_frames=None, out=None,
+                             record_ld=None, status=None):
+        """vbx_analyze_frames_pcm16: the fused frame loop on 16-bit PCM samples (host int16 array or device buffer)."""
+        tmp = None
+        if isinstance(pcm, np.ndarray):
+            assert pcm.ndim == 1 and frame_len and stride
+            n_frames = frame_count(pcm.size, frame_len, stride) if n_frames is None else n_frames
+            tmp = self.to_device(pcm, np.int16)
+            ptr = tmp.ptr
+        else:
+            assert frame_len and stride and n_frames is not None
+            ptr = _ptr(pcm)
+        F = int(n_frames)
+        rec = int(self.L.vbx_record_doubles(C.byref(params)))
+        ld = record_ld if record_ld is not None else rec + (rec & 1)
+        seg = None if seg_start is None else np.ascontiguousarray(seg_start, dtype=np.int64)
+        o = out if out is not None else self.empty((F, ld))
+        st = status if status is not None else (self.empty((3, F), np.int32) if out is None else None)
+        self._check(self.L.vbx_analyze_frames_pcm16(self.ctx, ptr, F, int(frame_len), int(stride), C.byref(params),
+                                                    None if seg is None else seg.ctypes.data, 0 if seg is None else seg.size,
+                                                    _ptr(o), ld, _ptr(st)))
         if out is not None:
             return None
         res = (o.numpy(), st.numpy())
