@@ -181,6 +181,7 @@ def test_analyze_frames_pcm16_rectangular_seed_and_other_params(vb, pkg):
         params = pkg.AnalysisParams.make(48000.0, **kw)
         a, sa = vb.analyze_frames_pcm16(pcm, params, frame_len=N, stride=H)
         b, sb = vb.analyze_frames(wide, params, frame_len=N, stride=H, n_frames=F)
-        assert np.array_equal(sa, sb) and np.array_equal(a, b, equal_nan=True), kw     # silent frames: Levinson on zeros is NaN in both
+        rec = int(vb.L.vbx_record_doubles(params))               # (an odd record is padded to an even row; the pad is never written)
+        assert np.array_equal(sa, sb) and np.array_equal(a[:, :rec], b[:, :rec], equal_nan=True), kw   # silent frames: Levinson on zeros is NaN in both
     assert np.any(sb[1] == 1)                                    # the silent frames: Err(LPC) from Burg
     wide.free()
