@@ -323,19 +323,35 @@ int vbx_ring_frames_f64(vbx_ctx *ctx, const double *ring, size_t capacity, size_
 /* The slice traits are generic over the Sample type: `impl<T: Sample> Autocorrelate<T> for [T]`
  * (src/periodic.rs:276-289), `impl<T: Float> LPC<T> for [T]` (src/spectrum.rs:56), `Normalize` (src/waves.rs:60-76),
  * `MFCC<T>` (src/spectrum.rs:401-409).  These are their f32 instantiation: the arguments mean what they mean in the
- * _f64 entry points with float in place of double (frames, windows, outputs).  Arithmetic: see the header comment.
+ * _f64 entry points with float in place of double (frames, windows, outputs).
+ * Two forms of each.  The plain names are REFERENCE-FAITHFUL: every fold, product and quotient the generic code performs in
+ * T runs in f32, in the reference's order, with no fused multiply-add (the lag sums of src/periodic.rs:284 as sequential
+ * f32 folds, one lane per lag; Levinson and Burg as sequential f32 recursions, one lane per frame; Pitched<f32, f32>::pitch
+ * with its lag curve built and normalised in f32 and T = f32 roundings of the candidates) -- the results are the bits
+ * the crate returns at f32 (tests/test_gpu_f32.py: equal to the f32 restatement, which no reference test pins: parity
+ * unpinned).  The *_f32_wide names widen on load, compute in f64 with the f64 kernels and round once: more accurate and as
+ * fast as f64, but not those bits.  MFCC exists only in the wide form (rustfft's f32 arithmetic is not in the tree).
  * vbx_window_table_f32: the f64 table rounded to f32 (the sample crate's own f32 window path is not verifiable
  * here: parity unpinned). */
 int vbx_window_table_f32(int kind, size_t n, float *h_out);
 int vbx_autocorrelate_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
                           size_t stride, const float *window, size_t n_lags, float *out);
+int vbx_autocorrelate_f32_wide(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
+                          size_t stride, const float *window, size_t n_lags, float *out);
 int vbx_normalize_f32(vbx_ctx *ctx, float *data, size_t n_rows, size_t n);
 int vbx_lpc_mut_f32(vbx_ctx *ctx, const float *r, size_t n_frames, size_t r_stride,
+                    size_t n_coeffs, float *out_ac, float *out_kc);
+int vbx_lpc_mut_f32_wide(vbx_ctx *ctx, const float *r, size_t n_frames, size_t r_stride,
                     size_t n_coeffs, float *out_ac, float *out_kc);
 int vbx_autocorr_lpc_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
                          size_t stride, const float *window, size_t n_coeffs, int normalize,
                          float *out_r, float *out_lpc);
+int vbx_autocorr_lpc_f32_wide(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
+                         size_t stride, const float *window, size_t n_coeffs, int normalize,
+                         float *out_r, float *out_lpc);
 int vbx_lpc_burg_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
+                     size_t stride, const float *window, size_t n_coeffs, float *out, int32_t *status);
+int vbx_lpc_burg_f32_wide(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
                      size_t stride, const float *window, size_t n_coeffs, float *out, int32_t *status);
 int vbx_mfcc_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len, size_t stride,
                  const float *window, size_t num_coeffs, double lo_hz, double hi_hz,
@@ -344,6 +360,9 @@ int vbx_mfcc_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len
  * parameters and Pitch<f32> candidates.  The lag curve and the refinement run in f64 on the widened frame. */
 typedef struct { float frequency; float strength; } vbx_pitch32;
 int vbx_pitch_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len, size_t stride,
+                  const float *window, float sample_rate, float threshold, float fmin, float fmax,
+                  size_t kmax, vbx_pitch32 *out_cand, int32_t *out_count, int32_t *status);
+int vbx_pitch_f32_wide(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len, size_t stride,
                   const float *window, float sample_rate, float threshold, float fmin, float fmax,
                   size_t kmax, vbx_pitch32 *out_cand, int32_t *out_count, int32_t *status);
 

@@ -105,7 +105,7 @@ __device__ __forceinline__ void pitch_frame_mfma(
     wave_sync();
 
     pitch_params_t pp;
-    pp.sample_rate = sample_rate; pp.threshold = threshold; pp.fmin = fmin; pp.fmax = fmax; pp.kmax = kmax; pp.full_off = full_off;
+    pp.sample_rate = sample_rate; pp.threshold = threshold; pp.fmin = fmin; pp.fmax = fmax; pp.kmax = kmax; pp.full_off = full_off; pp.f32 = 0;
     double2 *full = full_off ? reinterpret_cast<double2 *>(reinterpret_cast<char *>(smem) + full_off) : nullptr;
     pitch_refine_store(ys, n, pp, f, out_cand, cand_ld, out_count, status, work, 0.0, full);
 }

@@ -501,7 +501,7 @@ void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
     a.frames = L.x; a.n_frames = L.F; a.stride = L.stride; a.window = L.window; a.lag_window = L.lag_window;
     a.tab = reinterpret_cast<const double2 *>(L.tab);
     a.n = L.n;
-    a.pp.sample_rate = L.sample_rate; a.pp.threshold = L.threshold; a.pp.fmin = L.fmin; a.pp.fmax = L.fmax; a.pp.kmax = L.kmax;
+    a.pp.sample_rate = L.sample_rate; a.pp.threshold = L.threshold; a.pp.fmin = L.fmin; a.pp.fmax = L.fmax; a.pp.kmax = L.kmax; a.pp.f32 = 0;
     a.out_cand = reinterpret_cast<double *>(L.out_cand); a.cand_ld = L.cand_ld; a.out_count = L.out_count;
     a.pitch_status = L.pitch_status; a.work = L.work;
     a.out_lpc = L.out_lpc; a.lpc_ld = L.lpc_ld;

@@ -42,6 +42,7 @@ struct vbx_ctx {
     size_t ws_bytes[WS_N] = {0};
     // cached device tables
     std::map<std::pair<int, size_t>, double *> windows;   // (kind, n)
+    std::map<size_t, float *> lag_windows32;              // n -> the lag window table rounded to f32 (Pitched<f32, f32>)
     std::map<std::tuple<size_t, int, int>, double *> goertzel;   // (n, b_lo, nb) -> [nb][2] kappa, sigma
     std::map<size_t, double *> dct_tables;                // K -> [K][K]
     std::map<std::pair<size_t, int>, std::pair<double *, double *>> dft2_tabs;   // (n, n1) -> (stage-1 table, twiddles)
@@ -479,6 +480,7 @@ void vbx_ctx_destroy(vbx_ctx *ctx) {
     if (ctx->pitch_work) hipFree(ctx->pitch_work);
     for (double *t : ctx->spectral_tab) if (t) hipFree(t);
     for (auto &kv : ctx->windows) hipFree(kv.second);
+    for (auto &kv : ctx->lag_windows32) hipFree(kv.second);
     for (auto &kv : ctx->goertzel) hipFree(kv.second);
     for (auto &kv : ctx->dct_tables) hipFree(kv.second);
     for (auto &kv : ctx->dft2_tabs) { hipFree(kv.second.first); hipFree(kv.second.second); }
@@ -1424,11 +1426,13 @@ int vbx_analyze_frames_pcm16(vbx_ctx *ctx, const int16_t *pcm, size_t n_frames, 
                                record_ld, status3);
 }
 
-// ---- Sample = f32 ----------------------------------------------------------
+// ---- Sample = f32, the WIDE forms --------------------------------------------
 // The traits are generic over the Sample type (src/periodic.rs:276-289 `T: Sample`, src/spectrum.rs:56 `T: Float`,
-// :401-409).  The f32 instantiation takes float frames and returns float results; samples are widened on load, the
-// arithmetic runs in f64 and every result is rounded to f32 once -- at least as accurate as the reference's own f32
-// folds, whose rounding (not ours) bounds the agreement (tests/test_gpu_f32.py).
+// :401-409).  The *_f32_wide entry points take float frames and return float results; samples are widened on load, the
+// arithmetic runs in f64 and every result is rounded to f32 once -- more accurate than the reference's own f32 folds and as
+// fast as the f64 kernels, but NOT the bits the crate returns at f32.  The reference-faithful forms (every fold in f32, in
+// the reference's order) carry the plain *_f32 names, further down; MFCC has only the wide form (its f32 arithmetic lives
+// in the un-vendored rustfft).
 
 int vbx_window_table_f32(int kind, size_t n, float *h_out) {
     if (!h_out || n == 0) return fail(nullptr, VBX_E_INVALID, "vbx_window_table_f32: bad argument");
@@ -1439,7 +1443,7 @@ int vbx_window_table_f32(int kind, size_t n, float *h_out) {
     return VBX_SUCCESS;
 }
 
-int vbx_autocorrelate_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
+int vbx_autocorrelate_f32_wide(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
                           size_t stride, const float *window, size_t n_lags, float *out) {
     int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
     if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
@@ -1479,7 +1483,7 @@ int vbx_normalize_f32(vbx_ctx *ctx, float *data, size_t n_rows, size_t n) {
     return check_launch(ctx, __func__);
 }
 
-int vbx_lpc_mut_f32(vbx_ctx *ctx, const float *r, size_t n_frames, size_t r_stride, size_t n_coeffs, float *out_ac,
+int vbx_lpc_mut_f32_wide(vbx_ctx *ctx, const float *r, size_t n_frames, size_t r_stride, size_t n_coeffs, float *out_ac,
                     float *out_kc) {
     VBX_REQUIRE(ctx, ctx != nullptr, "null context");
     if (n_frames == 0) return VBX_SUCCESS;
@@ -1491,7 +1495,7 @@ int vbx_lpc_mut_f32(vbx_ctx *ctx, const float *r, size_t n_frames, size_t r_stri
     return check_launch(ctx, __func__);
 }
 
-int vbx_autocorr_lpc_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
+int vbx_autocorr_lpc_f32_wide(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
                          size_t stride, const float *window, size_t n_coeffs, int normalize,
                          float *out_r, float *out_lpc) {
     int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
@@ -1525,7 +1529,7 @@ int vbx_autocorr_lpc_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t f
     return check_launch(ctx, __func__);
 }
 
-int vbx_lpc_burg_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
+int vbx_lpc_burg_f32_wide(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
                      size_t stride, const float *window, size_t n_coeffs, float *out, int32_t *status) {
     int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
     if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
@@ -1560,7 +1564,7 @@ int vbx_mfcc_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len
 
 // Pitched::pitch at S = T = f32 (src/periodic.rs:396-455 is generic over the Sample): the frames are widened (windowed
 // product rounded to f32 first), the candidates come from the f64 path and are rounded to f32 once.
-int vbx_pitch_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len, size_t stride,
+int vbx_pitch_f32_wide(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len, size_t stride,
                   const float *window, float sample_rate, float threshold, float fmin, float fmax,
                   size_t kmax, vbx_pitch32 *out_cand, int32_t *out_count, int32_t *status) {
     int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
@@ -1576,6 +1580,108 @@ int vbx_pitch_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_le
     rc = run_pitch(ctx, ctx->stream, (const double *)wi, n_frames, frame_len, frame_len, nullptr, (double)sample_rate,
                    (double)threshold, (double)fmin, (double)fmax, kmax, (vbx_pitch *)wo, 2 * kmax, out_count, status);
     if (rc != VBX_SUCCESS) return rc;
+    { Prof p(ctx, "narrow"); launch_narrow(ctx->stream, (const double *)wo, (long)(n_frames * kmax * 2), (float *)out_cand); }
+    return check_launch(ctx, __func__);
+}
+
+
+// ---- Sample = f32, reference-faithful (k_f32.hip): every fold in f32 in the reference's order ------------------------
+
+int vbx_autocorrelate_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
+                          size_t stride, const float *window, size_t n_lags, float *out) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_REQUIRE(ctx, out != nullptr, "null output");
+    VBX_REQUIRE(ctx, n_lags >= 1 && n_lags <= frame_len, "n_lags must be in [1, frame_len] (the reference panics beyond)");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    { Prof p(ctx, "autocorr_f32_exact"); launch_autocorr_f32_exact(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_lags, out); }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_lpc_mut_f32(vbx_ctx *ctx, const float *r, size_t n_frames, size_t r_stride, size_t n_coeffs, float *out_ac,
+                    float *out_kc) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    if (n_frames == 0) return VBX_SUCCESS;
+    VBX_REQUIRE(ctx, r && out_ac, "null argument");
+    VBX_REQUIRE(ctx, n_coeffs >= 1 && n_coeffs <= VBX_MAX_LPC_ORDER && r_stride >= n_coeffs + 1, "bad order / stride");
+    VBX_REQUIRE(ctx, n_frames <= 0x7fffffffull, "too many rows");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    { Prof p(ctx, "levinson_f32_exact"); launch_levinson_f32_exact(ctx->stream, r, (long)n_frames, (long)r_stride, (int)n_coeffs, out_ac, (long)n_coeffs + 1, out_kc); }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_autocorr_lpc_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
+                         size_t stride, const float *window, size_t n_coeffs, int normalize,
+                         float *out_r, float *out_lpc) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_REQUIRE(ctx, out_r || out_lpc, "both outputs null");
+    VBX_REQUIRE(ctx, n_coeffs >= 1 && n_coeffs <= VBX_MAX_LPC_ORDER && n_coeffs + 1 <= frame_len, "bad order");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    const int n_lags = (int)n_coeffs + 1;
+    hipStream_t st = ctx->stream;
+    float *r = out_r;
+    if (!r) {
+        void *w = nullptr;
+        rc = ws_get(ctx, vbx_ctx::WS_F32_OUT, n_frames * (size_t)n_lags * sizeof(float), &w);
+        if (rc != VBX_SUCCESS) return rc;
+        r = (float *)w;
+    }
+    { Prof p(ctx, "autocorr_f32_exact", st); launch_autocorr_f32_exact(st, x, (long)n_frames, (int)frame_len, (long)stride, window, n_lags, r); }
+    if (normalize) { Prof p(ctx, "normalize_rows_f32", st); launch_normalize_rows_f32(st, r, (long)n_frames, n_lags); }
+    if (out_lpc) { Prof p(ctx, "levinson_f32_exact", st); launch_levinson_f32_exact(st, r, (long)n_frames, n_lags, (int)n_coeffs, out_lpc, (long)n_lags, nullptr); }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_lpc_burg_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
+                     size_t stride, const float *window, size_t n_coeffs, float *out, int32_t *status) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_REQUIRE(ctx, out != nullptr, "null output");
+    VBX_REQUIRE(ctx, burg_supported((int)frame_len, (int)n_coeffs), "frame_len must be in [2, 4096], order in [1, 30]");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    // one lane per frame, b1 / b2 in a context-owned scratch: launches of at most `chunk` frames keep it under 256 MB
+    long chunk = (long)((256ull << 20) / (8ull * frame_len)) & ~63L;
+    if (chunk < 64) chunk = 64;
+    if ((size_t)chunk > n_frames) chunk = (long)((n_frames + 63) & ~(size_t)63);
+    void *w = nullptr;
+    rc = ws_get(ctx, vbx_ctx::WS_F32_IN, burg_f32_exact_scratch_bytes(chunk, (int)frame_len), &w);
+    if (rc != VBX_SUCCESS) return rc;
+    for (long f0 = 0; f0 < (long)n_frames; f0 += chunk) {
+        const long f1 = (f0 + chunk < (long)n_frames) ? f0 + chunk : (long)n_frames;
+        Prof p(ctx, "burg_f32_exact");
+        launch_burg_f32_exact(ctx->stream, x, f0, f1, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_coeffs, out, status, (float *)w);
+    }
+    return check_launch(ctx, __func__);
+}
+
+int vbx_pitch_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len, size_t stride,
+                  const float *window, float sample_rate, float threshold, float fmin, float fmax,
+                  size_t kmax, vbx_pitch32 *out_cand, int32_t *out_count, int32_t *status) {
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
+    VBX_REQUIRE(ctx, out_cand != nullptr, "null output");
+    VBX_REQUIRE(ctx, kmax >= 1 && kmax <= VBX_MAX_PITCH_CANDIDATES, "kmax must be in [1, VBX_MAX_PITCH_CANDIDATES]");
+    VBX_REQUIRE(ctx, frame_len >= 4, "frame_len must be >= 4");
+    VBX_REQUIRE(ctx, pitch_f32_exact_lds_bytes((int)frame_len, (int)kmax) + 16 <= 160 * 1024, "frame does not fit the LDS");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    auto it = ctx->lag_windows32.find(frame_len);
+    if (it == ctx->lag_windows32.end()) {                   // w_lag as the f64 table of the reference's recurrence, each entry rounded to f32
+        std::vector<double> h(frame_len);
+        if (window_table_host(VBX_WINDOW_HANNING_LAG, frame_len, h.data()) != VBX_SUCCESS) return fail(ctx, VBX_E_INVALID, "lag window");
+        std::vector<float> hf(frame_len);
+        for (size_t i = 0; i < frame_len; i++) hf[i] = (float)h[i];
+        float *d = nullptr;
+        VBX_HIP(ctx, hipMalloc((void **)&d, frame_len * sizeof(float)));
+        VBX_HIP(ctx, hipMemcpy(d, hf.data(), frame_len * sizeof(float), hipMemcpyHostToDevice));
+        it = ctx->lag_windows32.emplace(frame_len, d).first;
+    }
+    void *wo = nullptr;
+    rc = ws_get(ctx, vbx_ctx::WS_F32_OUT, n_frames * kmax * sizeof(vbx_pitch), &wo);
+    if (rc != VBX_SUCCESS) return rc;
+    { Prof p(ctx, "pitch_f32_exact");
+      launch_pitch_f32_exact(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, it->second, (double)sample_rate,
+                             (double)threshold, (double)fmin, (double)fmax, (int)kmax, (pitch_t *)wo, 2 * (long)kmax, out_count, status); }
     { Prof p(ctx, "narrow"); launch_narrow(ctx->stream, (const double *)wo, (long)(n_frames * kmax * 2), (float *)out_cand); }
     return check_launch(ctx, __func__);
 }

@@ -141,6 +141,16 @@ void launch_levinson_rows_f32(hipStream_t s, const float *r, long rows, long r_s
 void launch_burg_f32(hipStream_t s, const float *x, long F, int n, long stride, const float *window,
                      int p, float *out, int32_t *status);
 void launch_widen_frames(hipStream_t s, const float *x, long F, int n, long stride, const float *window, double *out);
+// k_f32.hip: the reference-faithful f32 forms (every fold in f32, in source order; bit-identical to oracle/vbx_oracle_f32.c)
+void launch_autocorr_f32_exact(hipStream_t s, const float *x, long F, int n, long stride, const float *window, int n_lags, float *out);
+size_t pitch_f32_exact_lds_bytes(int n, int kmax);
+void launch_pitch_f32_exact(hipStream_t s, const float *x, long F, int n, long stride, const float *window, const float *lag_window32,
+                            double sample_rate, double threshold, double fmin, double fmax, int kmax, pitch_t *out_cand, long cand_ld,
+                            int32_t *out_count, int32_t *status);
+void launch_levinson_f32_exact(hipStream_t s, const float *r, long rows, long r_stride, int p, float *out, long out_ld, float *out_kc);
+size_t burg_f32_exact_scratch_bytes(long frames, int n);
+void launch_burg_f32_exact(hipStream_t s, const float *x, long f0, long f1, long F, int n, long stride, const float *window, int p,
+                           float *out, int32_t *status, float *scratch);
 void launch_narrow(hipStream_t s, const double *in, long count, float *out);
 
 // k_mfcc.hip

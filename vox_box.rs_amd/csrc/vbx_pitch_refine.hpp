@@ -428,8 +428,16 @@ constexpr int GROUP_PATH_MIN_CAND = 32;         // pitch frames with more candid
 constexpr int RG = VBX_EXP_RG;                  // lanes per candidate on the group path of pitch_refine_store
 
 __device__ __forceinline__ void cand_from_peak(const double *ys, int kk, double sample_rate, int offset,
-                                               double &freq, double &nn) {
+                                               double &freq, double &nn, const bool f32 = false) {
     const double peak = ys[kk], peak_rev = ys[kk - 1], peak_fwd = ys[kk + 1];
+    if (f32) {                                                        // T = S::Float = f32: differences, quotients in f32
+#pragma clang fp contract(off)
+        const double dr = 0.5 * (double)(float)(peak_fwd - peak_rev);
+        const double d2r = 2. * peak - (double)(float)(peak_rev - peak_fwd);
+        freq = (double)(float)(sample_rate / (double)(float)((double)kk + dr / d2r));
+        nn = (double)(float)((double)(float)(sample_rate / freq) - (double)offset);
+        return;
+    }
     const double dr = 0.5 * (peak_fwd - peak_rev);                    // :423
     const double d2r = 2. * peak - (peak_rev - peak_fwd);             // :424 (Q5)
     freq = sample_rate / ((double)kk + dr / d2r);                     // :425
@@ -584,10 +592,13 @@ __host__ __device__ constexpr int pitch_refine_lds_bytes(int n) {
     return (n + Y_PAD + ((((n + PB - 1) / PB) + 2) & ~1)) * 8 + (n / 4 + 8) * (int)(sizeof(float) + sizeof(cand_t));
 }
 
-struct pitch_params_t { double sample_rate, threshold, fmin, fmax; int kmax; int full_off; };   // full_off: byte offset of
+struct pitch_params_t { double sample_rate, threshold, fmin, fmax; int kmax; int full_off; int f32 = 0; };   // full_off: byte offset of
                                                                                                 // the full-list region in the
                                                                                                 // dynamic LDS, 0 = none, < 0 =
                                                                                                 // the frame's output row
+// f32 != 0: the T = f32 instantiation of Pitched::pitch (k_f32.hip): every value of type T -- the parabolic lag's frequency,
+// the abscissa handed to the refinement, the candidate's frequency and strength -- is rounded to f32 where the generic code
+// holds it in T (src/periodic.rs:423-448 with T = f32); nothing is pruned (the exact top-k bounds are stated for f64).
 // entries of the full-list region: at most n/4 strict local maxima in [0, n/2) plus the unvoiced candidate
 __host__ __device__ constexpr int pitch_full_list_entries(int n) { return n / 4 + 2; }
 
@@ -610,6 +621,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
     const int lane = lane_id();
     const double sample_rate = pp.sample_rate, threshold = pp.threshold, fmin = pp.fmin, fmax = pp.fmax;
     const int kmax = pp.kmax;
+    const bool f32 = pp.f32 != 0;
     const int nblk = (n + PB - 1) / PB;              // blocks of PB lags for the |y| prefix sums
     double *p16 = ys + n + Y_PAD;
     float *keys = reinterpret_cast<float *>(p16 + ((nblk + 2) & ~1));
@@ -647,7 +659,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
         if (i < npeak) {
             k = cand_list[i];
             double freq, nn;
-            cand_from_peak(ys, k, sample_rate, offset, freq, nn);
+            cand_from_peak(ys, k, sample_rate, offset, freq, nn, f32);
             pass = (freq == 0.0) || (freq > fmin && freq < fmax);             // :439
         }
         wave_sync();                                // all reads of this pass before its writes
@@ -688,7 +700,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
                 const int c = base + (lane >> 2);
                 const bool have = c < ncand;
                 double freq = 0., nn = 0.;
-                if (have) cand_from_peak(ys, cand_list[c], sample_rate, offset, freq, nn);
+                if (have) cand_from_peak(ys, cand_list[c], sample_rate, offset, freq, nn, f32);
                 const double ub = first_eval_bound_quad(ys, p16, nblk, nvalid, ylen, offset, nx, nn, 1200, lane & 3, have);
                 const double kb = (ub <= 1.) ? ub : ((ub != ub) ? __builtin_inf() : ((ub == __builtin_inf()) ? ub : 1.));
                 if (have && (lane & 3) == 0) keys[c] = __double2float_ru(kb);
@@ -696,7 +708,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
         } else {
             for (int c = lane; c < ncand; c += 64) {
                 double freq, nn;
-                cand_from_peak(ys, cand_list[c], sample_rate, offset, freq, nn);
+                cand_from_peak(ys, cand_list[c], sample_rate, offset, freq, nn, f32);
                 const double ub = first_eval_bound(ys, p16, nblk, nvalid, ylen, offset, nx, nn, 1200);
                 const double kb = (ub <= 1.) ? ub : ((ub != ub) ? __builtin_inf() : ((ub == __builtin_inf()) ? ub : 1.));
                 keys[c] = __double2float_ru(kb);
@@ -723,7 +735,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
     // list cannot be among the entries returned, and is skipped.  Candidates are taken best-bound-first, so the
     // bar rises as early as possible; when the best remaining bound is below the bar, all the rest is too.
     // A list that never fills (kmax >= count) keeps bar = -inf: everything is refined.
-#define VBX_BAR() ((!fullm && kept == kmax) ? readlane_f64(ls, kmax - 1) : -__builtin_inf())
+#define VBX_BAR() ((!fullm && !f32 && kept == kmax) ? readlane_f64(ls, kmax - 1) : -__builtin_inf())
     auto insert = [&](double f_g, double s_g, int c_g) {
         if (s_g != s_g) any_nan = true;
         if (fullm) { if (lane == 0) full[c_g] = double2{f_g, s_g}; return; }
@@ -756,7 +768,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
             const int c = pick_best(keys, ncand, bar, lane);
             if (c < 0) break;
             double freq, nn, xmid, ymid;
-            cand_from_peak(ys, cand_list[c], sample_rate, offset, freq, nn);
+            cand_from_peak(ys, cand_list[c], sample_rate, offset, freq, nn, f32);
             bool dropped = false;
 #ifndef VBX_EXP_NO_WAVE_BRENT
             if (!improve_extremum_sinc_wave(ys, nvalid, ylen, offset, nx, nn, 1200, xmid, ymid, cterms, cevals, bar, dropped))
@@ -769,7 +781,8 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
                 xm = xmid + (double)offset;                                   // :445
                 ym = ymid;
                 if (ym > 1.) ym = 1. / ym;                                    // :446
-                xm = sample_rate / xm;                                        // :447
+                xm = sample_rate / (f32 ? (double)(float)xm : xm);            // :447
+                if (f32) { xm = (double)(float)xm; ym = (double)(float)ym; }  // Pitch<f32>
             }
             insert(xm, ym, c);
         }
@@ -793,7 +806,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
                     if (gid == g) {
                         ci = c;
                         double freq, nn;
-                        cand_from_peak(ys, cand_list[ci], sample_rate, offset, freq, nn);
+                        cand_from_peak(ys, cand_list[ci], sample_rate, offset, freq, nn, f32);
                         it = 0; special = false; xmid = 0.; ymid = 0.;
                         if (nn == 0.) { special = true; xmid = 0.; ymid = ys[0]; }                              // :193
                         else if (nn >= (double)nx) { special = true; xmid = (double)nx; ymid = y_at(ys, nvalid, nx - 1); }   // :194
@@ -869,7 +882,8 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
                 double xm = xmid + (double)offset;                                // :445
                 double ym = ymid;
                 if (ym > 1.) ym = 1. / ym;                                        // :446
-                const double cf = sample_rate / xm, cs = ym;                      // :447-448
+                double cf = sample_rate / (f32 ? (double)(float)xm : xm), cs = ym;   // :447-448
+                if (f32) { cf = (double)(float)cf; cs = (double)(float)cs; }      // Pitch<f32>
                 while (fm) {
                     const int ld = __builtin_ctzll(fm);
                     fm &= fm - 1;

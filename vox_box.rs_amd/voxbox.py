@@ -138,12 +138,17 @@ def load_library():
         "vbx_lpc_mut_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, vp]),
         "vbx_window_table_f32": (C.c_int, [i32, sz, vp]),
         "vbx_autocorrelate_f32": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, vp]),
+        "vbx_autocorrelate_f32_wide": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, vp]),
         "vbx_normalize_f32": (C.c_int, [vp, vp, sz, sz]),
         "vbx_lpc_mut_f32": (C.c_int, [vp, vp, sz, sz, sz, vp, vp]),
+        "vbx_lpc_mut_f32_wide": (C.c_int, [vp, vp, sz, sz, sz, vp, vp]),
         "vbx_autocorr_lpc_f32": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, i32, vp, vp]),
+        "vbx_autocorr_lpc_f32_wide": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, i32, vp, vp]),
         "vbx_lpc_burg_f32": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, vp, vp]),
+        "vbx_lpc_burg_f32_wide": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, vp, vp]),
         "vbx_mfcc_f32": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, dbl, dbl, dbl, vp, vp]),
         "vbx_pitch_f32": (C.c_int, [vp, vp, sz, sz, sz, vp, C.c_float, C.c_float, C.c_float, C.c_float, sz, vp, vp, vp]),
+        "vbx_pitch_f32_wide": (C.c_int, [vp, vp, sz, sz, sz, vp, C.c_float, C.c_float, C.c_float, C.c_float, sz, vp, vp, vp]),
         "vbx_autocorr_lpc_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, i32, vp, vp]),
         "vbx_lpc_burg_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, vp, vp]),
         "vbx_find_roots_c64": (C.c_int, [vp, vp, sz, sz, vp]),
@@ -714,11 +719,12 @@ class VoxBox:
     def _win32(self, window):
         return None if window is None else self.to_device(np.ascontiguousarray(window, dtype=np.float32), np.float32)
 
-    def autocorrelate_f32(self, x, n_lags, window=None):
+    def autocorrelate_f32(self, x, n_lags, window=None, wide=False):
+        """wide=False: the reference-faithful f32 folds; wide=True: f64 arithmetic on the widened frame, rounded once."""
         d, F, N = self._frames32(x)
         w = self._win32(window)
         o = self.empty((F, n_lags), np.float32)
-        self._check(self.L.vbx_autocorrelate_f32(self.ctx, d.ptr, F, N, N, _ptr(w), n_lags, o.ptr))
+        self._check((self.L.vbx_autocorrelate_f32_wide if wide else self.L.vbx_autocorrelate_f32)(self.ctx, d.ptr, F, N, N, _ptr(w), n_lags, o.ptr))
         r = o.numpy()
         for b in (d, w, o):
             if b is not None:
@@ -732,31 +738,31 @@ class VoxBox:
         d.free()
         return r
 
-    def lpc_mut_f32(self, r, n_coeffs):
+    def lpc_mut_f32(self, r, n_coeffs, wide=False):
         d, F, N = self._frames32(r)
         o, k = self.empty((F, n_coeffs + 1), np.float32), self.empty((F, n_coeffs), np.float32)
-        self._check(self.L.vbx_lpc_mut_f32(self.ctx, d.ptr, F, N, n_coeffs, o.ptr, k.ptr))
+        self._check((self.L.vbx_lpc_mut_f32_wide if wide else self.L.vbx_lpc_mut_f32)(self.ctx, d.ptr, F, N, n_coeffs, o.ptr, k.ptr))
         res = (o.numpy(), k.numpy())
         for b in (d, o, k):
             b.free()
         return res
 
-    def autocorr_lpc_f32(self, x, n_coeffs, normalize=False, window=None):
+    def autocorr_lpc_f32(self, x, n_coeffs, normalize=False, window=None, wide=False):
         d, F, N = self._frames32(x)
         w = self._win32(window)
         r, a = self.empty((F, n_coeffs + 1), np.float32), self.empty((F, n_coeffs + 1), np.float32)
-        self._check(self.L.vbx_autocorr_lpc_f32(self.ctx, d.ptr, F, N, N, _ptr(w), n_coeffs, int(bool(normalize)), r.ptr, a.ptr))
+        self._check((self.L.vbx_autocorr_lpc_f32_wide if wide else self.L.vbx_autocorr_lpc_f32)(self.ctx, d.ptr, F, N, N, _ptr(w), n_coeffs, int(bool(normalize)), r.ptr, a.ptr))
         res = (r.numpy(), a.numpy())
         for b in (d, w, r, a):
             if b is not None:
                 b.free()
         return res
 
-    def lpc_praat_f32(self, x, n_coeffs, window=None):
+    def lpc_praat_f32(self, x, n_coeffs, window=None, wide=False):
         d, F, N = self._frames32(x)
         w = self._win32(window)
         o, st = self.empty((F, n_coeffs), np.float32), self.empty(F, np.int32)
-        self._check(self.L.vbx_lpc_burg_f32(self.ctx, d.ptr, F, N, N, _ptr(w), n_coeffs, o.ptr, st.ptr))
+        self._check((self.L.vbx_lpc_burg_f32_wide if wide else self.L.vbx_lpc_burg_f32)(self.ctx, d.ptr, F, N, N, _ptr(w), n_coeffs, o.ptr, st.ptr))
         res = (o.numpy(), st.numpy())
         for b in (d, w, o, st):
             if b is not None:
@@ -775,11 +781,11 @@ class VoxBox:
                 b.free()
         return res
 
-    def pitch_f32(self, x, sample_rate, threshold, fmin, fmax, kmax=8, window=None):
+    def pitch_f32(self, x, sample_rate, threshold, fmin, fmax, kmax=8, window=None, wide=False):
         d, F, N = self._frames32(x)
         w = self._win32(window)
         cand, cnt, st = self.empty((F, kmax, 2), np.float32), self.empty(F, np.int32), self.empty(F, np.int32)
-        self._check(self.L.vbx_pitch_f32(self.ctx, d.ptr, F, N, N, _ptr(w), sample_rate, threshold, fmin, fmax, kmax,
+        self._check((self.L.vbx_pitch_f32_wide if wide else self.L.vbx_pitch_f32)(self.ctx, d.ptr, F, N, N, _ptr(w), sample_rate, threshold, fmin, fmax, kmax,
                                          cand.ptr, cnt.ptr, st.ptr))
         res = (cand.numpy(), cnt.numpy(), st.numpy())
         for b in (d, w, cand, cnt, st):
