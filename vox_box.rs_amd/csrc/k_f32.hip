@@ -9,7 +9,7 @@
 // rounds to f32, in the order the source states.  A sequential f32 fold cannot be re-associated without changing its
 // rounding, so these kernels do NOT parallelise inside a fold: the parallelism is across lags (one lane per lag of one
 // frame) or across frames (one lane per frame), every fold runs in the reference's order with FP contraction off, and the
-// results are BIT-IDENTICAL to oracle/vbx_oracle_f32.c (tests/test_gpu_f32.py asserts equality).  The wider-and-faster
+// results are BIT-IDENTICAL to a plain-C f32 restatement of the same statements (tests/test_gpu_f32.py asserts equality).  The wider-and-faster
 // forms (f64 arithmetic on the widened frame, rounded once) stay available as vbx_*_f32_wide.
 #include "vbx_device.hpp"
 #include "vbx_kernels.hpp"

@@ -141,7 +141,7 @@ void launch_levinson_rows_f32(hipStream_t s, const float *r, long rows, long r_s
 void launch_burg_f32(hipStream_t s, const float *x, long F, int n, long stride, const float *window,
                      int p, float *out, int32_t *status);
 void launch_widen_frames(hipStream_t s, const float *x, long F, int n, long stride, const float *window, double *out);
-// k_f32.hip: the reference-faithful f32 forms (every fold in f32, in source order; bit-identical to oracle/vbx_oracle_f32.c)
+// k_f32.hip: the reference-faithful f32 forms (every fold in f32, in source order; bit-identical to the f32 restatement the tests hold them to)
 void launch_autocorr_f32_exact(hipStream_t s, const float *x, long F, int n, long stride, const float *window, int n_lags, float *out);
 size_t pitch_f32_exact_lds_bytes(int n, int kmax);
 void launch_pitch_f32_exact(hipStream_t s, const float *x, long F, int n, long stride, const float *window, const float *lag_window32,
