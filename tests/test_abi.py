@@ -191,7 +191,7 @@ def test_rust_binding_is_complete_and_in_sync(pkg):
     utility = {n for n in declared if re.match(r"vbx_(abi_version|ctx_|sync|last_error|device_info|malloc|free|memcpy|memset|timer_|profile_|"
                                                r"selftest|internal_|synth_speech|window_table_f32|degree_|off_low_|hz_to_mel|mel_to_hz|"
                                                r"find_formants_(real|complex)_work_size|improve_extremum_ex|interpolate_sinc|improve_extremum_f64|"
-                                               r"ring_frames|preemphasis|dct_|lpc_f64$)", n) or n.endswith("_f32") or n.endswith("_c32")}
+                                               r"ring_frames|preemphasis|dct_|lpc_f64$)", n) or n.endswith(("_f32", "_c32", "_f32_wide"))}
     missing = declared - utility - used
     assert not missing, f"ABI entry points without a caller in bindings/rust/src/gpu.rs: {sorted(missing)}"
     for stub in ("unimplemented!", "todo!", "unreachable!"):
