@@ -64,8 +64,8 @@ ALG_BYTES = {
     "autocorr_lpc": lambda n, hop, p: hop * 8 + 2 * (p + 1) * 8,
     "burg": lambda n, hop, p: hop * 8 + p * 8 + 4,
     "formant_resonances": lambda n, hop, p: p * 8 + 4 + 32 * 16 + 4,
-    "tracker": lambda n, hop, p: 32 * 16 + 8 + 64,
-    "tracker_chunked": lambda n, hop, p: 2 * (32 * 16 + 8) + 64,      # warm-up: every row is read twice
+    "tracker": lambda n, hop, p: (p // 2) * 16 + 8 + 64,             # a row is read up to its count (<= p / 2 resonances), not all 32 slots
+    "tracker_chunked": lambda n, hop, p: 2 * ((p // 2) * 16 + 8) + 64,   # warm-up: every row is read twice
     "mfcc": lambda n, hop, p: hop * 8 + 13 * 8,
     "pcm16": lambda n, hop, p: 10,
 }
