@@ -83,6 +83,7 @@ __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
         if (vec16) {
             const double2 *xv = reinterpret_cast<const double2 *>(xf);
 #pragma unroll
+            // (non-temporal loads here: 1.166 against 0.834 ms per million frames -- measured round 3, not adopted)
             for (int e = 0; e < EPL; e += 2) { const double2 v = xv[e / 2]; dst[e] = v.x; if (e + 1 < EPL) dst[e + 1] = v.y; }
         } else if (full) {
 #pragma unroll
