@@ -973,3 +973,25 @@ def test_pitch_fft_path_defers_undecidable_frames(vb, oracle):
         if es == 0:
             k = min(4, en)
             assert np.all(np.abs(cand[f, :k, 0] - ec[:k, 0]) <= 1e-4 * np.abs(ec[:k, 0]) + 1e-12)
+
+
+def test_pitch_fft_path_defers_frames_with_a_peak_on_the_frequency_bound(vb, oracle):
+    """The frequency filter (src/periodic.rs:439) is a discrete decision on the curve as well: a peak whose parabolic
+    frequency lies within the transforms' rounding error of fmin or fmax is not decided by the FFT kernel either.  A pure
+    tone's lag-curve peaks give known parabolic frequencies; with fmax (or fmin) set EXACTLY on one of them the frame must be
+    deferred, and with the bound a hair away it must not -- and in every case the count is the oracle's."""
+    N = 1200
+    w = oracle.window("hanning", N)
+    t = np.arange(N) / SR
+    x = (np.sin(2 * np.pi * 200.0 * t) * w)[None, :]
+    # the parabolic frequencies of the frame's peaks, from the oracle's own lag curve
+    y = _lag_curve(oracle, x[0])
+    peaks = [k for k in range(1, N // 2 - 1) if y[k - 1] < y[k] > y[k + 1]]
+    k = peaks[0]
+    dr, d2r = 0.5 * (y[k + 1] - y[k - 1]), 2.0 * y[k] - (y[k - 1] - y[k + 1])
+    f_par = SR / (k + dr / d2r)
+    for fmin, fmax, deferred in ((75.0, f_par, 1), (f_par, 20000.0, 1), (75.0, f_par * (1 + 1e-9), 0), (75.0, f_par * (1 - 1e-9), 0), (75.0, 600.0, 0)):
+        cand, cnt, st = vb.pitch(x, SR, 0.2, fmin, fmax, kmax=4)
+        assert vb.last_unsure_count() == deferred, (fmin, fmax, vb.last_unsure_count())
+        es, ec, en = oracle.pitch(x[0], SR, 0.2, fmin, fmax)
+        assert st[0] == es and cnt[0] == en, (fmin, fmax, cnt[0], en)

@@ -604,11 +604,15 @@ __host__ __device__ constexpr int pitch_full_list_entries(int n) { return n / 4 
 
 // Phases a-c of Pitched::pitch on the lag curve ys[0..n) (zero padded to n + Y_PAD; the curve is
 // (r / max|r|) / w_lag, src/periodic.rs:404-408), one wavefront per frame; writes the frame's outputs.
-// unc_tol > 0: the curve carries an absolute error of up to unc_tol per entry (FFT-based autocorrelation).  The one
-// place where the path turns y into a DISCRETE decision is the strict 3-point peak test (:370-374): if any lag's test
-// could come out differently within that error (a peak or a non-peak by less than unc_tol, e.g. a curve that is
-// exactly zero over a stretch), nothing is written and the function returns false: the caller hands the frame to the
-// kernel that computes the lag sums directly.  Returns true when the frame's outputs were written.
+// unc_tol > 0: the curve carries an absolute error of up to unc_tol per entry (FFT-based autocorrelation).  Two places
+// turn y into a DISCRETE decision from the curve alone: the strict 3-point peak test (:370-374) and the frequency filter
+// on the parabolic lag (:439).  If any lag's peak test could come out differently within that error (a peak or a non-peak
+// by less than unc_tol, e.g. a curve that is exactly zero over a stretch), or a peak's frequency lies within the error's
+// reach of fmin / fmax, nothing is written and the function returns false: the caller hands the frame to the kernel that
+// computes the lag sums directly.  (The third discrete decision, the ORDER of the refined strengths, is not decidable
+// this way: the Brent iteration is chaotic below its stopping width, so two strengths closer than ~1e-6 can come out in
+// either order from ANY summation of the lag sums, the direct one included -- the tests count those as tie swaps.)
+// Returns true when the frame's outputs were written.
 // full != nullptr (LDS, pitch_full_list_entries(n) entries): the WHOLE Vec of :452-454 is wanted (kmax > 64, more than
 // the lane-resident list holds).  Nothing is pruned; every refined candidate is parked at its candidate index, and the
 // frame ends with a rank sort by (strength desc, candidate index asc) == the reference's stable sort, whose first kmax
@@ -651,6 +655,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
     }
     wave_sync();
     if (unc_tol > 0.0 && __any(unsure)) return false;
+    unsure = false;
     int ncand = 0;
     for (int base = 0; base < npeak; base += 64) {  // in place: the write position never passes the read position
         const int i = base + lane;
@@ -661,6 +666,14 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
             double freq, nn;
             cand_from_peak(ys, k, sample_rate, offset, freq, nn, f32);
             pass = (freq == 0.0) || (freq > fmin && freq < fmax);             // :439
+            if (unc_tol > 0.0) {
+                // the filter is a discrete decision too: the parabolic lag k + dr / d2r inherits the curve's error (each of
+                // the three samples within unc_tol); a frequency that close to fmin or fmax could fall on the other side
+                const double c = ys[k], d2r = 2. * c - (ys[k - 1] - ys[k + 1]), dr = 0.5 * (ys[k + 1] - ys[k - 1]);
+                const double dlag = unc_tol * (1.0 + 4.0 * fabs(dr / d2r)) / fabs(d2r);            // bound of the lag's error
+                const double tol_f = 2.0 * freq * dlag / fabs((double)k + dr / d2r);
+                if (!(fabs(freq - fmin) > tol_f && fabs(freq - fmax) > tol_f)) unsure = true;      // NaN: unsure
+            }
         }
         wave_sync();                                // all reads of this pass before its writes
         const unsigned long long mask = __ballot(pass);
@@ -668,6 +681,8 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
         ncand += __popcll(mask);
         wave_sync();
     }
+
+    if (unc_tol > 0.0 && __any(unsure)) return false;         // a frequency within the curve's error of fmin / fmax
 
     // a') first-evaluation bounds.  p16: prefix sums of |y| over blocks of PB; keys[c]: upper bound of candidate c's
     // strength, stored as a float rounded UP (still an upper bound; the whole frame then fits 12 wavefronts per CU)
