@@ -42,8 +42,8 @@ def bench_line(run):
 # bench.py profile name -> (workload suffix of the pmc_* runs, kernel-name PREFIXES in the counter files, unit).  Several
 # prefixes = one logical kernel made of several launches (the chunked tracker scan): their per-step totals are summed.
 KEYS = {
-    "analyze": ("pipeline", ["void analyze_kernel<true, true, true, 0>"], "frame"),
-    "pitch": ("config3", ["void analyze_kernel<false, false, true, 0>"], "frame"),
+    "analyze": ("pipeline", ["void analyze_kernel<true, true, true, 0,"], "frame"),
+    "pitch": ("config3", ["void analyze_kernel<false, false, true, 0,"], "frame"),
     "analyze_2048": ("pipeline_2048", ["void analyze_pow2_kernel<2, true, true, true, 0>"], "frame"),     # --frame-len 2048 --hop 1024
     "pitch_2048": ("config3_2048", ["void analyze_pow2_kernel<2, false, false, true, 0>"], "frame"),
     "pitch_1024": ("config3_1024", ["void analyze_pow2_kernel<1, false, false, true, 0>"], "frame"),
