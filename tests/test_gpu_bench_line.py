@@ -55,3 +55,16 @@ def test_config_workloads_pick_the_measured_dominant_kernel():
     assert "whole_config" in d and d["whole_config"]["fp64_frac"] > 0
     d = _bench("--workload", "config3", "--frame-len", "2048", "--hop", "1024", "--hours", "0.25", "--steps", "2", "--warmup", "1", "--no-cpu")
     assert "2048-sample frames" in d["metric"] and d["config"]["frame_len"] == 2048 and d["roofline"]["kernel"] == "pitch"
+
+
+def test_two_ranks_without_a_second_gpu_fail_loudly_and_never_fall_back():
+    """`--gpus 2` with both ranks forced onto GPU 0: RCCL refuses the duplicate device, so the library's communicator does not
+    come up -- the bench must then FAIL on every rank (gloo-reduced flag), quickly, with the reason; it must not print a line
+    measured over some other transport (round 2 fell back to torch.distributed P2P inside the timed region)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["VBX_BENCH_ONE_GPU"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--hours", "0.25", "--steps", "1", "--warmup", "0", "--no-cpu"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith('{"metric"')], p.stdout[-500:]
+    assert "no fallback transport" in p.stderr and "ncclCommInitRank" in p.stderr, p.stderr[-1500:]
