@@ -264,4 +264,59 @@ inline void find_formants(Context &c, const Frames &f, double sample_rate, size_
                                   res_count, lpc_coeffs, status));
 }
 
+// The user's whole frame loop in one call (examples/pitch_detection.rs:23-30, tests/lib.rs:71-83): per frame
+// pitch(..)[0], autocorrelate(p + 1) -> lpc(p), find_formants(..) with the state carried per utterance, mfcc(..), written as
+// one record of record_doubles(params) doubles per frame.  `records` [F, record_ld], `status3` [3, F] (optional).
+using AnalysisParams = vbx_analysis_params;
+inline AnalysisParams analysis_params(double sample_rate, size_t lpc_order = 12, size_t formant_order = 12, size_t mfcc_coeffs = 13) {
+    AnalysisParams p{};
+    p.sample_rate = sample_rate; p.pitch_threshold = 0.2; p.pitch_fmin = 75.0; p.pitch_fmax = 600.0;
+    p.lpc_order = lpc_order; p.formant_order = formant_order; p.n_est = formant_order ? 4 : 0;
+    for (size_t e = 0; e < 4; e++) { p.est_init[e].frequency = VBX_MALE_FORMANT_ESTIMATES[e]; p.est_init[e].bandwidth = 1.0; }
+    p.mfcc_coeffs = mfcc_coeffs; p.mfcc_lo_hz = 100.0; p.mfcc_hi_hz = 8000.0;
+    return p;
+}
+inline size_t record_doubles(const AnalysisParams &p) { return vbx_record_doubles(&p); }
+inline void analyze_frames(Context &c, const Frames &f, const AnalysisParams &p, Segments seg, double *records, size_t record_ld,
+                           int32_t *status3 = nullptr) {
+    if (f.window != nullptr) throw Error(VBX_E_INVALID, "analyze_frames applies the windows itself: pass rectangular frames");
+    c.check(vbx_analyze_frames_f64(c.get(), f.x, f.n_frames, f.frame_len, f.stride, &p, seg.h_seg_start, seg.n, records, record_ld, status3));
+}
+// the same on the WAV reader's 16-bit PCM (tests/lib.rs:17-19 before the `/ 32767`): bit-identical records, a quarter of the bytes
+inline void analyze_frames_pcm16(Context &c, const int16_t *pcm, size_t n_frames, size_t frame_len, size_t stride, const AnalysisParams &p,
+                                 Segments seg, double *records, size_t record_ld, int32_t *status3 = nullptr) {
+    c.check(vbx_analyze_frames_pcm16(c.get(), pcm, n_frames, frame_len, stride, &p, seg.h_seg_start, seg.n, records, record_ld, status3));
+}
+
+// Frame-range sharding of one recording over the GPUs of a node (no counterpart in the reference) and the gather of the
+// per-frame records to one rank: grouped ncclSend / ncclRecv inside the library, one communicator per process.
+struct Shard { size_t lo, hi, s0, s1; };
+inline Shard shard(size_t n_frames, int world, int rank, Segments seg, size_t frame_len, size_t hop) {
+    Shard r{};
+    if (vbx_shard_range(n_frames, world, rank, seg.h_seg_start, seg.n, &r.lo, &r.hi) != VBX_SUCCESS ||
+        vbx_shard_samples(r.lo, r.hi, frame_len, hop, &r.s0, &r.s1) != VBX_SUCCESS)
+        throw Error(VBX_E_INVALID, "shard: bad argument");
+    return r;
+}
+class Comm {
+public:
+    static std::vector<unsigned char> unique_id() {
+        std::vector<unsigned char> id(VBX_UNIQUE_ID_BYTES);
+        if (vbx_comm_unique_id(id.data()) != VBX_SUCCESS) throw Error(VBX_E_RUNTIME, vbx_last_error(nullptr));
+        return id;
+    }
+    Comm(Context &c, const std::vector<unsigned char> &id, int world, int rank) : ctx_(c) { c.check(vbx_comm_create(c.get(), id.data(), world, rank, &h_)); }
+    ~Comm() { vbx_comm_destroy(h_); }
+    Comm(const Comm &) = delete;
+    Comm &operator=(const Comm &) = delete;
+    void gather_records(const double *local, const std::vector<int64_t> &rows, size_t row_doubles, int dst, double *out, int slot = 0) {
+        ctx_.check(vbx_gather_records_f64(ctx_.get(), h_, local, rows.data(), row_doubles, dst, out, slot));
+    }
+    void wait(int slot) { ctx_.check(vbx_comm_wait(ctx_.get(), h_, slot)); }
+    void sync() { ctx_.check(vbx_comm_sync(h_)); }
+private:
+    Context &ctx_;
+    vbx_comm *h_ = nullptr;
+};
+
 }  // namespace voxbox
