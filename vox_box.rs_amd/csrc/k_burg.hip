@@ -35,14 +35,23 @@ namespace vbx {
 template <int G, int EPL, typename T, typename TIN = T>
 __global__ __launch_bounds__(64) void burg_kernel(
     const TIN *__restrict__ x, long n_frames, int n, long stride, const T *__restrict__ window,
-    int p, T *__restrict__ out, int32_t *__restrict__ status, const frame_map_t map) {
+    int p, T *__restrict__ out, int32_t *__restrict__ status, const frame_map_t map,
+    const int32_t *__restrict__ list = nullptr, const int32_t *__restrict__ list_count = nullptr) {
     constexpr int NG = 64 / G;
     static_assert(G >= VBX_MAX_LPC_ORDER_K || G == 16, "one coefficient per lane of the group");
     const int lane = lane_id();
     const int gid = lane / G, lig = lane % G;
     // one-frame workgroups of a hop-strided view: neighbouring frames on the same XCD (vbx_device.hpp, xcd_item)
-    const long blk = (NG == 1) ? xcd_item(blockIdx.x, gridDim.x) : (long)blockIdx.x;
-    const long f = frame_map(map, blk * NG + gid, n_frames);
+    const long blk = (NG == 1 && list == nullptr) ? xcd_item(blockIdx.x, gridDim.x) : (long)blockIdx.x;
+    // list != nullptr: the frames named by list[0 .. *list_count) (the ones k_burg_fast.hip's guard turned away), a fixed
+    // grid striding over a count only the device knows
+    for (long it = blk * NG;; it += (long)gridDim.x * NG) {
+    long f;
+    if (list != nullptr) {
+        const long cnt = *list_count;
+        if (it >= cnt) break;
+        f = (it + gid < cnt) ? (long)list[it + gid] : -1;
+    } else f = frame_map(map, it + gid, n_frames);
     const bool have = f >= 0;
     const TIN *xf = x + (have ? f : 0) * stride;
     constexpr bool PCM = sizeof(TIN) == 2;
@@ -174,6 +183,8 @@ __global__ __launch_bounds__(64) void burg_kernel(
         if (lig < p) out[f * (long)p + lig] = (T)((st == 0) ? co * -1.0 : 0.0);   // :142-144
         if (status != nullptr && lig == 0) status[f] = st;
     }
+    if (list == nullptr) break;
+    }
 }
 
 bool burg_supported(int n, int p) {
@@ -221,6 +232,33 @@ void launch_burg_pcm16(hipStream_t s, const int16_t *x, long F, int n, long stri
     else VBX_BURG16(64, 64);
 #undef VBX_BURG16
 }
+// the direct recursion on the frames of a device-side list (k_burg_fast.hip)
+template <typename TIN>
+static void launch_burg_list_t(hipStream_t s, const TIN *x, long F, int n, long stride, const double *window,
+                               int p, double *out, int32_t *status, const int32_t *list, const int32_t *count) {
+    dim3 b(64);
+    const frame_map_t map{0, 0, 0};
+    const long cap = 8192;                                   // wavefronts (8 per SIMD); each strides over the list
+#define VBX_BURGL(GG, E)                                                                                                   \
+    hipLaunchKernelGGL((burg_kernel<GG, E, double, TIN>), dim3((unsigned)((F + (64 / GG) - 1) / (64 / GG) < cap ? (F + (64 / GG) - 1) / (64 / GG) : cap)), b, 0, s, \
+                       x, F, n, stride, window, p, out, status, map, list, count)
+    const bool g16 = burg_small_groups_ok(p);
+    if (g16 && n <= 16 * 32) VBX_BURGL(16, 32);
+    else if (n <= 32 * 32) VBX_BURGL(32, 32);
+    else if (n <= 64 * 20) VBX_BURGL(64, 20);
+    else if (n <= 64 * 32) VBX_BURGL(64, 32);
+    else VBX_BURGL(64, 64);
+#undef VBX_BURGL
+}
+void launch_burg_list(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
+                      int p, double *out, int32_t *status, const int32_t *list, const int32_t *count) {
+    launch_burg_list_t<double>(s, x, F, n, stride, window, p, out, status, list, count);
+}
+void launch_burg_pcm16_list(hipStream_t s, const int16_t *x, long F, int n, long stride, const double *window,
+                            int p, double *out, int32_t *status, const int32_t *list, const int32_t *count) {
+    launch_burg_list_t<int16_t>(s, x, F, n, stride, window, p, out, status, list, count);
+}
+
 void launch_burg_f32(hipStream_t s, const float *x, long F, int n, long stride, const float *window,
                      int p, float *out, int32_t *status) {
     launch_burg_t<float>(s, x, F, n, stride, window, p, out, status, frame_map_t{0, 0, 0});

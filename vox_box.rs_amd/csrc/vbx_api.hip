@@ -37,8 +37,9 @@ struct vbx_ctx {
     std::string arch;
     int cu_count = 0;
     // workspaces (grown on demand, never shrunk)
-    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_UNSURE, WS_F32_IN, WS_F32_OUT, WS_TRK, WS_N };
+    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_UNSURE, WS_F32_IN, WS_F32_OUT, WS_TRK, WS_BURG_LIST, WS_N };
     void *ws[WS_N] = {nullptr};
+    const int32_t *burg_list_count = nullptr;             // device counter of the last one-pass Burg call (tests)
     size_t ws_bytes[WS_N] = {0};
     // cached device tables
     std::map<std::pair<int, size_t>, double *> windows;   // (kind, n)
@@ -845,6 +846,37 @@ int vbx_autocorr_lpc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t 
     return run_autocorr_lpc(ctx, ctx->stream, x, n_frames, frame_len, stride, window, n_coeffs, normalize, out_r, out_lpc, n_coeffs + 1);
 }
 
+// Burg on a batch: the one-pass form (k_burg_fast.hip) where it exists, the frames its guard turns away and every other
+// shape through the direct recursion (k_burg.hip)
+static int run_burg(vbx_ctx *ctx, hipStream_t stm, const double *x, const int16_t *pcm, long F, int n, long stride,
+                    const double *window, int p, double *coeffs, int32_t *st, frame_map_t map = frame_map_t{0, 0, 0}) {
+    if (burg_fast_supported(n, p)) {
+        void *w = nullptr;
+        int rc = ws_get(ctx, vbx_ctx::WS_BURG_LIST, burg_fast_scratch_bytes(F), &w);
+        if (rc != VBX_SUCCESS) return rc;
+        int32_t *list = burg_fast_list(w, F);
+        ctx->burg_list_count = list;
+        VBX_HIP(ctx, hipMemsetAsync(list, 0, sizeof(int32_t), stm));
+        const long items = frame_map_items(map, F), chunk = burg_fast_chunk(F);
+        for (long i0 = 0; i0 < items; i0 += chunk) {
+            const long m = (items - i0 < chunk) ? items - i0 : chunk;
+            { Prof pr(ctx, "burg_lags", stm);
+              if (pcm) launch_burg_lags_pcm16(stm, pcm, F, n, stride, window, map, i0, m, w);
+              else launch_burg_lags(stm, x, F, n, stride, window, map, i0, m, w); }
+            { Prof pr(ctx, "burg_recursion", stm); launch_burg_recursion(stm, F, map, i0, m, coeffs, st, w); }
+        }
+        Prof pr(ctx, "burg_direct_list", stm);
+        if (pcm) launch_burg_pcm16_list(stm, pcm, F, n, stride, window, p, coeffs, st, list + 2, list);
+        else launch_burg_list(stm, x, F, n, stride, window, p, coeffs, st, list + 2, list);
+        return VBX_SUCCESS;
+    }
+    Prof pr(ctx, "burg", stm);
+    ctx->burg_list_count = nullptr;
+    if (pcm) launch_burg_pcm16(stm, pcm, F, n, stride, window, p, coeffs, st, map);
+    else launch_burg(stm, x, F, n, stride, window, p, coeffs, st, map);
+    return VBX_SUCCESS;
+}
+
 int vbx_lpc_burg_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
                      size_t stride, const double *window, size_t n_coeffs, double *out, int32_t *status) {
     int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
@@ -852,7 +884,8 @@ int vbx_lpc_burg_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t fram
     VBX_REQUIRE(ctx, out != nullptr, "null output");
     VBX_REQUIRE(ctx, burg_supported((int)frame_len, (int)n_coeffs), "frame_len must be in [2, 4096], order in [1, 30]");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
-    { Prof p(ctx, "burg"); launch_burg(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_coeffs, out, status); }
+    rc = run_burg(ctx, ctx->stream, x, nullptr, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_coeffs, out, status);
+    if (rc != VBX_SUCCESS) return rc;
     return check_launch(ctx, __func__);
 }
 
@@ -1048,9 +1081,8 @@ static int run_find_formants(vbx_ctx *ctx, hipStream_t stm, const double *x, siz
     const int n_slices = seg_len > 0 ? want_slices : 1;
     const long tc = (seg_len + n_slices - 1) / n_slices;
     if (n_slices == 1) {
-        { Prof pr(ctx, "burg", stm);                                                                                              // :75
-          if (pcm) launch_burg_pcm16(stm, pcm, F, (int)frame_len, (long)stride, hann, p, coeffs, st);
-          else launch_burg(stm, x, F, (int)frame_len, (long)stride, hann, p, coeffs, st); }
+        rc = run_burg(ctx, stm, x, pcm, F, (int)frame_len, (long)stride, hann, p, coeffs, st);                                      // :75
+        if (rc != VBX_SUCCESS) return rc;
         { Prof pr(ctx, "formant_resonances", stm); launch_formant_resonances(stm, coeffs, F, p, sample_rate, res, cnt, st); }      // :80-110
         rc = run_tracker(ctx, stm, chunked, res, F, VBX_MAX_RESONANCES, cnt, d_seg, (long)nseg, d_est, (int)n_est, st,
                          (res_t *)out_formants, (long)formants_ld);                                                                    // :114
@@ -1064,9 +1096,8 @@ static int run_find_formants(vbx_ctx *ctx, hipStream_t stm, const double *x, siz
     }
     for (int j = 0; j < n_slices && j * tc < seg_len; j++) {
         const frame_map_t map{seg_len, j * tc, (seg_len - j * tc < tc) ? seg_len - j * tc : tc};   // the last slice may be shorter
-        { Prof pr(ctx, "burg", stm);
-          if (pcm) launch_burg_pcm16(stm, pcm, F, (int)frame_len, (long)stride, hann, p, coeffs, st, map);
-          else launch_burg(stm, x, F, (int)frame_len, (long)stride, hann, p, coeffs, st, map); }
+        rc = run_burg(ctx, stm, x, pcm, F, (int)frame_len, (long)stride, hann, p, coeffs, st, map);
+        if (rc != VBX_SUCCESS) return rc;
         { Prof pr(ctx, "formant_resonances", stm); launch_formant_resonances(stm, coeffs, F, p, sample_rate, res, cnt, st, map); }
         VBX_HIP(ctx, hipEventRecord(ctx->ev_slice[j], stm));
         VBX_HIP(ctx, hipStreamWaitEvent(ctx->trk, ctx->ev_slice[j], 0));
@@ -1707,6 +1738,18 @@ int vbx_internal_last_unsure_count(vbx_ctx *ctx, int32_t *h_count) {
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     VBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     VBX_HIP(ctx, hipMemcpy(h_count, ctx->ws[vbx_ctx::WS_UNSURE], sizeof(int32_t), hipMemcpyDeviceToHost));
+    return VBX_SUCCESS;
+}
+
+// internal (tests only): how many frames of the last Burg / find_formants call the one-pass form's guard handed to the
+// direct recursion (k_burg_fast.hip); -1 if the last such call did not take the one-pass form
+int vbx_internal_last_burg_direct_count(vbx_ctx *ctx, int32_t *h_count) {
+    VBX_REQUIRE(ctx, ctx && h_count, "null argument");
+    *h_count = -1;
+    if (!ctx->burg_list_count) return VBX_SUCCESS;
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    VBX_HIP(ctx, hipDeviceSynchronize());
+    VBX_HIP(ctx, hipMemcpy(h_count, ctx->burg_list_count, sizeof(int32_t), hipMemcpyDeviceToHost));
     return VBX_SUCCESS;
 }
 

@@ -172,6 +172,7 @@ def load_library():
         "vbx_synth_speech_f64": (C.c_int, [vp, vp, sz, C.c_uint64, dbl, C.c_uint64]),
         "vbx_selftest_lanes": (C.c_int, [vp, vp]),
         "vbx_internal_last_unsure_count": (C.c_int, [vp, vp]),
+        "vbx_internal_last_burg_direct_count": (C.c_int, [vp, vp]),
         "vbx_record_doubles": (sz, [C.POINTER(AnalysisParams)]),
         "vbx_analyze_frames_f64": (C.c_int, [vp, vp, sz, sz, sz, C.POINTER(AnalysisParams), vp, sz, vp, sz, vp]),
         "vbx_analyze_frames_pcm16": (C.c_int, [vp, vp, sz, sz, sz, C.POINTER(AnalysisParams), vp, sz, vp, sz, vp]),
@@ -916,6 +917,13 @@ class VoxBox:
         """Frames of the last FFT-path pitch / analyze call that were redone by the direct-sum kernel (test probe)."""
         n = C.c_int32(0)
         self._check(self.L.vbx_internal_last_unsure_count(self.ctx, C.byref(n)))
+        return int(n.value)
+
+    def last_burg_direct_count(self):
+        """Frames of the last Burg / find_formants call that the one-pass form's guard sent through the direct recursion
+        (test probe); -1 if that call did not take the one-pass form."""
+        n = C.c_int32(0)
+        self._check(self.L.vbx_internal_last_burg_direct_count(self.ctx, C.byref(n)))
         return int(n.value)
 
     def selftest_lanes(self):
