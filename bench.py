@@ -62,7 +62,10 @@ ALG_BYTES = {
     "pitch": lambda n, hop, p: hop * 8 + 16,                      # new samples in, top candidate out
     "analyze": lambda n, hop, p: hop * 8 + 16 + 13 * 8 + 13 * 8,  # fused: + MFCC + LPC rows out
     "autocorr_lpc": lambda n, hop, p: hop * 8 + 2 * (p + 1) * 8,
-    "burg": lambda n, hop, p: hop * 8 + p * 8 + 4,
+    "burg": lambda n, hop, p: hop * 8 + p * 8 + 4,                # the direct recursion (VBX_BURG_DIRECT=1; orders other than 12)
+    "burg_lags": lambda n, hop, p: hop * 8 + 3 * (p + 1) * 8,     # one-pass Burg: new samples in, lag sums + edge samples out
+    "burg_recursion": lambda n, hop, p: 3 * (p + 1) * 8 + p * 8 + 4,
+    "burg_direct_list": lambda n, hop, p: hop * 8 + p * 8 + 4,    # per frame ON THE LIST (~1 % of the batch)
     "formant_resonances": lambda n, hop, p: p * 8 + 4 + 32 * 16 + 4,
     "tracker": lambda n, hop, p: (p // 2) * 16 + 8 + 64,             # a row is read up to its count (<= p / 2 resonances), not all 32 slots
     "tracker_chunked": lambda n, hop, p: 2 * ((p // 2) * 16 + 8) + 64,   # warm-up: every row is read twice

@@ -22,8 +22,10 @@ def test_traffic_file_has_every_kernel_the_bench_can_ask_for():
     tab = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     # (workload, dominant kernel, frame_len, stride) -> plausible measured bytes per unit (algorithmic .. 3x)
     asked = [("pipeline", "analyze", 1200, 480), ("config3", "pitch", 1200, 480), ("config2", "autocorr_lpc", 512, 512),
-             ("config4", "burg", 512, 512), ("config4", "formant_resonances", 512, 512), ("config4", "tracker_chunked", 512, 512),
-             ("pipeline", "burg", 1200, 480), ("pipeline", "formant_resonances", 1200, 480), ("pipeline", "tracker_chunked", 1200, 480),
+             ("config4", "burg_lags", 512, 512), ("config4", "burg_recursion", 512, 512),
+             ("config4", "formant_resonances", 512, 512), ("config4", "tracker_chunked", 512, 512),
+             ("pipeline", "burg_lags", 1200, 480), ("pipeline", "burg_recursion", 1200, 480),
+             ("pipeline", "formant_resonances", 1200, 480), ("pipeline", "tracker_chunked", 1200, 480),
              ("frontend", "pcm16", 1200, 480)]
     for wl, dom, n, hop in asked:
         key = b.traffic_key(wl, dom, n, hop)
@@ -51,7 +53,7 @@ def test_headline_roofline_is_the_executed_fraction():
     """The headline `frac` of the pitch / analyze line is built from the flops the kernel EXECUTES; the comparison with the
     reference's O(N^2) sums lives under its own key and cannot exceed-1 its way into `frac`."""
     b = _bench()
-    prof = {"analyze": (3 * 178.0, 3), "burg": (3 * 22.0, 3)}
+    prof = {"analyze": (3 * 178.0, 3), "burg_lags": (3 * 9.0, 3 * 18), "burg_recursion": (3 * 1.0, 3 * 18)}
     work = (3 * 4_500_000, 3 * 4_500_000 * 40, 3 * 4_500_000 * 24, 3 * 4_500_000 * 16_000)
     roof, hbm, kms, _ = b.roofline_for("pipeline", prof, work, 4_500_000, 1200, 480, 3)
     assert roof["kernel"] == "analyze" and roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s"

@@ -47,8 +47,13 @@ KEYS = {
     "analyze_2048": ("pipeline_2048", ["void analyze_pow2_kernel<2, true, true, true, 0>"], "frame"),     # --frame-len 2048 --hop 1024
     "pitch_2048": ("config3_2048", ["void analyze_pow2_kernel<2, false, false, true, 0>"], "frame"),
     "pitch_1024": ("config3_1024", ["void analyze_pow2_kernel<1, false, false, true, 0>"], "frame"),
-    "burg_512": ("config4", ["void burg_kernel<16, 32, double"], "frame"),
-    "burg": ("pipeline", ["void burg_kernel<64, 20, double"], "frame"),
+    # Burg = the one-pass form (k_burg_fast.hip): lag sums, recursion, and the direct recursion on the frames its guard sent on
+    "burg_lags_512": ("config4", ["void burg_lags_kernel<8, 12, double"], "frame"),
+    "burg_lags": ("pipeline", ["void burg_lags_kernel<20, 12, double"], "frame"),
+    "burg_recursion_512": ("config4", ["void burg_recursion_kernel<12>"], "frame"),
+    "burg_recursion": ("pipeline", ["void burg_recursion_kernel<12>"], "frame"),
+    "burg_direct_list_512": ("config4", ["void burg_kernel<16, 32, double"], "frame"),
+    "burg_direct_list": ("pipeline", ["void burg_kernel<64, 20, double"], "frame"),
     "formant_resonances_512": ("config4", ["formant_resonances_kernel"], "frame"),
     "formant_resonances": ("pipeline", ["formant_resonances_kernel"], "frame"),
     "tracker_chunked_512": ("config4", ["void tracker_spec_kernel<4>", "void tracker_check_kernel<4>", "void tracker_repair_kernel<4>",
