@@ -213,7 +213,15 @@ int vbx_autocorr_lpc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t 
                          double *out_r, double *out_lpc);
 
 /* LPC::lpc_praat(n_coeffs) per frame (Burg, src/spectrum.rs:94-146).  out: [F, n_coeffs]
- * (no leading 1, sign-flipped as the reference); status[F]: VBX_FRAME_ERR_LPC when denum <= 0. */
+ * (no leading 1, sign-flipped as the reference); status[F]: VBX_FRAME_ERR_LPC when denum <= 0.
+ * Order 12 on frames of 256..2048 samples (also inside vbx_find_formants_f64 and vbx_analyze_frames_*): one pass over
+ * the frame -- its 13 lag sums and first / last 13 samples, then an O(p^2) recursion per frame that yields the reference's
+ * reflection coefficients (csrc/k_burg_fast.hip).  That recursion is exact in real arithmetic but amplifies the lag sums'
+ * rounding by the frame's conditioning (~1e-11 of the row's largest coefficient on speech), so the kernel bounds its own
+ * error per frame: a row is written only if the bound is inside 5e-7 in the parity metric
+ * |d| <= 1e-6 max(|a_j|, 1e-6 max|a|); every other frame (about 1 % of speech frames, every pure tone / DC / silent / NaN
+ * frame) is computed by the reference's own per-order sums, as all frames of every other order and length are.
+ * Environment: VBX_BURG_DIRECT=1 (read per call) takes the per-order sums for every frame. */
 int vbx_lpc_burg_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
                      size_t stride, const double *window, size_t n_coeffs, double *out, int32_t *status);
 

@@ -37,9 +37,10 @@ struct vbx_ctx {
     std::string arch;
     int cu_count = 0;
     // workspaces (grown on demand, never shrunk)
-    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_UNSURE, WS_F32_IN, WS_F32_OUT, WS_TRK, WS_BURG_LIST, WS_N };
+    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_UNSURE, WS_F32_IN, WS_F32_OUT, WS_TRK, WS_BURG_LIST, WS_ROOTS_LIST, WS_N };
     void *ws[WS_N] = {nullptr};
     const int32_t *burg_list_count = nullptr;             // device counter of the last one-pass Burg call (tests)
+    const int32_t *roots_list_count = nullptr;            // the same for the resonance kernel of find_formants
     size_t ws_bytes[WS_N] = {0};
     // cached device tables
     std::map<std::pair<int, size_t>, double *> windows;   // (kind, n)
@@ -1029,6 +1030,27 @@ int vbx_estimate_formants_f64(vbx_ctx *ctx, const vbx_resonance *res, size_t n_f
     return check_launch(ctx, __func__);
 }
 
+// Burg coefficients -> resonance rows: the conjugate-pair form (k_roots_fast.hip) where it exists (it does the frames that
+// fail its own check again by the reference's iteration), every other order through the reference's iteration (k_roots.hip)
+static int run_formant_resonances(vbx_ctx *ctx, hipStream_t stm, const double *coeffs, long F, int p, double sample_rate,
+                                  res_t *res, int32_t *cnt, int32_t *st, frame_map_t map = frame_map_t{0, 0, 0}) {
+    if (formant_resonances_fast_supported(p)) {
+        void *w = nullptr;
+        int rc = ws_get(ctx, vbx_ctx::WS_ROOTS_LIST, 4 * sizeof(int32_t), &w);
+        if (rc != VBX_SUCCESS) return rc;
+        int32_t *redo = (int32_t *)w;
+        ctx->roots_list_count = redo;
+        if (map.seg_len == 0 || map.t0 == 0) VBX_HIP(ctx, hipMemsetAsync(redo, 0, sizeof(int32_t), stm));   // once per call
+        Prof pr(ctx, "formant_resonances", stm);
+        launch_formant_resonances_fast(stm, coeffs, F, p, sample_rate, res, cnt, st, map, redo);
+        return VBX_SUCCESS;
+    }
+    ctx->roots_list_count = nullptr;
+    Prof pr(ctx, "formant_resonances", stm);
+    launch_formant_resonances(stm, coeffs, F, p, sample_rate, res, cnt, st, map);
+    return VBX_SUCCESS;
+}
+
 static int run_find_formants(vbx_ctx *ctx, hipStream_t stm, const double *x, size_t n_frames, size_t frame_len,
                              size_t stride, double sample_rate, size_t n_coeffs,
                              const int64_t *h_seg_start, size_t n_segments,
@@ -1083,7 +1105,8 @@ static int run_find_formants(vbx_ctx *ctx, hipStream_t stm, const double *x, siz
     if (n_slices == 1) {
         rc = run_burg(ctx, stm, x, pcm, F, (int)frame_len, (long)stride, hann, p, coeffs, st);                                      // :75
         if (rc != VBX_SUCCESS) return rc;
-        { Prof pr(ctx, "formant_resonances", stm); launch_formant_resonances(stm, coeffs, F, p, sample_rate, res, cnt, st); }      // :80-110
+        rc = run_formant_resonances(ctx, stm, coeffs, F, p, sample_rate, res, cnt, st);                                            // :80-110
+        if (rc != VBX_SUCCESS) return rc;
         rc = run_tracker(ctx, stm, chunked, res, F, VBX_MAX_RESONANCES, cnt, d_seg, (long)nseg, d_est, (int)n_est, st,
                          (res_t *)out_formants, (long)formants_ld);                                                                    // :114
         if (rc != VBX_SUCCESS) return rc;
@@ -1098,7 +1121,8 @@ static int run_find_formants(vbx_ctx *ctx, hipStream_t stm, const double *x, siz
         const frame_map_t map{seg_len, j * tc, (seg_len - j * tc < tc) ? seg_len - j * tc : tc};   // the last slice may be shorter
         rc = run_burg(ctx, stm, x, pcm, F, (int)frame_len, (long)stride, hann, p, coeffs, st, map);
         if (rc != VBX_SUCCESS) return rc;
-        { Prof pr(ctx, "formant_resonances", stm); launch_formant_resonances(stm, coeffs, F, p, sample_rate, res, cnt, st, map); }
+        rc = run_formant_resonances(ctx, stm, coeffs, F, p, sample_rate, res, cnt, st, map);
+        if (rc != VBX_SUCCESS) return rc;
         VBX_HIP(ctx, hipEventRecord(ctx->ev_slice[j], stm));
         VBX_HIP(ctx, hipStreamWaitEvent(ctx->trk, ctx->ev_slice[j], 0));
         { Prof pr(ctx, "tracker", ctx->trk); launch_tracker(ctx->trk, res, F, VBX_MAX_RESONANCES, cnt, d_seg, (long)nseg, d_est, (int)n_est, st, (res_t *)out_formants, (long)formants_ld, j * tc, tc); }
@@ -1750,6 +1774,17 @@ int vbx_internal_last_burg_direct_count(vbx_ctx *ctx, int32_t *h_count) {
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     VBX_HIP(ctx, hipDeviceSynchronize());
     VBX_HIP(ctx, hipMemcpy(h_count, ctx->burg_list_count, sizeof(int32_t), hipMemcpyDeviceToHost));
+    return VBX_SUCCESS;
+}
+
+// internal (tests only): the same count for the resonance kernel of the last find_formants call (k_roots_fast.hip)
+int vbx_internal_last_roots_direct_count(vbx_ctx *ctx, int32_t *h_count) {
+    VBX_REQUIRE(ctx, ctx && h_count, "null argument");
+    *h_count = -1;
+    if (!ctx->roots_list_count) return VBX_SUCCESS;
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    VBX_HIP(ctx, hipDeviceSynchronize());
+    VBX_HIP(ctx, hipMemcpy(h_count, ctx->roots_list_count, sizeof(int32_t), hipMemcpyDeviceToHost));
     return VBX_SUCCESS;
 }
 

@@ -77,6 +77,12 @@ void launch_to_resonance(hipStream_t s, const cplx_t *roots, long F, int n_roots
 // Burg coefficients [F,p] -> reversed complex polynomial -> roots -> resonances [F,32] (find_formants core)
 void launch_formant_resonances(hipStream_t s, const double *coeffs, long F, int p, double sample_rate,
                                res_t *out_res, int32_t *out_count, int32_t *status, frame_map_t map = frame_map_t{0, 0, 0});
+// k_roots_fast.hip: the same rows from the real polynomial's conjugate pairs (converged Laguerre solves, quadratic
+// deflation, a polish step that doubles as the check); a frame that fails the check is done again inside the kernel by
+// the reference's iteration.  redo_count: optional device counter of those frames.
+bool formant_resonances_fast_supported(int p);
+void launch_formant_resonances_fast(hipStream_t s, const double *coeffs, long F, int p, double sample_rate,
+                                    res_t *out_res, int32_t *out_count, int32_t *status, frame_map_t map, int32_t *redo_count);
 
 // k_tracker.hip
 void launch_tracker(hipStream_t s, const res_t *res, long F, int n_res, const int32_t *res_count,

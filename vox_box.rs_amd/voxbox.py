@@ -173,6 +173,7 @@ def load_library():
         "vbx_selftest_lanes": (C.c_int, [vp, vp]),
         "vbx_internal_last_unsure_count": (C.c_int, [vp, vp]),
         "vbx_internal_last_burg_direct_count": (C.c_int, [vp, vp]),
+        "vbx_internal_last_roots_direct_count": (C.c_int, [vp, vp]),
         "vbx_record_doubles": (sz, [C.POINTER(AnalysisParams)]),
         "vbx_analyze_frames_f64": (C.c_int, [vp, vp, sz, sz, sz, C.POINTER(AnalysisParams), vp, sz, vp, sz, vp]),
         "vbx_analyze_frames_pcm16": (C.c_int, [vp, vp, sz, sz, sz, C.POINTER(AnalysisParams), vp, sz, vp, sz, vp]),
@@ -924,6 +925,13 @@ class VoxBox:
         (test probe); -1 if that call did not take the one-pass form."""
         n = C.c_int32(0)
         self._check(self.L.vbx_internal_last_burg_direct_count(self.ctx, C.byref(n)))
+        return int(n.value)
+
+    def last_roots_direct_count(self):
+        """Frames of the last find_formants call whose resonances came from the reference's root iteration because the
+        conjugate-pair kernel handed them on (test probe); -1 if that call did not use it."""
+        n = C.c_int32(0)
+        self._check(self.L.vbx_internal_last_roots_direct_count(self.ctx, C.byref(n)))
         return int(n.value)
 
     def selftest_lanes(self):
