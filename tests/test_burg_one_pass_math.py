@@ -46,6 +46,15 @@ def test_recursion_equals_the_direct_sums_on_speech(pkg, oracle):
         assert trusted.mean() > 0.9, (N, trusted.mean())                  # ~1-2 % go to the direct recursion
 
 
+def test_recursion_at_the_other_orders(pkg, oracle):
+    X = _speech_frames(pkg, oracle, 512, 512, 600)
+    for order in (8, 10, 13, 16):
+        exp = np.array([oracle.lpc_burg(x, order)[1] for x in X])
+        co, trusted = burg_one_pass(X, order)
+        m = parity_metric(co, exp)
+        assert m[trusted].max() < 1e-7 and trusted.mean() > 0.85, (order, m[trusted].max(), trusted.mean())
+
+
 def test_guard_turns_away_what_the_recursion_cannot_do(oracle):
     rng = np.random.default_rng(11)
     for N in (512, 1200):

@@ -12,12 +12,12 @@ P = 12
 HANN_PERIODIC = 2
 
 
-def _both(vb, monkeypatch, x, **kw):
+def _both(vb, monkeypatch, x, order=P, **kw):
     monkeypatch.delenv("VBX_BURG_DIRECT", raising=False)
-    fast = vb.lpc_praat(x, P, **kw)
+    fast = vb.lpc_praat(x, order, **kw)
     sent = vb.last_burg_direct_count()
     monkeypatch.setenv("VBX_BURG_DIRECT", "1")
-    direct = vb.lpc_praat(x, P, **kw)
+    direct = vb.lpc_praat(x, order, **kw)
     assert vb.last_burg_direct_count() == -1
     monkeypatch.delenv("VBX_BURG_DIRECT", raising=False)
     return fast, direct, sent
@@ -43,6 +43,31 @@ def test_one_pass_equals_direct_and_oracle_on_speech(vb, oracle, monkeypatch, n,
         es, ec = oracle.lpc_burg(host[f * hop:f * hop + n] * wh, P)
         assert es == 0 and np.all(rel_close(co[f], ec)), f
     audio.free()
+
+
+@pytest.mark.parametrize("order", [8, 10, 13, 14, 16])
+def test_one_pass_at_the_other_orders(vb, oracle, monkeypatch, order):
+    """The orders with an instantiation besides BASELINE's 12 (10 and 13 are what the reference's own callers use:
+    tests/lib.rs:23,52): the same three statements at two frame shapes; orders without one (11 here) take the direct
+    recursion and say so."""
+    for n, hop in ((512, 512), (1200, 480)):
+        F = 12000
+        audio = vb.synth_speech((F - 1) * hop + n, sample_offset=23 * 48000)
+        w = vb.window(HANN_PERIODIC, n)
+        (co, st), (cd, sd), sent = _both(vb, monkeypatch, audio, order=order, frame_len=n, stride=hop, n_frames=F, window=w)
+        assert np.array_equal(st, sd) and np.all(st == 0)
+        m = parity_metric(co, cd)
+        assert m.max() <= 1e-7, (order, n, m.max())
+        assert 0 <= sent <= F // 10, (order, n, sent)
+        host = audio.numpy()
+        wh = oracle.window("hanning_periodic", n)
+        for f in range(0, F, 211):
+            es, ec = oracle.lpc_burg(host[f * hop:f * hop + n] * wh, order)
+            assert es == 0 and np.all(rel_close(co[f], ec)), (order, n, f)
+        audio.free()
+    x = vb.synth_speech(40 * 512).numpy().reshape(40, 512)
+    vb.lpc_praat(x, 11)
+    assert vb.last_burg_direct_count() == -1
 
 
 def test_one_pass_guard_on_adversarial_frames(vb, oracle, monkeypatch):

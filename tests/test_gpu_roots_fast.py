@@ -50,6 +50,28 @@ def test_resonance_rows_equal_the_reference_iterations(vb, pkg, oracle, monkeypa
     audio.free()
 
 
+@pytest.mark.parametrize("order", [8, 10, 13, 14, 16])
+def test_the_other_orders(vb, pkg, oracle, monkeypatch, order):
+    """Orders 10 and 13 are what the reference's own callers pass (tests/lib.rs:23,52); an odd order always has a real root."""
+    F, n, hop = 20000, 512, 256
+    audio = vb.synth_speech((F - 1) * hop + n, sample_offset=29 * 48000)
+    est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+    seg = np.arange(0, F, 500, dtype=np.int64)
+    run = lambda: vb.find_formants(audio, SR, order, est0, seg_start=seg, frame_len=n, stride=hop, n_frames=F)
+    a, b, redone = _both(vb, monkeypatch, run)
+    assert 0 <= redone <= F // 1000, redone
+    assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["count"], b["count"])
+    assert _rel(a["res"], b["res"]) <= 1e-8
+    assert np.max(np.abs(a["formants"] - b["formants"]) / np.abs(b["formants"])) <= 1e-8
+    s = oracle.soak(audio.numpy(), n, hop, 0, 2000, order, SR, oracle.SOAK_FORMANTS)
+    assert np.array_equal(a["status"][:2000], s["ff_status"]) and np.array_equal(a["count"][:2000], s["res_count"])
+    assert _rel(a["res"][:2000], s["res"]) <= 1e-8
+    audio.free()
+    # an order without an instantiation takes the reference's iteration
+    vb.find_formants(audio if False else vb.synth_speech(20 * 512).numpy().reshape(20, 512), SR, 11, est0)
+    assert vb.last_roots_direct_count() == -1
+
+
 def _frames_from_polys(rng, kind, count, n=512):
     """Frames whose order-12 Burg polynomial is of a given kind, built by filtering noise through an all-pole filter."""
     out = []

@@ -259,20 +259,31 @@ __global__ __launch_bounds__(64) void formant_resonances_fast_kernel(
     if (status != nullptr && st == 0 && rst != 0) status[f] = rst;
 }
 
+// the orders with an instantiation: 12 (BASELINE), 10 and 13 (the reference's own callers: tests/lib.rs:23,52,
+// examples/formant_extraction/src/main.rs:53), 8, 14, 16
 bool formant_resonances_fast_supported(int p) {
     const char *e = getenv("VBX_ROOTS_DIRECT");              // 1: the reference's iteration for every frame (A/B, tests)
-    return !(e && atoi(e) != 0) && p == 12;
+    return !(e && atoi(e) != 0) && (p == 8 || p == 10 || p == 12 || p == 13 || p == 14 || p == 16);
 }
 
 // redo_count (optional): a device counter the kernel adds the number of frames done by the reference's iteration to
 void launch_formant_resonances_fast(hipStream_t s, const double *coeffs, long F, int p, double sample_rate,
                                     res_t *out_res, int32_t *out_count, int32_t *status, frame_map_t map, int32_t *redo_count) {
-    (void)p;
     const long items = frame_map_items(map, F);
     if (items <= 0) return;
-    const size_t lds = (size_t)13 * ROOTS_BLOCK * sizeof(c64);
-    hipLaunchKernelGGL((formant_resonances_fast_kernel<12>), dim3((unsigned)((items + 63) / 64)), dim3(64), lds, s,
-                       coeffs, F, sample_rate, out_res, out_count, status, map, redo_count);
+    const size_t lds = (size_t)(p + 1) * ROOTS_BLOCK * sizeof(c64);
+#define VBX_RF(PP) hipLaunchKernelGGL((formant_resonances_fast_kernel<PP>), dim3((unsigned)((items + 63) / 64)), dim3(64), lds, s, \
+                                      coeffs, F, sample_rate, out_res, out_count, status, map, redo_count)
+    switch (p) {
+        case 8: VBX_RF(8); break;
+        case 10: VBX_RF(10); break;
+        case 12: VBX_RF(12); break;
+        case 13: VBX_RF(13); break;
+        case 14: VBX_RF(14); break;
+        case 16: VBX_RF(16); break;
+        default: break;
+    }
+#undef VBX_RF
 }
 
 }  // namespace vbx

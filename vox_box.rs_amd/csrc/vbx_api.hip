@@ -853,18 +853,18 @@ static int run_burg(vbx_ctx *ctx, hipStream_t stm, const double *x, const int16_
                     const double *window, int p, double *coeffs, int32_t *st, frame_map_t map = frame_map_t{0, 0, 0}) {
     if (burg_fast_supported(n, p)) {
         void *w = nullptr;
-        int rc = ws_get(ctx, vbx_ctx::WS_BURG_LIST, burg_fast_scratch_bytes(F), &w);
+        int rc = ws_get(ctx, vbx_ctx::WS_BURG_LIST, burg_fast_scratch_bytes(F, p), &w);
         if (rc != VBX_SUCCESS) return rc;
-        int32_t *list = burg_fast_list(w, F);
+        int32_t *list = burg_fast_list(w, F, p);
         ctx->burg_list_count = list;
         VBX_HIP(ctx, hipMemsetAsync(list, 0, sizeof(int32_t), stm));
         const long items = frame_map_items(map, F), chunk = burg_fast_chunk(F);
         for (long i0 = 0; i0 < items; i0 += chunk) {
             const long m = (items - i0 < chunk) ? items - i0 : chunk;
             { Prof pr(ctx, "burg_lags", stm);
-              if (pcm) launch_burg_lags_pcm16(stm, pcm, F, n, stride, window, map, i0, m, w);
-              else launch_burg_lags(stm, x, F, n, stride, window, map, i0, m, w); }
-            { Prof pr(ctx, "burg_recursion", stm); launch_burg_recursion(stm, F, map, i0, m, coeffs, st, w); }
+              if (pcm) launch_burg_lags_pcm16(stm, pcm, F, n, stride, window, p, map, i0, m, w);
+              else launch_burg_lags(stm, x, F, n, stride, window, p, map, i0, m, w); }
+            { Prof pr(ctx, "burg_recursion", stm); launch_burg_recursion(stm, F, p, map, i0, m, coeffs, st, w); }
         }
         Prof pr(ctx, "burg_direct_list", stm);
         if (pcm) launch_burg_pcm16_list(stm, pcm, F, n, stride, window, p, coeffs, st, list + 2, list);

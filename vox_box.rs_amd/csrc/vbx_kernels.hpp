@@ -54,17 +54,17 @@ void launch_burg_pcm16_list(hipStream_t s, const int16_t *x, long F, int n, long
 
 // k_burg_fast.hip: the same coefficients from the frame's lag sums and edge samples (one pass over the frame), in chunks
 // of burg_fast_chunk(F) items: launch_burg_lags, then launch_burg_recursion, per chunk; the frames its guard turns away
-// are appended to burg_fast_list(ws, F) ([0] = count, indices from [2]) for launch_burg_list / launch_burg_pcm16_list.
-// ws: burg_fast_scratch_bytes(F) bytes; the caller zeroes the list's count before the first chunk.
+// are appended to burg_fast_list(ws, F, p) ([0] = count, indices from [2]) for launch_burg_list / launch_burg_pcm16_list.
+// ws: burg_fast_scratch_bytes(F, p) bytes; the caller zeroes the list's count before the first chunk.
 bool burg_fast_supported(int n, int p);
 long burg_fast_chunk(long F);
-size_t burg_fast_scratch_bytes(long F);
-int32_t *burg_fast_list(void *ws, long F);
-void launch_burg_lags(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
+size_t burg_fast_scratch_bytes(long F, int p);
+int32_t *burg_fast_list(void *ws, long F, int p);
+void launch_burg_lags(hipStream_t s, const double *x, long F, int n, long stride, const double *window, int p,
                       frame_map_t map, long i0, long m, void *ws);
-void launch_burg_lags_pcm16(hipStream_t s, const int16_t *x, long F, int n, long stride, const double *window,
+void launch_burg_lags_pcm16(hipStream_t s, const int16_t *x, long F, int n, long stride, const double *window, int p,
                             frame_map_t map, long i0, long m, void *ws);
-void launch_burg_recursion(hipStream_t s, long F, frame_map_t map, long i0, long m, double *out, int32_t *status, void *ws);
+void launch_burg_recursion(hipStream_t s, long F, int p, frame_map_t map, long i0, long m, double *out, int32_t *status, void *ws);
 
 // k_roots.hip
 void launch_find_roots(hipStream_t s, cplx_t *polys, long F, int len, int32_t *status);
