@@ -214,8 +214,8 @@ int vbx_autocorr_lpc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t 
 
 /* LPC::lpc_praat(n_coeffs) per frame (Burg, src/spectrum.rs:94-146).  out: [F, n_coeffs]
  * (no leading 1, sign-flipped as the reference); status[F]: VBX_FRAME_ERR_LPC when denum <= 0.
- * Order 12 on frames of 256..2048 samples (also inside vbx_find_formants_f64 and vbx_analyze_frames_*): one pass over
- * the frame -- its 13 lag sums and first / last 13 samples, then an O(p^2) recursion per frame that yields the reference's
+ * Orders 8, 10, 12, 13, 14, 16 on frames of 256..2048 samples (also inside vbx_find_formants_f64 and vbx_analyze_frames_*): one pass over
+ * the frame -- its p + 1 lag sums and first / last p + 1 samples, then an O(p^2) recursion per frame that yields the reference's
  * reflection coefficients (csrc/k_burg_fast.hip).  That recursion is exact in real arithmetic but amplifies the lag sums'
  * rounding by the frame's conditioning (~1e-11 of the row's largest coefficient on speech), so the kernel bounds its own
  * error per frame: a row is written only if the bound is inside 5e-7 in the parity metric
@@ -279,7 +279,14 @@ int vbx_estimate_formants_f64(vbx_ctx *ctx, const vbx_resonance *res, size_t n_f
  * -> Resonance::from_root (im > 0) -> sort -> estimate_formants.  `window` must be NULL for
  * rectangular input frames as in tests/lib.rs:71 (the periodic Hanning is applied inside).
  * out_formants: [F, n_est]; out_res (optional): [F, 32] zero padded; out_res_count (optional): [F];
- * out_coeffs (optional): [F, n_coeffs] Burg coefficients; status[F]. */
+ * out_coeffs (optional): [F, n_coeffs] Burg coefficients; status[F].
+ * At the orders 8, 10, 12, 13, 14, 16 the resonance rows come from converged roots of the real polynomial found pair by
+ * pair (csrc/k_roots_fast.hip: one Laguerre solve per conjugate pair, deflation by the real quadratic, a Newton step on the
+ * original polynomial as polish and check) instead of a replay of find_roots_mut's iteration: the reference runs that
+ * iteration to convergence too (20 steps per root) and sorts the result by frequency, so the rows agree to ~1e-10 relative
+ * (gate 1e-4; counts and statuses equal).  A frame that fails the check is redone by the reference's own iteration, as
+ * every frame of the other orders is.  Environment: VBX_ROOTS_DIRECT=1 (read per call) replays the reference's
+ * iteration for every frame; VBX_BURG_DIRECT=1 see vbx_lpc_burg_f64. */
 int vbx_find_formants_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
                           size_t stride, double sample_rate, size_t n_coeffs,
                           const int64_t *h_seg_start, size_t n_segments,

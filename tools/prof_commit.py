@@ -54,8 +54,8 @@ KEYS = {
     "burg_recursion": ("pipeline", ["void burg_recursion_kernel<12>"], "frame"),
     "burg_direct_list_512": ("config4", ["void burg_kernel<16, 32, double"], "frame"),
     "burg_direct_list": ("pipeline", ["void burg_kernel<64, 20, double"], "frame"),
-    "formant_resonances_512": ("config4", ["formant_resonances_kernel"], "frame"),
-    "formant_resonances": ("pipeline", ["formant_resonances_kernel"], "frame"),
+    "formant_resonances_512": ("config4", ["void formant_resonances_fast_kernel<12>"], "frame"),     # k_roots_fast.hip
+    "formant_resonances": ("pipeline", ["void formant_resonances_fast_kernel<12>"], "frame"),
     "tracker_chunked_512": ("config4", ["void tracker_spec_kernel<4>", "void tracker_check_kernel<4>", "void tracker_repair_kernel<4>",
                                         "void tracker_sweep_kernel<4>"], "frame"),
     "tracker_chunked": ("pipeline", ["void tracker_spec_kernel<4>", "void tracker_check_kernel<4>", "void tracker_repair_kernel<4>",
