@@ -42,9 +42,12 @@ def _oracle_records(oracle, pkg, audio, F, seg, N=N, H=H):
     return rec, st
 
 
-# (1200, 480), (1024, 512), (2048, 1024): pitch + LPC + MFCC from one FFT of the frame; (1103, 441), (1600, 640): pitch + LPC
-# from the FFT (the frame is zero padded), MFCC by its own kernel; (4096, 2048): complex FFT of 4096; (256, 128): no fused kernel
-@pytest.mark.parametrize("N,H", [(1200, 480), (1024, 512), (2048, 1024), (1103, 441), (1600, 640), (512, 256), (4096, 2048), (256, 128)])
+# (1200, 480), (1024, 512), (2048, 1024): pitch + LPC + MFCC from one FFT of the frame; (512, 256): the same from the zero-padded
+# frame (512 divides the 1024 plan's 2048 points: its DFT bins are every 4th bin); (800, 320), (600, 240): likewise in the
+# 1200 plan (2400 = 3 * 800 = 4 * 600) instead of the 1024 plan their length would pick; (1103, 441), (1600, 640), (960, 480):
+# pitch + LPC from the FFT, MFCC by its own kernel; (4096, 2048): complex FFT of 4096; (256, 128): no fused kernel
+@pytest.mark.parametrize("N,H", [(1200, 480), (1024, 512), (2048, 1024), (1103, 441), (1600, 640), (512, 256), (4096, 2048), (256, 128),
+                                 (800, 320), (600, 240), (960, 480)])
 def test_analyze_frames_matches_the_oracle_and_the_separate_entry_points(vb, pkg, oracle, audio_d, N, H):
     audio = audio_d.numpy()
     F = pkg.frame_count(audio.size, N, H)

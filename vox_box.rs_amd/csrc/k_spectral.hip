@@ -175,7 +175,8 @@ __device__ __forceinline__ void fft1200(double (&re)[20], double (&im)[20], doub
 #ifndef VBX_SPECTRAL_WAVES
 #define VBX_SPECTRAL_WAVES 2
 #endif
-// FULL: the frame fills the transform (n == 1200, the bounds tests fold away); otherwise 1025 <= n < 1200, zero padded.
+// FULL: the frame fills the transform (n == 1200, the bounds tests fold away); otherwise n < 1200, zero padded: 1025..1199,
+// and 600 / 800 when MFCC is wanted (they divide M = 2400: spectral_plan_mfcc).
 // MODE: SP_ANALYZE the fused analysis; SP_MFCC_ONLY MFCC::mfcc alone (vbx_mfcc_f64 on a full frame): the forward transform and
 // the mel / DCT tail, nothing after them; SP_AC_ONLY Autocorrelate::autocorrelate alone (vbx_autocorrelate_f64 with many lags):
 // both transforms, the fold seed, the lag sums stored.
@@ -316,15 +317,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
         wave_sync();
     }
 
-    // ---- MFCC::mfcc from the powers: X_N[k'] = X_M[2 k'], i.e. bin m/2 from P[m] and bin 600 - m/2 from P[N - m] ----
+    // ---- MFCC::mfcc from the powers: the frame's n-point DFT bin k' is X_M[q k'], q = M / n (2 for the full frame; a
+    //      shorter frame whose length divides M = 2400 -- 800, 600 -- is zero padded and its bins are every q-th one): bin m / q
+    //      from P[m] and bin n/2 - m / q from P[N - m] ----
     if (MFCC) {
         const int nbp = (a.nb + 1) & ~1;
+        const int q = FULL ? 2 : a.mfcc_q, half = FULL ? SP_N / 2 : a.n / 2;
         double *pu = ex, *pd = ex + nbp, *en = ex + 2 * nbp; // the exchange buffer is free between the two transforms
 #pragma unroll
         for (int t = 0; t < 10; t++) {
             const int m = lane + 64 * t;
-            if (m <= 600 && (m & 1) == 0) {
-                const int b1 = (m >> 1) - b_lo, b2 = (SP_N / 2 - (m >> 1)) - b_lo;
+            if (m <= 600 && (FULL ? (m & 1) == 0 : m % q == 0)) {
+                const int mq = FULL ? (m >> 1) : m / q;
+                const int b1 = mq - b_lo, b2 = (half - mq) - b_lo;
                 if (b1 >= 0 && b1 < a.nb) {
                     const double2 sl = *reinterpret_cast<const double2 *>(a.slopes + 2 * b1);
                     pu[b1] = fabs(pk[t]) * sl.x;             // norm_sqr * multiplier (src/spectrum.rs:426-428)
@@ -487,12 +492,30 @@ void spectral_fill_tab(int plan, double *h) {
 }
 
 // The fused kernel serves: pitch for every frame length with a plan; LPC of order 12 with it; MFCC with it when the frame
-// fills the transform exactly (the mel filters read the n-point DFT bins = every second bin of the 2n-point transform).
+// divides the transform (the mel filters read the n-point DFT bins = every (M / n)-th bin of the M-point transform).
 bool spectral_supported(int n, int lpc_order, int mfcc_nb, int mfcc_b_lo, int num_coeffs) {
     const int plan = spectral_plan(n);
     if (plan == SPECTRAL_PLAN_NONE) return false;
     if (lpc_order != 0 && lpc_order != SP_LPC_P) return false;
-    if (num_coeffs != 0 && (n != spectral_plan_nc(plan) || num_coeffs > 64 || mfcc_nb < 1 || mfcc_b_lo < 0 || mfcc_b_lo + mfcc_nb > n / 2)) return false;
+    if (num_coeffs != 0 && ((2 * spectral_plan_nc(plan)) % n != 0 || (n & 1) || num_coeffs > 64 || mfcc_nb < 1 || mfcc_b_lo < 0 || mfcc_b_lo + mfcc_nb > n / 2)) return false;
+    return true;
+}
+
+// The plan for the fused frame loop when MFCC is wanted: the frame's DFT bins must be bins of the transform, i.e. the frame
+// length must divide the transform's M = 2 Nc.  512 divides the 1024 plan's 2048; 600 and 800 do not, but they divide the
+// 1200 plan's 2400 -- a 17 % longer transform instead of a second kernel over the same frames (MFCC::mfcc alone costs about
+// what the whole fused kernel does).
+int spectral_plan_mfcc(int n) {
+    const int plan = spectral_plan(n);
+    if (plan == SPECTRAL_PLAN_NONE) return plan;
+    if ((2 * spectral_plan_nc(plan)) % n == 0) return plan;
+    if (n <= SP_N && (2 * SP_N) % n == 0 && !(n & 1)) return SPECTRAL_PLAN_1200;
+    return plan;
+}
+bool spectral_supported_plan(int plan, int n, int lpc_order, int mfcc_nb, int mfcc_b_lo, int num_coeffs) {
+    if (plan == SPECTRAL_PLAN_NONE || n > spectral_plan_nc(plan)) return false;
+    if (lpc_order != 0 && lpc_order != SP_LPC_P) return false;
+    if (num_coeffs != 0 && ((2 * spectral_plan_nc(plan)) % n != 0 || (n & 1) || num_coeffs > 64 || mfcc_nb < 1 || mfcc_b_lo < 0 || mfcc_b_lo + mfcc_nb > n / 2)) return false;
     return true;
 }
 
@@ -510,6 +533,7 @@ void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
     a.unsure_list = L.unsure_list; a.unsure_count = L.unsure_count;
     a.out_r = L.out_r; a.n_lags = L.n_lags;
     a.pcm = (L.pcm && L.n == SP_N) ? 1 : 0;                  // the host side only asks for it on full 1200-sample frames
+    a.mfcc_q = (L.plan != SPECTRAL_PLAN_NONE && L.n > 0) ? (2 * spectral_plan_nc(L.plan)) / L.n : 2;
     if (L.plan != SPECTRAL_PLAN_1200) { launch_analyze_pow2(s, L, a); return; }
     const dim3 grid((unsigned)L.F), block(64);
     const size_t base = spectral_lds_bytes(L.n);
@@ -533,8 +557,10 @@ void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
     // several candidates per frame and no full-list region in LDS (12 wavefronts of 13.5 KB fit the CU): the form compiled
     // for three wavefronts per SIMD (pitch alone; the fused frame loop keeps kmax = 1)
     const bool w3 = !lpc && !mf && L.kmax >= 2 && extra == 0 && 12 * lds <= 160 * 1024;
-    if (L.n != SP_N) {                                       // spectral_supported(): no MFCC from a padded transform
-        if (lpc) hipLaunchKernelGGL((analyze_kernel<true, false, false>), grid, block, lds, s, a);
+    if (L.n != SP_N) {                                       // a padded frame; MFCC joins when its length divides 2400
+        if (lpc && mf) hipLaunchKernelGGL((analyze_kernel<true, true, false>), grid, block, lds, s, a);
+        else if (mf) hipLaunchKernelGGL((analyze_kernel<false, true, false>), grid, block, lds, s, a);
+        else if (lpc) hipLaunchKernelGGL((analyze_kernel<true, false, false>), grid, block, lds, s, a);
         else if (w3) hipLaunchKernelGGL((analyze_kernel<false, false, false, SP_ANALYZE, 3>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((analyze_kernel<false, false, false>), grid, block, lds, s, a);
     } else if (lpc && mf) hipLaunchKernelGGL((analyze_kernel<true, true, true>), grid, block, lds, s, a);

@@ -1364,12 +1364,18 @@ static int analyze_frames_impl(vbx_ctx *ctx, const char *fn, const double *x, co
         if (rc != VBX_SUCCESS) return rc;
         nb = hb.back() - hb.front();
     }
-    // (MFCC joins the fused kernel only when the frame fills the transform: n = 1024, 1200, 2048, 4096; LPC only at the order
+    // (MFCC joins the fused kernel when the frame's length divides the transform's: n = 512, 600, 800, 1024, 1200, 2048, 4096; LPC only at the order
     // the kernel's register Levinson is built for -- what cannot join runs from its own kernel on the side stream)
     const bool fused = !ctx->pitch_force_mfma && spectral_supported((int)frame_len, 0, 0, 0, 0);
     const bool fused_lpc = fused && h_p->lpc_order == SPECTRAL_LPC_ORDER;
+    // the transform: the one its length asks for, or -- if MFCC can join only there -- the one whose length the frame divides
+    int plan = fused ? spectral_plan((int)frame_len) : SPECTRAL_PLAN_NONE;
+    if (fused && !bad_bins && h_p->mfcc_coeffs) {
+        const int pm = spectral_plan_mfcc((int)frame_len);
+        if (spectral_supported_plan(pm, (int)frame_len, 0, nb, hb.front(), (int)h_p->mfcc_coeffs)) plan = pm;
+    }
     const bool fused_mfcc = fused && !bad_bins && h_p->mfcc_coeffs &&
-                            spectral_supported((int)frame_len, 0, nb, hb.front(), (int)h_p->mfcc_coeffs);
+                            spectral_supported_plan(plan, (int)frame_len, 0, nb, hb.front(), (int)h_p->mfcc_coeffs);
     // 16-bit PCM frames: the fused kernel of full 1200-sample frames, the pitch fallback and Burg read them directly;
     // anything that would send another kernel over the samples takes one widening pass into a context-owned f64 copy
     const bool pcm_native = pcm16 != nullptr && fused && frame_len == (size_t)SPECTRAL_N &&
@@ -1432,7 +1438,7 @@ static int analyze_frames_impl(vbx_ctx *ctx, const char *fn, const double *x, co
     if (fused) {
         const double *lagw = nullptr, *tab = nullptr;
         rc = get_window_dev(ctx, VBX_WINDOW_HANNING_LAG, frame_len, &lagw); if (rc != VBX_SUCCESS) return rc;
-        rc = get_spectral_tab(ctx, spectral_plan((int)frame_len), &tab); if (rc != VBX_SUCCESS) return rc;
+        rc = get_spectral_tab(ctx, plan, &tab); if (rc != VBX_SUCCESS) return rc;
         if (fused_mfcc) {
             rc = get_dct_dev(ctx, h_p->mfcc_coeffs, &dct); if (rc != VBX_SUCCESS) return rc;
             rc = get_slopes_dev(ctx, frame_len, h_p->mfcc_coeffs, h_p->mfcc_lo_hz, h_p->mfcc_hi_hz, h_p->sample_rate, hb, &slopes);
@@ -1444,7 +1450,7 @@ static int analyze_frames_impl(vbx_ctx *ctx, const char *fn, const double *x, co
             VBX_HIP(ctx, hipMemsetAsync(ctx->pitch_work, 0, wb, ctx->stream));
         }
         spectral_launch_t L{};
-        L.plan = spectral_plan((int)frame_len); L.n = (int)frame_len;
+        L.plan = plan; L.n = (int)frame_len;
         L.x = x; L.F = (long)n_frames; L.stride = (long)stride; L.window = hann; L.lag_window = lagw; L.tab = tab;
         L.sample_rate = h_p->sample_rate; L.threshold = h_p->pitch_threshold; L.fmin = h_p->pitch_fmin; L.fmax = h_p->pitch_fmax;
         L.kmax = 1;

@@ -133,6 +133,8 @@ constexpr int SPECTRAL_AC_MIN_LAGS = 64;                        // vbx_autocorre
                                                                 // (from 1024 samples on the FFT wins wherever the few-lag kernel does not apply)
 constexpr int SPECTRAL_MIN_N = 512;                             // shorter frames: the direct lag sums are as fast (measured)
 int spectral_plan(int n);                                       // the plan that serves frame length n, or SPECTRAL_PLAN_NONE
+int spectral_plan_mfcc(int n);                                  // the same when MFCC should join the fused kernel (k_spectral.hip)
+bool spectral_supported_plan(int plan, int n, int lpc_order, int mfcc_nb, int mfcc_b_lo, int num_coeffs);
 int spectral_plan_nc(int plan);                                 // its complex FFT length
 int spectral_tab_complex(int plan);                             // complex entries of its twiddle table
 void spectral_fill_tab(int plan, double *h_out);                // the table, host side: [2 * spectral_tab_complex(plan)]

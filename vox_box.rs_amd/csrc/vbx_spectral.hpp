@@ -38,6 +38,7 @@ struct spectral_args_t {
     const int32_t *bins; const double *slopes; const double *dct; int num_coeffs; int nb;
     int32_t *unsure_list; int32_t *unsure_count;
     double *out_r; int n_lags;                               // SP_AC_ONLY: [F, n_lags] lag sums
+    int mfcc_q;                                              // the frame's DFT bin k' is the transform's bin mfcc_q * k' (M / n)
     int pcm;                                                 // 1: `frames` points to int16 PCM samples (widened in registers:
                                                              // s / 32767, vbx_device.hpp pcm16_value); full frames only
 };

@@ -203,7 +203,7 @@ __device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16
 // U = 1, 2: two wavefronts per SIMD.  U = 1 (Nc = 1024) needs ~210 registers.  U = 2 (Nc = 2048: 32 complex values per lane, 17
 // spectrum pairs) needs ~290: at 256 a dozen to fifty of them spill, and the frame state (23 KB of LDS) admits six frames
 // per CU.  Measured at n = 2048: 25.2 M frames/s against 18.6 M with one wavefront per SIMD and no spills.
-// FULL: the frame fills the transform (n == Nc, the bounds tests fold away and MFCC can join); otherwise n < Nc.
+// FULL: the frame fills the transform (n == Nc, the bounds tests fold away); otherwise n < Nc (MFCC joins when n divides M).
 // MODE (vbx_spectral.hpp): SP_ANALYZE the fused analysis; SP_MFCC_ONLY MFCC::mfcc alone (the forward transform and the mel / DCT
 // tail only); SP_AC_ONLY Autocorrelate::autocorrelate alone (both transforms, the fold seed, the lag sums stored).
 template <int U, bool LPC, bool MFCC, bool FULL, int MODE = SP_ANALYZE>
@@ -339,16 +339,19 @@ void analyze_pow2_kernel(const spectral_args_t a) {
         wave_sync();
     }
 
-    // ---- MFCC::mfcc from the powers (n == Nc only): X_n[k'] = X_M[2 k'] ----
+    // ---- MFCC::mfcc from the powers: X_n[k'] = X_M[q k'], q = M / n -- 2 for a frame of Nc samples, 1 for one of 2 Nc (HALF),
+    //      4, 8, .. for a shorter frame whose length divides M (512 in the 1024 plan) ----
     if (MFCC) {
         const int nbp = (a.nb + 1) & ~1;
+        const int qm = HALF ? 0 : FULL ? 1 : a.mfcc_q - 1;    // q is a power of two: m % q == 0  <=>  (m & (q - 1)) == 0
+        const int qs = HALF ? 0 : FULL ? 1 : 31 - __builtin_clz((unsigned)a.mfcc_q);
+        const int half = HALF ? NC : FULL ? NC / 2 : n / 2;
         double *pu = ex, *pd = ex + nbp, *en = ex + 2 * nbp; // the exchange buffer is free between the two transforms
 #pragma unroll
         for (int t = 0; t < TP; t++) {
             const int m = lane + 64 * t;
-            if (m <= NC / 2 && (HALF || (m & 1) == 0)) {
-                // padded frame of Nc samples: its DFT bin k' is the transform's bin 2 k'; frame of 2 Nc samples: bin m itself
-                const int b1 = (HALF ? m : (m >> 1)) - b_lo, b2 = (HALF ? NC - m : NC / 2 - (m >> 1)) - b_lo;
+            if (m <= NC / 2 && (m & qm) == 0) {
+                const int b1 = (m >> qs) - b_lo, b2 = (half - (m >> qs)) - b_lo;
                 if (b1 >= 0 && b1 < a.nb) {
                     const double2 sl = *reinterpret_cast<const double2 *>(a.slopes + 2 * b1);
                     pu[b1] = fabs(pk[t]) * sl.x;             // norm_sqr * multiplier (src/spectrum.rs:426-428)
@@ -488,7 +491,11 @@ void launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a
         else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, false, SP_AC_ONLY>), grid, block, pow2_lds_bytes<U>(0, 0), s, a);
         return;
     }
-    if (L.n != pow2_geom<U>::NC) {                           // spectral_supported(): no MFCC from a padded transform
+    if (L.n != pow2_geom<U>::NC) {                           // a padded frame; MFCC joins when its length divides M (U = 1: 512)
+        if constexpr (U == 1) {
+            if (lpc && mf) { hipLaunchKernelGGL((analyze_pow2_kernel<U, true, true, false>), grid, block, lds, s, a); return; }
+            if (mf) { hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, false>), grid, block, lds, s, a); return; }
+        }
         if (lpc) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, false, false>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, false>), grid, block, lds, s, a);
     } else if (lpc && mf) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, true, true>), grid, block, lds, s, a);
