@@ -93,7 +93,7 @@ def parse():
     ap.add_argument("--host-fed", action="store_true", help="pipeline only: the recording starts in pinned HOST memory as 16-bit PCM "
                     "and crosses PCIe inside the timed region, in chunks, double-buffered against the kernels (vbx_analyze_frames_pcm16); "
                     "reported under its own metric name, never as the headline `value`")
-    ap.add_argument("--chunk-frames", type=int, default=500_000, help="--host-fed: frames per H2D chunk (whole utterances)")
+    ap.add_argument("--chunk-frames", type=int, default=250_000, help="--host-fed: frames per H2D chunk (whole utterances)")
     return ap.parse_args()
 
 
