@@ -23,7 +23,7 @@
 // doubles per frame -- lag sums, first samples, last samples -- in a scratch laid out [value][frame]; burg_recursion_kernel
 // runs the recursion, 64 frames per wavefront.  Fully unrolled on registers the recursion needs ~300 of them (one wavefront
 // per SIMD): fused behind the streaming loop it cost that loop its occupancy, and only the 16 lanes that own a frame of
-// the wavefront's batch would run it.  The scratch (312 B per frame) is why the batch is cut into chunks of BF_CHUNK frames.
+// the wavefront's batch would run it.  The scratch (312 B per frame at order 12) is why the batch is cut into chunks of BF_CHUNK frames.
 //
 // Accuracy.  num and den are differences of terms of size c[0] |A|^2: the lag sums' own rounding (~eps c[0]) reaches mu
 // amplified by kappa = c[0] |A|_1^2 / den.  On speech kappa eps is ~1e-12 (coefficients within ~1e-11 of the row's largest);
@@ -44,9 +44,10 @@ namespace vbx {
 #endif
 constexpr int BF_FPW = VBX_BF_FPW;         // frames per wavefront (burg_lags_kernel)
 #ifndef VBX_BF_CHUNK
-#define VBX_BF_CHUNK 262144
+#define VBX_BF_CHUNK 524288
 #endif
-constexpr long BF_CHUNK = VBX_BF_CHUNK;    // frames per pair of launches: 80 MB of scratch
+constexpr long BF_CHUNK = VBX_BF_CHUNK;    // frames per pair of launches: 164 MB of scratch at order 12 (config 4, frames/s at
+                                           // 131072 / 262144 / 524288 / 1048576 per chunk: 366 / 380 / 389 / 389 M)
 // bound used by the guard: 64 kappa eps max|a| <= BF_TARGET * max(|a_j|, 1e-6 max|a|) for every j.  The observed error is
 // at most 40 kappa eps max|a| (20,000 speech frames at 512 and at 1200 samples, 6,000 adversarial frames).
 constexpr double BF_KAPPA_EPS = 64.0 * 2.220446049250313e-16;
