@@ -1,4 +1,5 @@
-// vbx_burg_fast.hpp (kernels; k_burg_fast.hip: dispatch; k_burg_fast_p*.hip: one instantiation per order) -- Burg LPC (LPC::lpc_praat_mut, src/spectrum.rs:101-146) in O(N P) + O(P^2) instead of O(N P) PER ORDER:
+// vbx_burg_fast.hpp (kernels; k_burg_fast.hip: dispatch; k_burg_fast_p*.hip: one instantiation per order) -- Burg LPC
+// (LPC::lpc_praat_mut, src/spectrum.rs:101-146) in O(N P) + O(P^2) instead of O(N P) PER ORDER:
 // the reflection coefficients from the frame's lag sums and its first and last P + 1 samples.
 //
 // The reference walks the forward / backward error arrays b2 / b1 once per order (:116-139).  Write a_i for the order-i
@@ -20,10 +21,10 @@
 // (P + 1 lag sums: the few-lag autocorrelation of k_lpc.hip), and the recursion runs one frame per LANE.
 //
 // Two kernels.  burg_lags_kernel streams the frames (HBM- / issue-bound, 2-4 wavefronts per SIMD) and leaves 3 (P + 1)
-// doubles per frame -- lag sums, first samples, last samples -- in a scratch laid out [value][frame]; burg_recursion_kernel
-// runs the recursion, 64 frames per wavefront.  Fully unrolled on registers the recursion needs ~300 of them (one wavefront
-// per SIMD): fused behind the streaming loop it cost that loop its occupancy, and only the 16 lanes that own a frame of
-// the wavefront's batch would run it.  The scratch (312 B per frame at order 12) is why the batch is cut into chunks of BF_CHUNK frames.
+// doubles per frame -- lag sums, first samples, last samples -- in a scratch tiled [64 frames][value][frame]; burg_recursion_kernel
+// runs the recursion, 64 frames per wavefront.  Fully unrolled on registers the recursion wants ~290 of them: fused behind the
+// streaming loop it cost that loop its occupancy (one wavefront per SIMD), and only the 16 lanes that own a frame of the
+// wavefront's batch would run it.  The scratch (312 B per frame at order 12) is why the batch is cut into chunks of BF_CHUNK frames.
 //
 // Accuracy.  num and den are differences of terms of size c[0] |A|^2: the lag sums' own rounding (~eps c[0]) reaches mu
 // amplified by kappa = c[0] |A|_1^2 / den.  On speech kappa eps is ~1e-12 (coefficients within ~1e-11 of the row's largest);
@@ -31,7 +32,8 @@
 // coefficients could be off by more than BF_TARGET in the parity metric of tests/ (|d| <= 1e-6 max(|a_j|, 1e-6 max|a|)) --
 // a badly conditioned frame, or one with a coefficient that happens to be tiny -- or whose denominator is not positive
 // (the reference's Err(LPC), NaN input) is NOT written: its index goes to a list, and the direct kernel runs on the list
-// (launch_burg_fast).  About 2 % of speech frames; a pure tone or a silent frame always.
+// (run_burg, vbx_api.hip).  About 1 % of speech frames at order 12 (0.25 % at order 8, 1.9 % at 16); a pure tone or a silent
+// frame always.
 #pragma once
 
 #include "vbx_device.hpp"
