@@ -220,6 +220,27 @@ def test_soak_config4(vb, oracle, pkg):
     assert not any(cls.values()), cls
 
 
+@pytest.mark.parametrize("order,n,hop", [(10, 1024, 512), (13, 512, 256), (13, 1200, 480)])
+def test_soak_reference_orders(vb, oracle, pkg, order, n, hop):
+    """find_formants at the orders the reference's own callers pass (tests/lib.rs:52: 10 on 1024 / 512 frames; tests/lib.rs:23
+    and examples/formant_extraction/src/main.rs:53: 13): 15,000 consecutive frames each against the oracle's walk -- Burg
+    coefficients, resonance rows, tracks, every class zero (both orders take the one-pass Burg and the conjugate-pair root
+    kernel; an odd order always has a real root)."""
+    F = 15000
+    audio_d = vb.synth_speech((F - 1) * hop + n, sample_offset=7 * 48000)
+    audio = audio_d.numpy()
+    est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+    seg = np.arange(0, F, SEG, dtype=np.int64)
+    ff = vb.find_formants(audio_d, SR, order, est0, seg_start=seg, frame_len=n, stride=hop, n_frames=F)
+    assert vb.last_burg_direct_count() >= 0 and vb.last_roots_direct_count() >= 0       # both rewrites were on the path
+    audio_d.free()
+    s = oracle.soak(audio, n, hop, 0, F, order, SR, oracle.SOAK_FORMANTS)
+    cls = _formant_classes(oracle, ff, s, est0, seg)
+    REPORT["order_%d_%d_%d" % (order, n, hop)] = {"frames": F, "disagreements": cls}
+    print("\nsoak order %d at %d / %d:" % (order, n, hop), cls)
+    assert not any(cls.values()), cls
+
+
 def test_zz_soak_report():
     """Writes what the soak tests counted to gpurun_out/soak_report.json (copied to profiles/ by the builder)."""
     import json
