@@ -57,6 +57,58 @@ def test_chunked_scan_equals_sequential_scan(vb, pkg, monkeypatch, n_est, kind):
                                                                       int(np.argmax(np.any(a != b, axis=(1, 2)))))
 
 
+@pytest.mark.parametrize("n_est", [1, 2, 3, 4, 5, 6])
+def test_index_form_equals_general_form(vb, pkg, oracle, monkeypatch, n_est):
+    """The tracker's step on entry INDICES (rows as find_formants writes them: `count` real entries with ascending positive
+    frequencies, then zeros) against the general step on (frequency, bandwidth) values (VBX_TRACKER_GENERAL=1): bit for bit,
+    through both scans -- rows with 0..6 real entries, all-zero rows, skipped frames, estimates that start unsorted and
+    on top of each other (duplicate picks, the unassigned-peak fill and its swaps), and rows that do NOT qualify mixed in
+    (equal frequencies, a zero frequency among the real ones, more than six entries: the whole wavefront then takes the
+    general step).  And against the oracle's sequential tracker on a stretch of the rows."""
+    rng = np.random.default_rng(7 * n_est + 1)
+    F = 12000
+    res = _rows(rng, F, 8, 0, 6, 0.05)
+    cnt = np.sum(res[:, :, 0] > 0, axis=1).astype(np.int32)
+    res[:, :, 0] = np.round(res[:, :, 0] / 250.0) * 250.0 * (res[:, :, 0] > 0)      # coarse grid: near and exact ties of distance
+    for t in range(F):                                                             # keep the rows strictly ascending
+        k = cnt[t]
+        f = np.unique(res[t, :k, 0][res[t, :k, 0] > 0])
+        res[t, :, :] = 0.0
+        res[t, :f.size, 0] = f
+        res[t, :f.size, 1] = rng.uniform(20.0, 900.0, f.size)
+        cnt[t] = f.size
+    spoiled = res.copy(); scnt = cnt.copy()
+    for t in rng.integers(0, F, 60):                                               # rows the index form must not take
+        k = scnt[t]
+        kind = rng.integers(0, 3)
+        if kind == 0 and k >= 2: spoiled[t, 1, 0] = spoiled[t, 0, 0]               # equal frequencies
+        elif kind == 1 and k >= 2: spoiled[t, 0, 0] = 0.0                          # a zero among the real entries
+        else:
+            spoiled[t, :7, 0] = np.sort(rng.uniform(100.0, 7000.0, 7)); spoiled[t, :7, 1] = 50.0; scnt[t] = 7
+    est0 = np.array([[1000.0, 60.0], [1000.0, 70.0], [250.0, 80.0], [4000.0, 90.0], [3900.0, 100.0], [6500.0, 120.0]])[:n_est]
+    seg = np.array(sorted({0, 100, 101, 5000, 5064, 9000} | set(rng.integers(9100, 11000, 20).tolist())), dtype=np.int64)
+    status = (rng.random(F) < 0.03).astype(np.int32) * 2
+    for rows, counts in ((res, cnt), (spoiled, scnt)):
+        for chunked in ("0", "1"):
+            monkeypatch.setenv("VBX_TRACKER_CHUNKED", chunked)
+            monkeypatch.delenv("VBX_TRACKER_GENERAL", raising=False)
+            a = vb.estimate_formants(rows, est0, seg_start=seg, frame_status=status, res_count=counts)
+            monkeypatch.setenv("VBX_TRACKER_GENERAL", "1")
+            b = vb.estimate_formants(rows, est0, seg_start=seg, frame_status=status, res_count=counts)
+            monkeypatch.delenv("VBX_TRACKER_GENERAL")
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (n_est, chunked, int(np.argmax(np.any(a != b, axis=(1, 2)))))
+        monkeypatch.delenv("VBX_TRACKER_CHUNKED")
+    # the oracle's sequential tracker on the first utterances of the qualifying rows (zero-padded rows, as the reference passes them)
+    a = vb.estimate_formants(res, est0, seg_start=seg, frame_status=status, res_count=cnt)
+    est = est0.copy()
+    for t in range(0, 400):
+        if t in set(seg.tolist()):
+            est = est0.copy()
+        if status[t] == 0:
+            est = oracle.estimate_formants(est, res[t])
+        assert np.array_equal(a[t], est), (n_est, t)
+
+
 def test_chunked_scan_short_batches_and_edges(vb, pkg, monkeypatch):
     """Batches shorter than a chunk or the warm-up, one-frame utterances, a batch that ends on the chunk grid."""
     rng = np.random.default_rng(7)

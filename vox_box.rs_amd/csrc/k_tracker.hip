@@ -168,6 +168,122 @@ __device__ __forceinline__ void estimate_formants_step(double (&ef)[NS], double 
     }
 }
 
+// ---- the same step on INDICES -------------------------------------------------------------------------------------------
+// find_formants hands the tracker rows of a particular shape: `cnt` (<= 6 at order 12) real resonances with strictly
+// ascending, positive frequencies, then zeros.  On such a row two entries are equal (derive(PartialEq), :149) exactly when
+// they are the same entry -- every zero standing for the one zero entry the reference's strict '<' can ever pick -- so the
+// slots can hold entry INDICES instead of (frequency, bandwidth) pairs:
+//   Step 2  the nearest entry per estimate: its index and its distance (the same comparisons in the same order);
+//   Step 3  "same resonance" is index equality, and the two distances the reference compares (:257-258) are the ones Step 2
+//           already holds (both slots hold the same entry);
+//   Step 4  contained / placed / swapped on small integers;
+//   the sort by frequency is a sort by index (the row ascends; None and the zero entry, whose frequency is not > 0, carry
+//   no winner and go last), and the winners are read off the row by index.
+// 6-slot select chains on doubles become integer compares and min / max: about half the vector instructions of the
+// general step and almost none of its exec-mask branching.  trk_row_qualifies() is the shape test; a wavefront in which any
+// lane's row fails it (or any caller without counts: vbx_estimate_formants_f64 on arbitrary rows) takes the general step.
+template <int NE>
+__device__ __forceinline__ bool trk_row_qualifies(const res_t (&pre)[TRK_PF], int n_res, int cnt) {
+    bool q = cnt >= 0 && cnt <= NS && cnt < n_res;            // a zero entry follows the real ones
+    double prev = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        q = q && (i >= cnt || pre[i].frequency > prev);       // false for NaN
+        prev = pre[i].frequency;
+    }
+    return q;
+}
+
+template <int NE>
+__device__ __forceinline__ void estimate_formants_step_idx(double (&ef)[NS], double (&eb)[NS], const res_t (&pre)[TRK_PF], int cnt) {
+    // entry i of the row as Step 2 sees it: real for i < cnt, the zero entry at i == cnt, nothing beyond
+    double fr[NS + 1];
+#pragma unroll
+    for (int i = 0; i <= NS; i++) fr[i] = (i < cnt && i < TRK_PF) ? pre[i < TRK_PF ? i : 0].frequency : 0.0;
+    int sidx[NS];                                             // slot -> entry index
+    bool some[NS];
+    double bd[NE];
+#pragma unroll
+    for (int q = 0; q < NS; q++) { sidx[q] = 0; some[q] = q < NE; }
+#pragma unroll
+    for (int e = 0; e < NE; e++) bd[e] = fabs(fr[0] - ef[e]);
+#pragma unroll
+    for (int i = 1; i <= NS; i++) {
+        const bool valid = i <= cnt;
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            const double d = fabs(fr[i] - ef[e]);
+            const bool lt = valid && d < bd[e];               // strict '<': the first wins ties
+            sidx[e] = lt ? i : sidx[e];
+            bd[e] = lt ? d : bd[e];
+        }
+    }
+    // Step 3 (:250-272)
+    bool has_unassigned = false;
+    {
+        int w = 0;
+#pragma unroll
+        for (int r = 1; r < NE; r++) {
+            int wi = 0; double wd = 0.0;
+#pragma unroll
+            for (int q = 0; q < NE; q++) { wi = (q == w) ? sidx[q] : wi; wd = (q == w) ? bd[q] : wd; }
+            const bool same = sidx[r] == wi;
+            const bool closer = bd[r] < wd;                   // |v.f - est[r]| < |v.f - est[w]|: both slots hold entry v
+#pragma unroll
+            for (int q = 0; q < NE; q++) some[q] = some[q] && !(same && closer && q == w) && !(same && !closer && q == r);
+            has_unassigned = has_unassigned || same;
+            w = (same && !closer) ? w : r;
+        }
+    }
+    // Step 4 (:274-310)
+    if (__any(has_unassigned)) {
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            const int pj = (j < cnt) ? j : cnt;               // the peak: entry j, or the zero entry
+            bool contained = false;
+#pragma unroll
+            for (int q = 0; q < NS; q++) contained = contained || (some[q] && sidx[q] == pj);
+            const bool place = has_unassigned && !contained;
+            const bool here = place && !some[j];
+            const bool left = place && some[j] && j > 0 && !some[j > 0 ? j - 1 : 0];
+            const bool right = place && some[j] && !left && j + 1 < NS && !some[j + 1 < NS ? j + 1 : j];
+            if (j > 0) { sidx[j - 1] = left ? sidx[j] : sidx[j - 1]; some[j - 1] = some[j - 1] || left; }
+            if (j + 1 < NS) { sidx[j + 1] = right ? sidx[j] : sidx[j + 1]; some[j + 1] = some[j + 1] || right; }
+            sidx[j] = (here || left || right) ? pj : sidx[j];
+            some[j] = some[j] || here;
+        }
+    }
+    // :312-332: the winners (Some, frequency > 0: a real entry) in ascending frequency = ascending index
+    int key[NS];
+#pragma unroll
+    for (int q = 0; q < NS; q++) key[q] = (some[q] && sidx[q] < cnt) ? sidx[q] : 15;
+#define VBX_CE(a, b) { const int lo_ = min(key[a], key[b]), hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; }
+    VBX_CE(0, 1) VBX_CE(2, 3) VBX_CE(4, 5)                    // a 12-exchange network for six keys
+    VBX_CE(0, 2) VBX_CE(3, 5) VBX_CE(1, 4)
+    VBX_CE(0, 1) VBX_CE(2, 3) VBX_CE(4, 5)
+    VBX_CE(1, 2) VBX_CE(3, 4)
+    VBX_CE(2, 3)
+#undef VBX_CE
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+        const int k = key[e];
+        double nf = ef[e], nb = eb[e];
+#pragma unroll
+        for (int i = 0; i < NS; i++) { nf = (k == i) ? pre[i].frequency : nf; nb = (k == i) ? pre[i].bandwidth : nb; }
+        ef[e] = nf; eb[e] = nb;
+    }
+}
+
+// one step, by whichever form the wavefront's rows allow.  `general`: VBX_TRACKER_GENERAL=1 (tests: the two forms are
+// compared bit for bit).  Must be called from converged code... of the lanes that call it: the ballots see only those.
+template <int NE>
+__device__ __forceinline__ void estimate_formants_any(double (&ef)[NS], double (&eb)[NS], const res_t (&pre)[TRK_PF],
+                                                      const res_t *__restrict__ row, int n_res, int cnt, bool counted, bool general) {
+    const bool fast = counted && !general && trk_row_qualifies<NE>(pre, n_res, cnt);
+    if (__all(fast)) estimate_formants_step_idx<NE>(ef, eb, pre, cnt);
+    else estimate_formants_step<NE>(ef, eb, pre, row, n_res, cnt);
+}
+
 // Frames [f0 + t0, f0 + t0 + tc) of every segment (t0 = 0, tc = LONG_MAX: whole segments).  A slice that does not start
 // a segment continues from the estimates after the previous frame, which are exactly what `out` holds for it -- so the
 // scan of a long batch can be cut into time slices that run while the resonances of the next slice are still being
@@ -178,7 +294,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(const res_t *__restrict__ r
                                const int64_t *__restrict__ seg_start, long n_seg,
                                const res_t *__restrict__ est_init,
                                const int32_t *__restrict__ frame_status, double *__restrict__ out, long out_ld,
-                               long t0, long tc) {
+                               long t0, long tc, int general) {
     const long sg = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (sg >= n_seg) return;
     const long s0 = (seg_start != nullptr) ? seg_start[sg] : 0;
@@ -213,7 +329,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(const res_t *__restrict__ r
         int nxt_cnt = 0;
         bool nxt_ok = false;
         if (f + 1 < f1) fetch(f + 1, nxt, nxt_cnt, nxt_ok);
-        if (cur_ok) estimate_formants_step<NE>(ef, eb, cur, res + f * (long)n_res, n_res, cur_cnt);
+        if (cur_ok) estimate_formants_any<NE>(ef, eb, cur, res + f * (long)n_res, n_res, cur_cnt, res_count != nullptr, general != 0);
 #pragma unroll
         for (int e = 0; e < NE; e++) { double2 o; o.x = ef[e]; o.y = eb[e]; *reinterpret_cast<double2 *>(out + f * out_ld + 2 * e) = o; }
 #pragma unroll
@@ -251,6 +367,7 @@ constexpr int TRK_CHUNK = VBX_TRK_CHUNK, TRK_WARM = VBX_TRK_WARM, TRK_ROUNDS = V
 struct trk_in_t {
     const res_t *res; long n_frames; int n_res; const int32_t *res_count; const int64_t *seg_start; long n_seg;
     const res_t *est_init; const int32_t *frame_status; double *out; long out_ld;
+    int general;                  // 1: the general step for every frame (VBX_TRACKER_GENERAL)
 };
 struct trk_spec_t {               // per chunk g
     double *entry;                // [G][2 NS]: the state chunk g's rows were computed from
@@ -301,7 +418,7 @@ __device__ __forceinline__ void trk_frame(const trk_in_t &in, long f, double (&e
     res_t pre[TRK_PF];
 #pragma unroll
     for (int i = 0; i < TRK_PF; i++) pre[i] = (i < in.n_res) ? row[i] : res_t{0.0, 0.0};
-    estimate_formants_step<NE>(ef, eb, pre, row, in.n_res, cnt);
+    estimate_formants_any<NE>(ef, eb, pre, row, in.n_res, cnt, in.res_count != nullptr, in.general != 0);
 }
 // index of the utterance that holds frame f, and the frame at which the next one starts
 __device__ __forceinline__ long trk_segment_of(const trk_in_t &in, long f, long &next_start) {
@@ -433,6 +550,9 @@ __global__ __launch_bounds__(64) void tracker_sweep_kernel(const trk_in_t in, co
     }
 }
 
+// VBX_TRACKER_GENERAL=1 (read per launch): the general step on every frame instead of the index form
+static int tracker_general() { const char *e = getenv("VBX_TRACKER_GENERAL"); return (e && atoi(e) != 0) ? 1 : 0; }
+
 size_t tracker_chunked_workspace_bytes(long F) {
     const size_t G = (size_t)((F + TRK_CHUNK - 1) / TRK_CHUNK);
     return G * (2 * 2 * NS * sizeof(double) + 2 * sizeof(int32_t) + sizeof(int64_t)) + 64;
@@ -444,7 +564,7 @@ void launch_tracker_chunked(hipStream_t s, const res_t *res, long F, int n_res, 
                             const int32_t *frame_status, res_t *out, long out_ld, void *ws) {
     const long G = (F + TRK_CHUNK - 1) / TRK_CHUNK;
     trk_in_t in{res, F, n_res, res_count, seg_start, seg_start != nullptr ? n_seg : 1, est_init, frame_status,
-                reinterpret_cast<double *>(out), out_ld};
+                reinterpret_cast<double *>(out), out_ld, tracker_general()};
     trk_spec_t sp;
     char *w = reinterpret_cast<char *>(ws);
     sp.entry = reinterpret_cast<double *>(w); w += (size_t)G * 2 * NS * sizeof(double);
@@ -481,7 +601,7 @@ void launch_tracker(hipStream_t s, const res_t *res, long F, int n_res, const in
     const dim3 grid((unsigned)((n_seg + bs - 1) / bs)), block(bs);
     double *o = reinterpret_cast<double *>(out);
 #define VBX_TRK(NE) hipLaunchKernelGGL(tracker_kernel<NE>, grid, block, 0, s, res, F, n_res, res_count, seg_start, n_seg, \
-                                       est_init, frame_status, o, out_ld, t0, tc)
+                                       est_init, frame_status, o, out_ld, t0, tc, tracker_general())
     switch (n_est) {
         case 1: VBX_TRK(1); break;
         case 2: VBX_TRK(2); break;

@@ -1030,6 +1030,29 @@ int vbx_estimate_formants_f64(vbx_ctx *ctx, const vbx_resonance *res, size_t n_f
     return check_launch(ctx, __func__);
 }
 
+// internal (tests only; not part of the public header): the same scan with the per-row counts find_formants keeps beside
+// its resonance rows (rows of `count` real entries with ascending positive frequencies, then zeros, may take the tracker's
+// index form: k_tracker.hip)
+int vbx_internal_estimate_formants_counted(vbx_ctx *ctx, const vbx_resonance *res, size_t n_frames, size_t n_res,
+                                           const int32_t *res_count, const int64_t *h_seg_start, size_t n_segments,
+                                           const vbx_resonance *h_est_init, size_t n_est,
+                                           const int32_t *frame_status, vbx_resonance *out) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    if (n_frames == 0) return VBX_SUCCESS;
+    VBX_REQUIRE(ctx, res && res_count && h_est_init && out, "null argument");
+    VBX_REQUIRE(ctx, n_res >= 1 && n_res <= 0x7fffffff && n_est >= 1 && n_est <= VBX_FORMANT_SLOTS, "bad size");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t *d_seg = nullptr; size_t nseg = 1; const res_t *d_est = nullptr;
+    int rc = upload_segments(ctx, ctx->stream, h_seg_start, n_segments, n_frames, &d_seg, &nseg);
+    if (rc != VBX_SUCCESS) return rc;
+    rc = upload_estimates(ctx, ctx->stream, h_est_init, n_est, &d_est);
+    if (rc != VBX_SUCCESS) return rc;
+    rc = run_tracker(ctx, ctx->stream, tracker_wants_chunks(h_seg_start, n_segments, n_frames), (const res_t *)res, (long)n_frames,
+                     (int)n_res, res_count, d_seg, (long)nseg, d_est, (int)n_est, frame_status, (res_t *)out, 2 * (long)n_est);
+    if (rc != VBX_SUCCESS) return rc;
+    return check_launch(ctx, __func__);
+}
+
 // Burg coefficients -> resonance rows: the conjugate-pair form (k_roots_fast.hip) where it exists (it does the frames that
 // fail its own check again by the reference's iteration), every other order through the reference's iteration (k_roots.hip)
 static int run_formant_resonances(vbx_ctx *ctx, hipStream_t stm, const double *coeffs, long F, int p, double sample_rate,

@@ -173,6 +173,7 @@ def load_library():
         "vbx_selftest_lanes": (C.c_int, [vp, vp]),
         "vbx_internal_last_unsure_count": (C.c_int, [vp, vp]),
         "vbx_internal_last_burg_direct_count": (C.c_int, [vp, vp]),
+        "vbx_internal_estimate_formants_counted": (C.c_int, [vp, vp, sz, sz, vp, vp, sz, vp, sz, vp, vp]),
         "vbx_internal_last_roots_direct_count": (C.c_int, [vp, vp]),
         "vbx_record_doubles": (sz, [C.POINTER(AnalysisParams)]),
         "vbx_analyze_frames_f64": (C.c_int, [vp, vp, sz, sz, sz, C.POINTER(AnalysisParams), vp, sz, vp, sz, vp]),
@@ -663,8 +664,9 @@ class VoxBox:
             b.free()
         return res
 
-    def estimate_formants(self, res, est_init, seg_start=None, frame_status=None):
-        """FormantExtractor over [F, n_res, 2] resonance rows; returns estimates [F, n_est, 2]."""
+    def estimate_formants(self, res, est_init, seg_start=None, frame_status=None, res_count=None):
+        """FormantExtractor over [F, n_res, 2] resonance rows; returns estimates [F, n_est, 2].  res_count (test probe): the
+        per-row counts find_formants keeps beside its rows -- the scan may then take the tracker's index form."""
         r = np.ascontiguousarray(res, dtype=np.float64)
         e = np.ascontiguousarray(est_init, dtype=np.float64)
         F, n_res, n_est = r.shape[0], r.shape[1], e.shape[0]
@@ -672,11 +674,17 @@ class VoxBox:
         o = self.empty((F, n_est, 2))
         seg = None if seg_start is None else np.ascontiguousarray(seg_start, dtype=np.int64)
         fs = None if frame_status is None else self.to_device(np.ascontiguousarray(frame_status, dtype=np.int32))
-        self._check(self.L.vbx_estimate_formants_f64(
-            self.ctx, d.ptr, F, n_res, None if seg is None else seg.ctypes.data, 0 if seg is None else seg.size,
-            e.ctypes.data, n_est, _ptr(fs), o.ptr))
+        rc_d = None if res_count is None else self.to_device(np.ascontiguousarray(res_count, dtype=np.int32))
+        if rc_d is not None:
+            self._check(self.L.vbx_internal_estimate_formants_counted(
+                self.ctx, d.ptr, F, n_res, rc_d.ptr, None if seg is None else seg.ctypes.data, 0 if seg is None else seg.size,
+                e.ctypes.data, n_est, _ptr(fs), o.ptr))
+        else:
+            self._check(self.L.vbx_estimate_formants_f64(
+                self.ctx, d.ptr, F, n_res, None if seg is None else seg.ctypes.data, 0 if seg is None else seg.size,
+                e.ctypes.data, n_est, _ptr(fs), o.ptr))
         out = o.numpy()
-        for b in (d, o, fs):
+        for b in (d, o, fs, rc_d):
             if b is not None:
                 b.free()
         return out
