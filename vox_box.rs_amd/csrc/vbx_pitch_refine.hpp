@@ -586,6 +586,35 @@ __device__ __forceinline__ int pick_best(float *keys, int ncand, double bar, int
 }
 
 
+// The same eligibility (bound >= bar), another ORDER: among the eligible candidates the one whose refinement will most
+// likely end highest.  Brent minimises the mirrored interpolant (Q6 + Q8), which falls towards the integer lag k from both
+// sides with limits y[k-1] and y[k+1]: a refinement usually ends at the smaller neighbour sample, well below the bound f(v0)
+// it started from.  Taking the candidate with the largest min(y[k-1], y[k+1]) first raises the bar to (nearly) its final
+// height at once, and the competitors -- whose bounds may exceed the winner's final strength -- are retired after a few
+// evaluations instead of being refined to the end first (replay on the oracle, 172 voiced frames: 28.2 -> 25.3 evaluations
+// per frame; refining the best candidate alone takes 24.7).  The order changes nothing that is returned: a candidate that
+// is never picked has a bound below the final bar, one that is abandoned has a running minimum below it.
+__device__ __forceinline__ int pick_best_pred(float *keys, const cand_t *cand_list, const double *ys, int ncand, double bar, int lane) {
+    double bv = -__builtin_inf(); int bi = 0x7fffffff;
+    for (int i = lane; i < ncand; i += 64) {
+        const float kv = keys[i];                             // -inf: retired (the bar itself is -inf until kmax are kept)
+        if (kv > -__builtin_inff() && (double)kv >= bar) {
+            const int k = (int)cand_list[i];
+            double p = fmin(ys[k - 1], ys[k + 1]);
+            if (!(p == p)) p = __builtin_inf();               // NaN data: such a candidate is refined like any other
+            if (bi == 0x7fffffff || p > bv) { bv = p; bi = i; }
+        }
+    }
+    const double gm = wave_max(bv);
+    int pick = (bi != 0x7fffffff && bv == gm) ? bi : 0x7fffffff;
+    for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(pick, o, 64); pick = (other < pick) ? other : pick; }
+    if (pick == 0x7fffffff) return -1;
+    if (lane == 0) keys[pick] = -__builtin_inff();
+    wave_sync();
+    return pick;
+}
+
+
 // LDS of the refinement, in this order from `ys`:  y[n + Y_PAD] | p16[nblk + 1 (+pad)] | keys[n/4 + 8] (float) |
 // candidate list (uint16).  pitch_refine_lds_doubles(n) is that footprint in doubles (rounded up).
 __host__ __device__ constexpr int pitch_refine_lds_bytes(int n) {
@@ -763,7 +792,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
     };
     unsigned cterms = 0, cevals = 0;                // sinc terms / evaluations executed (uniform)
 
-    // b, c) refinement, best bound first, one candidate at a time with all 64 lanes on its sinc sums
+    // b, c) refinement, most promising candidate first (pick_best_pred), one at a time with all 64 lanes on its sinc sums
     // (improve_extremum, :192-229): every lane runs the reference's Brent iteration on identical values (the wave
     // sums are bit-identical in all lanes).  In a voiced frame the first strength becomes the bar that retires every
     // other candidate without an evaluation.  Finished candidates enter the lane-resident list ordered by
@@ -780,7 +809,11 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
     if (ncand <= GROUP_PATH_MIN_CAND && !(kmax >= VBX_EXP_GROUP_KMAX && ncand >= 4)) {
         for (;;) {
             const double bar = VBX_BAR();
+#ifdef VBX_EXP_ORDER_BY_BOUND
             const int c = pick_best(keys, ncand, bar, lane);
+#else
+            const int c = pick_best_pred(keys, cand_list, ys, ncand, bar, lane);
+#endif
             if (c < 0) break;
             double freq, nn, xmid, ymid;
             cand_from_peak(ys, cand_list[c], sample_rate, offset, freq, nn, f32);
