@@ -809,11 +809,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
     if (ncand <= GROUP_PATH_MIN_CAND && !(kmax >= VBX_EXP_GROUP_KMAX && ncand >= 4)) {
         for (;;) {
             const double bar = VBX_BAR();
-#ifdef VBX_EXP_ORDER_BY_BOUND
-            const int c = pick_best(keys, ncand, bar, lane);
-#else
-            const int c = pick_best_pred(keys, cand_list, ys, ncand, bar, lane);
-#endif
+            const int c = (kmax > ncand) ? pick_best(keys, ncand, bar, lane) : pick_best_pred(keys, cand_list, ys, ncand, bar, lane);
             if (c < 0) break;
             double freq, nn, xmid, ymid;
             cand_from_peak(ys, cand_list[c], sample_rate, offset, freq, nn, f32);
@@ -847,7 +843,9 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
             {   // hand the best remaining candidates to the idle groups, in group order
                 unsigned long long im = __ballot(ci < 0) & LEADERS;
                 while (im != 0ull && !exhausted) {
-                    const int c = pick_best(keys, ncand, VBX_BAR(), lane);
+                    // (the order only matters while a bar can rise: with kmax > ncand every candidate is refined to the end)
+                    const int c = (kmax > ncand) ? pick_best(keys, ncand, VBX_BAR(), lane)
+                                                 : pick_best_pred(keys, cand_list, ys, ncand, VBX_BAR(), lane);
                     if (c < 0) { exhausted = true; break; }
                     const int g = __builtin_ctzll(im) / RG;
                     im &= im - 1ull;
