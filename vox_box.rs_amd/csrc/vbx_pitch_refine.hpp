@@ -13,33 +13,43 @@
 namespace vbx {
 
 
+// p * x + c with the CONSTANT c in a scalar register pair.  Left to the compiler, a Horner step with a 64-bit literal becomes
+// v_mov_b32 x2 (the literal into the accumulator) + v_fmac_f64: three vector instructions per coefficient, two of them moves --
+// and these kernels are bound by vector-instruction issue (the four polynomials of one sinc evaluation were 125 of its ~350
+// instructions, 83 of them such moves).  As v_fma_f64 with a scalar addend the literal is built by the scalar unit.
+__device__ __forceinline__ double fma_sc(double p, double x, const double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(x), "s"(c));
+    return r;
+}
+
 // sin(x), cos(x) for |x| <= pi/2 (a little beyond is fine): Taylor to x^21 / x^22 (< 2e-18 truncation)
 __device__ __forceinline__ double sin_poly(double x) {
     const double x2 = x * x;
     double p = -1.9572941063391261231e-20;           // -1/21!
-    p = fma(p, x2, 8.2206352466243297170e-18);       //  1/19!
-    p = fma(p, x2, -2.8114572543455207632e-15);      // -1/17!
-    p = fma(p, x2, 7.6471637318198164759e-13);       //  1/15!
-    p = fma(p, x2, -1.6059043836821614599e-10);      // -1/13!
-    p = fma(p, x2, 2.5052108385441718775e-08);       //  1/11!
-    p = fma(p, x2, -2.7557319223985890653e-06);      // -1/9!
-    p = fma(p, x2, 1.9841269841269841270e-04);       //  1/7!
-    p = fma(p, x2, -8.3333333333333333333e-03);      // -1/5!
-    p = fma(p, x2, 1.6666666666666666667e-01);       //  1/3!
+    p = fma_sc(p, x2, 8.2206352466243297170e-18);    //  1/19!
+    p = fma_sc(p, x2, -2.8114572543455207632e-15);   // -1/17!
+    p = fma_sc(p, x2, 7.6471637318198164759e-13);    //  1/15!
+    p = fma_sc(p, x2, -1.6059043836821614599e-10);   // -1/13!
+    p = fma_sc(p, x2, 2.5052108385441718775e-08);    //  1/11!
+    p = fma_sc(p, x2, -2.7557319223985890653e-06);   // -1/9!
+    p = fma_sc(p, x2, 1.9841269841269841270e-04);    //  1/7!
+    p = fma_sc(p, x2, -8.3333333333333333333e-03);   // -1/5!
+    p = fma_sc(p, x2, 1.6666666666666666667e-01);    //  1/3!
     return x * fma(-x2, p, 1.0);
 }
 __device__ __forceinline__ double cos_poly(double x) {
     const double x2 = x * x;
     double p = 8.8967913924505732867e-22;            //  1/22!
-    p = fma(p, x2, -4.1103176233121648585e-19);      // -1/20!
-    p = fma(p, x2, 1.5619206968586226462e-16);       //  1/18!
-    p = fma(p, x2, -4.7794773323873852974e-14);      // -1/16!
-    p = fma(p, x2, 1.1470745597729724714e-11);       //  1/14!
-    p = fma(p, x2, -2.0876756987868098979e-09);      // -1/12!
-    p = fma(p, x2, 2.7557319223985890653e-07);       //  1/10!
-    p = fma(p, x2, -2.4801587301587301587e-05);      // -1/8!
-    p = fma(p, x2, 1.3888888888888888889e-03);       //  1/6!
-    p = fma(p, x2, -4.1666666666666666667e-02);      // -1/4!
+    p = fma_sc(p, x2, -4.1103176233121648585e-19);   // -1/20!
+    p = fma_sc(p, x2, 1.5619206968586226462e-16);    //  1/18!
+    p = fma_sc(p, x2, -4.7794773323873852974e-14);   // -1/16!
+    p = fma_sc(p, x2, 1.1470745597729724714e-11);    //  1/14!
+    p = fma_sc(p, x2, -2.0876756987868098979e-09);   // -1/12!
+    p = fma_sc(p, x2, 2.7557319223985890653e-07);    //  1/10!
+    p = fma_sc(p, x2, -2.4801587301587301587e-05);   // -1/8!
+    p = fma_sc(p, x2, 1.3888888888888888889e-03);    //  1/6!
+    p = fma_sc(p, x2, -4.1666666666666666667e-02);   // -1/4!
     p = fma(p, x2, 0.5);                             //  1/2!
     return fma(-x2, p, 1.0);
 }
