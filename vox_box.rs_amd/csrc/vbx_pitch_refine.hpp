@@ -61,6 +61,11 @@ __device__ __forceinline__ double cos_0_pi(double theta) { return -sin_poly(thet
 __device__ __forceinline__ double y_at(const double *y, int nvalid, int idx) {
     return (idx < nvalid) ? y[idx] : 0.0;
 }
+// the same without a branch where the curve is followed by stored zeros (pitch_refine_store's LDS image: Y_PAD of them
+// after y[n)): an index past the data reads the first of those
+__device__ __forceinline__ double y_at_padded(const double *y, int nvalid, int idx) {
+    return y[(idx < nvalid) ? idx : nvalid];
+}
 
 
 // ------------------------------------------------------------------------------------------
@@ -516,8 +521,8 @@ __device__ __forceinline__ double first_eval_bound(const double *ys, const doubl
         const double kl = 4.0 * sl * sl, kr = 4.0 * sr * sr;
         for (int m = 0; m < nh; m++) {
             const double pl = phil + (double)m, pr = phir + (double)m;
-            const double tl = y_at(ys, nvalid, offset + nr - m) * rcp_nr1(pl) * fma(0.5, cl, 0.5);
-            const double tr = y_at(ys, nvalid, offset + nl + m) * rcp_nr1(pr) * fma(0.5, cr, 0.5);
+            const double tl = y_at_padded(ys, nvalid, offset + nr - m) * rcp_nr1(pl) * fma(0.5, cl, 0.5);
+            const double tr = y_at_padded(ys, nvalid, offset + nl + m) * rcp_nr1(pr) * fma(0.5, cr, 0.5);
             const double t = tl + tr;
             head += (m & 1) ? -t : t;
             cl += dl; dl = fma(-kl, cl, dl);
