@@ -24,7 +24,7 @@ def test_find_formants_time_sliced_uneven_last_utterance(vb, oracle, pkg, monkey
     assert seg.size >= 64 and F >= 65536 and (n_seg - 1) * seg_len < F
     audio = vb.synth_speech((F - 1) * H + N, sample_offset=7 * 48000)
     est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
-    monkeypatch.delenv("VBX_TRACKER_CHUNKED", raising=False)
+    monkeypatch.setenv("VBX_TRACKER_CHUNKED", "0")           # the time-sliced path (the default is the chunked scan since round 3)
     a = vb.find_formants(audio, SR, P, est0, seg_start=seg, frame_len=N, stride=H, n_frames=F)
     monkeypatch.setenv("VBX_TRACKER_CHUNKED", "1")           # one launch each of Burg, roots, the chunked scan
     b = vb.find_formants(audio, SR, P, est0, seg_start=seg, frame_len=N, stride=H, n_frames=F)

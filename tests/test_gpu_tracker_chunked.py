@@ -2,7 +2,8 @@
 final in-order sweep) must return the sequential scan's rows BIT FOR BIT, whatever the resonances look like: frames that
 overwrite every estimate (the state is forgotten within a chunk: nothing to repair), frames with too few resonances (the
 state persists: most chunks are redone), utterance boundaries anywhere relative to the chunk grid, skipped frames.
-VBX_TRACKER_CHUNKED=1 / 0 selects the scan; without it utterances of 384 frames or more take the chunked one."""
+VBX_TRACKER_CHUNKED=1 / 0 selects the scan; without it utterances of 384 frames or more, and batches of 65,536 frames or more, take the
+chunked one."""
 import numpy as np
 import pytest
 

@@ -990,7 +990,11 @@ static bool tracker_wants_chunks(const int64_t *h_seg_start, size_t n_segments, 
         const long end = (i + 1 < n_segments) ? (long)h_seg_start[i + 1] : (long)n_frames;
         if (end - (long)h_seg_start[i] > longest) longest = end - (long)h_seg_start[i];
     }
-    return longest >= 384;                                     // 2 ms of scan on one lane; the chunked scan takes about 1
+    // 2 ms of scan on one lane, where the chunked scan takes about 0.6 for any batch; and large batches of SHORT utterances
+    // too since round 3: with Burg in one pass and the roots from conjugate pairs nothing is left for the time slices of
+    // run_find_formants to hide the sequential scan behind (a million frames in utterances of 64 / 256 / 383 frames: sliced
+    // 2.15 / 2.21 / 2.27 ms, chunked 1.84 / 2.15 / 2.13)
+    return longest >= 384 || n_frames >= 65536;
 }
 
 static int run_tracker(vbx_ctx *ctx, hipStream_t st, bool chunked, const res_t *res, long F, int n_res, const int32_t *res_count,
@@ -1107,7 +1111,8 @@ static int run_find_formants(vbx_ctx *ctx, hipStream_t stm, const double *x, siz
     // enough for that to matter take the chunked scan after Burg and the root finder (run_tracker).  The alternative kept
     // behind VBX_TRACKER_CHUNKED=0 -- round 2's first answer, for batches of equal-length utterances: the work is cut into
     // time slices, and while the tracker walks frames [t0, t0 + tc) of every utterance on its own stream, Burg and the root
-    // finder already produce the next slice (config 4: 152 M frames/s against the chunked scan's 156 M).
+    // finder already produce the next slice (config 4 in round 2: 152 M frames/s against the chunked scan's 156 M).  Since
+    // round 3 only VBX_TRACKER_CHUNKED=0 reaches it (tracker_wants_chunks).
     long seg_len = 0;
     const bool chunked = tracker_wants_chunks(h_seg_start, n_segments, n_frames);   // long utterances: the chunked scan instead
     if (!chunked && h_seg_start != nullptr && n_segments >= 64 && F >= 65536) {
