@@ -68,7 +68,7 @@ def test_the_other_orders(vb, pkg, oracle, monkeypatch, order):
     assert _rel(a["res"][:2000], s["res"]) <= 1e-8
     audio.free()
     # an order without an instantiation takes the reference's iteration
-    vb.find_formants(audio if False else vb.synth_speech(20 * 512).numpy().reshape(20, 512), SR, 11, est0)
+    vb.find_formants(vb.synth_speech(20 * 512).numpy().reshape(20, 512), SR, 11, est0)
     assert vb.last_roots_direct_count() == -1
 
 
