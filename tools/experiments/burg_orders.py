@@ -16,7 +16,7 @@ for p in (8, 10, 12, 13, 14, 16, 11):
         best = 1e9
         for rep in range(3):
             vb.timer_begin()
-            r = vb.find_formants(audio, 48000.0, p, est0, seg_start=seg, frame_len=N, stride=H, n_frames=F, keep_device=True) if False else vb.find_formants(audio, 48000.0, p, est0, seg_start=seg, frame_len=N, stride=H, n_frames=F)
+            r = vb.find_formants(audio, 48000.0, p, est0, seg_start=seg, frame_len=N, stride=H, n_frames=F)
             best = min(best, vb.timer_end())
         res[mode] = (r, best, vb.last_burg_direct_count(), vb.last_roots_direct_count())
     a, b = res["0"][0], res["1"][0]

@@ -20,7 +20,7 @@ def metric(got, exp):
 
 for N, H in ((512, 512), (1200, 480), (1024, 256), (600, 200), (130, 64), (2048, 1024)):
     audio = vb.synth_speech((F - 1) * H + N, sample_offset=3 * 48000)
-    w = vb.window(pkg.voxbox.WINDOW_HANNING_PERIODIC if hasattr(pkg, "voxbox") else 2, N)
+    w = vb.window(pkg.WINDOW_HANNING_PERIODIC, N)
     out = (vb.empty((F, P)), vb.empty(F, np.int32))
     res = {}
     for mode in ("0", "1"):

@@ -8,7 +8,7 @@ est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
 audio = vb.synth_speech((F - 1) * H + N, sample_offset=3 * 48000)
 seg = np.arange(0, F, 1000, dtype=np.int64)
 os.environ["VBX_ROOTS_DIRECT"]="0"
-a = vb.find_formants(audio, 48000.0, 12, est0, seg_start=seg, frame_len=N, stride=H, n_frames=F, want_coeffs=True) if False else vb.find_formants(audio, 48000.0, 12, est0, seg_start=seg, frame_len=N, stride=H, n_frames=F)
+a = vb.find_formants(audio, 48000.0, 12, est0, seg_start=seg, frame_len=N, stride=H, n_frames=F)
 print("redo", vb.last_roots_direct_count())
 os.environ["VBX_ROOTS_DIRECT"]="1"
 b = vb.find_formants(audio, 48000.0, 12, est0, seg_start=seg, frame_len=N, stride=H, n_frames=F)
