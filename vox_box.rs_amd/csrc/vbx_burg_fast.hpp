@@ -44,7 +44,10 @@ namespace vbx {
 #ifndef VBX_BF_FPW
 #define VBX_BF_FPW 16
 #endif
-constexpr int BF_FPW = VBX_BF_FPW;         // frames per wavefront (burg_lags_kernel)
+constexpr int BF_FPW = VBX_BF_FPW;         // frames per wavefront (burg_lags_kernel) ...
+// ... but 8 for frames of up to 512 samples (8 samples per lane): config 4's lag kernel 0.47 -> 0.43 ms per 524,288 frames
+// (lpc_burg at 512: 813 -> 907 M frames/s); at 1024 and 2048 samples 8 is slower (474 -> 451, 250 -> 230 M), at 1200 the same
+template <int EPL> struct bf_fpw { static constexpr int value = (EPL == 8 && BF_FPW == 16) ? 8 : BF_FPW; };
 #ifndef VBX_BF_CHUNK
 #define VBX_BF_CHUNK 524288
 #endif
@@ -140,7 +143,7 @@ template <int EPL, int P, typename TIN>
 __global__ __launch_bounds__(64) void burg_lags_kernel(
     const TIN *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
     const frame_map_t map, long item0, long items, double *__restrict__ scratch) {
-    constexpr int FPW = BF_FPW;
+    constexpr int FPW = bf_fpw<EPL>::value;
     constexpr int NL = P + 1;
     constexpr int TS = NL | 1;
     constexpr bool PCM = sizeof(TIN) == 2;
@@ -305,7 +308,8 @@ void launch_burg_recursion_p(hipStream_t s, const double *scratch, long F, frame
     void launch_burg_lags_p(hipStream_t s, const TIN *x, long F, int n, long stride, const double *window,                   \
                             frame_map_t map, long i0, long m, double *scratch) {                                              \
         const dim3 grid((unsigned)((m + BF_FPW - 1) / BF_FPW)), b(64);                                                        \
-        if (n <= 64 * 8) hipLaunchKernelGGL((burg_lags_kernel<8, PP, TIN>), grid, b, 0, s, x, F, n, stride, window, map, i0, m, scratch);        \
+        const dim3 grid8((unsigned)((m + bf_fpw<8>::value - 1) / bf_fpw<8>::value));                                          \
+        if (n <= 64 * 8) hipLaunchKernelGGL((burg_lags_kernel<8, PP, TIN>), grid8, b, 0, s, x, F, n, stride, window, map, i0, m, scratch);       \
         else if (n <= 64 * 16) hipLaunchKernelGGL((burg_lags_kernel<16, PP, TIN>), grid, b, 0, s, x, F, n, stride, window, map, i0, m, scratch); \
         else if (n <= 64 * 20) hipLaunchKernelGGL((burg_lags_kernel<20, PP, TIN>), grid, b, 0, s, x, F, n, stride, window, map, i0, m, scratch); \
         else hipLaunchKernelGGL((burg_lags_kernel<32, PP, TIN>), grid, b, 0, s, x, F, n, stride, window, map, i0, m, scratch);                  \
