@@ -278,12 +278,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void bu
     const double *scratch /* no __restrict__: invariant loads would all be hoisted to the top */, long n_frames, const frame_map_t map, long item0, long items,
     double *__restrict__ out, int32_t *__restrict__ status, int32_t *__restrict__ list, int32_t *__restrict__ list_count) {
     constexpr int NL = P + 1;
+    // the wavefront's tile of the scratch ([value][64 frames], contiguous) into LDS first: 3 (P + 1) coalesced loads in
+    // flight at once.  Read from global memory where each order uses them (the memory barrier in burg_from_lags keeps the
+    // loads there, for the registers' sake), every order waited a full memory latency: 99 us per 524,288 frames, of which
+    // this takes two thirds.
+    __shared__ double T[3 * NL * 64];
     const long col = (long)blockIdx.x * 64 + threadIdx.x;
+    {
+        const double *tile = scratch + (long)blockIdx.x * (3 * NL * 64);
+#pragma unroll
+        for (int v = 0; v < 3 * NL; v++) T[v * 64 + threadIdx.x] = tile[v * 64 + threadIdx.x];
+    }
+    wave_sync();
     if (col >= items) return;
     const long f = frame_map(map, item0 + col, n_frames);
     if (f < 0) return;
     double a[P + 1];
-    const double *t = scratch + (col >> 6) * (3 * NL * 64) + (col & 63);     // tile, lane
+    const double *t = T + threadIdx.x;
     const bool trusted = burg_from_lags<P>(t, t + NL * 64, t + 2 * NL * 64, a);
     if (!trusted) {
         list[atomicAdd(list_count, 1)] = (int32_t)f;
