@@ -37,7 +37,7 @@ struct vbx_ctx {
     std::string arch;
     int cu_count = 0;
     // workspaces (grown on demand, never shrunk)
-    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_UNSURE, WS_F32_IN, WS_F32_OUT, WS_TRK, WS_BURG_LIST, WS_ROOTS_LIST, WS_N };
+    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_UNSURE, WS_F32_IN, WS_F32_OUT, WS_TRK, WS_BURG_LIST, WS_ROOTS_LIST, WS_LONG, WS_N };
     void *ws[WS_N] = {nullptr};
     const int32_t *burg_list_count = nullptr;             // device counter of the last one-pass Burg call (tests)
     const int32_t *roots_list_count = nullptr;            // the same for the resonance kernel of find_formants
@@ -371,12 +371,15 @@ int get_slopes_dev(vbx_ctx *ctx, size_t n, size_t k, double lo, double hi, doubl
     return VBX_SUCCESS;
 }
 
-int check_frames(vbx_ctx *ctx, const char *fn, const void *x, size_t n_frames, size_t frame_len, size_t stride) {
+// max_len: VBX_MAX_FRAME_LEN for the entry points whose kernels keep a frame in registers / LDS, VBX_MAX_LONG_FRAME_LEN for
+// the ones that also have a tiled form for longer frames (k_long.hip)
+int check_frames(vbx_ctx *ctx, const char *fn, const void *x, size_t n_frames, size_t frame_len, size_t stride,
+                 size_t max_len = VBX_MAX_FRAME_LEN) {
     if (!ctx) return fail(nullptr, VBX_E_INVALID, std::string(fn) + ": null context");
     if (n_frames == 0) return 1;   // empty batch: nothing to do
     if (!x) return fail(ctx, VBX_E_INVALID, std::string(fn) + ": null frame pointer");
-    if (frame_len < 1 || frame_len > VBX_MAX_FRAME_LEN)
-        return fail(ctx, VBX_E_INVALID, std::string(fn) + ": frame_len must be in [1, 4096]");
+    if (frame_len < 1 || frame_len > max_len)
+        return fail(ctx, VBX_E_INVALID, std::string(fn) + ": frame_len must be in [1, " + std::to_string(max_len) + "]");
     if (stride < 1) return fail(ctx, VBX_E_INVALID, std::string(fn) + ": stride must be >= 1");
     if (n_frames > 0x7fffffffull) return fail(ctx, VBX_E_INVALID, std::string(fn) + ": too many frames for one launch");
     return VBX_SUCCESS;
@@ -648,6 +651,15 @@ size_t vbx_find_formants_complex_work_size(size_t n_coeffs) { return n_coeffs * 
 // frame (many lags of a 512..4096-sample frame), or the matrix-core tiles.
 static int run_autocorrelate(vbx_ctx *ctx, hipStream_t st, const double *x, size_t n_frames, size_t frame_len, size_t stride,
                              const double *window, size_t n_lags, double *out) {
+    if (frame_len > VBX_MAX_FRAME_LEN) {
+        // a frame that no wavefront's LDS image holds: the matrix-core lag tiles over chunked images (k_long.hip)
+        void *w = nullptr;
+        int rc = ws_get(ctx, vbx_ctx::WS_LONG, autocorr_long_scratch_bytes((long)n_frames, (long)frame_len, (long)n_lags), &w);
+        if (rc != VBX_SUCCESS) return rc;
+        Prof p(ctx, "autocorr_long", st);
+        launch_autocorr_long(st, x, (long)n_frames, (long)frame_len, (long)stride, window, (long)n_lags, out, (double *)w);
+        return VBX_SUCCESS;
+    }
     if (fewlags_supported((int)frame_len, (int)n_lags, false)) {
         Prof p(ctx, "autocorr_fewlags", st);
         launch_autocorr_fewlags(st, x, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_lags, 0, out, nullptr);
@@ -673,7 +685,7 @@ static int run_autocorrelate(vbx_ctx *ctx, hipStream_t st, const double *x, size
 
 int vbx_autocorrelate_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
                           size_t stride, const double *window, size_t n_lags, double *out) {
-    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride, VBX_MAX_LONG_FRAME_LEN);
     if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
     VBX_REQUIRE(ctx, out != nullptr, "null output");
     VBX_REQUIRE(ctx, n_lags >= 1 && n_lags <= frame_len, "n_lags must be in [1, frame_len] (the reference panics beyond)");
@@ -841,16 +853,35 @@ static int run_autocorr_lpc(vbx_ctx *ctx, hipStream_t st, const double *x, size_
 int vbx_autocorr_lpc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
                          size_t stride, const double *window, size_t n_coeffs, int normalize,
                          double *out_r, double *out_lpc) {
-    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride, VBX_MAX_LONG_FRAME_LEN);
     if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     return run_autocorr_lpc(ctx, ctx->stream, x, n_frames, frame_len, stride, window, n_coeffs, normalize, out_r, out_lpc, n_coeffs + 1);
+}
+
+static bool burg_order_ok(size_t frame_len, size_t n_coeffs) {
+    return frame_len >= 2 && n_coeffs >= 1 && n_coeffs <= VBX_MAX_LPC_ORDER;
 }
 
 // Burg on a batch: the one-pass form (k_burg_fast.hip) where it exists, the frames its guard turns away and every other
 // shape through the direct recursion (k_burg.hip)
 static int run_burg(vbx_ctx *ctx, hipStream_t stm, const double *x, const int16_t *pcm, long F, int n, long stride,
                     const double *window, int p, double *coeffs, int32_t *st, frame_map_t map = frame_map_t{0, 0, 0}) {
+    if (n > VBX_MAX_FRAME_LEN) {
+        // a frame longer than a wavefront's registers hold (tests/lib.rs:27-41 passes a whole file as one): one workgroup per
+        // frame, the error arrays in an L2-resident scratch (k_long.hip); batches of frames so that the scratch stays <= 1 GiB
+        ctx->burg_list_count = nullptr;
+        long per = (long)((size_t(1) << 30) / burg_long_scratch_bytes(1, n));
+        if (per < 1) per = 1;
+        if (per > F) per = F;
+        void *w = nullptr;
+        int rc = ws_get(ctx, vbx_ctx::WS_LONG, burg_long_scratch_bytes(per, n), &w);
+        if (rc != VBX_SUCCESS) return rc;
+        Prof pr(ctx, "burg_long", stm);
+        for (long f0 = 0; f0 < F; f0 += per)
+            launch_burg_long(stm, x, f0, (f0 + per < F) ? f0 + per : F, F, n, stride, window, p, coeffs, st, (double *)w);
+        return VBX_SUCCESS;
+    }
     if (burg_fast_supported(n, p)) {
         void *w = nullptr;
         int rc = ws_get(ctx, vbx_ctx::WS_BURG_LIST, burg_fast_scratch_bytes(F, p), &w);
@@ -880,10 +911,10 @@ static int run_burg(vbx_ctx *ctx, hipStream_t stm, const double *x, const int16_
 
 int vbx_lpc_burg_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
                      size_t stride, const double *window, size_t n_coeffs, double *out, int32_t *status) {
-    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride, VBX_MAX_LONG_FRAME_LEN);
     if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
     VBX_REQUIRE(ctx, out != nullptr, "null output");
-    VBX_REQUIRE(ctx, burg_supported((int)frame_len, (int)n_coeffs), "frame_len must be in [2, 4096], order in [1, 30]");
+    VBX_REQUIRE(ctx, burg_order_ok(frame_len, n_coeffs), "frame_len must be >= 2, order in [1, 30]");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     rc = run_burg(ctx, ctx->stream, x, nullptr, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_coeffs, out, status);
     if (rc != VBX_SUCCESS) return rc;
@@ -1085,7 +1116,7 @@ static int run_find_formants(vbx_ctx *ctx, hipStream_t stm, const double *x, siz
                              vbx_resonance *out_formants, size_t formants_ld, vbx_resonance *out_res, int32_t *out_res_count,
                              double *out_coeffs, int32_t *status, const int16_t *pcm = nullptr /* the frames as 16-bit PCM instead of x */) {
     VBX_REQUIRE(ctx, h_est_init && out_formants, "null argument");
-    VBX_REQUIRE(ctx, burg_supported((int)frame_len, (int)n_coeffs), "frame_len must be in [2, 4096], order in [1, 30]");
+    VBX_REQUIRE(ctx, burg_order_ok(frame_len, n_coeffs), "frame_len must be >= 2, order in [1, 30]");
     VBX_REQUIRE(ctx, n_est >= 1 && n_est <= VBX_FORMANT_SLOTS, "n_est must be in [1, 6]");
     VBX_REQUIRE(ctx, formants_ld >= 2 * n_est && formants_ld % 2 == 0, "formant rows must be 16-byte aligned and hold n_est entries");
     const long F = (long)n_frames; const int p = (int)n_coeffs;
@@ -1166,7 +1197,7 @@ int vbx_find_formants_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t
                           const vbx_resonance *h_est_init, size_t n_est,
                           vbx_resonance *out_formants, vbx_resonance *out_res, int32_t *out_res_count,
                           double *out_coeffs, int32_t *status) {
-    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride, VBX_MAX_LONG_FRAME_LEN);
     if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     return run_find_formants(ctx, ctx->stream, x, n_frames, frame_len, stride, sample_rate, n_coeffs, h_seg_start, n_segments,
@@ -1274,7 +1305,7 @@ int vbx_pcm16_to_f64(vbx_ctx *ctx, const int16_t *pcm, size_t n_samples, double 
 
 int vbx_rms_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
                 const double *window, double *out) {
-    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride, VBX_MAX_LONG_FRAME_LEN);
     if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
     VBX_REQUIRE(ctx, out != nullptr, "null output");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
@@ -1284,11 +1315,18 @@ int vbx_rms_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len
 
 int vbx_preemphasis_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
                         double factor, double *out) {
-    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride, VBX_MAX_LONG_FRAME_LEN);
     if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
     VBX_REQUIRE(ctx, out != nullptr, "null output");
     VBX_REQUIRE(ctx, out != x || stride == frame_len, "in-place filtering needs a dense batch (stride == frame_len)");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
+    if (frame_len > VBX_MAX_FRAME_LEN) {          // a whole signal (src/waves.rs:86 takes any slice): tiles + a carry pass (k_long.hip)
+        void *w = nullptr;
+        rc = ws_get(ctx, vbx_ctx::WS_LONG, preemphasis_long_scratch_bytes((long)n_frames, (long)frame_len), &w);
+        if (rc != VBX_SUCCESS) return rc;
+        { Prof p(ctx, "preemphasis_long"); launch_preemphasis_long(ctx->stream, x, (long)n_frames, (long)frame_len, (long)stride, 2.0 * M_PI * factor, out, (double *)w); }
+        return check_launch(ctx, __func__);
+    }
     { Prof p(ctx, "preemphasis"); launch_preemphasis(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, 2.0 * M_PI * factor, out); }
     return check_launch(ctx, __func__);
 }
@@ -1299,7 +1337,7 @@ int vbx_ring_frames_f64(vbx_ctx *ctx, const double *ring, size_t capacity, size_
     if (n_frames == 0) return VBX_SUCCESS;
     VBX_REQUIRE(ctx, ring && out, "null argument");
     VBX_REQUIRE(ctx, capacity >= 1 && head < capacity, "head must lie inside the ring");
-    VBX_REQUIRE(ctx, frame_len >= 1 && frame_len <= VBX_MAX_FRAME_LEN && stride >= 1, "bad frame geometry");
+    VBX_REQUIRE(ctx, frame_len >= 1 && frame_len <= VBX_MAX_LONG_FRAME_LEN && stride >= 1, "bad frame geometry");
     VBX_REQUIRE(ctx, (n_frames - 1) * stride + frame_len <= capacity, "the view is longer than the deque can be");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     { Prof p(ctx, "ring_frames"); launch_ring_frames(ctx->stream, ring, (long)capacity, (long)head, (long)n_frames, (int)frame_len, (long)stride, out); }
@@ -1312,7 +1350,7 @@ size_t vbx_resampled_len(size_t frame_len, double resample_ratio) {
 
 int vbx_resample_linear_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
                             double resample_ratio, double *out) {
-    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride, VBX_MAX_LONG_FRAME_LEN);
     if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
     VBX_REQUIRE(ctx, out != nullptr, "null output");
     VBX_REQUIRE(ctx, resample_ratio > 0.0 && resample_ratio <= 64.0, "resample_ratio must be in (0, 64]");

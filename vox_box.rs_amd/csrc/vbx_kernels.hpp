@@ -209,6 +209,16 @@ void launch_pcm16(hipStream_t s, const int16_t *pcm, size_t n, double denom, dou
 void launch_rms(hipStream_t s, const double *x, long F, int n, long stride, const double *window, double *out);
 void launch_preemphasis(hipStream_t s, const double *x, long F, int n, long stride, double c, double *out);
 
+// k_long.hip: frames of more than VBX_MAX_FRAME_LEN_K samples (tiles out of HBM / L2 instead of registers / LDS)
+size_t burg_long_scratch_bytes(long frames, long n);
+void launch_burg_long(hipStream_t s, const double *x, long f0, long f1, long F, long n, long stride, const double *window,
+                      int p, double *out, int32_t *status, double *ws /* burg_long_scratch_bytes(f1 - f0, n) */);
+size_t autocorr_long_scratch_bytes(long F, long n, long n_lags);
+void launch_autocorr_long(hipStream_t s, const double *x, long F, long n, long stride, const double *window, long n_lags,
+                          double *out, double *ws);
+size_t preemphasis_long_scratch_bytes(long F, long n);
+void launch_preemphasis_long(hipStream_t s, const double *x, long F, long n, long stride, double c, double *out, double *ws);
+
 // k_synth.hip
 void launch_synth(hipStream_t s, double *out, size_t n_samples, uint64_t sample_offset, double sample_rate, uint64_t seed);
 
