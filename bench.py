@@ -94,6 +94,10 @@ def parse():
                     "and crosses PCIe inside the timed region, in chunks, double-buffered against the kernels (vbx_analyze_frames_pcm16); "
                     "reported under its own metric name, never as the headline `value`")
     ap.add_argument("--chunk-frames", type=int, default=250_000, help="--host-fed: frames per H2D chunk (whole utterances)")
+    ap.add_argument("--utterance-frames", type=int, default=0, help="pipeline / config3: frames per utterance (the formant tracker "
+                    "restarts from the initial estimates at every utterance start).  0 (default): the WHOLE recording is one "
+                    "utterance, what the reference's user loop over a file is (tests/lib.rs:75-79) -- at N > 1 the even frame split "
+                    "cuts it and the track is carried across the rank boundaries (vbx_comm_stitch_tracks_f64)")
     return ap.parse_args()
 
 
@@ -546,17 +550,24 @@ def run_rank(args):
     N, H = args.frame_len, args.hop
     wl = args.workload
     # shard geometry (host arithmetic only: also what the dry run reports)
+    plan = None
     if wl in ("pipeline", "config3"):
         total_frames_per_gpu = int(round(args.hours * 3600 * SR / H))         # 100 frames per second at the default hop
-        total_frames_per_gpu -= total_frames_per_gpu % SEG_FRAMES             # whole utterances per rank
+        total_frames_per_gpu -= total_frames_per_gpu % SEG_FRAMES
         F = max(total_frames_per_gpu, SEG_FRAMES)
-        # weak scaling: the recording is world * F frames long and splits by contiguous ranges at utterance boundaries
-        seg_all = np.arange(0, world * F, SEG_FRAMES, dtype=np.int64)
-        lo, hi = pkg.shard_range(world * F, world, rank, seg_all)
+        # weak scaling: the recording is world * F frames long and splits by contiguous frame ranges.  One utterance (the
+        # default) or utterances of --utterance-frames frames; a cut inside an utterance is stitched (vbx_shard_plan).
+        UTT = args.utterance_frames
+        seg_all = None if UTT <= 0 else np.arange(0, world * F, UTT, dtype=np.int64)
+        plan = pkg.shard_plan(world * F, world, rank, seg_all)
+        lo, hi, warm = plan.lo, plan.hi, plan.warm
         assert hi - lo == F
-        s0, s1 = pkg.shard_samples(lo, hi, N, H)                              # includes the frame_len - hop halo
+        seg = pkg.shard_local_segments(plan, seg_all)                         # utterance starts of frames [lo - warm, hi)
+        s0, s1 = pkg.shard_samples(lo - warm, hi, N, H)                       # includes the frame_len - hop halo
     else:
         F = args.frames
+        warm = 0
+        seg = np.arange(0, F, SEG_FRAMES, dtype=np.int64)
     counts = [F] * world
     gather_desc = ("library (vbx_gather_records_f64: grouped ncclSend/ncclRecv on the communicator's own stream, one direct "
                    "xGMI link per peer; control plane = torch.distributed gloo)") if world > 1 else None
@@ -564,7 +575,8 @@ def run_rank(args):
         REC = 36
         off, cnt, op = pkg.gather_plan(counts, rank, 0, REC)
         seen = [None] * world
-        mine = (rank, local, os.environ.get("MASTER_PORT"), [int(x) for x in op], [int(x) for x in off])
+        mine = (rank, local, os.environ.get("MASTER_PORT"), [int(x) for x in op], [int(x) for x in off],
+                plan.as_dict() if plan is not None else None)
         if world > 1:
             dist.all_gather_object(seen, mine)
         else:
@@ -574,7 +586,8 @@ def run_rank(args):
                               "control_plane": dist.get_backend() if world > 1 else None, "data_plane": gather_desc,
                               "rccl_comms_per_rank_planned": 1 if world > 1 else 0, "torch_nccl_process_groups": 0,
                               "gather_plan": {"rows": counts, "record_doubles": REC, "ops_by_rank": [s[3] for s in seen],
-                                              "offsets": seen[0][4]}}), flush=True)
+                                              "offsets": seen[0][4]},
+                              "utterance_frames": args.utterance_frames, "shard_plans": [s[5] for s in seen]}), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return 0
@@ -644,7 +657,7 @@ def run_rank(args):
         win = vb.window(pkg.WINDOW_HANNING, 512)
         desc = ("batched autocorrelation + LPC order-12" if wl == "config2" else
                 "LPC(Burg)->Laguerre roots->formant track") + f", {F} x 512-sample f64 frames/GPU"
-    seg = np.arange(0, F, SEG_FRAMES, dtype=np.int64)
+    FA = F + warm                 # frames this rank analyses: its range plus the tracker's warm-up frames before it
 
     # outputs (torch owns the device memory; the C ABI gets raw pointers).  The pipeline writes one record per frame
     # straight into the buffer the gather sends (rank 0: straight into the gathered array), double-buffered so that
@@ -659,8 +672,9 @@ def run_rank(args):
             rec = [g[:F] for g in gathered]                                   # rank 0 owns rows [0, F): written in place
         else:
             gathered = [None] * nbuf
-            rec = [torch.empty((F, REC), dtype=f64, device=dev) for _ in range(nbuf)]
-        st3 = torch.empty((3, F), dtype=torch.int32, device=dev)
+            rec = [torch.empty((FA, REC), dtype=f64, device=dev) for _ in range(nbuf)]      # rows [warm, FA) are the rank's own
+        st3 = torch.empty((3, FA), dtype=torch.int32, device=dev)
+        stitch = comm is not None and (plan.continues_prev or plan.continues_next)
     else:
         REC = 0
         o_cand = torch.empty((F, args.kmax, 2), dtype=f64, device=dev)
@@ -677,17 +691,19 @@ def run_rank(args):
             b = i % len(rec)
             if comm is not None:
                 comm.wait(b)                                                  # device-side: buffer b's last transfer is done
-            vb.analyze_frames(audio, params, seg_start=seg, frame_len=frame_len, stride=stride, n_frames=F,
+            vb.analyze_frames(audio, params, seg_start=seg, frame_len=frame_len, stride=stride, n_frames=FA,
                               out=rec[b], record_ld=REC, status=st3)
-            if comm is not None:   # per-frame records to rank 0 over RCCL/xGMI (the path's only exchange)
-                comm.gather_records(rec[b], counts, REC, 0, out=gathered[b], slot=b)
+            if stitch:             # an utterance cut by the rank boundary: the tracker's state along the chain of ranks
+                comm.stitch_tracks(rec[b].data_ptr() + 16, FA, REC, plan, None, slot=b)
+            if comm is not None:   # per-frame records to rank 0 over RCCL/xGMI
+                comm.gather_records(rec[b].data_ptr() + warm * REC * 8, counts, REC, 0, out=gathered[b], slot=b)
         elif wl == "config4":
             vb.find_formants(audio, SR, P, est0, seg_start=seg, frame_len=frame_len, stride=stride, n_frames=F, out=ff)
         elif wl == "config2":
             vb.autocorr_lpc(audio, P, frame_len=frame_len, stride=stride, n_frames=F, window=win, out=(o_r, o_a))
         elif wl == "config3":
-            vb.pitch(audio, SR, 0.2, 75.0, 600.0, kmax=args.kmax, frame_len=frame_len, stride=stride, n_frames=F, window=win,
-                     out=(o_cand, o_cnt, o_pst))
+            vb.pitch(audio.data_ptr() + warm * stride * 8, SR, 0.2, 75.0, 600.0, kmax=args.kmax, frame_len=frame_len, stride=stride,
+                     n_frames=F, window=win, out=(o_cand, o_cnt, o_pst))
 
     dt, prof, work = timed(vb, torch, step, args.warmup, args.steps, barrier if world > 1 else None)
     if world > 1:
@@ -707,6 +723,10 @@ def run_rank(args):
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "frames_per_gpu": F, "frame_len": frame_len, "hop": stride,
                        "lpc_order": P, "mfcc": 13, "pitch_kmax": args.kmax if wl != "pipeline" else 1,
+                       "utterance_frames": (args.utterance_frames if args.utterance_frames > 0 else "whole recording = one utterance")
+                                           if wl == "pipeline" else None,
+                       "tracker_across_ranks": ("warm-up of %d frames + state hand-off along the ranks (vbx_comm_stitch_tracks_f64)" % warm
+                                                if (world > 1 and plan is not None and (plan.continues_prev or plan.continues_next)) else None),
                        "record_bytes": REC * 8,
                        "parallelism": f"frame-range split x{world}, one process per GPU, RCCL gather of the records to rank 0",
                        "gather": gather_desc, "control_plane": "gloo (CPU tensors)" if world > 1 else None,

@@ -991,6 +991,20 @@ impl<'g> Records<'g> {
         let conv = |s: &[i32]| s.iter().map(|&c| FrameStatus::from_code(c)).collect::<Vec<_>>();
         Ok((self.data.to_vec()?, conv(&st[0..f]), conv(&st[f..2 * f]), conv(&st[2 * f..3 * f])))
     }
+
+    /// One-device form of [`Comm::stitch_tracks`] (`vbx_track_stitch_f64`): these records -- the LAST `analyze` call on their
+    /// `Gpu` -- hold a shard whose tracker started from a guess; `state` holds the true state before row `first` (the
+    /// `n_est` resonances of the formant row the previous shard ends with).  Rows `[first, stop)` are corrected where
+    /// they differ; the result is the sequential scan's, bit for bit.
+    pub fn stitch_tracks_from(&self, first: usize, stop: usize, state: &DeviceBuf<f64>, n_est: usize) -> GpuResult<()> {
+        assert!(first <= stop && stop <= self.n_frames);
+        assert!(n_est >= 1 && state.len() >= 2 * n_est && self.record_ld >= 2 + 2 * n_est);
+        let gpu = self.data.gpu;
+        let formants = unsafe { self.data.as_mut_ptr().add(2) } as *mut ffi::VbxResonance;
+        gpu.check(unsafe {
+            ffi::vbx_track_stitch_f64(gpu.raw, formants, self.n_frames, self.record_ld, first, stop, state.as_ptr() as *const ffi::VbxResonance, ptr::null_mut())
+        })
+    }
 }
 
 impl<'g> FrameBatch<'g> {
@@ -1067,8 +1081,9 @@ impl<'g> PcmBatch<'g> {
 // multi-GPU: frame-range sharding and the record gather (one process per GPU, RCCL inside the library)
 // ---------------------------------------------------------------------------------------------------------------
 
-/// Frames `[lo, hi)` of `rank` out of `world` (`vbx_shard_range`): contiguous ranges, cut at utterance boundaries when
-/// `seg_start` is given so that no tracker segment straddles two ranks.
+/// Frames `[lo, hi)` of `rank` out of `world` (`vbx_shard_range`): the even split; with `seg_start` a cut moves up to an
+/// utterance start within 1/32 of a shard after it.  A cut inside an utterance is carried across by [`shard_plan`] +
+/// [`Comm::stitch_tracks`].
 pub fn shard_range(n_frames: usize, world: i32, rank: i32, seg_start: &[i64]) -> GpuResult<(usize, usize)> {
     let (mut lo, mut hi) = (0usize, 0usize);
     let (seg_ptr, n_seg) = if seg_start.is_empty() { (ptr::null(), 0) } else { (seg_start.as_ptr(), seg_start.len()) };
@@ -1077,6 +1092,35 @@ pub fn shard_range(n_frames: usize, world: i32, rank: i32, seg_start: &[i64]) ->
         return Err(GpuError { code: rc, message: last_error(ptr::null()) });
     }
     Ok((lo, hi))
+}
+
+/// One rank's part of a recording sharded by frame ranges (`vbx_shard_plan`): its frames, the warm-up frames before them
+/// and whether its formant track continues from the previous rank / into the next one.
+pub fn shard_plan(n_frames: usize, world: i32, rank: i32, seg_start: &[i64]) -> GpuResult<ffi::VbxShardPlan> {
+    let mut plan = ffi::VbxShardPlan::default();
+    let (seg_ptr, n_seg) = if seg_start.is_empty() { (ptr::null(), 0) } else { (seg_start.as_ptr(), seg_start.len()) };
+    let rc = unsafe { ffi::vbx_shard_plan(n_frames, world, rank, seg_ptr, n_seg, &mut plan) };
+    if rc != ffi::VBX_SUCCESS {
+        return Err(GpuError { code: rc, message: last_error(ptr::null()) });
+    }
+    Ok(plan)
+}
+
+/// Utterance starts of the frames `[lo - warm, hi)` of a plan, re-based to the shard (`vbx_shard_local_segments`): the
+/// `seg_start` of the rank's own `analyze` / `find_formants` call.
+pub fn shard_local_segments(plan: &ffi::VbxShardPlan, seg_start: &[i64]) -> GpuResult<Vec<i64>> {
+    let (seg_ptr, n_seg) = if seg_start.is_empty() { (ptr::null(), 0) } else { (seg_start.as_ptr(), seg_start.len()) };
+    let mut n = 0usize;
+    let rc = unsafe { ffi::vbx_shard_local_segments(plan, seg_ptr, n_seg, ptr::null_mut(), 0, &mut n) };
+    if rc != ffi::VBX_SUCCESS {
+        return Err(GpuError { code: rc, message: last_error(ptr::null()) });
+    }
+    let mut out = vec![0i64; n];
+    let rc = unsafe { ffi::vbx_shard_local_segments(plan, seg_ptr, n_seg, out.as_mut_ptr(), out.len(), &mut n) };
+    if rc != ffi::VBX_SUCCESS {
+        return Err(GpuError { code: rc, message: last_error(ptr::null()) });
+    }
+    Ok(out)
 }
 
 /// Samples `[s0, s1)` the frames `[lo, hi)` read, including the `frame_len - hop` halo (`vbx_shard_samples`).
@@ -1106,6 +1150,7 @@ pub struct Comm<'g> {
     gpu: &'g Gpu,
     raw: *mut ffi::VbxComm,
     world: usize,
+    rank: usize,
 }
 
 impl<'g> Comm<'g> {
@@ -1122,7 +1167,7 @@ impl<'g> Comm<'g> {
     pub fn new(gpu: &'g Gpu, id: &[u8; ffi::VBX_UNIQUE_ID_BYTES], world: i32, rank: i32) -> GpuResult<Comm<'g>> {
         let mut raw: *mut ffi::VbxComm = ptr::null_mut();
         gpu.check(unsafe { ffi::vbx_comm_create(gpu.raw, id.as_ptr() as *const c_void, world, rank, &mut raw) })?;
-        Ok(Comm { gpu, raw, world: world as usize })
+        Ok(Comm { gpu, raw, world: world as usize, rank: rank as usize })
     }
 
     /// Live communicators of this process (`vbx_comm_live_count`): 1 while a `Comm` exists.
@@ -1133,11 +1178,40 @@ impl<'g> Comm<'g> {
     /// Queues the gather of `records` (this rank's rows) to rank `dst` behind the kernels already queued on the context
     /// (`vbx_gather_records_f64`); `rows[r]` = frames of rank r; on `dst`, `out` receives every rank's rows in rank order
     /// (it may be the buffer `records` points into, at this rank's offset: no copy).  `slot` names the buffer for `wait`.
-    pub fn gather_records(&self, records: &Records, rows: &[i64], dst: i32, out: Option<&DeviceBuf<f64>>, slot: i32) -> GpuResult<()> {
-        assert_eq!(rows.len(), self.world);
+    ///
+    /// `first_row`: rows of `records` before it are not sent (a shard's warm-up frames, `VbxShardPlan::warm`).  The sizes are
+    /// checked here, on the host, against the gather's own transfer list (`vbx_gather_plan`): a short `out` or an inflated
+    /// row count would otherwise let ncclRecv / the device copy write past the allocation from safe code.
+    pub fn gather_records(&self, records: &Records, first_row: usize, rows: &[i64], dst: i32, out: Option<&DeviceBuf<f64>>, slot: i32) -> GpuResult<()> {
+        assert_eq!(rows.len(), self.world, "one row count per rank");
+        assert!(dst >= 0 && (dst as usize) < self.world, "dst must be a rank of the communicator");
+        assert!(rows.iter().all(|&r| r >= 0), "row counts are not negative");
+        assert!(first_row <= records.n_frames && rows[self.rank] as usize == records.n_frames - first_row,
+                "rows[rank] must be the rows this rank sends");
+        let (off, cnt, _) = gather_plan(rows, self.rank as i32, dst, records.record_ld)?;
+        if self.rank == dst as usize {
+            let need = (off[self.world - 1] + cnt[self.world - 1]) as usize;
+            let o = out.expect("the destination rank passes the gathered buffer");
+            assert!(o.len() >= need, "the gathered buffer holds {} doubles, the gather writes {}", o.len(), need);
+        }
+        let local = unsafe { records.data.as_ptr().add(first_row * records.record_ld) };
         self.gpu.check(unsafe {
-            ffi::vbx_gather_records_f64(self.gpu.raw, self.raw, records.data.as_ptr(), rows.as_ptr(), records.record_ld, dst,
+            ffi::vbx_gather_records_f64(self.gpu.raw, self.raw, local, rows.as_ptr(), records.record_ld, dst,
                                         out.map_or(ptr::null_mut(), |o| o.as_mut_ptr()), slot)
+        })
+    }
+
+    /// The formant tracks of `records` (the LAST `analyze` call on this `Gpu`: the plan's frames `[lo - warm, hi)`) continued
+    /// from the previous rank's last row, and this rank's last row passed on (`vbx_comm_stitch_tracks_f64`): with it the
+    /// gathered tracks of an utterance cut by the rank boundaries are the single-process scan's, bit for bit
+    /// (src/spectrum.rs:357-369).  Queue [`Comm::gather_records`] after it with the same `slot`.
+    pub fn stitch_tracks(&self, records: &Records, params: &AnalysisParams, plan: &ffi::VbxShardPlan, slot: i32) -> GpuResult<()> {
+        assert!(params.formant_order > 0, "the records carry no formant tracks");
+        assert_eq!(records.n_frames, plan.hi - plan.lo + plan.warm, "the records are the plan's frames [lo - warm, hi)");
+        assert!(records.record_ld >= 2 + 2 * params.est_init.len());
+        let formants = unsafe { records.data.as_mut_ptr().add(2) } as *mut ffi::VbxResonance;      // record columns: pitch, then the formants
+        self.gpu.check(unsafe {
+            ffi::vbx_comm_stitch_tracks_f64(self.gpu.raw, self.raw, formants, records.n_frames, records.record_ld, plan, ptr::null_mut(), slot)
         })
     }
 

@@ -65,7 +65,7 @@ extern "C" {
 #define VBX_MAX_LPC_ORDER 30        /* 2*order resonances must fit the tracker's fixed arrays */
 #define VBX_MAX_FRAME_LEN 4096      /* register/LDS-resident frame kernels: vbx_pitch_f64, vbx_mfcc_f64, vbx_analyze_frames_*
                                        and the f32 instantiation */
-#define VBX_MAX_LONG_FRAME_LEN (1u << 26) /* every other frame-batch entry point (the reference's slices have no cap,
+#define VBX_MAX_LONG_FRAME_LEN 67108864 /* 2^26; every other frame-batch entry point (the reference's slices have no cap,
                                        tests/lib.rs:27-41 passes a 31,232-sample file as ONE frame): vbx_autocorrelate_f64,
                                        vbx_autocorr_lpc_f64, vbx_lpc_burg_f64, vbx_find_formants_f64, vbx_rms_f64,
                                        vbx_preemphasis_f64, vbx_resample_linear_f64, vbx_ring_frames_f64 take frames up to
@@ -441,12 +441,44 @@ int vbx_analyze_frames_pcm16(vbx_ctx *ctx, const int16_t *pcm, size_t n_frames, 
  * fixed-size per-frame records to a destination rank: grouped ncclSend / ncclRecv (RCCL), each peer's payload
  * crossing its own xGMI link.  No reduction, no all-to-all.
  *
- * vbx_shard_range: frames [*lo, *hi) of rank `rank` (first ranks take the remainder); with h_seg_start the cut is
- * moved to the next utterance boundary so that no tracker segment straddles two ranks.
+ * vbx_shard_range: frames [*lo, *hi) of rank `rank`: the even split (first ranks take the remainder); with h_seg_start
+ * (ascending utterance starts, h_seg_start[0] == 0) a cut moves up to an utterance start that lies within 1/32 of a shard
+ * after it.  A cut INSIDE an utterance is fine: ONE long utterance -- what the reference's user loop over a file produces
+ * (tests/lib.rs:75-79, src/spectrum.rs:357-369) -- splits evenly, and its formant track is carried across the cut (below).
  * vbx_shard_samples: the samples [*s0, *s1) those frames read, i.e. including the frame_len - hop halo. */
 int vbx_shard_range(size_t n_frames, int world, int rank, const int64_t *h_seg_start, size_t n_segments,
                     size_t *lo, size_t *hi);
 int vbx_shard_samples(size_t lo, size_t hi, size_t frame_len, size_t hop, size_t *s0, size_t *s1);
+
+/* The formant tracker is the one sequential step of the path (EstimateFormants, src/spectrum.rs:232-333: the estimates after
+ * frame t feed frame t + 1).  A rank whose range starts inside an utterance therefore
+ *   1. analyses `warm` extra frames before its range, frames [lo - warm, hi), starting the tracker from the initial estimates:
+ *      the tracker forgets -- after a few dozen frames its state no longer depends on where it started -- so the rows of
+ *      [lo, hi) are, almost always, already the sequential scan's;
+ *   2. receives the formant row its predecessor ENDS with (the true state before frame lo), compares it bit for bit with its
+ *      own row of frame lo - 1, and where they differ redoes the scan from the true state until it meets rows it already
+ *      holds (vbx_track_stitch_f64; over a communicator: vbx_comm_stitch_tracks_f64, which also passes the rank's own last
+ *      row on).  The result is the single-process scan, bit for bit, for every world size.
+ * vbx_shard_plan: lo, hi as vbx_shard_range; warm = min(frames since the utterance's start, VBX_SHARD_WARM_FRAMES);
+ * stop = index, counted from frame lo - warm, at which the utterance that holds frame lo ends inside the shard (or the
+ * shard's end); continues_prev: the utterance starts more than `warm` frames before lo (the state must come from rank - 1);
+ * continues_next: the same for the next rank's first frame.
+ * vbx_shard_local_segments: the utterance starts of frames [lo - warm, hi), re-based to the shard (first entry 0): the
+ * h_seg_start of the rank's vbx_analyze_frames_f64 / vbx_find_formants_f64 call.  *n_out = entries needed (h_out may be NULL). */
+#define VBX_SHARD_WARM_FRAMES 64
+typedef struct {
+    size_t lo, hi, warm, stop;
+    int continues_prev, continues_next;
+} vbx_shard_plan_t;
+int vbx_shard_plan(size_t n_frames, int world, int rank, const int64_t *h_seg_start, size_t n_segments, vbx_shard_plan_t *h_out);
+int vbx_shard_local_segments(const vbx_shard_plan_t *h_plan, const int64_t *h_seg_start, size_t n_segments,
+                             int64_t *h_out, size_t cap, size_t *n_out);
+/* Step 2 on one device: `formants` are the rows the LAST vbx_find_formants_f64 (out_formants, formants_ld = 2 n_est) or
+ * vbx_analyze_frames_* call (out_records + 2, formants_ld = record_ld) on this context wrote, n_frames of them (call it right
+ * after that call: it reads the resonance rows the context still holds); d_state_in (device, n_est entries) is the true state
+ * before frame `first`; rows [first, stop) are corrected where needed.  *d_changed (device, optional) = rows rewritten. */
+int vbx_track_stitch_f64(vbx_ctx *ctx, vbx_resonance *formants, size_t n_frames, size_t formants_ld, size_t first, size_t stop,
+                         const vbx_resonance *d_state_in, int32_t *d_changed);
 
 typedef struct vbx_comm vbx_comm;
 #define VBX_UNIQUE_ID_BYTES 128
@@ -463,6 +495,13 @@ void vbx_comm_destroy(vbx_comm *comm);
  * batch overlaps it; `slot` in [0, VBX_COMM_SLOTS) names the buffer being sent for vbx_comm_wait. */
 int vbx_gather_records_f64(vbx_ctx *ctx, vbx_comm *comm, const double *local, const int64_t *h_rows,
                            size_t row_doubles, int dst, double *out, int slot);
+/* Step 2 across ranks (RCCL, on the communicator's stream, behind the work queued on the context's stream): receives the
+ * previous rank's last formant row when h_plan->continues_prev (it sends it after its own stitch: the ranks of one utterance
+ * form a chain of 2 n_est doubles each over the direct xGMI links), corrects this rank's rows, and sends this rank's last row
+ * on when h_plan->continues_next.  n_frames = hi - lo + warm rows as in vbx_track_stitch_f64.  Queue the record gather after
+ * it with the same `slot`: vbx_comm_wait(slot) then covers both. */
+int vbx_comm_stitch_tracks_f64(vbx_ctx *ctx, vbx_comm *comm, vbx_resonance *formants, size_t n_frames, size_t formants_ld,
+                               const vbx_shard_plan_t *h_plan, int32_t *d_changed, int slot);
 /* The transfer list of that gather as one rank sees it, on the host (no GPU, no RCCL: what vbx_gather_records_f64 posts,
  * exposed so that a caller -- and the CPU tests -- can check the layout for any world size and uneven h_rows):
  * for every rank r, h_offset[r] = element offset (doubles) of rank r's rows in `out`, h_count[r] = doubles rank r

@@ -136,12 +136,109 @@ def test_library_shard_helpers_match_the_python_ones(pkg):
         for world in (1, 2, 3, 8):
             assert [pkg.shard_range(n_frames, world, r) for r in range(world)] == \
                    [sh.frame_range(r, world, n_frames) for r in range(world)]
-    for seg, n in ((np.arange(0, 10000, 1000), 10000), (np.array([0, 60, 131]), 197), (np.array([0]), 50),
-                   (np.arange(0, 36000000, 1000), 36000000)):
-        for world in (1, 2, 4, 8):
-            assert [pkg.shard_range(n, world, r, seg) for r in range(world)] == sh.segment_aligned_ranges(world, seg, n)
+    for seg, n in ((np.arange(0, 10000, 1000), 10000), (np.array([0, 60, 131]), 197), (np.array([0]), 50), (None, 50),
+                   (np.arange(0, 36000000, 1000), 36000000), (np.array([0]), 36000000), (np.array([0, 5, 2000, 2070, 4000]), 4100),
+                   (None, 3), (np.array([0]), 5)):
+        for world in (1, 2, 3, 4, 8):
+            rr = sh.shard_ranges(world, seg, n)
+            assert [pkg.shard_range(n, world, r, seg) for r in range(world)] == rr
+            assert rr[0][0] == 0 and rr[-1][1] == n and all(b == c for (_, b), (c, _) in zip(rr, rr[1:]))
+            for r in range(world):
+                pl = pkg.shard_plan(n, world, r, seg)
+                assert pl.as_dict() == sh.plan(n, world, r, seg)
+                assert np.array_equal(pkg.shard_local_segments(pl, seg), sh.plan_local_segments(pl.as_dict(), seg))
+                if r + 1 < world:                     # what one rank sends the next one expects
+                    assert pl.continues_next == pkg.shard_plan(n, world, r + 1, seg).continues_prev
+    # ONE utterance (what the reference's loop over a file is, tests/lib.rs:75-79) splits evenly; utterances that end on the
+    # even cuts are not cut at all
+    assert [pkg.shard_range(36_000_000, 8, r, np.array([0])) for r in range(8)] == [sh.frame_range(r, 8, 36_000_000) for r in range(8)]
+    p1 = pkg.shard_plan(36_000_000, 8, 1, np.array([0])).as_dict()
+    assert p1 == dict(lo=4_500_000, hi=9_000_000, warm=64, stop=4_500_064, continues_prev=1, continues_next=1)
+    pa = pkg.shard_plan(36_000_000, 8, 3, np.arange(0, 36_000_000, 1000)).as_dict()
+    assert pa["warm"] == 0 and pa["continues_prev"] == 0 and pa["continues_next"] == 0 and pa["lo"] % 1000 == 0
     assert pkg.shard_samples(100, 200, N, H) == sh.sample_range(100, 200, N, H)
     assert pkg.shard_samples(5, 5, N, H) == sh.sample_range(5, 5, N, H)
+
+
+def _one_utterance_worker(rank, world, port, out_path, warm_frames, seg_list):
+    """One rank of a recording whose utterances are cut by the rank boundaries: resonance rows of its frames [lo - warm, hi)
+    (oracle), the track from the initial estimates, the state hand-off along the chain of ranks (gloo send / recv of the
+    last formant row), the repair step (shard.stitch_rows = what tracker_stitch_kernel does), the gather."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import importlib
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    o = g.load_oracle()
+    synth = importlib.import_module(g.PKG_NAME + ".synth")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = pkg.shard
+    n_samples = 4 * 48000 + 777
+    F = pkg.frame_count(n_samples, N, H)
+    seg = None if seg_list is None else np.array(seg_list, dtype=np.int64)
+    pl = sh.plan(F, world, rank, seg, warm_frames=warm_frames)
+    if warm_frames == sh.WARM_FRAMES:
+        assert pl == pkg.shard_plan(F, world, rank, seg).as_dict()
+    first = pl["lo"] - pl["warm"]
+    s0, s1 = sh.sample_range(first, pl["hi"], N, H)
+    audio = synth.synth_speech(s1 - s0, sample_offset=s0 + 3 * 48000)        # each rank generates ITS shard only
+    n = pl["hi"] - first
+    est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+    sk = o.soak(audio, N, H, 0, n, P, SR, o.SOAK_FORMANTS, n_threads=2)
+    lseg = sh.plan_local_segments(pl, seg)
+    rows = o.soak_track(sk["res"], sk["ff_status"], est0, lseg)               # tracked from a GUESS at frame lo - warm
+    changed = 0
+    if pl["continues_prev"]:
+        state = torch.zeros(8, dtype=torch.float64)
+        dist.recv(state, src=rank - 1)
+        step = lambda st, t: (o.estimate_formants(st, sk["res"][t]) if sk["ff_status"][t] == 0 else st)
+        changed = sh.stitch_rows(rows, pl["warm"], pl["stop"], state.numpy().reshape(4, 2), step)
+    if pl["continues_next"]:
+        dist.send(torch.from_numpy(rows[-1].reshape(-1).copy()), dst=rank + 1)
+    rec = rows[pl["warm"]:].reshape(pl["hi"] - pl["lo"], 8)
+    counts = [b - a for a, b in sh.shard_ranges(world, seg, F)]
+    full = sh.gather_records(torch.from_numpy(np.ascontiguousarray(rec)), counts, dst=0)
+    ch = [None] * world
+    dist.all_gather_object(ch, changed)
+    if rank == 0:
+        np.save(out_path, full.numpy())
+        np.save(out_path + ".changed.npy", np.array(ch))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,warm_frames,seg_list", [(2, 64, None), (3, 64, None), (3, 1, None), (2, 0, None),
+                                                        (3, 64, [0, 150, 260]), (3, 3, [0, 131, 140, 300])])
+def test_cut_utterances_track_like_a_single_process(tmp_path, pkg, oracle, world, warm_frames, seg_list):
+    """SURVEY 8e "Exception": the tracker across rank boundaries.  One utterance (or utterances cut by the even split) over
+    2 and 3 gloo ranks gives formant tracks bit-identical to the single-process sequential scan -- with the default warm-up
+    (the guess is right, nothing is rewritten) and with a warm-up too short to be right (the repair step runs)."""
+    import importlib
+    import torch.multiprocessing as mp
+    import __graft_entry__ as g
+    synth = importlib.import_module(g.PKG_NAME + ".synth")
+    out = str(tmp_path / "tracks.npy")
+    mp.start_processes(_one_utterance_worker, args=(world, _free_port(), out, warm_frames, seg_list), nprocs=world, join=True,
+                       start_method="spawn")
+    got = np.load(out)
+    changed = np.load(out + ".changed.npy")
+    n_samples = 4 * 48000 + 777
+    audio = synth.synth_speech(n_samples, sample_offset=3 * 48000)
+    F = pkg.frame_count(n_samples, N, H)
+    est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+    sk = oracle.soak(audio, N, H, 0, F, P, SR, oracle.SOAK_FORMANTS)
+    exp = oracle.soak_track(sk["res"], sk["ff_status"], est0, None if seg_list is None else np.array(seg_list, dtype=np.int64))
+    assert got.shape == (F, 8)
+    assert np.array_equal(got, exp.reshape(F, 8))
+    assert changed[0] == 0
+    if warm_frames >= 64:
+        assert np.all(changed == 0), changed          # the warmed-up guess was right: nothing rewritten
+    if warm_frames <= 1 and seg_list is None:
+        assert np.any(changed > 0), changed           # the repair path did run
 
 
 def test_gather_plan_for_uneven_shards(pkg):

@@ -550,6 +550,34 @@ __global__ __launch_bounds__(64) void tracker_sweep_kernel(const trk_in_t in, co
     }
 }
 
+// ---- a track that continues ACROSS two launches (a recording sharded over GPUs by frame ranges) ---------------
+// The shard's rows [first, stop) were tracked from a GUESS of the state after frame first - 1 (the rank warmed its tracker up
+// over the `first` frames before its range, starting from the initial estimates).  state_in is the TRUE state: the formant row
+// the previous shard ends with.  If it is, bit for bit, the row this shard holds at first - 1, every later row follows from it
+// and stands.  Otherwise the scan is redone from the true state until it meets a row it already holds (the tracker forgets:
+// a few dozen frames) -- the repair step of the chunked scan, with the previous rank in the role of the previous chunk.
+// changed: number of rows rewritten (0: the guess was right).  One lane: a chain of dependent steps.
+template <int NE>
+__global__ __launch_bounds__(64) void tracker_stitch_kernel(const trk_in_t in, long first, long stop,
+                                                            const double *__restrict__ state_in, int32_t *__restrict__ changed) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double ef[NS], eb[NS];
+#pragma unroll
+    for (int e = 0; e < NS; e++) { ef[e] = 0.0; eb[e] = 0.0; }
+#pragma unroll
+    for (int e = 0; e < NE; e++) { ef[e] = state_in[2 * e]; eb[e] = state_in[2 * e + 1]; }
+    int n = 0;
+    if (!(first > 0 && trk_row_is<NE>(in, first - 1, ef, eb))) {
+        for (long f = first; f < stop; f++) {
+            trk_frame<NE>(in, f, ef, eb);
+            if (trk_row_is<NE>(in, f, ef, eb)) break;          // met the rows already there: the rest follows from them
+            trk_store_row<NE>(in, f, ef, eb);
+            n++;
+        }
+    }
+    if (changed != nullptr) *changed = n;
+}
+
 // VBX_TRACKER_GENERAL=1 (read per launch): the general step on every frame instead of the index form
 static int tracker_general() { const char *e = getenv("VBX_TRACKER_GENERAL"); return (e && atoi(e) != 0) ? 1 : 0; }
 
@@ -592,6 +620,22 @@ void launch_tracker_chunked(hipStream_t s, const res_t *res, long F, int n_res, 
         default: VBX_TRK_CH(6); break;
     }
 #undef VBX_TRK_CH
+}
+
+void launch_tracker_stitch(hipStream_t s, const res_t *res, long F, int n_res, const int32_t *res_count, int n_est,
+                           const int32_t *frame_status, res_t *out, long out_ld, long first, long stop,
+                           const double *state_in, int32_t *changed) {
+    trk_in_t in{res, F, n_res, res_count, nullptr, 1, nullptr, frame_status, reinterpret_cast<double *>(out), out_ld, tracker_general()};
+#define VBX_TRK_ST(NE) hipLaunchKernelGGL(tracker_stitch_kernel<NE>, dim3(1), dim3(64), 0, s, in, first, stop, state_in, changed)
+    switch (n_est) {
+        case 1: VBX_TRK_ST(1); break;
+        case 2: VBX_TRK_ST(2); break;
+        case 3: VBX_TRK_ST(3); break;
+        case 4: VBX_TRK_ST(4); break;
+        case 5: VBX_TRK_ST(5); break;
+        default: VBX_TRK_ST(6); break;
+    }
+#undef VBX_TRK_ST
 }
 
 void launch_tracker(hipStream_t s, const res_t *res, long F, int n_res, const int32_t *res_count,

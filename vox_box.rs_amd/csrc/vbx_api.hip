@@ -74,6 +74,10 @@ struct vbx_ctx {
     size_t stage_cap[2] = {0, 0};
     std::vector<char> staged[2];                          // content now on the device
     hipEvent_t stage_ev[2] = {nullptr, nullptr};          // completion of the last staged copy
+    // what the tracker of the last find_formants / analyze_frames call ran on (vbx_track_stitch_f64 continues that track)
+    struct { const res_t *res = nullptr; const int32_t *cnt = nullptr, *st = nullptr; long F = 0; int n_est = 0;
+             res_t *out = nullptr; long out_ld = 0; } last_track;
+    double *stitch_state = nullptr;                       // 2 * VBX_FORMANT_SLOTS doubles: the state a stitch received (vbx_comm.hip)
 };
 
 namespace {
@@ -483,6 +487,7 @@ void vbx_ctx_destroy(vbx_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < vbx_ctx::WS_N; i++) if (ctx->ws[i]) hipFree(ctx->ws[i]);
     if (ctx->pitch_work) hipFree(ctx->pitch_work);
+    if (ctx->stitch_state) hipFree(ctx->stitch_state);
     for (double *t : ctx->spectral_tab) if (t) hipFree(t);
     for (auto &kv : ctx->windows) hipFree(kv.second);
     for (auto &kv : ctx->lag_windows32) hipFree(kv.second);
@@ -1161,6 +1166,8 @@ static int run_find_formants(vbx_ctx *ctx, hipStream_t stm, const double *x, siz
     static const int want_slices = [] { const char *e = getenv("VBX_FF_SLICES"); const int v = e ? atoi(e) : 6; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
     const int n_slices = seg_len > 0 ? want_slices : 1;
     const long tc = (seg_len + n_slices - 1) / n_slices;
+    ctx->last_track.res = res; ctx->last_track.cnt = cnt; ctx->last_track.st = st; ctx->last_track.F = F;
+    ctx->last_track.n_est = (int)n_est; ctx->last_track.out = (res_t *)out_formants; ctx->last_track.out_ld = (long)formants_ld;
     if (n_slices == 1) {
         rc = run_burg(ctx, stm, x, pcm, F, (int)frame_len, (long)stride, hann, p, coeffs, st);                                      // :75
         if (rc != VBX_SUCCESS) return rc;
@@ -1203,6 +1210,40 @@ int vbx_find_formants_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t
     return run_find_formants(ctx, ctx->stream, x, n_frames, frame_len, stride, sample_rate, n_coeffs, h_seg_start, n_segments,
                              h_est_init, n_est, out_formants, 2 * n_est, out_res, out_res_count, out_coeffs, status);
 }
+
+// The tracks of the LAST vbx_find_formants_f64 / vbx_analyze_frames_* call on this context, continued from the true state
+// before frame `first` (k_tracker.hip, tracker_stitch_kernel); stream: the context's, or the communicator's (vbx_comm.hip)
+int vbx_internal_track_stitch(vbx_ctx *ctx, void *stream, vbx_resonance *formants, size_t n_frames, size_t formants_ld,
+                              size_t first, size_t stop, const double *d_state_in, int32_t *d_changed) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    VBX_REQUIRE(ctx, formants && d_state_in, "null argument");
+    const auto &lt = ctx->last_track;
+    VBX_REQUIRE(ctx, lt.res != nullptr && lt.out == (res_t *)formants && lt.F == (long)n_frames && lt.out_ld == (long)formants_ld,
+                "the formant rows are not the ones the last find_formants / analyze_frames call on this context wrote");
+    VBX_REQUIRE(ctx, first <= stop && stop <= n_frames, "need first <= stop <= n_frames");
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    { Prof p(ctx, "tracker_stitch", st);
+      launch_tracker_stitch(st, lt.res, lt.F, VBX_MAX_RESONANCES, lt.cnt, lt.n_est, lt.st, lt.out, lt.out_ld, (long)first, (long)stop,
+                            d_state_in, d_changed); }
+    return check_launch(ctx, "vbx_track_stitch_f64");
+}
+
+int vbx_track_stitch_f64(vbx_ctx *ctx, vbx_resonance *formants, size_t n_frames, size_t formants_ld, size_t first, size_t stop,
+                         const vbx_resonance *d_state_in, int32_t *d_changed) {
+    return vbx_internal_track_stitch(ctx, nullptr, formants, n_frames, formants_ld, first, stop, (const double *)d_state_in, d_changed);
+}
+
+// 2 * VBX_FORMANT_SLOTS doubles of context-owned device memory (the state a communicator receives from the previous rank)
+double *vbx_internal_stitch_state(vbx_ctx *ctx) {
+    if (!ctx) return nullptr;
+    if (!ctx->stitch_state) {
+        if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+        if (hipMalloc((void **)&ctx->stitch_state, (2 * VBX_FORMANT_SLOTS + 2) * sizeof(double)) != hipSuccess) { ctx->stitch_state = nullptr; return nullptr; }
+    }
+    return ctx->stitch_state;
+}
+int vbx_internal_last_track_n_est(vbx_ctx *ctx) { return ctx ? ctx->last_track.n_est : 0; }
 
 // ---- spectrum.rs: MFCC --------------------------------------------------------------------
 

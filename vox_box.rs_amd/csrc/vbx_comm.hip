@@ -16,6 +16,10 @@
 extern "C" int vbx_internal_fail(vbx_ctx *ctx, int code, const char *msg);
 extern "C" void *vbx_internal_stream(vbx_ctx *ctx);
 extern "C" int vbx_internal_device(vbx_ctx *ctx);
+extern "C" int vbx_internal_track_stitch(vbx_ctx *ctx, void *stream, vbx_resonance *formants, size_t n_frames, size_t formants_ld,
+                                         size_t first, size_t stop, const double *d_state_in, int32_t *d_changed);
+extern "C" double *vbx_internal_stitch_state(vbx_ctx *ctx);
+extern "C" int vbx_internal_last_track_n_est(vbx_ctx *ctx);
 
 struct vbx_comm {
     ncclComm_t nccl = nullptr;
@@ -70,6 +74,18 @@ int vbx_gather_plan(const int64_t *h_rows, int world, int rank, int dst, size_t 
     return VBX_SUCCESS;
 }
 
+// last utterance start <= f (0 without a segment list)
+static size_t seg_start_of(const int64_t *h_seg_start, size_t n_segments, size_t f) {
+    size_t best = 0;
+    if (h_seg_start) for (size_t i = 0; i < n_segments; i++) { if ((size_t)h_seg_start[i] <= f) best = (size_t)h_seg_start[i]; else break; }
+    return best;
+}
+// first utterance start > f, or n_frames
+static size_t seg_start_after(const int64_t *h_seg_start, size_t n_segments, size_t f, size_t n_frames) {
+    if (h_seg_start) for (size_t i = 0; i < n_segments; i++) if ((size_t)h_seg_start[i] > f) return (size_t)h_seg_start[i] < n_frames ? (size_t)h_seg_start[i] : n_frames;
+    return n_frames;
+}
+
 int vbx_shard_range(size_t n_frames, int world, int rank, const int64_t *h_seg_start, size_t n_segments,
                     size_t *lo, size_t *hi) {
     if (!lo || !hi || world < 1 || rank < 0 || rank >= world) return fail(nullptr, VBX_E_INVALID, "vbx_shard_range: bad argument");
@@ -77,19 +93,64 @@ int vbx_shard_range(size_t n_frames, int world, int rank, const int64_t *h_seg_s
         const size_t base = n_frames / (size_t)world, rem = n_frames % (size_t)world;
         return (size_t)(r + 1) * base + ((size_t)(r + 1) < rem ? (size_t)(r + 1) : rem);
     };
-    auto cut = [&](int r) -> size_t {                // end of rank r, moved up to an utterance boundary
+    // The even cut, unless an utterance starts within 1/32 of a shard after it: a rank that begins where an utterance
+    // begins needs nothing from its predecessor.  A cut INSIDE an utterance is fine too -- the track is carried across
+    // it (vbx_shard_plan, vbx_comm_stitch_tracks_f64) -- so one long utterance splits evenly.
+    const size_t slack = n_frames / (size_t)world / 32;
+    auto cut = [&](int r) -> size_t {
         if (r < 0) return 0;
         if (r >= world - 1) return n_frames;
         const size_t target = even_hi(r);
         if (!h_seg_start || n_segments == 0) return target;
-        for (size_t i = 0; i < n_segments; i++)      // first boundary >= target
-            if ((size_t)h_seg_start[i] >= target) return (size_t)h_seg_start[i] < n_frames ? (size_t)h_seg_start[i] : n_frames;
-        return n_frames;
+        for (size_t i = 0; i < n_segments; i++) {    // first boundary >= target
+            const size_t b = (size_t)h_seg_start[i];
+            if (b >= target) return (b <= target + slack && b <= n_frames) ? b : target;
+        }
+        return target;
     };
     size_t a = cut(rank - 1), b = cut(rank);
-    // cuts are monotone in r because targets are
     if (b < a) b = a;
     *lo = a; *hi = b;
+    return VBX_SUCCESS;
+}
+
+int vbx_shard_plan(size_t n_frames, int world, int rank, const int64_t *h_seg_start, size_t n_segments, vbx_shard_plan_t *out) {
+    if (!out) return fail(nullptr, VBX_E_INVALID, "vbx_shard_plan: null output");
+    if (h_seg_start && n_segments > 0) {
+        if (h_seg_start[0] != 0) return fail(nullptr, VBX_E_INVALID, "vbx_shard_plan: seg_start[0] must be 0");
+        for (size_t i = 1; i < n_segments; i++)
+            if (h_seg_start[i] < h_seg_start[i - 1]) return fail(nullptr, VBX_E_INVALID, "vbx_shard_plan: seg_start must ascend");
+    }
+    size_t lo = 0, hi = 0;
+    int rc = vbx_shard_range(n_frames, world, rank, h_seg_start, n_segments, &lo, &hi);
+    if (rc != VBX_SUCCESS) return rc;
+    // does the utterance that holds frame `c` reach back further than a warm-up can cover exactly?
+    auto continued = [&](size_t c) { return c > 0 && c < n_frames && c - seg_start_of(h_seg_start, n_segments, c) > (size_t)VBX_SHARD_WARM_FRAMES; };
+    out->lo = lo; out->hi = hi;
+    out->warm = 0; out->stop = 0; out->continues_prev = 0; out->continues_next = 0;
+    if (hi <= lo) return VBX_SUCCESS;                // an empty shard (more ranks than frames): nothing to do, nothing to pass on
+    const size_t back = lo - seg_start_of(h_seg_start, n_segments, lo);
+    out->warm = back < (size_t)VBX_SHARD_WARM_FRAMES ? back : (size_t)VBX_SHARD_WARM_FRAMES;
+    out->continues_prev = continued(lo) ? 1 : 0;
+    out->continues_next = continued(hi) ? 1 : 0;
+    const size_t next = seg_start_after(h_seg_start, n_segments, lo, n_frames);
+    out->stop = ((next < hi) ? next : hi) - (lo - out->warm);
+    return VBX_SUCCESS;
+}
+
+int vbx_shard_local_segments(const vbx_shard_plan_t *h_plan, const int64_t *h_seg_start, size_t n_segments,
+                             int64_t *h_out, size_t cap, size_t *n_out) {
+    if (!h_plan || !n_out) return fail(nullptr, VBX_E_INVALID, "vbx_shard_local_segments: null argument");
+    const size_t first = h_plan->lo - h_plan->warm;
+    size_t n = 0;
+    if (h_out && n < cap) h_out[n] = 0;
+    n++;
+    if (h_seg_start) for (size_t i = 0; i < n_segments; i++) {
+        const size_t b = (size_t)h_seg_start[i];
+        if (b > first && b < h_plan->hi) { if (h_out && n < cap) h_out[n] = (int64_t)(b - first); n++; }
+    }
+    *n_out = n;
+    if (h_out && n > cap) return fail(nullptr, VBX_E_INVALID, "vbx_shard_local_segments: output too small");
     return VBX_SUCCESS;
 }
 
@@ -175,6 +236,40 @@ int vbx_gather_records_f64(vbx_ctx *ctx, vbx_comm *c, const double *local, const
         ncclResult_t end = ncclGroupEnd();
         if (res != ncclSuccess) return fail(ctx, VBX_E_RUNTIME, std::string("ncclSend/ncclRecv: ") + ncclGetErrorString(res));
         if (end != ncclSuccess) return fail(ctx, VBX_E_RUNTIME, std::string("ncclGroupEnd: ") + ncclGetErrorString(end));
+    }
+    VBXC_HIP(ctx, hipEventRecord(c->done[slot], c->stream));
+    c->used[slot] = true;
+    return VBX_SUCCESS;
+}
+
+int vbx_comm_stitch_tracks_f64(vbx_ctx *ctx, vbx_comm *c, vbx_resonance *formants, size_t n_frames, size_t formants_ld,
+                               const vbx_shard_plan_t *h_plan, int32_t *d_changed, int slot) {
+    if (!ctx || !c || !h_plan) return fail(ctx, VBX_E_INVALID, "vbx_comm_stitch_tracks_f64: null argument");
+    if (slot < 0 || slot >= VBX_COMM_SLOTS) return fail(ctx, VBX_E_INVALID, "vbx_comm_stitch_tracks_f64: bad slot");
+    const bool recv = h_plan->continues_prev != 0, send = h_plan->continues_next != 0;
+    if ((recv && c->rank == 0) || (send && c->rank == c->world - 1))
+        return fail(ctx, VBX_E_INVALID, "vbx_comm_stitch_tracks_f64: the plan continues past the first / last rank");
+    if ((recv || send) && (!formants || n_frames != h_plan->hi - h_plan->lo + h_plan->warm || h_plan->stop > n_frames))
+        return fail(ctx, VBX_E_INVALID, "vbx_comm_stitch_tracks_f64: the rows are not the plan's frames [lo - warm, hi)");
+    VBXC_HIP(ctx, hipSetDevice(c->device));
+    hipStream_t main = (hipStream_t)vbx_internal_stream(ctx);
+    VBXC_HIP(ctx, hipEventRecord(c->ready, main));                       // the shard's own scan is done
+    VBXC_HIP(ctx, hipStreamWaitEvent(c->stream, c->ready, 0));
+    const int n_est = vbx_internal_last_track_n_est(ctx);
+    if (recv) {
+        double *state = vbx_internal_stitch_state(ctx);
+        if (!state || n_est < 1) return fail(ctx, VBX_E_RUNTIME, "vbx_comm_stitch_tracks_f64: no tracker state on this context");
+        // the row the previous rank ends with: 2 n_est doubles over the direct link from rank - 1 (it sends after ITS stitch)
+        VBXC_NCCL(ctx, ncclRecv(state, (size_t)(2 * n_est), ncclDouble, c->rank - 1, c->nccl, c->stream));
+        int rc = vbx_internal_track_stitch(ctx, (void *)c->stream, formants, n_frames, formants_ld, h_plan->warm, h_plan->stop, state, d_changed);
+        if (rc != VBX_SUCCESS) return rc;
+    } else if (d_changed) {
+        VBXC_HIP(ctx, hipMemsetAsync(d_changed, 0, sizeof(int32_t), c->stream));
+    }
+    if (send) {
+        if (n_est < 1) return fail(ctx, VBX_E_RUNTIME, "vbx_comm_stitch_tracks_f64: no tracker state on this context");
+        const double *last = (const double *)formants + (n_frames - 1) * formants_ld;
+        VBXC_NCCL(ctx, ncclSend(last, (size_t)(2 * n_est), ncclDouble, c->rank + 1, c->nccl, c->stream));
     }
     VBXC_HIP(ctx, hipEventRecord(c->done[slot], c->stream));
     c->used[slot] = true;

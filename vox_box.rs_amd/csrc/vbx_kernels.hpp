@@ -96,6 +96,11 @@ void launch_tracker_chunked(hipStream_t s, const res_t *res, long F, int n_res, 
                             const int64_t *seg_start, long n_seg, const res_t *est_init, int n_est,
                             const int32_t *frame_status, res_t *out, long out_ld, void *ws);
 
+// a shard's track continued from the row the previous shard ends with (k_tracker.hip, tracker_stitch_kernel)
+void launch_tracker_stitch(hipStream_t s, const res_t *res, long F, int n_res, const int32_t *res_count, int n_est,
+                           const int32_t *frame_status, res_t *out, long out_ld, long first, long stop,
+                           const double *state_in /* 2 n_est doubles */, int32_t *changed /* rows rewritten, or NULL */);
+
 // k_pitch.hip
 size_t pitch_lds_bytes(int n);
 // the sorted candidate list lives one entry per lane up to this many entries; a larger kmax parks the whole

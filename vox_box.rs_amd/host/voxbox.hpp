@@ -298,6 +298,31 @@ inline Shard shard(size_t n_frames, int world, int rank, Segments seg, size_t fr
         throw Error(VBX_E_INVALID, "shard: bad argument");
     return r;
 }
+// One rank's part of a recording whose utterances the frame split may cut (vbx_shard_plan): its frames, the tracker's warm-up
+// frames before them, the utterance starts re-based to the shard, and whether the track continues from / into a neighbour.
+struct ShardPlan {
+    vbx_shard_plan_t plan{};
+    std::vector<int64_t> local_seg_start;
+    size_t first() const { return plan.lo - plan.warm; }              // first frame the rank analyses
+    size_t n_frames() const { return plan.hi - plan.lo + plan.warm; }  // frames it analyses
+};
+inline ShardPlan shard_plan(size_t n_frames, int world, int rank, Segments seg) {
+    ShardPlan p;
+    size_t n = 0;
+    if (vbx_shard_plan(n_frames, world, rank, seg.h_seg_start, seg.n, &p.plan) != VBX_SUCCESS ||
+        vbx_shard_local_segments(&p.plan, seg.h_seg_start, seg.n, nullptr, 0, &n) != VBX_SUCCESS)
+        throw Error(VBX_E_INVALID, "shard_plan: bad argument");
+    p.local_seg_start.resize(n);
+    if (vbx_shard_local_segments(&p.plan, seg.h_seg_start, seg.n, p.local_seg_start.data(), n, &n) != VBX_SUCCESS)
+        throw Error(VBX_E_INVALID, "shard_plan: bad argument");
+    return p;
+}
+// the one-device form of Comm::stitch_tracks (vbx_track_stitch_f64)
+inline void track_stitch(Context &c, vbx_resonance *formants, size_t n_frames, size_t formants_ld, size_t first, size_t stop,
+                         const vbx_resonance *d_state_in, int32_t *d_changed = nullptr) {
+    c.check(vbx_track_stitch_f64(c.get(), formants, n_frames, formants_ld, first, stop, d_state_in, d_changed));
+}
+
 class Comm {
 public:
     static std::vector<unsigned char> unique_id() {
@@ -305,18 +330,34 @@ public:
         if (vbx_comm_unique_id(id.data()) != VBX_SUCCESS) throw Error(VBX_E_RUNTIME, vbx_last_error(nullptr));
         return id;
     }
-    Comm(Context &c, const std::vector<unsigned char> &id, int world, int rank) : ctx_(c) { c.check(vbx_comm_create(c.get(), id.data(), world, rank, &h_)); }
+    Comm(Context &c, const std::vector<unsigned char> &id, int world, int rank) : ctx_(c), world_(world), rank_(rank) {
+        if (id.size() != VBX_UNIQUE_ID_BYTES) throw Error(VBX_E_INVALID, "Comm: the id must hold VBX_UNIQUE_ID_BYTES bytes");
+        c.check(vbx_comm_create(c.get(), id.data(), world, rank, &h_));
+    }
     ~Comm() { vbx_comm_destroy(h_); }
     Comm(const Comm &) = delete;
     Comm &operator=(const Comm &) = delete;
-    void gather_records(const double *local, const std::vector<int64_t> &rows, size_t row_doubles, int dst, double *out, int slot = 0) {
+    // local: rows[rank] rows of row_doubles doubles; out (dst only): out_doubles doubles, at least what the gather writes
+    // (checked here against its transfer list, vbx_gather_plan: the library cannot know the size of a raw device pointer)
+    void gather_records(const double *local, const std::vector<int64_t> &rows, size_t row_doubles, int dst, double *out,
+                        size_t out_doubles, int slot = 0) {
+        if ((int)rows.size() != world_ || dst < 0 || dst >= world_) throw Error(VBX_E_INVALID, "gather_records: one row count per rank, dst a rank");
+        std::vector<int64_t> off(rows.size()), cnt(rows.size());
+        ctx_.check(vbx_gather_plan(rows.data(), world_, rank_, dst, row_doubles, off.data(), cnt.data(), nullptr));
+        if (rank_ == dst && (!out || out_doubles < (size_t)(off.back() + cnt.back())))
+            throw Error(VBX_E_INVALID, "gather_records: the gathered buffer is smaller than the rows the ranks send");
         ctx_.check(vbx_gather_records_f64(ctx_.get(), h_, local, rows.data(), row_doubles, dst, out, slot));
+    }
+    // formants: the formant column of the records the LAST analyze / find_formants call wrote for the plan's frames
+    void stitch_tracks(vbx_resonance *formants, size_t formants_ld, const ShardPlan &p, int32_t *d_changed = nullptr, int slot = 0) {
+        ctx_.check(vbx_comm_stitch_tracks_f64(ctx_.get(), h_, formants, p.n_frames(), formants_ld, &p.plan, d_changed, slot));
     }
     void wait(int slot) { ctx_.check(vbx_comm_wait(ctx_.get(), h_, slot)); }
     void sync() { ctx_.check(vbx_comm_sync(h_)); }
 private:
     Context &ctx_;
     vbx_comm *h_ = nullptr;
+    int world_ = 1, rank_ = 0;
 };
 
 }  // namespace voxbox

@@ -34,6 +34,74 @@ def segment_aligned_ranges(world, seg_start, n_frames):
     return out
 
 
+WARM_FRAMES = 64          # == VBX_SHARD_WARM_FRAMES
+
+
+def shard_ranges(world, seg_start, n_frames):
+    """vbx_shard_range for every rank: the even split; a cut moves up to an utterance start that lies within 1/32 of a
+    shard after it, otherwise it stays where it is -- inside the utterance (the track is carried across, `plan`)."""
+    bounds = None if seg_start is None else np.asarray(seg_start, dtype=np.int64)
+    slack = n_frames // world // 32
+    cuts = [0]
+    for r in range(world):
+        if r == world - 1:
+            c = n_frames
+        else:
+            c = frame_range(r, world, n_frames)[1]
+            if bounds is not None and bounds.size:
+                idx = int(np.searchsorted(bounds, c, side="left"))
+                if idx < bounds.size and bounds[idx] <= c + slack and bounds[idx] <= n_frames:
+                    c = int(bounds[idx])
+        cuts.append(max(c, cuts[-1]))
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def plan(n_frames, world, rank, seg_start=None, warm_frames=WARM_FRAMES):
+    """vbx_shard_plan as a dict: lo, hi, warm (extra leading frames [lo - warm, lo) that warm the tracker up), stop (index
+    from frame lo - warm at which the utterance holding frame lo ends inside the shard), continues_prev / continues_next."""
+    seg = np.array([0], dtype=np.int64) if seg_start is None else np.asarray(seg_start, dtype=np.int64)
+    lo, hi = shard_ranges(world, seg_start, n_frames)[rank]
+    start_of = lambda f: int(seg[np.searchsorted(seg, f, side="right") - 1]) if seg.size else 0
+    continued = lambda c: 0 < c < n_frames and c - start_of(c) > warm_frames
+    out = dict(lo=lo, hi=hi, warm=0, stop=0, continues_prev=0, continues_next=0)
+    if hi <= lo:
+        return out
+    out["warm"] = min(lo - start_of(lo), warm_frames)
+    out["continues_prev"] = int(continued(lo))
+    out["continues_next"] = int(continued(hi))
+    after = seg[seg > lo]
+    nxt = min(int(after[0]), n_frames) if after.size else n_frames
+    out["stop"] = min(nxt, hi) - (lo - out["warm"])
+    return out
+
+
+def plan_local_segments(pl, seg_start=None):
+    """vbx_shard_local_segments: utterance starts of frames [lo - warm, hi), re-based (first entry 0)."""
+    first = pl["lo"] - pl["warm"]
+    if seg_start is None:
+        return np.array([0], dtype=np.int64)
+    seg = np.asarray(seg_start, dtype=np.int64)
+    return np.concatenate([[0], seg[(seg > first) & (seg < pl["hi"])] - first]).astype(np.int64)
+
+
+def stitch_rows(rows, first, stop, state_in, step):
+    """The repair step of vbx_track_stitch_f64 on host arrays (the CPU tests' stand-in for the kernel; `step(state, t)` is
+    one tracker step on local frame t and returns the new state).  rows: [n, n_est, 2] formant rows of frames
+    [lo - warm, hi) tracked from a guess; state_in: the row the previous rank ends with.  Rows [first, stop) are rewritten
+    until the redone scan meets a row it already holds.  Returns the number of rows rewritten."""
+    state = np.array(state_in, dtype=np.float64, copy=True)
+    if first > 0 and rows[first - 1].tobytes() == state.tobytes():
+        return 0
+    n = 0
+    for t in range(first, stop):
+        state = step(state, t)
+        if rows[t].tobytes() == state.tobytes():
+            break
+        rows[t] = state
+        n += 1
+    return n
+
+
 def sample_range(lo, hi, frame_len, hop):
     """Samples [s0, s1) a rank needs for frames [lo, hi): includes the (frame_len - hop) halo."""
     if hi <= lo:

@@ -46,6 +46,15 @@ class _Resonance(C.Structure):
     _fields_ = [("frequency", C.c_double), ("bandwidth", C.c_double)]
 
 
+class ShardPlan(C.Structure):
+    """vbx_shard_plan_t (include/voxbox_hip.h): one rank's part of a recording sharded by frame ranges."""
+    _fields_ = [("lo", C.c_size_t), ("hi", C.c_size_t), ("warm", C.c_size_t), ("stop", C.c_size_t),
+                ("continues_prev", C.c_int), ("continues_next", C.c_int)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
 class AnalysisParams(C.Structure):
     """vbx_analysis_params (include/voxbox_hip.h): the parts of the user's frame loop that vbx_analyze_frames_f64 runs."""
     _fields_ = [("sample_rate", C.c_double),
@@ -180,6 +189,10 @@ def load_library():
         "vbx_analyze_frames_pcm16": (C.c_int, [vp, vp, sz, sz, sz, C.POINTER(AnalysisParams), vp, sz, vp, sz, vp]),
         "vbx_shard_range": (C.c_int, [sz, i32, i32, vp, sz, C.POINTER(sz), C.POINTER(sz)]),
         "vbx_shard_samples": (C.c_int, [sz, sz, sz, sz, C.POINTER(sz), C.POINTER(sz)]),
+        "vbx_shard_plan": (C.c_int, [sz, i32, i32, vp, sz, C.POINTER(ShardPlan)]),
+        "vbx_shard_local_segments": (C.c_int, [C.POINTER(ShardPlan), vp, sz, vp, sz, C.POINTER(sz)]),
+        "vbx_track_stitch_f64": (C.c_int, [vp, vp, sz, sz, sz, sz, vp, vp]),
+        "vbx_comm_stitch_tracks_f64": (C.c_int, [vp, vp, vp, sz, sz, C.POINTER(ShardPlan), vp, i32]),
         "vbx_comm_unique_id": (C.c_int, [vp]),
         "vbx_comm_create": (C.c_int, [vp, vp, i32, i32, C.POINTER(vp)]),
         "vbx_comm_destroy": (None, [vp]),
@@ -243,6 +256,32 @@ def shard_range(n_frames, world, rank, seg_start=None):
     return lo.value, hi.value
 
 
+def shard_plan(n_frames, world, rank, seg_start=None):
+    """vbx_shard_plan: this rank's frames [lo, hi), the warm-up frames before them and whether its track continues from the
+    previous rank / into the next one."""
+    plan = ShardPlan()
+    seg = None if seg_start is None else np.ascontiguousarray(seg_start, dtype=np.int64)
+    rc = load_library().vbx_shard_plan(n_frames, world, rank, None if seg is None else seg.ctypes.data,
+                                       0 if seg is None else seg.size, C.byref(plan))
+    if rc != 0:
+        raise VoxBoxError("vbx_shard_plan: bad argument")
+    return plan
+
+
+def shard_local_segments(plan, seg_start=None):
+    """vbx_shard_local_segments: utterance starts of the frames [lo - warm, hi), re-based to the shard."""
+    seg = None if seg_start is None else np.ascontiguousarray(seg_start, dtype=np.int64)
+    n = C.c_size_t()
+    L = load_library()
+    sp, sn = (None if seg is None else seg.ctypes.data), (0 if seg is None else seg.size)
+    if L.vbx_shard_local_segments(C.byref(plan), sp, sn, None, 0, C.byref(n)) != 0:
+        raise VoxBoxError("vbx_shard_local_segments: bad argument")
+    out = np.zeros(n.value, dtype=np.int64)
+    if L.vbx_shard_local_segments(C.byref(plan), sp, sn, out.ctypes.data, out.size, C.byref(n)) != 0:
+        raise VoxBoxError("vbx_shard_local_segments: bad argument")
+    return out
+
+
 def shard_samples(lo, hi, frame_len, hop):
     s0, s1 = C.c_size_t(), C.c_size_t()
     if load_library().vbx_shard_samples(lo, hi, frame_len, hop, C.byref(s0), C.byref(s1)) != 0:
@@ -289,6 +328,12 @@ class Comm:
         r = np.ascontiguousarray(rows, dtype=np.int64)
         self.vb._check(self.vb.L.vbx_gather_records_f64(self.vb.ctx, self.h, _ptr(local), r.ctypes.data, row_doubles, dst,
                                                         _ptr(out), slot))
+
+    def stitch_tracks(self, formants, n_frames, formants_ld, plan, changed=None, slot=0):
+        """vbx_comm_stitch_tracks_f64: the formant rows of the last analyze / find_formants call, continued from the previous
+        rank's last row (and this rank's last row passed on), on the communicator's stream."""
+        self.vb._check(self.vb.L.vbx_comm_stitch_tracks_f64(self.vb.ctx, self.h, _ptr(formants), n_frames, formants_ld,
+                                                            C.byref(plan), _ptr(changed), slot))
 
     def wait(self, slot):
         self.vb._check(self.vb.L.vbx_comm_wait(self.vb.ctx, self.h, slot))
@@ -718,6 +763,12 @@ class VoxBox:
             if v is not None:
                 v.free()
         return res
+
+    def track_stitch(self, formants, n_frames, formants_ld, first, stop, state_in, changed=None):
+        """vbx_track_stitch_f64: rows [first, stop) of the LAST find_formants / analyze_frames call's formant tracks, corrected
+        to follow from `state_in` (device pointer: the row the previous shard ends with)."""
+        self._check(self.L.vbx_track_stitch_f64(self.ctx, _ptr(formants), n_frames, formants_ld, first, stop, _ptr(state_in),
+                                                _ptr(changed)))
 
     # -- Sample = f32 (SURVEY 8f N4): float frames in, float results out ---------------
     def _frames32(self, x):
