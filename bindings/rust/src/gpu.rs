@@ -1094,6 +1094,17 @@ pub fn shard_range(n_frames: usize, world: i32, rank: i32, seg_start: &[i64]) ->
     Ok((lo, hi))
 }
 
+/// The mel filter bank's bins `floor((N + 1) hz / sr)` at `num_coeffs + 2` mel-spaced points (`vbx_mfcc_bins`,
+/// src/spectrum.rs:411-414) and whether the reference panics on every frame of this geometry (a bin beyond the spectrum).
+pub fn mfcc_bins(frame_len: usize, num_coeffs: usize, freq_bounds: (f64, f64), sample_rate: f64) -> GpuResult<(Vec<i32>, bool)> {
+    let mut bins = vec![0i32; num_coeffs + 2];
+    let rc = unsafe { ffi::vbx_mfcc_bins(frame_len, num_coeffs, freq_bounds.0, freq_bounds.1, sample_rate, bins.as_mut_ptr()) };
+    if rc < 0 {
+        return Err(GpuError { code: rc, message: last_error(ptr::null()) });
+    }
+    Ok((bins, rc == 1))
+}
+
 /// One rank's part of a recording sharded by frame ranges (`vbx_shard_plan`): its frames, the warm-up frames before them
 /// and whether its formant track continues from the previous rank / into the next one.
 pub fn shard_plan(n_frames: usize, world: i32, rank: i32, seg_start: &[i64]) -> GpuResult<ffi::VbxShardPlan> {

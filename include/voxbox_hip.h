@@ -307,6 +307,11 @@ int vbx_find_formants_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t
 int vbx_mfcc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
                  const double *window, size_t num_coeffs, double lo_hz, double hi_hz,
                  double sample_rate, double *out, int32_t *status);
+/* The mel filter bank's bins for that call, on the host: h_bins[num_coeffs + 2] = floor((frame_len + 1) * hz / sample_rate)
+ * at num_coeffs + 2 mel-spaced points (src/spectrum.rs:411-414; two points lie beyond hi_hz, and the scale is frame_len + 1:
+ * Q14).  Returns 1 (not an error code) when the geometry makes the reference panic on every frame -- a bin beyond the
+ * spectrum or descending bins -- which vbx_mfcc_f64 reports as VBX_FRAME_ERR_PANIC per frame. */
+int vbx_mfcc_bins(size_t frame_len, size_t num_coeffs, double lo_hz, double hi_hz, double sample_rate, int32_t *h_bins);
 
 /* dct (src/spectrum.rs:384-398) on rows: in/out [F, n]. */
 int vbx_dct_f64(vbx_ctx *ctx, const double *in, size_t n_rows, size_t n, double *out);

@@ -10,7 +10,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libvbx_oracle.so")
+# VBX_ORACLE_ASAN=1: the AddressSanitizer + UBSan build (tests/test_sanitizers.py; the process needs libasan preloaded)
+_ASAN = os.environ.get("VBX_ORACLE_ASAN") == "1"
+_SO = os.path.join(_HERE, "libvbx_oracle_asan.so" if _ASAN else "libvbx_oracle.so")
 
 OK, ERR_LPC, ERR_POLYNOMIAL, ERR_NAN, ERR_PANIC, ERR_WORKSPACE = range(6)
 MAX_RESONANCES = 32
@@ -21,7 +23,7 @@ def build(force=False):
     if force or not os.path.exists(_SO) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_SO) for s in src
     ):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["asan"] if _ASAN else []))
     return _SO
 
 

@@ -30,7 +30,7 @@ def test_default_workload_line():
     assert "workload" in d["config"] and d["config"]["frame_len"] == 1200 and d["config"]["hop"] == 480
     assert d["value"] > 1e6
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["kernel"] == "analyze" and 0.0 < r["frac"] < 1.0
+    assert r["bound"] in ("hbm", "fp64_valu") and r["kernel"] == "analyze" and 0.0 < r["frac"] < 1.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["traffic"] is not None and r["traffic"] > 0.9 * 4064 * d["config"]["frames_per_gpu"]     # at least the algorithmic bytes
     # the headline fraction is the EXECUTED one (FFTs + evaluated sinc terms); the comparison with the reference's O(N^2) sums has its own key

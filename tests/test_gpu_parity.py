@@ -860,6 +860,7 @@ def test_mfcc_and_formants_odd_signals(vb, oracle):
     #    frames no implementation, the reference included, has digits to compare; the probe below detects them per frame.
     n_hz = {k: 0 for k in range(len(gens))}
     n_co = {k: 0 for k in range(len(gens))}
+    n_cnt = {k: 0 for k in range(len(gens))}
     for f in range(X.shape[0]):
         es, ef, eres, eco = oracle.find_formants(X[f], SR, 12, est0)
         assert out["status"][f] == es, (f, out["status"][f], es)  # every frame its own segment: no carried state
@@ -867,7 +868,14 @@ def test_mfcc_and_formants_odd_signals(vb, oracle):
             continue
         assert np.all(np.isfinite(out["formants"][f]))
         probe = X[f] * (1.0 + 1e-13 * rng.standard_normal(N))
-        ps, pf, _, pco = oracle.find_formants(probe, SR, 12, est0)
+        ps, pf, pres, pco = oracle.find_formants(probe, SR, 12, est0)
+        # the resonance COUNT is compared on every frame -- the ill-conditioned classes too -- on which the oracle's own count
+        # survives the 1e-13 perturbation (a cluster of near-multiple roots may still put one of them on either side of the
+        # 50 Hz / Nyquist - 50 Hz filter of src/spectrum.rs:176-182: then not even the count has a reference value)
+        e_cnt, p_cnt = int(np.sum(eres[:, 0] != 0.0)), int(np.sum(pres[:, 0] != 0.0))
+        if ps == 0 and e_cnt == p_cnt:
+            assert out["count"][f] == e_cnt, (f, out["count"][f], e_cnt)
+            n_cnt[f % len(gens)] += 1
         if ps == 0 and np.all(rel_close(pco, eco, 1e-8)):        # the Burg recursion itself loses its digits on a pure tone
             assert np.all(rel_close(out["coeffs"][f], eco)), (f, np.max(np.abs(out["coeffs"][f] - eco)))
             n_co[f % len(gens)] += 1
@@ -880,7 +888,8 @@ def test_mfcc_and_formants_odd_signals(vb, oracle):
         if stable:
             assert np.all(np.abs(out["formants"][f, :, 0] - ef[:, 0]) <= 1e-4 * np.abs(ef[:, 0]) + 1e-9), f
             n_hz[f % len(gens)] += 1
-    print("\nframes per signal class with Burg coefficients / formant Hz compared:", n_co, n_hz)
+    print("\nframes per signal class with Burg coefficients / formant Hz / resonance count compared:", n_co, n_hz, n_cnt)
+    assert sum(n_cnt.values()) >= sum(n_hz.values())
     assert n_hz[0] == 6 and n_hz[3] == 6 and n_hz[7] == 6        # noise, DC + noise, square + noise: all well conditioned
 
 

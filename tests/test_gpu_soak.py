@@ -174,9 +174,12 @@ def test_soak_pipeline_shard(vb, oracle, pkg):
     # the runner-up of an unvoiced frame is a noise candidate: <= 0.5 % of those refinements end on the other side of the
     # lag discontinuity (same frequency, another strength) -- _check_pitch in test_gpu_parity.py
     # classifies them candidate by candidate, here they are only bounded (1 % of the frames)
-    allowed = {"pitch_top_tie_swap": F // 10000, "fused_pitch_top_tie_swap": F // 10000,
-               "pitch_runner_up_tie_swap": F // 1000, "pitch_runner_up_bad": F // 100,
-               "fused_lpc_vs_oracle_1e-6": F // 5000}      # observed 4 of 50,000, none of them beyond the oracle's own rounding
+    # allowances = what rounds 2-4 observed on this stretch, plus one event (profiles/r03l_soak_report.json: every class 0 but
+    # the Levinson rows): a single refinement whose chaotic tail lands elsewhere after a change of summation order must not turn
+    # the suite red, anything systematic must
+    allowed = {"pitch_top_tie_swap": 1, "fused_pitch_top_tie_swap": 1,
+               "pitch_runner_up_tie_swap": 1, "pitch_runner_up_bad": 1,
+               "fused_lpc_vs_oracle_1e-6": 5}              # observed 4 of 50,000, none of them beyond the oracle's own rounding
     bad = {k: v for k, v in cls.items() if v > allowed.get(k, 0)}
     assert not bad, f"disagreements with the oracle over {F} consecutive frames: {bad} (all classes: {cls})"
     assert voiced > F // 2 and F - voiced > F // 10           # the stretch holds both kinds of frame

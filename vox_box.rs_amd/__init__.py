@@ -17,7 +17,7 @@ from .voxbox import (  # noqa: F401
     MALE_FORMANT_ESTIMATES, FEMALE_FORMANT_ESTIMATES,
     FRAME_OK, FRAME_ERR_LPC, FRAME_ERR_POLYNOMIAL, FRAME_ERR_NAN, FRAME_ERR_PANIC,
     AnalysisParams, Comm, comm_unique_id, comm_live_count, gather_plan, shard_range, shard_samples,
-    ShardPlan, shard_plan, shard_local_segments,
+    ShardPlan, shard_plan, shard_local_segments, mfcc_bins,
     GATHER_NONE, GATHER_RECV, GATHER_SEND, GATHER_COPY,
     MAX_PITCH_CANDIDATES, pitch_max_candidates,
 )

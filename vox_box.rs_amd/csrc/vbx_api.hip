@@ -3,6 +3,7 @@
 // numeric entry point launches gfx950 kernels on the context's stream.
 #include "../../include/voxbox_hip.h"
 #include "vbx_kernels.hpp"
+#include "vbx_host.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -133,40 +134,6 @@ int ws_get(vbx_ctx *ctx, int slot, size_t bytes, void **out) {
 }
 
 // ---- host-built tables (the library's own statement of the sample-crate recurrences) --------
-
-// sample 0.10 signal::Phase: yields phase, then phase = (phase + step) % 1.0
-void phase_ramp(std::vector<double> &ph, size_t n, double step) {
-    ph.resize(n);
-    double next = 0.0;
-    for (size_t i = 0; i < n; i++) { ph[i] = next; next = std::fmod(next + step, 1.0); }
-}
-
-int window_table_host(int kind, size_t n, double *out) {
-    const double pi2 = M_PI * 2.0;
-    std::vector<double> ph;
-    switch (kind) {
-        case VBX_WINDOW_HANNING:            // Window::<Hanning>::new(n)
-            phase_ramp(ph, n, 1.0 / ((double)n - 1.0));
-            for (size_t i = 0; i < n; i++) out[i] = 0.5 * (1.0 - std::cos(ph[i] * pi2));
-            return VBX_SUCCESS;
-        case VBX_WINDOW_HANNING_LAG:        // HanningLag::at_phase, src/periodic.rs:239-247 (Q3)
-            phase_ramp(ph, n, 1.0 / ((double)n - 1.0));
-            for (size_t i = 0; i < n; i++) {
-                const double v = ph[i] * pi2;
-                out[i] = (1.0 - ph[i]) * (2.0 / 3.0 + (1.0 / 3.0) * std::cos(v)) + (1.0 / pi2) * std::sin(v);
-            }
-            return VBX_SUCCESS;
-        case VBX_WINDOW_HANNING_PERIODIC: { // src/lib.rs:65-70
-            const double len_inv = 1.0 / (double)n;
-            for (size_t i = 0; i < n; i++) out[i] = 0.5 * (1.0 - std::cos(((double)i * len_inv) * pi2));
-            return VBX_SUCCESS;
-        }
-        case VBX_WINDOW_RECTANGLE:
-            for (size_t i = 0; i < n; i++) out[i] = 1.0;
-            return VBX_SUCCESS;
-    }
-    return VBX_E_INVALID;
-}
 
 int get_window_dev(vbx_ctx *ctx, int kind, size_t n, const double **out) {
     auto key = std::make_pair(kind, n);
@@ -319,20 +286,6 @@ int get_spectral_tab(vbx_ctx *ctx, int plan, const double **out) {
     }
     *out = ctx->spectral_tab[plan];
     return VBX_SUCCESS;
-}
-
-// src/spectrum.rs:411-414 (Q14)
-void mel_bins_host(size_t n, size_t k, double lo, double hi, double sr, std::vector<int32_t> &bins, bool &overflow) {
-    const double mlo = vbx_hz_to_mel(lo), mel_range = vbx_hz_to_mel(hi) - mlo;
-    bins.resize(k + 2);
-    overflow = false;
-    for (size_t i = 0; i < k + 2; i++) {
-        const double point = ((double)i / (double)k) * mel_range + mlo;
-        const double b = std::floor((double)(n + 1) * vbx_mel_to_hz(point) / sr);
-        if (!(b >= 0.0)) { bins[i] = 0; }
-        else if (b > 1.0e9) { bins[i] = 1000000000; overflow = true; }
-        else bins[i] = (int32_t)b;
-    }
 }
 
 int get_bins_dev(vbx_ctx *ctx, size_t n, size_t k, double lo, double hi, double sr,
@@ -632,23 +585,6 @@ int vbx_profile_names(vbx_ctx *ctx, char *h_buf, size_t cap) {
 }
 
 // ---- tables -------------------------------------------------------------------------------
-
-int vbx_window_table_f64(int kind, size_t n, double *h_out) {
-    if (!h_out || n < 1) return fail(nullptr, VBX_E_INVALID, "vbx_window_table_f64: bad argument");
-    int rc = window_table_host(kind, n, h_out);
-    if (rc != VBX_SUCCESS) return fail(nullptr, rc, "vbx_window_table_f64: unknown window kind");
-    return rc;
-}
-
-size_t vbx_frame_count(size_t n_samples, size_t frame_len, size_t hop) {
-    if (frame_len == 0 || hop == 0 || n_samples < frame_len) return 0;
-    return (n_samples - frame_len) / hop + 1;
-}
-
-double vbx_hz_to_mel(double hz) { return 1125. * std::log1p(hz / 700.); }       // src/spectrum.rs:375-377
-double vbx_mel_to_hz(double mel) { return 700. * (std::exp(mel / 1125.) - 1.); } // src/spectrum.rs:379-381
-size_t vbx_find_formants_real_work_size(size_t buf_len, size_t n_coeffs) { return buf_len * 2 + n_coeffs * 23 + 2; }
-size_t vbx_find_formants_complex_work_size(size_t n_coeffs) { return n_coeffs * 7 + 4; }
 
 // ---- periodic.rs --------------------------------------------------------------------------
 
@@ -961,17 +897,6 @@ int vbx_div_polynomial_c64(vbx_ctx *ctx, vbx_complex *polys, const vbx_complex *
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     { Prof p(ctx, "div_polynomial"); launch_div_polynomial(ctx->stream, (cplx_t *)polys, (const cplx_t *)others, (long)n_polys, (int)len, (cplx_t *)rem, status); }
     return check_launch(ctx, __func__);
-}
-
-size_t vbx_degree_c64(const vbx_complex *h_poly, size_t len) {          // src/polynomial.rs:26-28
-    if (!h_poly) return 0;
-    for (size_t i = len; i-- > 0;) if (!(h_poly[i].re == 0.0 && h_poly[i].im == 0.0)) return i;
-    return 0;
-}
-size_t vbx_off_low_c64(const vbx_complex *h_poly, size_t len) {         // src/polynomial.rs:30-32
-    if (!h_poly) return 0;
-    for (size_t i = 0; i < len; i++) if (!(h_poly[i].re == 0.0 && h_poly[i].im == 0.0)) return i;
-    return 0;
 }
 
 int vbx_find_roots_c32(vbx_ctx *ctx, vbx_complex32 *polys, size_t n_polys, size_t len, int32_t *status) {
@@ -1385,10 +1310,6 @@ int vbx_ring_frames_f64(vbx_ctx *ctx, const double *ring, size_t capacity, size_
     return check_launch(ctx, __func__);
 }
 
-size_t vbx_resampled_len(size_t frame_len, double resample_ratio) {
-    return (size_t)std::ceil(resample_ratio * (double)frame_len);          // src/lib.rs:42
-}
-
 int vbx_resample_linear_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
                             double resample_ratio, double *out) {
     int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride, VBX_MAX_LONG_FRAME_LEN);
@@ -1433,15 +1354,6 @@ static int ensure_side_stream(vbx_ctx *ctx) {
     VBX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     VBX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     return VBX_SUCCESS;
-}
-
-size_t vbx_record_doubles(const vbx_analysis_params *h_p) {
-    if (!h_p) return 0;
-    size_t n = 2;                                                   // Pitch { frequency, strength }
-    if (h_p->formant_order) n += 2 * h_p->n_est;                    // Resonance { frequency, bandwidth } x n_est
-    if (h_p->mfcc_coeffs) n += h_p->mfcc_coeffs;
-    if (h_p->lpc_order) n += h_p->lpc_order + 1;
-    return n;
 }
 
 // x: the frames as f64 samples, or -- pcm16 non-null -- as 16-bit PCM (the kernels that have a PCM form read it directly:
@@ -1601,15 +1513,6 @@ int vbx_analyze_frames_pcm16(vbx_ctx *ctx, const int16_t *pcm, size_t n_frames, 
 // fast as the f64 kernels, but NOT the bits the crate returns at f32.  The reference-faithful forms (every fold in f32, in
 // the reference's order) carry the plain *_f32 names, further down; MFCC has only the wide form (its f32 arithmetic lives
 // in the un-vendored rustfft).
-
-int vbx_window_table_f32(int kind, size_t n, float *h_out) {
-    if (!h_out || n == 0) return fail(nullptr, VBX_E_INVALID, "vbx_window_table_f32: bad argument");
-    std::vector<double> t(n);
-    int rc = vbx_window_table_f64(kind, n, t.data());
-    if (rc != VBX_SUCCESS) return rc;
-    for (size_t i = 0; i < n; i++) h_out[i] = (float)t[i];
-    return VBX_SUCCESS;
-}
 
 int vbx_autocorrelate_f32_wide(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame_len,
                           size_t stride, const float *window, size_t n_lags, float *out) {

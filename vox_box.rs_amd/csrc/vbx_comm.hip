@@ -53,114 +53,6 @@ extern "C" {
 
 int vbx_comm_live_count(void) { return g_live_comms.load(); }
 
-int vbx_gather_plan(const int64_t *h_rows, int world, int rank, int dst, size_t row_doubles,
-                    int64_t *h_offset, int64_t *h_count, int32_t *h_op) {
-    if (!h_rows || world < 1 || rank < 0 || rank >= world || dst < 0 || dst >= world || row_doubles < 1)
-        return fail(nullptr, VBX_E_INVALID, "vbx_gather_plan: bad argument");
-    int64_t off = 0;
-    for (int r = 0; r < world; r++) {
-        if (h_rows[r] < 0) return fail(nullptr, VBX_E_INVALID, "vbx_gather_plan: negative row count");
-        const int64_t cnt = h_rows[r] * (int64_t)row_doubles;
-        if (h_offset) h_offset[r] = off;
-        if (h_count) h_count[r] = cnt;
-        if (h_op) {
-            int32_t op = VBX_GATHER_NONE;
-            if (rank == dst) { if (cnt > 0) op = (r == dst) ? VBX_GATHER_COPY : VBX_GATHER_RECV; }
-            else if (r == dst && h_rows[rank] > 0) op = VBX_GATHER_SEND;       // whatever dst itself contributes
-            h_op[r] = op;
-        }
-        off += cnt;
-    }
-    return VBX_SUCCESS;
-}
-
-// last utterance start <= f (0 without a segment list)
-static size_t seg_start_of(const int64_t *h_seg_start, size_t n_segments, size_t f) {
-    size_t best = 0;
-    if (h_seg_start) for (size_t i = 0; i < n_segments; i++) { if ((size_t)h_seg_start[i] <= f) best = (size_t)h_seg_start[i]; else break; }
-    return best;
-}
-// first utterance start > f, or n_frames
-static size_t seg_start_after(const int64_t *h_seg_start, size_t n_segments, size_t f, size_t n_frames) {
-    if (h_seg_start) for (size_t i = 0; i < n_segments; i++) if ((size_t)h_seg_start[i] > f) return (size_t)h_seg_start[i] < n_frames ? (size_t)h_seg_start[i] : n_frames;
-    return n_frames;
-}
-
-int vbx_shard_range(size_t n_frames, int world, int rank, const int64_t *h_seg_start, size_t n_segments,
-                    size_t *lo, size_t *hi) {
-    if (!lo || !hi || world < 1 || rank < 0 || rank >= world) return fail(nullptr, VBX_E_INVALID, "vbx_shard_range: bad argument");
-    auto even_hi = [&](int r) {                      // end of rank r under the plain even split
-        const size_t base = n_frames / (size_t)world, rem = n_frames % (size_t)world;
-        return (size_t)(r + 1) * base + ((size_t)(r + 1) < rem ? (size_t)(r + 1) : rem);
-    };
-    // The even cut, unless an utterance starts within 1/32 of a shard after it: a rank that begins where an utterance
-    // begins needs nothing from its predecessor.  A cut INSIDE an utterance is fine too -- the track is carried across
-    // it (vbx_shard_plan, vbx_comm_stitch_tracks_f64) -- so one long utterance splits evenly.
-    const size_t slack = n_frames / (size_t)world / 32;
-    auto cut = [&](int r) -> size_t {
-        if (r < 0) return 0;
-        if (r >= world - 1) return n_frames;
-        const size_t target = even_hi(r);
-        if (!h_seg_start || n_segments == 0) return target;
-        for (size_t i = 0; i < n_segments; i++) {    // first boundary >= target
-            const size_t b = (size_t)h_seg_start[i];
-            if (b >= target) return (b <= target + slack && b <= n_frames) ? b : target;
-        }
-        return target;
-    };
-    size_t a = cut(rank - 1), b = cut(rank);
-    if (b < a) b = a;
-    *lo = a; *hi = b;
-    return VBX_SUCCESS;
-}
-
-int vbx_shard_plan(size_t n_frames, int world, int rank, const int64_t *h_seg_start, size_t n_segments, vbx_shard_plan_t *out) {
-    if (!out) return fail(nullptr, VBX_E_INVALID, "vbx_shard_plan: null output");
-    if (h_seg_start && n_segments > 0) {
-        if (h_seg_start[0] != 0) return fail(nullptr, VBX_E_INVALID, "vbx_shard_plan: seg_start[0] must be 0");
-        for (size_t i = 1; i < n_segments; i++)
-            if (h_seg_start[i] < h_seg_start[i - 1]) return fail(nullptr, VBX_E_INVALID, "vbx_shard_plan: seg_start must ascend");
-    }
-    size_t lo = 0, hi = 0;
-    int rc = vbx_shard_range(n_frames, world, rank, h_seg_start, n_segments, &lo, &hi);
-    if (rc != VBX_SUCCESS) return rc;
-    // does the utterance that holds frame `c` reach back further than a warm-up can cover exactly?
-    auto continued = [&](size_t c) { return c > 0 && c < n_frames && c - seg_start_of(h_seg_start, n_segments, c) > (size_t)VBX_SHARD_WARM_FRAMES; };
-    out->lo = lo; out->hi = hi;
-    out->warm = 0; out->stop = 0; out->continues_prev = 0; out->continues_next = 0;
-    if (hi <= lo) return VBX_SUCCESS;                // an empty shard (more ranks than frames): nothing to do, nothing to pass on
-    const size_t back = lo - seg_start_of(h_seg_start, n_segments, lo);
-    out->warm = back < (size_t)VBX_SHARD_WARM_FRAMES ? back : (size_t)VBX_SHARD_WARM_FRAMES;
-    out->continues_prev = continued(lo) ? 1 : 0;
-    out->continues_next = continued(hi) ? 1 : 0;
-    const size_t next = seg_start_after(h_seg_start, n_segments, lo, n_frames);
-    out->stop = ((next < hi) ? next : hi) - (lo - out->warm);
-    return VBX_SUCCESS;
-}
-
-int vbx_shard_local_segments(const vbx_shard_plan_t *h_plan, const int64_t *h_seg_start, size_t n_segments,
-                             int64_t *h_out, size_t cap, size_t *n_out) {
-    if (!h_plan || !n_out) return fail(nullptr, VBX_E_INVALID, "vbx_shard_local_segments: null argument");
-    const size_t first = h_plan->lo - h_plan->warm;
-    size_t n = 0;
-    if (h_out && n < cap) h_out[n] = 0;
-    n++;
-    if (h_seg_start) for (size_t i = 0; i < n_segments; i++) {
-        const size_t b = (size_t)h_seg_start[i];
-        if (b > first && b < h_plan->hi) { if (h_out && n < cap) h_out[n] = (int64_t)(b - first); n++; }
-    }
-    *n_out = n;
-    if (h_out && n > cap) return fail(nullptr, VBX_E_INVALID, "vbx_shard_local_segments: output too small");
-    return VBX_SUCCESS;
-}
-
-int vbx_shard_samples(size_t lo, size_t hi, size_t frame_len, size_t hop, size_t *s0, size_t *s1) {
-    if (!s0 || !s1 || frame_len < 1 || hop < 1) return fail(nullptr, VBX_E_INVALID, "vbx_shard_samples: bad argument");
-    *s0 = lo * hop;
-    *s1 = (hi <= lo) ? lo * hop : (hi - 1) * hop + frame_len;     // includes the frame_len - hop halo
-    return VBX_SUCCESS;
-}
-
 int vbx_comm_unique_id(void *h_id) {
     if (!h_id) return fail(nullptr, VBX_E_INVALID, "vbx_comm_unique_id: null argument");
     static_assert(sizeof(ncclUniqueId) == VBX_UNIQUE_ID_BYTES, "ncclUniqueId size");

@@ -173,6 +173,7 @@ def load_library():
         "vbx_find_formants_f64": (C.c_int, [vp, vp, sz, sz, sz, dbl, sz, vp, sz, vp, sz, vp, vp, vp, vp, vp]),
         "vbx_mfcc_f64": (C.c_int, [vp, vp, sz, sz, sz, vp, sz, dbl, dbl, dbl, vp, vp]),
         "vbx_dct_f64": (C.c_int, [vp, vp, sz, sz, vp]),
+        "vbx_mfcc_bins": (C.c_int, [sz, sz, dbl, dbl, dbl, vp]),
         "vbx_resampled_len": (sz, [sz, dbl]),
         "vbx_resample_linear_f64": (C.c_int, [vp, vp, sz, sz, sz, dbl, vp]),
         "vbx_pcm16_to_f64": (C.c_int, [vp, vp, sz, vp]),
@@ -243,6 +244,16 @@ def hz_to_mel(hz):
 
 def mel_to_hz(mel):
     return load_library().vbx_mel_to_hz(mel)
+
+
+def mfcc_bins(frame_len, num_coeffs, lo_hz, hi_hz, sample_rate):
+    """vbx_mfcc_bins: (bins[num_coeffs + 2], panics) -- the mel filter bank's bins (src/spectrum.rs:411-414) and whether the
+    reference panics on every frame of this geometry."""
+    out = np.zeros(num_coeffs + 2, dtype=np.int32)
+    rc = load_library().vbx_mfcc_bins(frame_len, num_coeffs, lo_hz, hi_hz, sample_rate, out.ctypes.data)
+    if rc < 0:
+        raise VoxBoxError("vbx_mfcc_bins: bad argument")
+    return out, bool(rc)
 
 
 def shard_range(n_frames, world, rank, seg_start=None):
