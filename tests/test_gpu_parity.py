@@ -832,6 +832,40 @@ def test_mfcc_four_kernels_agree(pkg, oracle, audio, monkeypatch):
     assert not np.array_equal(res["dft2"][0], res["goertzel"][0]) and not np.array_equal(res["fft"][0], res["dft2"][0])
 
 
+@pytest.mark.parametrize("n,k,lo,hi,sr", [(1103, 13, 100.0, 8000.0, 44100.0), (3000, 13, 100.0, 8000.0, 48000.0), (2500, 13, 100.0, 8000.0, 48000.0),
+                                          (997, 20, 50.0, 6000.0, 22050.0), (2049, 26, 133.0, 6855.0, 22050.0), (3301, 13, 100.0, 8000.0, 48000.0),
+                                          (601, 13, 100.0, 8000.0, 48000.0), (1200, 13, 100.0, 8000.0, 48000.0), (700, 40, 0.0, 10000.0, 48000.0),
+                                          (64, 5, 300.0, 3000.0, 8000.0), (1601, 64, 0.0, 8000.0, 16000.0)])
+def test_mfcc_chirp_z_kernel(pkg, oracle, audio, monkeypatch, n, k, lo, hi, sr):
+    """Frame lengths with no transform and no matrix-core factorisation of their own (1103 = 25 ms at 44.1 kHz is prime; 2500 and
+    3000 need more bins than the two-stage kernel's tiles hold) take the chirp-z kernel (k_mfcc_czt.hip) by default;
+    VBX_MFCC_CZT=1 sends every length through it that fits (n + top - 1 <= 4096), VBX_MFCC_CZT=0 none: both against the oracle,
+    and -- where the default is the chirp-z kernel -- the two must differ in the last bits (two kernels ran)."""
+    x = _frames(audio, n, 977, range(0, 40, 4)) * oracle.window("hanning", n) * 40.0
+    res = {}
+    for mode in ("1", "0", None):
+        if mode is not None:
+            monkeypatch.setenv("VBX_MFCC_CZT", mode)
+        v = pkg.VoxBox(0)
+        if mode is not None:
+            monkeypatch.delenv("VBX_MFCC_CZT")
+        try:
+            res[mode] = v.mfcc(x, k, (lo, hi), sr)
+        finally:
+            v.close()
+    for f in range(x.shape[0]):
+        es, em = oracle.mfcc(x[f], k, lo, hi, sr)
+        for mode in res:
+            assert res[mode][1][f] == es
+            assert np.all(rel_close(res[mode][0][f], em, 1e-6)), (mode, f, np.max(np.abs(res[mode][0][f] - em)))
+    if n != 1200:                                              # (a frame that IS a transform's keeps the FFT kernel either way)
+        assert not np.array_equal(res["1"][0], res["0"][0])
+    if n in (1103, 3000, 2500, 997, 2049, 3301, 601):
+        assert np.array_equal(res[None][0], res["1"][0])       # the default IS the chirp-z kernel here
+    if n in (1200, 64):
+        assert np.array_equal(res[None][0], res["0"][0])       # ... and is not here (its own transform; too short)
+
+
 def test_mfcc_and_formants_odd_signals(vb, oracle):
     """Noise, tones, impulses, DC, silence, extreme scales through MFCC (matrix-core kernel at N = 1200) and
     find_formants: statuses exact (silence -> Err(LPC)), values within BASELINE tolerance of the oracle."""

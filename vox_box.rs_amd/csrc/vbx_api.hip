@@ -38,7 +38,7 @@ struct vbx_ctx {
     std::string arch;
     int cu_count = 0;
     // workspaces (grown on demand, never shrunk)
-    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_UNSURE, WS_F32_IN, WS_F32_OUT, WS_TRK, WS_BURG_LIST, WS_ROOTS_LIST, WS_LONG, WS_N };
+    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_UNSURE, WS_F32_IN, WS_F32_OUT, WS_TRK, WS_BURG_LIST, WS_ROOTS_LIST, WS_LONG, WS_CZT, WS_N };
     void *ws[WS_N] = {nullptr};
     const int32_t *burg_list_count = nullptr;             // device counter of the last one-pass Burg call (tests)
     const int32_t *roots_list_count = nullptr;            // the same for the resonance kernel of find_formants
@@ -50,6 +50,8 @@ struct vbx_ctx {
     std::map<size_t, double *> dct_tables;                // K -> [K][K]
     std::map<std::pair<size_t, int>, std::pair<double *, double *>> dft2_tabs;   // (n, n1) -> (stage-1 table, twiddles)
     std::map<std::tuple<size_t, int, int>, std::array<double *, 4>> mfma_tabs;   // (n, n1, k2) -> ctab, twd, twm, wm
+    std::map<std::tuple<size_t, int, int>, std::pair<double *, double *>> czt_tabs;   // (n, top, L) -> (chirp, FFT of the chirp)
+    int mfcc_czt = -1;                                    // VBX_MFCC_CZT=0 / 1: never / wherever it fits (tests); -1: the measured choice
     std::map<std::tuple<size_t, size_t, double, double, double>, int32_t *> bins_cache;
     std::map<std::tuple<size_t, size_t, double, double, double>, double *> slopes_cache;   // [nb][2] i/up, i/down per bin
     std::map<std::pair<size_t, double>, std::pair<int32_t *, double *>> resample_tabs;   // (n, ratio) -> (index, fraction)
@@ -260,6 +262,24 @@ int get_mfcc_mfma_dev(vbx_ctx *ctx, size_t n, const mfcc_mplan_t &pl, const doub
     return VBX_SUCCESS;
 }
 
+// tables of the chirp-z MFCC kernel (k_mfcc_czt.hip)
+int get_czt_dev(vbx_ctx *ctx, size_t n, int top, int L, const double **chirp, const double **bhat) {
+    auto key = std::make_tuple(n, top, L);
+    auto it = ctx->czt_tabs.find(key);
+    if (it == ctx->czt_tabs.end()) {
+        std::vector<double> hc(2 * n), hb(2 * (size_t)L);
+        mfcc_czt_fill_tabs((int)n, top, L, hc.data(), hb.data());
+        double *dc = nullptr, *db = nullptr;
+        VBX_HIP(ctx, hipMalloc((void **)&dc, hc.size() * sizeof(double)));
+        VBX_HIP(ctx, hipMalloc((void **)&db, hb.size() * sizeof(double)));
+        VBX_HIP(ctx, hipMemcpy(dc, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice));
+        VBX_HIP(ctx, hipMemcpy(db, hb.data(), hb.size() * sizeof(double), hipMemcpyHostToDevice));
+        it = ctx->czt_tabs.emplace(key, std::make_pair(dc, db)).first;
+    }
+    *chirp = it->second.first; *bhat = it->second.second;
+    return VBX_SUCCESS;
+}
+
 int get_dct_dev(vbx_ctx *ctx, size_t k, const double **out) {
     auto it = ctx->dct_tables.find(k);
     if (it == ctx->dct_tables.end()) {
@@ -421,6 +441,7 @@ int vbx_ctx_create(vbx_ctx **out, int device, void *hip_stream) {
     { const char *e = std::getenv("VBX_MFCC_GOERTZEL"); ctx->mfcc_force_goertzel = e && e[0] == '1'; }
     { const char *e = std::getenv("VBX_MFCC_DFT2"); ctx->mfcc_force_dft2 = e && e[0] == '1'; }
     { const char *e = std::getenv("VBX_MFCC_MFMA"); ctx->mfcc_force_mfma = e && e[0] == '1'; }
+    { const char *e = std::getenv("VBX_MFCC_CZT"); ctx->mfcc_czt = e ? (e[0] == '1' ? 1 : 0) : -1; }
     { const char *e = std::getenv("VBX_PITCH_MFMA"); ctx->pitch_force_mfma = e && e[0] == '1'; }
     if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->owns_stream = false; }
     else {
@@ -448,6 +469,7 @@ void vbx_ctx_destroy(vbx_ctx *ctx) {
     for (auto &kv : ctx->dct_tables) hipFree(kv.second);
     for (auto &kv : ctx->dft2_tabs) { hipFree(kv.second.first); hipFree(kv.second.second); }
     for (auto &kv : ctx->mfma_tabs) for (double *q : kv.second) hipFree(q);
+    for (auto &kv : ctx->czt_tabs) { hipFree(kv.second.first); hipFree(kv.second.second); }
     for (auto &kv : ctx->bins_cache) hipFree(kv.second);
     for (auto &kv : ctx->slopes_cache) hipFree(kv.second);
     for (auto &kv : ctx->resample_tabs) { hipFree(kv.second.first); hipFree(kv.second.second); }
@@ -1213,8 +1235,31 @@ static int run_mfcc(vbx_ctx *ctx, hipStream_t stm, const double *x, size_t n_fra
     // the MFMA kernel's tiles, else on the vector ALU; otherwise (prime-ish lengths) Goertzel.  Every kernel writes
     // status 0 itself (no separate memset queued behind whatever the stream is running).
     const bool composite_ok = nb > 0 && !ctx->mfcc_force_goertzel;
-    const mfcc_mplan_t mp = (composite_ok && !ctx->mfcc_force_dft2) ? mfcc_mfma_plan((int)frame_len, hb.front(), nb) : mfcc_mplan_t{};
+    const mfcc_mplan_t mp = (composite_ok && !ctx->mfcc_force_dft2 && ctx->mfcc_czt != 1) ? mfcc_mfma_plan((int)frame_len, hb.front(), nb) : mfcc_mplan_t{};
     const mfcc_plan_t pl = (composite_ok && !mp.ok) ? mfcc_plan((int)frame_len, nb) : mfcc_plan_t{false, 0, 0, 0, 0};
+    // no matrix-core factorisation (prime-ish lengths such as 1103 = 25 ms at 44.1 kHz, or too many bins for the two-stage
+    // kernel's tiles: 2500, 3000): the needed bins by the chirp-z identity on a power-of-two transform (two complex FFTs per
+    // frame, k_mfcc_czt.hip) instead of evaluating them bin by bin on the vector ALU.  Measured, MFCC alone / the whole
+    // pipeline, M frames/s: 1103: 28.9 -> 61.9 / 15.2 -> 20.3; 2500: 7.4 -> 15.0 / 3.2 -> 4.0; 3000: 2.8 -> 15.2 / 1.8 -> 3.9.
+    // Where the matrix-core kernel has a plan it stays (1000, 1102, 1800: it is the faster one; 1500, 1600: within 5 %).
+    if (!mp.ok) {
+        const int top = hb.back();
+        const int cplan = (nb >= 1 && hb.front() >= 0 && num_coeffs <= 64) ? mfcc_czt_plan((int)frame_len, top) : SPECTRAL_PLAN_NONE;
+        const bool forced = ctx->mfcc_force_goertzel || ctx->mfcc_force_dft2 || ctx->mfcc_force_mfma;
+        // (below ~600 samples the Goertzel kernel's n * nb products cost less than two 1024-point transforms)
+        const bool want = ctx->mfcc_czt == 1 || (ctx->mfcc_czt == -1 && !forced && frame_len >= 600);
+        if (cplan != SPECTRAL_PLAN_NONE && want) {
+            const double *tab = nullptr, *chirp = nullptr, *bhat = nullptr;
+            rc = get_spectral_tab(ctx, cplan, &tab); if (rc != VBX_SUCCESS) return rc;
+            rc = get_czt_dev(ctx, frame_len, top, spectral_plan_nc(cplan), &chirp, &bhat); if (rc != VBX_SUCCESS) return rc;
+            void *cw = nullptr;
+            rc = ws_get(ctx, vbx_ctx::WS_CZT, 2 * (size_t)spectral_plan_nc(cplan) * sizeof(double), &cw); if (rc != VBX_SUCCESS) return rc;
+            { Prof p(ctx, "mfcc", stm);
+              launch_mfcc_czt(stm, cplan, x, (long)n_frames, (int)frame_len, (long)stride, window, tab, chirp, bhat, d_bins, slopes, dct,
+                              (int)num_coeffs, nb, out, (long)out_ld, status, (double *)cw); }
+            return check_launch(ctx, "vbx_mfcc_f64");
+        }
+    }
     if (mp.ok) {
         const double *ctab = nullptr, *twd = nullptr, *twm = nullptr, *wm = nullptr;
         rc = get_mfcc_mfma_dev(ctx, frame_len, mp, &ctab, &twd, &twm, &wm); if (rc != VBX_SUCCESS) return rc;
