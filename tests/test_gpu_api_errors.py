@@ -24,7 +24,13 @@ def test_misuse_is_reported_not_fatal(vb, pkg):
     assert rc == -1
     rc, msg = _rc(vb, L.vbx_autocorrelate_f64, None, 4, 512, 512, None, 13, out.ptr)          # null frames
     assert rc == -1 and "null" in msg
-    rc, msg = _rc(vb, L.vbx_autocorrelate_f64, x.ptr, 1, 5000, 5000, None, 13, out.ptr)       # frame_len > 4096
+    # frame_len: the entry points with a tiled long-frame form (k_long.hip) take up to VBX_MAX_LONG_FRAME_LEN samples, the
+    # register / LDS-resident ones (pitch, MFCC, the fused loop) VBX_MAX_FRAME_LEN
+    rc, msg = _rc(vb, L.vbx_autocorrelate_f64, x.ptr, 1, (1 << 26) + 1, 1, None, 13, out.ptr)
+    assert rc == -1 and "frame_len" in msg
+    rc, msg = _rc(vb, L.vbx_pitch_f64, x.ptr, 1, 5000, 5000, None, 48000.0, 0.2, 75.0, 600.0, 1, out.ptr, None, None)
+    assert rc == -1 and "frame_len" in msg
+    rc, msg = _rc(vb, L.vbx_mfcc_f64, x.ptr, 1, 4097, 4097, None, 13, 100.0, 8000.0, 48000.0, out.ptr, None)
     assert rc == -1 and "frame_len" in msg
     rc, msg = _rc(vb, L.vbx_lpc_burg_f64, x.ptr, 4, 512, 512, None, 31, out.ptr, None)       # order > 30
     assert rc == -1

@@ -11,7 +11,8 @@ static bool bf_order(int p) { return p == 8 || p == 10 || p == 12 || p == 13 || 
 bool burg_fast_supported(int n, int p) {
     const char *e = getenv("VBX_BURG_DIRECT");               // 1: the direct recursion for every frame (A/B, tests)
     const bool off = e && atoi(e) != 0;
-    return !off && bf_order(p) && n >= 256 && n <= 64 * 32;  // shorter frames: the direct form is as fast (measured at 130)
+    return !off && bf_order(p) && n >= 256 && n <= 4096;     // shorter frames: the direct form is as fast (measured at 130); above 1280
+                                                               // samples: the segmented lag kernel (burg_lags_seg_kernel)
 }
 
 // workspace: the scratch (the chunk rounded up to whole tiles of 64 frames x 3 (p + 1) doubles), then the list: count, pad, indices [F]

@@ -39,6 +39,8 @@
 #include "vbx_device.hpp"
 #include "vbx_kernels.hpp"
 
+#include <type_traits>
+
 namespace vbx {
 
 #ifndef VBX_BF_FPW
@@ -268,6 +270,120 @@ __global__ __launch_bounds__(64) void burg_lags_kernel(
     }
 }
 
+// The same lag sums for LONGER frames (1281 .. 4096 samples), 16 samples per lane and SEGMENT of 1024 samples: with all of a
+// lane's samples in registers (EPL = 32 above) the kernel wants 349 of them -- one wavefront per SIMD, and none at all beside
+// a wavefront of the pipeline's analyze kernel (231 registers): at 1600 samples the formant chain's lag kernel took 11 ms,
+// waiting for SIMDs to drain, where the 1200-sample one takes 1.2.  Here a frame is walked in segments; a lane's partial lag
+// sums stay in registers across them, lane 63's look-ahead (the first P samples of the next segment) comes from a
+// broadcast load, and the next segment's samples are in flight while this one's products are formed.  ~200 registers.
+template <int P>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void burg_lags_seg_kernel(
+    const double *__restrict__ x, long n_frames, int n, long stride, const double *__restrict__ window,
+    const frame_map_t map, long item0, long items, double *__restrict__ scratch) {
+    constexpr int EPL = 16, SEG = 64 * EPL, FPW = BF_FPW, NL = P + 1, TS = NL | 1;
+    static_assert(P <= EPL, "the look-ahead stays inside the next lane's samples");
+    __shared__ double TR[64 * TS];
+    __shared__ double REC[3 * NL * FPW];
+    const int lane = lane_id();
+    const long i0 = item0 + (long)blockIdx.x * FPW;
+    if (i0 >= item0 + items) return;
+    const int nf = (int)((item0 + items - i0 < FPW) ? (item0 + items - i0) : FPW);
+    const int nseg = (n + SEG - 1) / SEG;
+    const int red_lag = lane >> 2, red_part = lane & 3;
+    // windowed samples [base, base + EPL) of frame xf (zero past the frame)
+    auto load_seg = [&](const double *xf, int base, double (&dst)[EPL]) {
+        const bool al = ((((uintptr_t)xf) | ((uintptr_t)window)) & 15) == 0 && base + EPL <= n;
+        if (al) {
+#pragma unroll
+            for (int e = 0; e < EPL; e += 2) {
+                const double2 v = *reinterpret_cast<const double2 *>(xf + base + e);
+                double2 w = double2{1.0, 1.0};
+                if (window != nullptr) w = *reinterpret_cast<const double2 *>(window + base + e);
+                dst[e] = v.x * w.x; dst[e + 1] = v.y * w.y;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                const int i = base + e;
+                double v = 0.0;
+                if (i < n) { v = xf[i]; if (window != nullptr) v *= window[i]; }
+                dst[e] = v;
+            }
+        }
+    };
+    for (int g = 0; g < nf; g++) {
+        const long f = frame_map(map, i0 + g, n_frames);
+        const double *xf = x + (f < 0 ? 0 : f) * stride;
+        const int nn = (f < 0) ? 0 : n;                       // an item outside the batch: zeros, nothing read
+        double part[NL];
+#pragma unroll
+        for (int lag = 0; lag < NL; lag++) part[lag] = 0.0;
+        double cur[EPL], nxt[EPL];
+        if (nn > 0) load_seg(xf, lane * EPL, cur);
+        else {
+#pragma unroll
+            for (int e = 0; e < EPL; e++) cur[e] = 0.0;
+        }
+        for (int sgm = 0; sgm < nseg; sgm++) {
+            const int base = sgm * SEG + lane * EPL;
+            const bool more = sgm + 1 < nseg && nn > 0;
+            if (more) load_seg(xf, base + SEG, nxt);
+            double ext[EPL + NL - 1];
+#pragma unroll
+            for (int e = 0; e < EPL; e++) ext[e] = cur[e];
+            // look-ahead: the next lane's first P samples; lane 63's are the next segment's first P (one address for the wave)
+#pragma unroll
+            for (int k = 0; k < NL - 1; k++) {
+                double ahead = from_next_lane(ext[k]);
+                const int i = (sgm + 1) * SEG + k;
+                double t = 0.0;
+                if (more && i < n) { t = xf[i]; if (window != nullptr) t *= window[i]; }
+                ext[EPL + k] = (lane == 63) ? t : ahead;
+            }
+#pragma unroll
+            for (int lag = 0; lag < NL; lag++) {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int e = 0; e < EPL; e += 2) { s0 = fma(ext[e], ext[e + lag], s0); s1 = fma(ext[e + 1], ext[e + 1 + lag], s1); }
+                part[lag] += s0 + s1;
+            }
+            // the frame's first and last P + 1 samples
+            if (nn > 0 && (base <= P || base + EPL >= n - 1 - P)) {
+#pragma unroll
+                for (int e = 0; e < EPL; e++) {
+                    const int i = base + e;
+                    if (i <= P) REC[(NL + i) * FPW + g] = ext[e];
+                    if (i < n && i >= n - 1 - P) REC[(2 * NL + (n - 1 - i)) * FPW + g] = ext[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPL; e++) cur[e] = more ? nxt[e] : 0.0;
+        }
+#pragma unroll
+        for (int lag = 0; lag < NL; lag++) TR[lane * TS + lag] = part[lag];
+        wave_sync();
+#pragma unroll
+        for (int lbase = 0; lbase < NL; lbase += 16) {
+            const int rl = lbase + red_lag;
+            double tot = 0.0;
+            if (rl < NL) {
+#pragma unroll
+                for (int t = 0; t < 16; t++) tot += TR[(red_part * 16 + t) * TS + rl];
+            }
+            tot += dpp_f64<DPP_QUAD_XOR1>(tot);
+            tot += dpp_f64<0x4E>(tot);
+            if (red_part == 0 && rl < NL) REC[rl * FPW + g] = tot;
+        }
+        wave_sync();
+    }
+    const long c0 = i0 - item0;
+    double *o = scratch + (c0 >> 6) * (3 * NL * 64) + (c0 & 63);
+    for (int idx = lane; idx < 3 * NL * FPW; idx += 64) {
+        const int v = idx / FPW, g = idx % FPW;
+        if (g < nf) o[v * 64 + g] = REC[idx];
+    }
+}
+
 // lane <-> item: the recursion on the scratch's columns; the coefficient rows, the status, or the frame's index on the list
 // Two wavefronts per SIMD (256 registers, some of the recursion's state spilled to private memory): unconstrained the
 // compiler takes ~290, and then a wavefront of this kernel cannot start beside the pipeline's analyze kernel (two
@@ -323,7 +439,9 @@ void launch_burg_recursion_p(hipStream_t s, const double *scratch, long F, frame
         if (n <= 64 * 8) hipLaunchKernelGGL((burg_lags_kernel<8, PP, TIN>), grid8, b, 0, s, x, F, n, stride, window, map, i0, m, scratch);       \
         else if (n <= 64 * 16) hipLaunchKernelGGL((burg_lags_kernel<16, PP, TIN>), grid, b, 0, s, x, F, n, stride, window, map, i0, m, scratch); \
         else if (n <= 64 * 20) hipLaunchKernelGGL((burg_lags_kernel<20, PP, TIN>), grid, b, 0, s, x, F, n, stride, window, map, i0, m, scratch); \
-        else hipLaunchKernelGGL((burg_lags_kernel<32, PP, TIN>), grid, b, 0, s, x, F, n, stride, window, map, i0, m, scratch);                  \
+        else if constexpr (std::is_same<TIN, double>::value) {                                                                \
+            hipLaunchKernelGGL((burg_lags_seg_kernel<PP>), grid, b, 0, s, x, F, n, stride, window, map, i0, m, scratch);      \
+        } else hipLaunchKernelGGL((burg_lags_kernel<32, PP, TIN>), grid, b, 0, s, x, F, n, stride, window, map, i0, m, scratch);                \
     }                                                                                                                         \
     template <int PP>                                                                                                         \
     void launch_burg_recursion_p(hipStream_t s, const double *scratch, long F, frame_map_t map, long i0, long m,              \
