@@ -63,13 +63,14 @@ extern "C" {
 #define VBX_MAX_RESONANCES 32       /* MAX_RESONANCES, src/lib.rs:26 */
 #define VBX_FORMANT_SLOTS 6         /* FormantSlots, src/spectrum.rs:228 */
 #define VBX_MAX_LPC_ORDER 30        /* 2*order resonances must fit the tracker's fixed arrays */
-#define VBX_MAX_FRAME_LEN 4096      /* register/LDS-resident frame kernels: vbx_pitch_f64, vbx_mfcc_f64, vbx_analyze_frames_*
-                                       and the f32 instantiation */
-#define VBX_MAX_LONG_FRAME_LEN 67108864 /* 2^26; every other frame-batch entry point (the reference's slices have no cap,
-                                       tests/lib.rs:27-41 passes a 31,232-sample file as ONE frame): vbx_autocorrelate_f64,
-                                       vbx_autocorr_lpc_f64, vbx_lpc_burg_f64, vbx_find_formants_f64, vbx_rms_f64,
-                                       vbx_preemphasis_f64, vbx_resample_linear_f64, vbx_ring_frames_f64 take frames up to
-                                       this length; beyond VBX_MAX_FRAME_LEN they walk the frame in tiles out of HBM */
+#define VBX_MAX_FRAME_LEN 4096      /* frames up to here live in registers / LDS (the fast kernels); the f32 instantiation
+                                       (vbx_*_f32, vbx_*_f32_wide) takes no longer ones */
+#define VBX_MAX_LONG_FRAME_LEN 67108864 /* 2^26: every f64 frame-batch entry point takes frames up to this length -- the reference's
+                                       slices have no cap (tests/lib.rs:27-41 passes a 31,232-sample file as ONE frame of
+                                       find_formants).  Beyond VBX_MAX_FRAME_LEN the kernels walk the frame in tiles out of HBM
+                                       (k_long.hip): exact, but built for a whole recording per frame, not for millions of them;
+                                       vbx_pitch_f64 keeps the frame's 2 * frame_len lag curve in HBM and needs frame_len < 2^30,
+                                       and takes kmax up to VBX_PITCH_MAX_CANDIDATES(frame_len) there */
 #define VBX_MAX_PITCH_CANDIDATES 1026 /* kmax upper bound of vbx_pitch_f64: frame_len/4 strict local maxima in
                                         [0, frame_len/2) + the unvoiced candidate, at VBX_MAX_FRAME_LEN */
 /* the whole Vec of a frame never has more than this many entries (out_count <= vbx_pitch_max_candidates) */

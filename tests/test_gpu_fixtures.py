@@ -258,6 +258,92 @@ def test_real_speech_pitch_mfcc_formants(vb, oracle, pkg, golden_dir, name, n, h
                                                   pitch_top_swaps=stats.get("n_top_swap"))
 
 
+# ---- pitch, MFCC and the fused frame loop on long frames -----------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [4097, 5000, 9001])
+def test_pitch_long_frames(vb, oracle, pkg, golden_dir, n):
+    """Pitched::pitch (src/periodic.rs:377-456) on frames longer than the LDS-resident kernels hold: whole candidate Vec
+    (count exact, every candidate's Hz within 1e-4 and strength within 1e-4) and the top candidate alone (kmax = 1)."""
+    samples, sr = _read_wav16(os.path.join(golden_dir, "sample-two_vowels.wav"))
+    hop = 20011
+    F = pkg.frame_count(samples.size, n, hop)
+    w = oracle.window("hanning", n)
+    frames = np.stack([samples[t * hop:t * hop + n] * w for t in range(F)])
+    kfull = pkg.pitch_max_candidates(n)
+    cand, cnt, st = vb.pitch(frames, sr, 0.2, 75.0, 600.0, kmax=kfull)
+    top, cnt1, st1 = vb.pitch(frames, sr, 0.2, 75.0, 600.0, kmax=1)
+    n_flip = n_cand = 0
+    for f in range(F):
+        es, ec, en = oracle.pitch(frames[f], sr, 0.2, 75.0, 600.0)
+        assert st[f] == es == st1[f] and cnt[f] == en == cnt1[f], (f, st[f], es, cnt[f], en)
+        if es != 0:
+            continue
+        g = cand[f, :en][np.argsort(cand[f, :en, 0], kind="stable")]
+        e = ec[:en][np.argsort(ec[:en, 0], kind="stable")]
+        assert np.all(np.abs(g[:, 0] - e[:, 0]) <= 1e-4 * np.abs(e[:, 0])), (f, "frequency")
+        n_cand += en
+        n_flip += int(np.sum(np.abs(g[:, 1] - e[:, 1]) > 1e-4))       # a refinement that ended on the other side of the integer lag
+        assert np.all(np.diff(cand[f, :en, 1]) <= 0.0) and np.all(cand[f, en:] == 0.0)
+        assert np.array_equal(top[f, 0], cand[f, 0])                                  # kmax = 1 is the head of the whole Vec
+        assert abs(cand[f, 0, 0] - ec[0, 0]) <= 1e-4 * abs(ec[0, 0]) and abs(cand[f, 0, 1] - ec[0, 1]) <= 1e-4
+    assert n_flip <= max(1, n_cand // 1000), (n_flip, n_cand)
+    REPORT[f"pitch_long {n}"] = dict(frames=F, candidates=n_cand, flips=n_flip)
+
+
+def test_pitch_long_whole_file_and_odd_signals(vb, oracle, golden_dir):
+    """The whole down_sampled.wav as ONE frame (31,232 samples: 7,810 possible candidates), a silent frame (NaN -> status 3 as on
+    short frames) and a rectangular frame (x[0] != 0: the Q1 seed)."""
+    samples, sr = _read_wav16(os.path.join(golden_dir, "down_sampled.wav"))
+    n = samples.size
+    w = oracle.window("hanning", n)
+    X = np.stack([samples * w, np.zeros(n), samples])
+    cand, cnt, st = vb.pitch(X, sr, 0.2, 50.0, 500.0, kmax=8)
+    for f in range(3):
+        es, ec, en = oracle.pitch(X[f], sr, 0.2, 50.0, 500.0, cap=8)
+        assert st[f] == es and cnt[f] == (en if es == 0 else 0), (f, st[f], es, cnt[f], en)
+        if es == 0:
+            k = min(8, en)
+            assert np.all(np.abs(cand[f, :k, 0] - ec[:k, 0]) <= 1e-4 * np.abs(ec[:k, 0]) + 1e-12), (f, cand[f, :k], ec[:k])
+            assert np.all(np.abs(cand[f, :k, 1] - ec[:k, 1]) <= 1e-4), f
+
+
+@pytest.mark.parametrize("n,k,lo,hi", [(4097, 13, 100.0, 8000.0), (9001, 13, 100.0, 8000.0), (31232, 20, 50.0, 10000.0)])
+def test_mfcc_long_frames(vb, oracle, pkg, golden_dir, n, k, lo, hi):
+    samples, sr = _read_wav16(os.path.join(golden_dir, "sample-two_vowels.wav"))
+    hop = 30011
+    F = pkg.frame_count(samples.size, n, hop)
+    w = oracle.window("hanning", n)
+    han = vb.window(pkg.WINDOW_HANNING, n)
+    m, st = vb.mfcc(samples, k, (lo, hi), sr, frame_len=n, stride=hop, window=han)
+    for t in range(F):
+        es, em = oracle.mfcc(samples[t * hop:t * hop + n] * w, k, lo, hi, sr)
+        assert st[t] == es == 0
+        assert np.all(rel_close(m[t], em)), (t, np.max(np.abs(m[t] - em)))
+
+
+def test_analyze_frames_long(vb, oracle, pkg, golden_dir):
+    """The fused frame loop on 5,000-sample frames: every column of the record against the oracle."""
+    samples, sr = _read_wav16(os.path.join(golden_dir, "sample-two_vowels.wav"))
+    n, hop = 5000, 17001
+    F = pkg.frame_count(samples.size, n, hop)
+    params = pkg.AnalysisParams.make(sr, pitch=(0.2, 75.0, 600.0), lpc_order=12, formant_order=13, est_init=_est0(), mfcc=(13, 100.0, 8000.0))
+    rec, st3 = vb.analyze_frames(samples, params, frame_len=n, stride=hop)
+    cols = params.columns()
+    col = lambda key: rec[:, cols[key][0]:cols[key][0] + cols[key][1]]
+    assert np.all(st3 == 0)
+    w = oracle.window("hanning", n)
+    est = _est0()
+    for t in range(F):
+        fr = samples[t * hop:t * hop + n]
+        es, ec, en = oracle.pitch(fr * w, sr, 0.2, 75.0, 600.0, cap=1)
+        assert abs(col("pitch")[t, 0] - ec[0, 0]) <= 1e-4 * abs(ec[0, 0]) + 1e-12 and abs(col("pitch")[t, 1] - ec[0, 1]) <= 1e-4
+        assert np.all(rel_close(col("lpc")[t], oracle.lpc(oracle.autocorrelate(fr * w, 13), 12)))
+        s, m = oracle.mfcc(fr * w, 13, 100.0, 8000.0, sr)
+        assert np.all(rel_close(col("mfcc")[t], m))
+        s, est, _, _ = oracle.find_formants(fr, sr, 13, est)
+        assert np.all(np.abs(col("formants")[t].reshape(4, 2) - est) <= 1e-4 * np.abs(est)), t
+
+
 def test_zz_fixture_report():
     os.makedirs("gpurun_out", exist_ok=True)
     with open(os.path.join("gpurun_out", "fixture_parity_report.json"), "w") as f:

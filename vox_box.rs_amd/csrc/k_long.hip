@@ -13,11 +13,19 @@
 //                             in a fixed order and applies the fold seed (Q1)
 //   preemphasis_long_kernel   Filter::preemphasis (src/waves.rs:82-96) of a whole signal: per-tile backward recurrences, a
 //                             sequential carry pass over the tile ends, a fix-up pass
+//   pitch_long_*_kernel       Pitched::pitch (src/periodic.rs:377-456) on the lag curve in HBM: every lag by autocorr_long, the
+//                             curve (normalised, divided by the lag window, zero padded to 2n) as an array, the peak scan with
+//                             an order-preserving compaction, improve_extremum per candidate with 16 lanes each (the shared
+//                             refinement of vbx_pitch_refine.hpp reading y from memory), a rank sort = the reference's stable sort
+//   mfcc_long_*_kernel        MFCC::mfcc (src/spectrum.rs:401-441): the needed bins by the Goertzel-Reinsch recurrence of
+//                             k_mfcc.hip, 256 bins per wavefront, the filter sums' inputs in a scratch instead of LDS
 // Throughput is not the point of this file (a frame this long is a whole recording, not one of millions), exactness of the
 // reference's semantics at every length is; still nothing here is serial over the samples.
 #include "vbx_autocorr.hpp"
 #include "vbx_device.hpp"
 #include "vbx_kernels.hpp"
+#include "vbx_mfcc_tail.hpp"
+#include "vbx_pitch_refine.hpp"
 
 namespace vbx {
 
@@ -322,6 +330,220 @@ void launch_preemphasis_long(hipStream_t s, const double *x, long F, long n, lon
     hipLaunchKernelGGL(preemphasis_long_local_kernel, dim3((unsigned)(F * tiles)), dim3(256), 0, s, x, F, n, stride, c, out, ws);
     hipLaunchKernelGGL(preemphasis_long_carry_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, s, F, n, c, ws);
     hipLaunchKernelGGL(preemphasis_long_fix_kernel, dim3((unsigned)(F * tiles)), dim3(256), 0, s, F, n, c, out, (const double *)ws);
+}
+
+// ---- Pitched::pitch on a long frame ----------------------------------------------------------------------------------------
+// r: [F][n] normalised lag sums (Normalize::normalize, src/periodic.rs:404) -> y: [F][2n], (r / w_lag) then the zeros of
+// resize(2n, 0) (:406-411)
+__global__ void pitch_long_curve_kernel(const double *__restrict__ r, const double *__restrict__ lag_window, long n_frames, long n,
+                                        double *__restrict__ y) {
+    const long total = n_frames * 2 * n;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long f = e / (2 * n), i = e - f * 2 * n;
+        y[e] = (i < n) ? r[f * n + i] / lag_window[i] : 0.0;
+    }
+}
+
+// Peak scan (:413-417, Q4) + parabolic lag (Q5) + frequency filter (:439): the abscissae nn handed to improve_extremum, in
+// index order, and their number.  One workgroup of 256 per frame; a tile of 256 lags per step, compacted by a ballot per
+// wavefront and a prefix over the four wavefronts.
+__global__ __launch_bounds__(256) void pitch_long_peaks_kernel(const double *__restrict__ y, long n_frames, long n, double sample_rate,
+                                                               double fmin, double fmax, long cap, double *__restrict__ nn_out,
+                                                               int32_t *__restrict__ count) {
+    __shared__ int wcount[4];
+    const long f = blockIdx.x;
+    if (f >= n_frames) return;
+    const double *ys = y + f * 2 * n;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long b = n / 2;                                                       // brent_ixmax (:414)
+    const int offset = (int)(-b - 1);
+    long base_out = 0;
+    for (long k0 = 0; k0 < b; k0 += 256) {
+        const long k = k0 + t;
+        bool pass = false;
+        double nn = 0.0;
+        if (k >= 1 && k + 1 < b) {
+            const double c = ys[k];
+            if (ys[k - 1] < c && ys[k + 1] < c) {
+                double freq;
+                cand_from_peak(ys, (int)k, sample_rate, offset, freq, nn);
+                pass = (freq == 0.0) || (freq > fmin && freq < fmax);
+            }
+        }
+        const unsigned long long mask = __ballot(pass);
+        if (lane == 0) wcount[wave] = __popcll(mask);
+        __syncthreads();
+        long pos = base_out;
+        for (int w = 0; w < wave; w++) pos += wcount[w];
+        pos += __popcll(mask & ((1ull << lane) - 1ull));
+        if (pass && pos < cap) nn_out[f * cap + pos] = nn;
+        base_out += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        __syncthreads();
+    }
+    if (t == 0) count[f] = (int32_t)(base_out < cap ? base_out : cap);
+}
+
+// improve_extremum(.., Sinc(1200), true) (:440-450) per candidate: 16 lanes each; (frequency, strength) into the frame's
+// candidate row; flags[f] |= 4 where the reference would index out of bounds, |= 8 for a NaN strength (Q10)
+__global__ __launch_bounds__(64) void pitch_long_refine_kernel(const double *__restrict__ y, long n_frames, long n, double sample_rate,
+                                                               long cap, const double *__restrict__ nn_in, const int32_t *__restrict__ count,
+                                                               double2 *__restrict__ cand, int32_t *__restrict__ flags) {
+    const long f = blockIdx.y;
+    const long q = (long)blockIdx.x * PNG + lane_id() / PG;
+    const int cnt = count[f];
+    if ((long)blockIdx.x * PNG >= cnt) return;
+    const bool have = q < cnt;
+    const double *ys = y + f * 2 * n;
+    const long b = n / 2;
+    const int offset = (int)(-b - 1), nx = (int)(b - offset), ylen = (int)(2 * n);
+    int st = 0;
+    double xmid = 0., ymid = 0.;
+    improve_extremum_sinc<PG>(ys, ylen, ylen, offset, nx, have ? nn_in[f * cap + q] : 1.0, 1200, have, xmid, ymid, st);
+    if (have && (lane_id() & (PG - 1)) == 0) {
+#pragma clang fp contract(off)
+        double xm = xmid + (double)offset;                                      // :445
+        double ym = ymid;
+        if (ym > 1.) ym = 1. / ym;                                              // :446
+        cand[f * (cap + 1) + q] = double2{sample_rate / xm, ym};                // :447-448
+        int fl = (st & 4) ? 4 : 0;
+        if (ym != ym) fl |= 8;
+        if (fl) atomicOr(&flags[f], fl);
+    }
+}
+
+// maxima.push(Pitch(0, threshold)); stable sort by strength, descending (:452-453); the first kmax entries, the count, the status
+__global__ __launch_bounds__(256) void pitch_long_sort_kernel(long n_frames, long cap, const int32_t *__restrict__ count,
+                                                              double2 *__restrict__ cand, const int32_t *__restrict__ flags,
+                                                              double threshold, int kmax, double *__restrict__ out_cand, long cand_ld,
+                                                              int32_t *__restrict__ out_count, int32_t *__restrict__ status) {
+    const long f = blockIdx.x;
+    if (f >= n_frames) return;
+    const int t = threadIdx.x;
+    const int cnt = count[f];
+    double2 *row = cand + f * (cap + 1);
+    if (t == 0) row[cnt] = double2{0.0, threshold};
+    __syncthreads();
+    const int total_cand = cnt + 1;
+    int code = 0;
+    const int fl = flags[f];
+    if (fl & 4) code = 4;
+    else if (total_cand > 1 && ((fl & 8) || threshold != threshold)) code = 3;   // partial_cmp().unwrap() on NaN (Q10)
+    const int total = (code == 0) ? total_cand : 0;
+    double *orow = out_cand + f * cand_ld;
+    for (int i = t; i < kmax; i += 256) *reinterpret_cast<double2 *>(orow + 2 * i) = double2{0.0, 0.0};
+    __syncthreads();
+    for (int i = t; i < total; i += 256) {
+        const double2 me = row[i];
+        int rank = 0;
+        for (int j = 0; j < total; j++) { const double sj = row[j].y; rank += (sj > me.y || (sj == me.y && j < i)) ? 1 : 0; }
+        if (rank < kmax) *reinterpret_cast<double2 *>(orow + 2 * rank) = me;
+    }
+    if (t == 0) {
+        if (out_count != nullptr) out_count[f] = total;
+        if (status != nullptr) status[f] = code;
+    }
+}
+
+// scratch of one pitch call on F long frames: r [F][n] | y [F][2n] | nn [F][cap] | cand [F][cap + 1][2] | count [F] | flags [F]
+static long pitch_long_cap(long n) { return n / 4 + 2; }
+size_t pitch_long_scratch_bytes(long F, long n) {
+    const long cap = pitch_long_cap(n);
+    return ((size_t)F * (size_t)(3 * n + cap + 2 * (cap + 1)) + 2) * sizeof(double) + 2 * (size_t)F * sizeof(int32_t) + 64;
+}
+static long even_up(long v) { return (v + 1) & ~1L; }
+// r must hold Autocorrelate::autocorrelate(n) of every frame, already normalised (the caller runs autocorr_long and the
+// row normalisation: they have their own scratch)
+void launch_pitch_long(hipStream_t s, long F, long n, const double *lag_window, double sample_rate, double threshold, double fmin,
+                       double fmax, int kmax, double *out_cand, long cand_ld, int32_t *out_count, int32_t *status, void *ws) {
+    const long cap = pitch_long_cap(n);
+    double *r = (double *)ws;                                    // offsets in doubles: r 0 | y F n | nn 3 F n | cand (16-byte aligned)
+    double *y = r + F * n;
+    double *nn = r + 3 * F * n;
+    double2 *cand = reinterpret_cast<double2 *>(r + even_up(3 * F * n + F * cap));
+    int32_t *count = reinterpret_cast<int32_t *>(cand + F * (cap + 1));
+    int32_t *flags = count + F;
+    hipMemsetAsync(flags, 0, (size_t)F * sizeof(int32_t), s);
+    long blocks = (F * 2 * n + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(pitch_long_curve_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const double *)r, lag_window, F, n, y);
+    hipLaunchKernelGGL(pitch_long_peaks_kernel, dim3((unsigned)F), dim3(256), 0, s, (const double *)y, F, n, sample_rate, fmin, fmax, cap, nn, count);
+    hipLaunchKernelGGL(pitch_long_refine_kernel, dim3((unsigned)((cap + PNG - 1) / PNG), (unsigned)F), dim3(64), 0, s, (const double *)y, F, n,
+                       sample_rate, cap, (const double *)nn, (const int32_t *)count, cand, flags);
+    hipLaunchKernelGGL(pitch_long_sort_kernel, dim3((unsigned)F), dim3(256), 0, s, F, cap, (const int32_t *)count, cand, (const int32_t *)flags,
+                       threshold, kmax, out_cand, cand_ld, out_count, status);
+}
+double *pitch_long_r(void *ws) { return (double *)ws; }
+
+// ---- MFCC::mfcc on a long frame -----------------------------------------------------------------------------------------
+// The bins [b_lo, b_lo + nb) of the n-point DFT by the Goertzel-Reinsch recurrence (k_mfcc.hip: the same constants and steps),
+// four bins per lane, one wavefront per 256 bins; the samples reach the lanes as broadcasts of a 64-sample register chunk.
+// pu / pd (norm_sqr * slope, norm * slope: src/spectrum.rs:426-434) go to a scratch [F][2][nbp].
+constexpr int ML_BPL = 4;
+__global__ __launch_bounds__(64) void mfcc_long_bins_kernel(const double *__restrict__ x, long n_frames, long n, long stride,
+                                                            const double *__restrict__ window, const double *__restrict__ kappa_sigma,
+                                                            const double *__restrict__ slopes, int nb, long nbp, double *__restrict__ pupd) {
+    const long f = blockIdx.y;
+    const int lane = lane_id();
+    const int p0 = blockIdx.x * 64 * ML_BPL;
+    const double *xf = x + f * stride;
+    double kap[ML_BPL], sig[ML_BPL], sv[ML_BPL], dv[ML_BPL];
+#pragma unroll
+    for (int j = 0; j < ML_BPL; j++) {
+        const int bi = p0 + j * 64 + lane;
+        const bool ok = bi < nb;
+        kap[j] = ok ? kappa_sigma[2 * bi] : 0.0;
+        sig[j] = ok ? kappa_sigma[2 * bi + 1] : 1.0;
+        sv[j] = 0.0; dv[j] = 0.0;
+    }
+    for (long i0 = 0; i0 < n; i0 += 64) {
+        double chunk = 0.0;
+        if (i0 + lane < n) { chunk = xf[i0 + lane]; if (window != nullptr) chunk *= window[i0 + lane]; }
+        const int steps = (int)((n - i0 < 64) ? n - i0 : 64);
+        for (int q = 0; q < steps; q++) {
+            const double xi = readlane_f64(chunk, q);
+#pragma unroll
+            for (int j = 0; j < ML_BPL; j++) {
+                const double t = fma(-kap[j], sv[j], dv[j]);
+                dv[j] = fma(sig[j], t, xi);
+                sv[j] = fma(sig[j], sv[j], dv[j]);
+            }
+        }
+    }
+    double *pu = pupd + f * 2 * nbp, *pd = pu + nbp;
+#pragma unroll
+    for (int j = 0; j < ML_BPL; j++) {
+        const int bi = p0 + j * 64 + lane;
+        if (bi < nb) {
+            const double s2 = sig[j] * (sv[j] - dv[j]);
+            double m2 = fma(dv[j], dv[j], sig[j] * kap[j] * sv[j] * s2);
+            m2 = (m2 < 0.0) ? 0.0 : m2;
+            const double2 sl = *reinterpret_cast<const double2 *>(slopes + 2 * bi);
+            pu[bi] = fabs(m2) * sl.x;
+            pd[bi] = fabs(sqrt(m2)) * sl.y;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void mfcc_long_tail_kernel(long n_frames, const double *__restrict__ pupd, long nbp, const int32_t *__restrict__ bins,
+                                                            const double *__restrict__ dct, int num_coeffs, double *__restrict__ out, long out_ld,
+                                                            int32_t *__restrict__ status) {
+    __shared__ double en[64];
+    const long f = blockIdx.x;
+    if (f >= n_frames) return;
+    const int lane = lane_id();
+    const double *pu = pupd + f * 2 * nbp, *pd = pu + nbp;
+    mfcc_tail_m(pu, pd, en, bins, dct, num_coeffs, bins[0], lane, out + f * out_ld);
+    if (status != nullptr && lane == 0) status[f] = 0;
+}
+
+size_t mfcc_long_scratch_bytes(long F, int nb) { return (size_t)F * 2 * (size_t)((nb + 1) & ~1) * sizeof(double); }
+void launch_mfcc_long(hipStream_t s, const double *x, long F, long n, long stride, const double *window, const double *kappa_sigma,
+                      const int32_t *bins, const double *slopes, const double *dct, int num_coeffs, int nb, double *out, long out_ld,
+                      int32_t *status, double *ws) {
+    const long nbp = (nb + 1) & ~1;
+    hipLaunchKernelGGL(mfcc_long_bins_kernel, dim3((unsigned)((nb + 64 * ML_BPL - 1) / (64 * ML_BPL)), (unsigned)F), dim3(64), 0, s, x, F, n, stride,
+                       window, kappa_sigma, slopes, nb, nbp, ws);
+    hipLaunchKernelGGL(mfcc_long_tail_kernel, dim3((unsigned)F), dim3(64), 0, s, F, (const double *)ws, nbp, bins, dct, num_coeffs, out, out_ld, status);
 }
 
 }  // namespace vbx

@@ -38,7 +38,7 @@ struct vbx_ctx {
     std::string arch;
     int cu_count = 0;
     // workspaces (grown on demand, never shrunk)
-    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_UNSURE, WS_F32_IN, WS_F32_OUT, WS_TRK, WS_BURG_LIST, WS_ROOTS_LIST, WS_LONG, WS_CZT, WS_N };
+    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_UNSURE, WS_F32_IN, WS_F32_OUT, WS_TRK, WS_BURG_LIST, WS_ROOTS_LIST, WS_LONG, WS_LONG2, WS_CZT, WS_N };
     void *ws[WS_N] = {nullptr};
     const int32_t *burg_list_count = nullptr;             // device counter of the last one-pass Burg call (tests)
     const int32_t *roots_list_count = nullptr;            // the same for the resonance kernel of find_formants
@@ -722,14 +722,38 @@ static int run_pitch(vbx_ctx *ctx, hipStream_t st, const double *x, size_t n_fra
                      const double *window, double sample_rate, double threshold, double fmin, double fmax,
                      size_t kmax, vbx_pitch *out_cand, size_t cand_ld, int32_t *out_count, int32_t *status) {
     VBX_REQUIRE(ctx, out_cand != nullptr, "null output");
-    VBX_REQUIRE(ctx, kmax >= 1 && kmax <= VBX_MAX_PITCH_CANDIDATES, "kmax must be in [1, VBX_MAX_PITCH_CANDIDATES]");
+    const size_t kcap = frame_len > VBX_MAX_FRAME_LEN ? VBX_PITCH_MAX_CANDIDATES(frame_len) : (size_t)VBX_MAX_PITCH_CANDIDATES;
+    VBX_REQUIRE(ctx, kmax >= 1 && kmax <= kcap, "kmax must be in [1, VBX_MAX_PITCH_CANDIDATES] (long frames: [1, frame_len / 4 + 2])");
     VBX_REQUIRE(ctx, cand_ld >= 2 * kmax && cand_ld % 2 == 0, "candidate rows must be 16-byte aligned and hold kmax entries");
     VBX_REQUIRE(ctx, frame_len >= 4, "frame_len must be >= 4");
-    VBX_REQUIRE(ctx, pitch_lds_bytes((int)frame_len) + pitch_full_list_bytes((int)frame_len, (int)kmax) + 16 <= 160 * 1024,
-                "frame does not fit the LDS");
     const double *lagw = nullptr;
     int rc = get_window_dev(ctx, VBX_WINDOW_HANNING_LAG, frame_len, &lagw);
     if (rc != VBX_SUCCESS) return rc;
+    if (frame_len > VBX_MAX_FRAME_LEN) {
+        // a frame whose lag curve no LDS holds (k_long.hip): every lag by the chunked matrix-core tiles, the curve as an array in
+        // HBM, peak scan -> improve_extremum per candidate -> rank sort; batches of frames so that the scratch stays <= 2 GiB
+        VBX_REQUIRE(ctx, frame_len <= 0x3fffffff, "frame_len too large for the lag curve's 32-bit indices");
+        size_t per = (size_t(1) << 31) / pitch_long_scratch_bytes(1, (long)frame_len);
+        if (per < 1) per = 1;
+        if (per > n_frames) per = n_frames;
+        void *w2 = nullptr;
+        rc = ws_get(ctx, vbx_ctx::WS_LONG2, pitch_long_scratch_bytes((long)per, (long)frame_len), &w2);
+        if (rc != VBX_SUCCESS) return rc;
+        for (size_t f0 = 0; f0 < n_frames; f0 += per) {
+            const size_t m = (n_frames - f0 < per) ? n_frames - f0 : per;
+            double *r = pitch_long_r(w2);
+            rc = run_autocorrelate(ctx, st, x + f0 * stride, m, frame_len, stride, window, frame_len, r);      // :402
+            if (rc != VBX_SUCCESS) return rc;
+            { Prof p(ctx, "normalize_rows", st); launch_normalize_rows(st, r, (long)m, (int)frame_len); }       // :404
+            { Prof p(ctx, "pitch_long", st);
+              launch_pitch_long(st, (long)m, (long)frame_len, lagw, sample_rate, threshold, fmin, fmax, (int)kmax,
+                                (double *)out_cand + f0 * cand_ld, (long)cand_ld, out_count ? out_count + f0 : nullptr,
+                                status ? status + f0 : nullptr, w2); }
+        }
+        return check_launch(ctx, "vbx_pitch_f64");
+    }
+    VBX_REQUIRE(ctx, pitch_lds_bytes((int)frame_len) + pitch_full_list_bytes((int)frame_len, (int)kmax) + 16 <= 160 * 1024,
+                "frame does not fit the LDS");
     if (ctx->prof && !ctx->pitch_work) {
         const size_t wb = PITCH_WORK_SLOTS * 4 * sizeof(unsigned long long);
         VBX_HIP(ctx, hipMalloc((void **)&ctx->pitch_work, wb));
@@ -760,7 +784,7 @@ static int run_pitch(vbx_ctx *ctx, hipStream_t st, const double *x, size_t n_fra
 int vbx_pitch_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
                   const double *window, double sample_rate, double threshold, double fmin, double fmax,
                   size_t kmax, vbx_pitch *out_cand, int32_t *out_count, int32_t *status) {
-    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride, VBX_MAX_LONG_FRAME_LEN);
     if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     return run_pitch(ctx, ctx->stream, x, n_frames, frame_len, stride, window, sample_rate, threshold, fmin, fmax,
@@ -1211,6 +1235,17 @@ static int run_mfcc(vbx_ctx *ctx, hipStream_t stm, const double *x, size_t n_fra
     const double *dct = nullptr, *slopes = nullptr;
     rc = get_dct_dev(ctx, num_coeffs, &dct); if (rc != VBX_SUCCESS) return rc;
     rc = get_slopes_dev(ctx, frame_len, num_coeffs, lo_hz, hi_hz, sample_rate, hb, &slopes); if (rc != VBX_SUCCESS) return rc;
+    if (frame_len > VBX_MAX_FRAME_LEN) {          // a long frame: the Goertzel recurrence over HBM, the filter sums' inputs in a scratch (k_long.hip)
+        VBX_REQUIRE(ctx, nb >= 1, "no mel bins");
+        const double *tw = nullptr;
+        rc = get_goertzel_dev(ctx, frame_len, hb.front(), nb, &tw); if (rc != VBX_SUCCESS) return rc;
+        void *w = nullptr;
+        rc = ws_get(ctx, vbx_ctx::WS_CZT, mfcc_long_scratch_bytes((long)n_frames, nb), &w); if (rc != VBX_SUCCESS) return rc;
+        { Prof p(ctx, "mfcc_long", stm);
+          launch_mfcc_long(stm, x, (long)n_frames, (long)frame_len, (long)stride, window, tw, d_bins, slopes, dct, (int)num_coeffs, nb, out,
+                           (long)out_ld, status, (double *)w); }
+        return check_launch(ctx, "vbx_mfcc_f64");
+    }
     // frames that fill one of the FFT kernels' transforms (1024, 1200, 2048, 4096): the forward half of the fused spectral
     // kernel -- one real FFT of the zero-padded frame, whose even bins are the n-point DFT the mel filters read
     {
@@ -1285,7 +1320,7 @@ static int run_mfcc(vbx_ctx *ctx, hipStream_t stm, const double *x, size_t n_fra
 int vbx_mfcc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
                  const double *window, size_t num_coeffs, double lo_hz, double hi_hz,
                  double sample_rate, double *out, int32_t *status) {
-    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
+    int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride, VBX_MAX_LONG_FRAME_LEN);
     if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     return run_mfcc(ctx, ctx->stream, x, n_frames, frame_len, stride, window, num_coeffs, lo_hz, hi_hz, sample_rate,
@@ -1407,7 +1442,7 @@ static int ensure_side_stream(vbx_ctx *ctx) {
 static int analyze_frames_impl(vbx_ctx *ctx, const char *fn, const double *x, const int16_t *pcm16, size_t n_frames, size_t frame_len,
                                size_t stride, const vbx_analysis_params *h_p, const int64_t *h_seg_start, size_t n_segments,
                                double *out_records, size_t record_ld, int32_t *status3) {
-    int rc = check_frames(ctx, fn, pcm16 ? (const void *)pcm16 : (const void *)x, n_frames, frame_len, stride);
+    int rc = check_frames(ctx, fn, pcm16 ? (const void *)pcm16 : (const void *)x, n_frames, frame_len, stride, VBX_MAX_LONG_FRAME_LEN);
     if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
     VBX_REQUIRE(ctx, h_p && out_records, "null argument");
     const size_t rec = vbx_record_doubles(h_p);
@@ -1464,41 +1499,43 @@ static int analyze_frames_impl(vbx_ctx *ctx, const char *fn, const double *x, co
     // fork: the formant chain (Burg -> roots -> the latency-bound tracker scan) and the MFCC run on the side stream,
     // beside the FP64-bound pitch kernel
     VBX_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-    VBX_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    // (frames longer than VBX_MAX_FRAME_LEN: everything in order on the context's stream -- the long-frame kernels share one scratch)
+    hipStream_t side = frame_len > VBX_MAX_FRAME_LEN ? ctx->stream : ctx->side;
+    VBX_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_fork, 0));
     if (h_p->formant_order) {
         vbx_resonance est[VBX_FORMANT_SLOTS];
         for (size_t e = 0; e < h_p->n_est; e++) est[e] = h_p->est_init[e];
-        rc = run_find_formants(ctx, ctx->side, x, n_frames, frame_len, stride, h_p->sample_rate, h_p->formant_order,
+        rc = run_find_formants(ctx, side, x, n_frames, frame_len, stride, h_p->sample_rate, h_p->formant_order,
                                h_seg_start, n_segments, est, h_p->n_est, (vbx_resonance *)(out_records + c_form), record_ld,
                                nullptr, nullptr, nullptr, st_form, pcm_native ? pcm16 : nullptr);
         if (rc != VBX_SUCCESS) return rc;
     } else if (st_form) {
-        VBX_HIP(ctx, hipMemsetAsync(st_form, 0, n_frames * sizeof(int32_t), ctx->side));
+        VBX_HIP(ctx, hipMemsetAsync(st_form, 0, n_frames * sizeof(int32_t), side));
     }
     if (fused && h_p->lpc_order && !fused_lpc) {
-        rc = run_autocorr_lpc(ctx, ctx->side, x, n_frames, frame_len, stride, hann, h_p->lpc_order, 0, nullptr,
+        rc = run_autocorr_lpc(ctx, side, x, n_frames, frame_len, stride, hann, h_p->lpc_order, 0, nullptr,
                               out_records + c_lpc, record_ld);
         if (rc != VBX_SUCCESS) return rc;
     }
     if (fused && h_p->mfcc_coeffs && !fused_mfcc) {
-        rc = run_mfcc(ctx, ctx->side, x, n_frames, frame_len, stride, hann, h_p->mfcc_coeffs, h_p->mfcc_lo_hz, h_p->mfcc_hi_hz,
+        rc = run_mfcc(ctx, side, x, n_frames, frame_len, stride, hann, h_p->mfcc_coeffs, h_p->mfcc_lo_hz, h_p->mfcc_hi_hz,
                       h_p->sample_rate, out_records + c_mfcc, record_ld, st_mfcc);
         if (rc != VBX_SUCCESS) return rc;
     }
     if (!fused) {
         if (h_p->lpc_order) {
-            rc = run_autocorr_lpc(ctx, ctx->side, x, n_frames, frame_len, stride, hann, h_p->lpc_order, 0, nullptr,
+            rc = run_autocorr_lpc(ctx, side, x, n_frames, frame_len, stride, hann, h_p->lpc_order, 0, nullptr,
                                   out_records + c_lpc, record_ld);
             if (rc != VBX_SUCCESS) return rc;
         }
         if (h_p->mfcc_coeffs) {
-            rc = run_mfcc(ctx, ctx->side, x, n_frames, frame_len, stride, hann, h_p->mfcc_coeffs, h_p->mfcc_lo_hz, h_p->mfcc_hi_hz,
+            rc = run_mfcc(ctx, side, x, n_frames, frame_len, stride, hann, h_p->mfcc_coeffs, h_p->mfcc_lo_hz, h_p->mfcc_hi_hz,
                           h_p->sample_rate, out_records + c_mfcc, record_ld, st_mfcc);
             if (rc != VBX_SUCCESS) return rc;
         }
     }
-    if (!h_p->mfcc_coeffs && st_mfcc) VBX_HIP(ctx, hipMemsetAsync(st_mfcc, 0, n_frames * sizeof(int32_t), ctx->side));
-    VBX_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+    if (!h_p->mfcc_coeffs && st_mfcc) VBX_HIP(ctx, hipMemsetAsync(st_mfcc, 0, n_frames * sizeof(int32_t), side));
+    VBX_HIP(ctx, hipEventRecord(ctx->ev_join, side));
     if (fused) {
         const double *lagw = nullptr, *tab = nullptr;
         rc = get_window_dev(ctx, VBX_WINDOW_HANNING_LAG, frame_len, &lagw); if (rc != VBX_SUCCESS) return rc;

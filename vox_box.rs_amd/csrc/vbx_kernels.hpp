@@ -228,6 +228,14 @@ void launch_burg_long(hipStream_t s, const double *x, long f0, long f1, long F, 
 size_t autocorr_long_scratch_bytes(long F, long n, long n_lags);
 void launch_autocorr_long(hipStream_t s, const double *x, long F, long n, long stride, const double *window, long n_lags,
                           double *out, double *ws);
+size_t pitch_long_scratch_bytes(long F, long n);
+double *pitch_long_r(void *ws);                                  // [F][n]: the caller fills it with the NORMALISED lag sums of every frame
+void launch_pitch_long(hipStream_t s, long F, long n, const double *lag_window, double sample_rate, double threshold, double fmin,
+                       double fmax, int kmax, double *out_cand, long cand_ld, int32_t *out_count, int32_t *status, void *ws);
+size_t mfcc_long_scratch_bytes(long F, int nb);
+void launch_mfcc_long(hipStream_t s, const double *x, long F, long n, long stride, const double *window, const double *kappa_sigma,
+                      const int32_t *bins, const double *slopes, const double *dct, int num_coeffs, int nb, double *out, long out_ld,
+                      int32_t *status, double *ws);
 size_t preemphasis_long_scratch_bytes(long F, long n);
 void launch_preemphasis_long(hipStream_t s, const double *x, long F, long n, long stride, double c, double *out, double *ws);
 
