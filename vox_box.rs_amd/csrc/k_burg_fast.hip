@@ -8,6 +8,13 @@ namespace vbx {
 // examples/formant_extraction/src/main.rs:53), 8, 14, 16
 static bool bf_order(int p) { return p == 8 || p == 10 || p == 12 || p == 13 || p == 14 || p == 16; }
 
+__global__ void count_accumulate_kernel(const int32_t *count, int32_t *total, int reset) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *total = (reset ? 0 : *total) + *count;
+}
+void launch_count_accumulate(hipStream_t s, const int32_t *count, int32_t *total, bool reset) {
+    hipLaunchKernelGGL(count_accumulate_kernel, dim3(1), dim3(64), 0, s, count, total, reset ? 1 : 0);
+}
+
 bool burg_fast_supported(int n, int p) {
     const char *e = getenv("VBX_BURG_DIRECT");               // 1: the direct recursion for every frame (A/B, tests)
     const bool off = e && atoi(e) != 0;

@@ -884,9 +884,12 @@ static int run_burg(vbx_ctx *ctx, hipStream_t stm, const double *x, const int16_
               else launch_burg_lags(stm, x, F, n, stride, window, p, map, i0, m, w); }
             { Prof pr(ctx, "burg_recursion", stm); launch_burg_recursion(stm, F, p, map, i0, m, coeffs, st, w); }
         }
-        Prof pr(ctx, "burg_direct_list", stm);
-        if (pcm) launch_burg_pcm16_list(stm, pcm, F, n, stride, window, p, coeffs, st, list + 2, list);
-        else launch_burg_list(stm, x, F, n, stride, window, p, coeffs, st, list + 2, list);
+        { Prof pr(ctx, "burg_direct_list", stm);
+          if (pcm) launch_burg_pcm16_list(stm, pcm, F, n, stride, window, p, coeffs, st, list + 2, list);
+          else launch_burg_list(stm, x, F, n, stride, window, p, coeffs, st, list + 2, list); }
+        // the probe (vbx_internal_last_burg_direct_count) reports the whole CALL: list[0] restarts with every time slice of
+        // find_formants, list[1] adds the slices up (reset with the call's first slice)
+        launch_count_accumulate(stm, list, list + 1, map.seg_len == 0 || map.t0 == 0);
         return VBX_SUCCESS;
     }
     Prof pr(ctx, "burg", stm);
@@ -1871,7 +1874,7 @@ int vbx_internal_last_burg_direct_count(vbx_ctx *ctx, int32_t *h_count) {
     if (!ctx->burg_list_count) return VBX_SUCCESS;
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     VBX_HIP(ctx, hipDeviceSynchronize());
-    VBX_HIP(ctx, hipMemcpy(h_count, ctx->burg_list_count, sizeof(int32_t), hipMemcpyDeviceToHost));
+    VBX_HIP(ctx, hipMemcpy(h_count, ctx->burg_list_count + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
     return VBX_SUCCESS;
 }
 

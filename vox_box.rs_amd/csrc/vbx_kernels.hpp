@@ -66,6 +66,8 @@ void launch_burg_lags_pcm16(hipStream_t s, const int16_t *x, long F, int n, long
                             frame_map_t map, long i0, long m, void *ws);
 void launch_burg_recursion(hipStream_t s, long F, int p, frame_map_t map, long i0, long m, double *out, int32_t *status, void *ws);
 
+void launch_count_accumulate(hipStream_t s, const int32_t *count, int32_t *total, bool reset);   // total = (reset ? 0 : total) + count
+
 // k_roots.hip
 void launch_find_roots(hipStream_t s, cplx_t *polys, long F, int len, int32_t *status);
 void launch_laguerre(hipStream_t s, const cplx_t *polys, long F, int len, cplx_t start, cplx_t *out);

@@ -62,9 +62,9 @@ __device__ __forceinline__ double y_at(const double *y, int nvalid, int idx) {
     return (idx < nvalid) ? y[idx] : 0.0;
 }
 // the same without a branch where the curve is followed by stored zeros (pitch_refine_store's LDS image: Y_PAD of them
-// after y[n)): an index past the data reads the first of those
+// after y[n), nvalid = n + Y_PAD): an index past them reads the last of those zeros (never the array that follows the image)
 __device__ __forceinline__ double y_at_padded(const double *y, int nvalid, int idx) {
-    return y[(idx < nvalid) ? idx : nvalid];
+    return y[(idx < nvalid) ? idx : nvalid - 1];
 }
 
 
