@@ -24,14 +24,16 @@ def test_misuse_is_reported_not_fatal(vb, pkg):
     assert rc == -1
     rc, msg = _rc(vb, L.vbx_autocorrelate_f64, None, 4, 512, 512, None, 13, out.ptr)          # null frames
     assert rc == -1 and "null" in msg
-    # frame_len: the entry points with a tiled long-frame form (k_long.hip) take up to VBX_MAX_LONG_FRAME_LEN samples, the
-    # register / LDS-resident ones (pitch, MFCC, the fused loop) VBX_MAX_FRAME_LEN
+    # frame_len: every f64 entry point takes up to VBX_MAX_LONG_FRAME_LEN samples (beyond 4096: the tiled kernels of k_long.hip),
+    # the f32 instantiation VBX_MAX_FRAME_LEN
     rc, msg = _rc(vb, L.vbx_autocorrelate_f64, x.ptr, 1, (1 << 26) + 1, 1, None, 13, out.ptr)
     assert rc == -1 and "frame_len" in msg
-    rc, msg = _rc(vb, L.vbx_pitch_f64, x.ptr, 1, 5000, 5000, None, 48000.0, 0.2, 75.0, 600.0, 1, out.ptr, None, None)
+    rc, msg = _rc(vb, L.vbx_pitch_f64, x.ptr, 1, (1 << 26) + 1, 1, None, 48000.0, 0.2, 75.0, 600.0, 1, out.ptr, None, None)
     assert rc == -1 and "frame_len" in msg
-    rc, msg = _rc(vb, L.vbx_mfcc_f64, x.ptr, 1, 4097, 4097, None, 13, 100.0, 8000.0, 48000.0, out.ptr, None)
+    rc, msg = _rc(vb, L.vbx_autocorrelate_f32, x.ptr, 1, 5000, 5000, None, 13, out.ptr)
     assert rc == -1 and "frame_len" in msg
+    rc, msg = _rc(vb, L.vbx_pitch_f64, x.ptr, 1, 5000, 5000, None, 48000.0, 0.2, 75.0, 600.0, 2000, out.ptr, None, None)   # kmax > 5000 / 4 + 2
+    assert rc == -1 and "kmax" in msg
     rc, msg = _rc(vb, L.vbx_lpc_burg_f64, x.ptr, 4, 512, 512, None, 31, out.ptr, None)       # order > 30
     assert rc == -1
     rc, msg = _rc(vb, L.vbx_pitch_f64, x.ptr, 4, 512, 512, None, 48000.0, 0.2, 75.0, 600.0, 1027, out.ptr, None, None)

@@ -29,20 +29,23 @@ static __global__ void czt_fold_kernel(const double *__restrict__ window, const 
     cw[i] = o;
 }
 
-template <int U>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(U == 4 ? 1 : 2, U == 4 ? 1 : 2)))
+// U units per thread, W wavefronts per frame (vbx_spectral_pow2.hpp): L = 1024 <1, 1>, 2048 <2, 1>, 4096 <2, 2>
+template <int U, int W>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void mfcc_czt_kernel(const double *x, long n_frames, int n, long stride,
                      // no __restrict__ on the tables: as invariant loads every twiddle of both transforms is hoisted to the top
                      // of the kernel and the transforms' own values spill (measured: 675 registers spilled against 16)
                      const double2 *tab, const double2 *chirp, const double2 *bhat,
                      const int32_t *__restrict__ bins, const double *__restrict__ slopes, const double *__restrict__ dct,
                      int num_coeffs, int nb, double *__restrict__ out, long out_ld, int32_t *__restrict__ status) {
-    using G = pow2_geom<U>;
-    constexpr int R = G::R, NC = G::NC;
+    using G = pow2_geom<U, W>;
+    constexpr int R = G::R, NC = G::NC, NT = G::NT, TQ = G::TQ;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const long f = xcd_item(blockIdx.x, n_frames);
     if (f >= n_frames) return;
     const int lane = lane_id();
+    const int tid = pow2_tid<W>();
+    const int wave = W == 1 ? 0 : (int)(threadIdx.x >> 6);
     double *ex = smem;
     const double *xf = x + f * stride;
 
@@ -56,60 +59,60 @@ void mfcc_czt_kernel(const double *x, long n_frames, int n, long stride,
             double v[8]; double2 c[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) {
-                const int i = 16 * R * (8 * h + q) + lane + 64 * u;
+                const int i = 16 * R * (8 * h + q) + tid + NT * u;
                 v[q] = xf[(i < n) ? i : n - 1];
                 c[q] = chirp[i];
             }
 #pragma unroll
             for (int q = 0; q < 8; q++) { re[u][8 * h + q] = v[q] * c[q].x; im[u][8 * h + q] = v[q] * c[q].y; }
         }
-    double xr[4][R], xi[4][R];
-    fft_pow2<U>(re, im, xr, xi, ex, tab);
+    double xr[TQ][R], xi[TQ][R];
+    fft_pow2<U, W>(re, im, xr, xi, ex, tab);
 
     // times FFT_L(chirp), conjugated for the inverse, back to the stage-1 layout through the exchange buffer: the real parts,
     // then the imaginary parts (the table is read again rather than kept: registers)
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
+    for (int t = 0; t < TQ; t++) {
 #pragma unroll
         for (int kc = 0; kc < R; kc++) {
-            const int k = lane + 64 * t + 256 * kc;
+            const int k = tid + NT * t + 256 * kc;
             const double2 b = bhat[k];
             ex[k] = fma(xr[t][kc], b.x, -(xi[t][kc] * b.y));
         }
     }
-    wave_sync();
+    pow2_sync<W>();
 #pragma unroll
     for (int u = 0; u < U; u++)
 #pragma unroll
-        for (int q = 0; q < 16; q++) re[u][q] = ex[16 * R * q + lane + 64 * u];
-    wave_sync();
+        for (int q = 0; q < 16; q++) re[u][q] = ex[16 * R * q + tid + NT * u];
+    pow2_sync<W>();
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
+    for (int t = 0; t < TQ; t++) {
 #pragma unroll
         for (int kc = 0; kc < R; kc++) {
-            const int k = lane + 64 * t + 256 * kc;
+            const int k = tid + NT * t + 256 * kc;
             const double2 b = bhat[k];
             ex[k] = -fma(xr[t][kc], b.y, xi[t][kc] * b.x);
         }
     }
-    wave_sync();
+    pow2_sync<W>();
 #pragma unroll
     for (int u = 0; u < U; u++)
 #pragma unroll
-        for (int q = 0; q < 16; q++) im[u][q] = ex[16 * R * q + lane + 64 * u];
-    wave_sync();
-    fft_pow2<U>(re, im, xr, xi, ex, tab);                    // = conj(L * conv): |conv[k]|^2 = (xr^2 + xi^2) / L^2
+        for (int q = 0; q < 16; q++) im[u][q] = ex[16 * R * q + tid + NT * u];
+    pow2_sync<W>();
+    fft_pow2<U, W>(re, im, xr, xi, ex, tab);                 // = conj(L * conv): |conv[k]|^2 = (xr^2 + xi^2) / L^2
 
     const int b_lo = bins[0];
     const int nbp = (nb + 1) & ~1;
     double *pu = ex, *pd = ex + nbp, *en = ex + 2 * nbp;
     constexpr double INV_L2 = 1.0 / ((double)NC * (double)NC);
-    wave_sync();
+    pow2_sync<W>();
 #pragma unroll
-    for (int t = 0; t < 4; t++)
+    for (int t = 0; t < TQ; t++)
 #pragma unroll
         for (int kc = 0; kc < R; kc++) {
-            const int b1 = lane + 64 * t + 256 * kc - b_lo;
+            const int b1 = tid + NT * t + 256 * kc - b_lo;
             if (b1 >= 0 && b1 < nb) {
                 const double p = fma(xr[t][kc], xr[t][kc], xi[t][kc] * xi[t][kc]) * INV_L2;
                 const double2 sl = *reinterpret_cast<const double2 *>(slopes + 2 * b1);
@@ -117,24 +120,25 @@ void mfcc_czt_kernel(const double *x, long n_frames, int n, long stride,
                 pd[b1] = fabs(sqrt(p)) * sl.y;               // norm * multiplier (:432-434)
             }
         }
-    wave_sync();
+    pow2_sync<W>();
+    if (wave != 0) return;
     if (num_coeffs <= 16) mfcc_tail_q(pu, pd, en, bins, dct, num_coeffs, b_lo, lane, out + f * out_ld);
     else mfcc_tail_m(pu, pd, en, bins, dct, num_coeffs, b_lo, lane, out + f * out_ld);
     if (status != nullptr && lane == 0) status[f] = 0;
 }
 
-template <int U>
+template <int U, int W>
 void launch_mfcc_czt_u(hipStream_t s, const double *x, long F, int n, long stride, const double *window, const double *tab,
                        const double *chirp, const double *bhat, const int32_t *bins, const double *slopes, const double *dct,
                        int num_coeffs, int nb, double *out, long out_ld, int32_t *status, double *cw_scratch) {
-    size_t lds = (size_t)pow2_geom<U>::EX * sizeof(double);
+    size_t lds = (size_t)pow2_geom<U, W>::EX * sizeof(double);
     const size_t mel = (size_t)(2 * ((nb + 1) & ~1) + 64) * sizeof(double);
     if (mel > lds) lds = mel;
-    constexpr int L = pow2_geom<U>::NC;           // cw_scratch: L double2 the caller owns
+    constexpr int L = pow2_geom<U, W>::NC;           // cw_scratch: L double2 the caller owns
     hipLaunchKernelGGL(czt_fold_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, window, reinterpret_cast<const double2 *>(chirp), n, L,
                        reinterpret_cast<double2 *>(cw_scratch));
     chirp = cw_scratch;
-    hipLaunchKernelGGL((mfcc_czt_kernel<U>), dim3((unsigned)F), dim3(64), lds, s, x, F, n, stride,
+    hipLaunchKernelGGL((mfcc_czt_kernel<U, W>), dim3((unsigned)F), dim3(64 * W), lds, s, x, F, n, stride,
                        reinterpret_cast<const double2 *>(tab), reinterpret_cast<const double2 *>(chirp),
                        reinterpret_cast<const double2 *>(bhat), bins, slopes, dct, num_coeffs, nb, out, out_ld, status);
 }

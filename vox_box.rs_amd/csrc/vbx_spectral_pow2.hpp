@@ -27,18 +27,24 @@ namespace vbx {
 #define VBX_POW2_U2_WAVES 2
 #endif
 
-template <int U>
+// U: 16-point units per THREAD and stage; W: wavefronts per frame (1, or 2 for the 4096-point transform: 64 complex values per
+// lane of ONE wavefront are 512 registers + ~150 spilled at one wavefront per SIMD and three per CU; as two wavefronts each
+// thread holds what a lane of the 2048-point kernel holds).  The transform's geometry depends on R = 4 U W alone.
+template <int U, int W = 1>
 struct pow2_geom {
-    static constexpr int R = 4 * U;                    // radix of the last stage
+    static constexpr int NT = 64 * W;                  // threads per frame
+    static constexpr int R = 4 * U * W;                // radix of the last stage
     static constexpr int NC = 256 * R;                 // complex FFT length
     static constexpr int UNITS = 16 * R;               // 16-point DFTs per stage
+    static constexpr int CW = NT / 16;                 // values of c per unit index u in stage 2 (4 per wavefront)
+    static constexpr int TQ = 256 / NT;                // stage-3 columns q = tid + NT t per thread
     static constexpr int S1 = 16 * R + 2;              // exchange 1 row stride [ka][n']: lane (ka, c) reads 2 ka + c mod 32
     static constexpr int S2 = 256 + 16;                // exchange 2 row stride [c][ka + 16 kb]
     static constexpr int T1 = 0;                       // twiddle table (complex entries): T1[16R][16] = W_Nc^(n' ka)
     static constexpr int T2 = T1 + UNITS * 16;         //                                  T2[R][16]   = W_16R^(c kb)
     static constexpr int TM = T2 + R * 16;             //                                  WM[Nc/2+1]  = W_2Nc^m
     static constexpr int TAB = TM + NC / 2 + 1;
-    static constexpr int TP = NC / 128 + 1;            // pairs (m, Nc - m), m = lane + 64 t <= Nc / 2, per lane
+    static constexpr int TP = NC / (2 * NT) + 1;       // pairs (m, Nc - m), m = tid + NT t <= Nc / 2, per thread
     static constexpr int EX = (16 * S1 > R * S2) ? 16 * S1 : R * S2;   // doubles of the exchange buffer
 };
 
@@ -103,19 +109,23 @@ __device__ __forceinline__ void dft_last(double (&vr)[R], double (&vi)[R], doubl
     }
 }
 
-// Complex FFT of length Nc.  In: lane l holds z[16R a + l + 64 u] in (re[u][a], im[u][a]).  Out: lane l holds
-// X[l + 64 t + 256 kc] in (xr[t][kc], xi[t][kc]).  ex: LDS exchange buffer (pow2_geom<U>::EX doubles).
-template <int U>
-__device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16], double (&xr)[4][4 * U], double (&xi)[4][4 * U],
-                                         double *ex, const double2 *__restrict__ tab) {
-    using G = pow2_geom<U>;
-    constexpr int R = G::R;
-    const int lane = lane_id();
+// thread index inside the frame's workgroup, and its barrier: one wavefront orders its own LDS traffic, two need s_barrier
+template <int W> __device__ __forceinline__ int pow2_tid() { return W == 1 ? lane_id() : (int)threadIdx.x; }
+template <int W> __device__ __forceinline__ void pow2_sync() { if constexpr (W == 1) wave_sync(); else __syncthreads(); }
+
+// Complex FFT of length Nc.  In: thread i holds z[16R a + i + NT u] in (re[u][a], im[u][a]).  Out: thread i holds
+// X[i + NT t + 256 kc] in (xr[t][kc], xi[t][kc]).  ex: LDS exchange buffer (pow2_geom<U, W>::EX doubles).
+template <int U, int W = 1>
+__device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16], double (&xr)[4 / W][4 * U * W],
+                                         double (&xi)[4 / W][4 * U * W], double *ex, const double2 *__restrict__ tab) {
+    using G = pow2_geom<U, W>;
+    constexpr int R = G::R, NT = G::NT, CW = G::CW, TQ = G::TQ;
+    const int tid = pow2_tid<W>();
     // stage 1
 #pragma unroll
     for (int u = 0; u < U; u++) {
         dft16(re[u], im[u]);
-        const double2 *tw = tab + G::T1 + (lane + 64 * u) * 16;
+        const double2 *tw = tab + G::T1 + (tid + NT * u) * 16;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             double2 w[8];
@@ -130,33 +140,33 @@ __device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16
         }
     }
     // exchange 1: [ka][n'] -> unit (ka2, c2) reads n' = R b + c2
-    const int ka2 = lane & 15, c2 = lane >> 4;              // unit e = lane + 64 u: (ka2, c2 + 4 u)
+    const int ka2 = tid & 15, c2 = tid >> 4;                // unit e = tid + NT u: (ka2, c2 + CW u)
     double br[U][16], bi[U][16];
-    wave_sync();
+    pow2_sync<W>();
 #pragma unroll
     for (int u = 0; u < U; u++)
 #pragma unroll
-        for (int k = 0; k < 16; k++) ex[k * G::S1 + lane + 64 * u] = re[u][dft16_slot(k)];
-    wave_sync();
+        for (int k = 0; k < 16; k++) ex[k * G::S1 + tid + NT * u] = re[u][dft16_slot(k)];
+    pow2_sync<W>();
 #pragma unroll
     for (int u = 0; u < U; u++)
 #pragma unroll
-        for (int b = 0; b < 16; b++) br[u][b] = ex[ka2 * G::S1 + R * b + c2 + 4 * u];
-    wave_sync();
+        for (int b = 0; b < 16; b++) br[u][b] = ex[ka2 * G::S1 + R * b + c2 + CW * u];
+    pow2_sync<W>();
 #pragma unroll
     for (int u = 0; u < U; u++)
 #pragma unroll
-        for (int k = 0; k < 16; k++) ex[k * G::S1 + lane + 64 * u] = im[u][dft16_slot(k)];
-    wave_sync();
+        for (int k = 0; k < 16; k++) ex[k * G::S1 + tid + NT * u] = im[u][dft16_slot(k)];
+    pow2_sync<W>();
 #pragma unroll
     for (int u = 0; u < U; u++)
 #pragma unroll
-        for (int b = 0; b < 16; b++) bi[u][b] = ex[ka2 * G::S1 + R * b + c2 + 4 * u];
+        for (int b = 0; b < 16; b++) bi[u][b] = ex[ka2 * G::S1 + R * b + c2 + CW * u];
     // stage 2
 #pragma unroll
     for (int u = 0; u < U; u++) {
         dft16(br[u], bi[u]);
-        const double2 *tw = tab + G::T2 + (c2 + 4 * u) * 16;
+        const double2 *tw = tab + G::T2 + (c2 + CW * u) * 16;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             double2 w[8];
@@ -170,56 +180,61 @@ __device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16
             }
         }
     }
-    // exchange 2: [c][ka + 16 kb] -> lane l reads q = l + 64 t for every c
-    double vr[4][R], vi[4][R];
-    wave_sync();
+    // exchange 2: [c][ka + 16 kb] -> thread i reads q = i + NT t for every c
+    double vr[TQ][R], vi[TQ][R];
+    pow2_sync<W>();
 #pragma unroll
     for (int u = 0; u < U; u++)
 #pragma unroll
-        for (int k = 0; k < 16; k++) ex[(c2 + 4 * u) * G::S2 + ka2 + 16 * k] = br[u][dft16_slot(k)];
-    wave_sync();
+        for (int k = 0; k < 16; k++) ex[(c2 + CW * u) * G::S2 + ka2 + 16 * k] = br[u][dft16_slot(k)];
+    pow2_sync<W>();
 #pragma unroll
-    for (int t = 0; t < 4; t++)
+    for (int t = 0; t < TQ; t++)
 #pragma unroll
-        for (int c = 0; c < R; c++) vr[t][c] = ex[c * G::S2 + lane + 64 * t];
-    wave_sync();
+        for (int c = 0; c < R; c++) vr[t][c] = ex[c * G::S2 + tid + NT * t];
+    pow2_sync<W>();
 #pragma unroll
     for (int u = 0; u < U; u++)
 #pragma unroll
-        for (int k = 0; k < 16; k++) ex[(c2 + 4 * u) * G::S2 + ka2 + 16 * k] = bi[u][dft16_slot(k)];
-    wave_sync();
+        for (int k = 0; k < 16; k++) ex[(c2 + CW * u) * G::S2 + ka2 + 16 * k] = bi[u][dft16_slot(k)];
+    pow2_sync<W>();
 #pragma unroll
-    for (int t = 0; t < 4; t++)
+    for (int t = 0; t < TQ; t++)
 #pragma unroll
-        for (int c = 0; c < R; c++) vi[t][c] = ex[c * G::S2 + lane + 64 * t];
-    wave_sync();
+        for (int c = 0; c < R; c++) vi[t][c] = ex[c * G::S2 + tid + NT * t];
+    pow2_sync<W>();
     // stage 3
 #pragma unroll
-    for (int t = 0; t < 4; t++) dft_last<R>(vr[t], vi[t], xr[t], xi[t]);
+    for (int t = 0; t < TQ; t++) dft_last<R>(vr[t], vi[t], xr[t], xi[t]);
 }
 
-// U = 4 (Nc = 4096: 64 complex values per lane): one wavefront per SIMD (512 registers); the frame state, 46 KB of LDS, admits
-// three frames per CU anyway.
-// U = 1, 2: two wavefronts per SIMD.  U = 1 (Nc = 1024) needs ~210 registers.  U = 2 (Nc = 2048: 32 complex values per lane, 17
+// Nc = 4096 (frames of 2049..4096 samples): <U = 2, W = 2>, two wavefronts per frame (round 4).  As ONE wavefront (U = 4: 64
+// complex values per lane) the kernel took 512 registers + ~150 spilled at one wavefront per SIMD, three frames = three
+// wavefronts per CU (the frame state is 46 KB of LDS): 5.7 M frames/s at 4096 / 2048.  The second wavefront leaves when the lag
+// curve is in LDS; the first runs the refinement as in every other kernel.
+// U = 1, 2 with W = 1: two wavefronts per SIMD.  U = 1 (Nc = 1024) needs ~210 registers.  U = 2 (Nc = 2048: 32 complex values per lane, 17
 // spectrum pairs) needs ~290: at 256 a dozen to fifty of them spill, and the frame state (23 KB of LDS) admits six frames
 // per CU.  Measured at n = 2048: 25.2 M frames/s against 18.6 M with one wavefront per SIMD and no spills.
 // FULL: the frame fills the transform (n == Nc, the bounds tests fold away); otherwise n < Nc (MFCC joins when n divides M).
 // MODE (vbx_spectral.hpp): SP_ANALYZE the fused analysis; SP_MFCC_ONLY MFCC::mfcc alone (the forward transform and the mel / DCT
 // tail only); SP_AC_ONLY Autocorrelate::autocorrelate alone (both transforms, the fold seed, the lag sums stored).
-template <int U, bool LPC, bool MFCC, bool FULL, int MODE = SP_ANALYZE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(U == 4 ? 1 : (U == 2 && MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? VBX_POW2_U2_WAVES : 2,
+template <int U, bool LPC, bool MFCC, bool FULL, int MODE = SP_ANALYZE, int W = 1>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(U == 4 ? 1 : (U == 2 && MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? VBX_POW2_U2_WAVES : 2,
                                                                      U == 4 ? ((MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? 1 : 2) : (MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? 2 : 4)))
 void analyze_pow2_kernel(const spectral_args_t a) {
     static_assert((MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) || (MFCC && FULL && !LPC), "the MFCC-only forms need the full frame and have no lag sums");
     static_assert(MODE != SP_AC_ONLY || (!MFCC && !LPC), "the autocorrelation-only form");
     constexpr bool PITCH = MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF;   // the second transform runs
     constexpr bool HALF = MODE == SP_MFCC_HALF;              // the frame has 2 Nc samples: every slot of the transform is data
-    using G = pow2_geom<U>;
-    constexpr int R = G::R, NC = G::NC, TP = G::TP;
+    using G = pow2_geom<U, W>;
+    constexpr int R = G::R, NC = G::NC, TP = G::TP, NT = G::NT, TQ = G::TQ;
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double bcast[4 + W];                          // W > 1: values one wavefront hands the other (x0, S[0], the row maximum)
     const long f = xcd_item(blockIdx.x, a.n_frames);
     if (f >= a.n_frames) return;
     const int lane = lane_id();
+    const int tid = pow2_tid<W>();                           // index inside the frame's workgroup (== lane for one wavefront)
+    const int wave = W == 1 ? 0 : (int)(threadIdx.x >> 6);
     const int n = HALF ? 2 * NC : FULL ? NC : a.n;           // frame length, <= NC (SP_MFCC_HALF: 2 NC)
     double *ex = smem;                                       // exchange buffer, later the lag curve y
     const double *xf = a.frames + f * a.stride;
@@ -234,7 +249,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
             double2 xv[NQ], wv[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
-                const int i = 32 * R * q + 2 * (lane + 64 * u);
+                const int i = 32 * R * q + 2 * (tid + NT * u);
                 xv[q] = double2{0.0, 0.0}; wv[q] = double2{1.0, 1.0};
                 if (al && i + 1 < n) {
                     xv[q] = *reinterpret_cast<const double2 *>(xf + i);
@@ -253,47 +268,52 @@ void analyze_pow2_kernel(const spectral_args_t a) {
             for (int q = NQ; q < 16; q++) { re[u][q] = 0.0; im[u][q] = 0.0; }
         }
     }
-    const double x0 = readlane_f64(re[0][0], 0);            // x_w[0], for the fold seed (Q1)
+    double x0 = readlane_f64(re[0][0], 0);                  // x_w[0], for the fold seed (Q1)
+    if constexpr (W > 1) {
+        if (tid == 0) bcast[0] = x0;
+        __syncthreads();
+        x0 = bcast[0];
+    }
 
     // ---- forward transform of the packed frame ----
-    double xr[4][R], xi[4][R];
-    fft_pow2<U>(re, im, xr, xi, ex, a.tab);
+    double xr[TQ][R], xi[TQ][R];
+    fft_pow2<U, W>(re, im, xr, xi, ex, a.tab);
 
     // ---- exchange 3: natural order, then each lane takes the pairs (m, Nc - m), m = lane + 64 t <= Nc / 2 ----
     double ar[TP], ai[TP], br[TP], bi[TP];
 #pragma unroll
-    for (int t = 0; t < 4; t++)
+    for (int t = 0; t < TQ; t++)
 #pragma unroll
-        for (int kc = 0; kc < R; kc++) ex[lane + 64 * t + 256 * kc] = xr[t][kc];
-    wave_sync();
+        for (int kc = 0; kc < R; kc++) ex[tid + NT * t + 256 * kc] = xr[t][kc];
+    pow2_sync<W>();
 #pragma unroll
     for (int t = 0; t < TP; t++) {
-        const int m = lane + 64 * t;
+        const int m = tid + NT * t;
         const bool ok = m <= NC / 2;
         ar[t] = ok ? ex[m] : 0.0;
         br[t] = ok ? ex[(m == 0) ? 0 : NC - m] : 0.0;
     }
-    wave_sync();
+    pow2_sync<W>();
 #pragma unroll
-    for (int t = 0; t < 4; t++)
+    for (int t = 0; t < TQ; t++)
 #pragma unroll
-        for (int kc = 0; kc < R; kc++) ex[lane + 64 * t + 256 * kc] = xi[t][kc];
-    wave_sync();
+        for (int kc = 0; kc < R; kc++) ex[tid + NT * t + 256 * kc] = xi[t][kc];
+    pow2_sync<W>();
 #pragma unroll
     for (int t = 0; t < TP; t++) {
-        const int m = lane + 64 * t;
+        const int m = tid + NT * t;
         const bool ok = m <= NC / 2;
         ai[t] = ok ? ex[m] : 0.0;
         bi[t] = ok ? ex[(m == 0) ? 0 : NC - m] : 0.0;
     }
-    wave_sync();
+    pow2_sync<W>();
 
     // ---- spectrum of the real sequence, powers, the inverse transform's input (k_spectral.hip: same formulas) ----
     const int b_lo = MFCC ? a.bins[0] : 0;
     double pk[TP], pn[TP];                                   // P[m], P[Nc - m]
 #pragma unroll
     for (int t = 0; t < TP; t++) {
-        const int m = lane + 64 * t;
+        const int m = tid + NT * t;
         const double2 w = a.tab[G::TM + ((m <= NC / 2) ? m : 0)];
         const double er = 0.5 * (ar[t] + br[t]), ei = 0.5 * (ai[t] - bi[t]);
         const double o_r = 0.5 * (ai[t] + bi[t]), o_i = -0.5 * (ar[t] - br[t]);
@@ -307,7 +327,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
         // ---- exchange 4: G in natural order -> stage-1 layout of the second transform ----
     #pragma unroll
         for (int t = 0; t < TP; t++) {
-            const int m = lane + 64 * t;
+            const int m = tid + NT * t;
             if (m <= NC / 2) {
                 const double2 w = a.tab[G::TM + m];
                 const double sm = pk[t] + pn[t], d = pk[t] - pn[t];
@@ -315,15 +335,15 @@ void analyze_pow2_kernel(const spectral_args_t a) {
                 if (m >= 1 && m < NC / 2) ex[NC - m] = fma(-d, w.y, sm);
             }
         }
-        wave_sync();
+        pow2_sync<W>();
     #pragma unroll
         for (int u = 0; u < U; u++)
     #pragma unroll
-            for (int q = 0; q < 16; q++) re[u][q] = ex[16 * R * q + lane + 64 * u];
-        wave_sync();
+            for (int q = 0; q < 16; q++) re[u][q] = ex[16 * R * q + tid + NT * u];
+        pow2_sync<W>();
     #pragma unroll
         for (int t = 0; t < TP; t++) {
-            const int m = lane + 64 * t;
+            const int m = tid + NT * t;
             if (m <= NC / 2) {
                 const double2 w = a.tab[G::TM + m];
                 const double gi = -((pk[t] - pn[t]) * w.x);
@@ -331,12 +351,12 @@ void analyze_pow2_kernel(const spectral_args_t a) {
                 if (m >= 1 && m < NC / 2) ex[NC - m] = gi;
             }
         }
-        wave_sync();
+        pow2_sync<W>();
     #pragma unroll
         for (int u = 0; u < U; u++)
     #pragma unroll
-            for (int q = 0; q < 16; q++) im[u][q] = ex[16 * R * q + lane + 64 * u];
-        wave_sync();
+            for (int q = 0; q < 16; q++) im[u][q] = ex[16 * R * q + tid + NT * u];
+        pow2_sync<W>();
     }
 
     // ---- MFCC::mfcc from the powers: X_n[k'] = X_M[q k'], q = M / n -- 2 for a frame of Nc samples, 1 for one of 2 Nc (HALF),
@@ -349,7 +369,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
         double *pu = ex, *pd = ex + nbp, *en = ex + 2 * nbp; // the exchange buffer is free between the two transforms
 #pragma unroll
         for (int t = 0; t < TP; t++) {
-            const int m = lane + 64 * t;
+            const int m = tid + NT * t;
             if (m <= NC / 2 && (m & qm) == 0) {
                 const int b1 = (m >> qs) - b_lo, b2 = (half - (m >> qs)) - b_lo;
                 if (b1 >= 0 && b1 < a.nb) {
@@ -364,30 +384,37 @@ void analyze_pow2_kernel(const spectral_args_t a) {
                 }
             }
         }
-        wave_sync();
-        if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
-        else mfcc_tail_m(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
-        if (a.mfcc_status != nullptr && lane == 0) a.mfcc_status[f] = 0;
-        wave_sync();
+        pow2_sync<W>();
+        if (wave == 0) {
+            if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
+            else mfcc_tail_m(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
+            if (a.mfcc_status != nullptr && lane == 0) a.mfcc_status[f] = 0;
+        }
+        pow2_sync<W>();
     }
 
     if constexpr (!PITCH) return;
 
     // ---- second transform: Y = FFT(G);  S[2j] = Re Y[j] / M, S[2j+1] = -Im Y[j] / M, j = lane + 64 t + 256 kc < Nc / 2 ----
-    fft_pow2<U>(re, im, xr, xi, ex, a.tab);
+    fft_pow2<U, W>(re, im, xr, xi, ex, a.tab);
 
-    constexpr int NS = 4 * (R / 2);                          // slots per lane: t < 4, kc < R / 2
+    constexpr int NS = TQ * (R / 2);                         // slots per thread: t < TQ, kc < R / 2
     constexpr double INV_M = 1.0 / (double)(2 * NC);
     double r_e[NS], r_o[NS];
     int jj[NS];
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-        const int t = s & 3, kc = s >> 2;
-        jj[s] = lane + 64 * t + 256 * kc;
+        const int t = s % TQ, kc = s / TQ;
+        jj[s] = tid + NT * t + 256 * kc;
         r_e[s] = xr[t][kc] * INV_M;
         r_o[s] = -(xi[t][kc] * INV_M);
     }
-    const double s0 = readlane_f64(r_e[0], 0);               // S[0], the scale of the transform's rounding error
+    double s0 = readlane_f64(r_e[0], 0);                     // S[0], the scale of the transform's rounding error
+    if constexpr (W > 1) {
+        if (tid == 0) bcast[1] = s0;
+        __syncthreads();
+        s0 = bcast[1];
+    }
     if (x0 != 0.0) {                                         // rectangular frames: the fold seed differs from S (uniform branch)
 #pragma unroll
         for (int s = 0; s < NS; s++) {
@@ -416,7 +443,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
         }
         return;
     }
-    if (LPC) {                                               // LPC::lpc(12) on the raw autocorrelation r[0..12]
+    if (LPC && wave == 0) {                                  // LPC::lpc(12) on the raw autocorrelation r[0..12] (threads 0..6 hold them)
         double rr[SP_LPC_P + 1], ac[SP_LPC_P + 1];
 #pragma unroll
         for (int k = 0; k <= SP_LPC_P; k++) rr[k] = readlane_f64((k & 1) ? r_o[0] : r_e[0], k >> 1);
@@ -435,9 +462,17 @@ void analyze_pow2_kernel(const spectral_args_t a) {
         if (i + 1 < n) amax = (ao > amax) ? ao : amax;
     }
     amax = wave_max(amax);
+    if constexpr (W > 1) {                                   // NaN never wins in either wavefront, nor here
+        if (lane == 0) bcast[4 + wave] = amax;
+        __syncthreads();
+        double m = bcast[4];
+#pragma unroll
+        for (int w = 1; w < W; w++) m = (bcast[4 + w] > m) ? bcast[4 + w] : m;
+        amax = m;
+    }
     const double scale = 1.0 / amax;                         // normalize (:404), then / lag window (:406-408)
     double *ys = smem;
-    wave_sync();                                             // every lane is done with the exchange buffer
+    pow2_sync<W>();                                          // every thread is done with the exchange buffer
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const int i = 2 * jj[s];
@@ -451,7 +486,11 @@ void analyze_pow2_kernel(const spectral_args_t a) {
             ys[i] = (r_e[s] * scale) / a.lag_window[i];
         }
     }
-    if (lane < Y_PAD) ys[n + lane] = 0.0;
+    if (tid < Y_PAD) ys[n + tid] = 0.0;
+    if constexpr (W > 1) {
+        __syncthreads();                                     // the curve is complete in LDS: the refinement is one wavefront's work
+        if (wave != 0) return;
+    }
 #ifndef VBX_EXP_NO_EXACT_TAIL
     if (!FULL) spectral_exact_tail(ys, n, xf, a.window, a.lag_window, x0, scale, lane);
 #endif
@@ -463,45 +502,47 @@ void analyze_pow2_kernel(const spectral_args_t a) {
     }
 }
 
-template <int U>
+template <int U, int W = 1>
 inline size_t pow2_lds_bytes(int n, int nb) {
     size_t need = (size_t)pitch_refine_lds_bytes(n);
-    const size_t exch = (size_t)pow2_geom<U>::EX * sizeof(double);
+    const size_t exch = (size_t)pow2_geom<U, W>::EX * sizeof(double);
     const size_t mel = (size_t)(2 * ((nb + 1) & ~1) + 64) * sizeof(double);
     if (exch > need) need = exch;
     if (mel > need) need = mel;
     return (need + 15) & ~(size_t)15;
 }
 
-template <int U>
+template <int U, int W = 1>
 void launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a) {
-    const dim3 grid((unsigned)L.F), block(64);
-    const size_t base = pow2_lds_bytes<U>(L.n, L.nb), extra = pitch_full_list_bytes(L.n, L.kmax);
+    const dim3 grid((unsigned)L.F), block(64 * W);
+    const size_t base = pow2_lds_bytes<U, W>(L.n, L.nb), extra = pitch_full_list_bytes(L.n, L.kmax);
     a.pp.full_off = extra ? (int)base : 0;
     const size_t lds = base + extra;
+    const size_t lds_mfcc = pow2_lds_bytes<U, W>(0, L.nb), lds_ac = pow2_lds_bytes<U, W>(0, 0);
+    constexpr int NC = pow2_geom<U, W>::NC;
     const bool lpc = L.out_lpc != nullptr, mf = L.out_mfcc != nullptr;
     if (L.mfcc_only) {                                       // n == Nc, or (L.n == 2 Nc) the unpadded form
-        if (L.n == 2 * pow2_geom<U>::NC) {
-            if constexpr (U <= 2) hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, true, SP_MFCC_HALF>), grid, block, pow2_lds_bytes<U>(0, L.nb), s, a);
-        } else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, true, SP_MFCC_ONLY>), grid, block, pow2_lds_bytes<U>(0, L.nb), s, a);
+        if (L.n == 2 * NC) {
+            if constexpr (U * W <= 2) hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, true, SP_MFCC_HALF, W>), grid, block, lds_mfcc, s, a);
+        } else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, true, SP_MFCC_ONLY, W>), grid, block, lds_mfcc, s, a);
         return;
     }
     if (L.out_r != nullptr) {                                // autocorrelate(n_lags) alone
-        if (L.n == pow2_geom<U>::NC) hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, true, SP_AC_ONLY>), grid, block, pow2_lds_bytes<U>(0, 0), s, a);
-        else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, false, SP_AC_ONLY>), grid, block, pow2_lds_bytes<U>(0, 0), s, a);
+        if (L.n == NC) hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, true, SP_AC_ONLY, W>), grid, block, lds_ac, s, a);
+        else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, false, SP_AC_ONLY, W>), grid, block, lds_ac, s, a);
         return;
     }
-    if (L.n != pow2_geom<U>::NC) {                           // a padded frame; MFCC joins when its length divides M (U = 1: 512)
-        if constexpr (U == 1) {
-            if (lpc && mf) { hipLaunchKernelGGL((analyze_pow2_kernel<U, true, true, false>), grid, block, lds, s, a); return; }
-            if (mf) { hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, false>), grid, block, lds, s, a); return; }
+    if (L.n != NC) {                           // a padded frame; MFCC joins when its length divides M (U = 1: 512)
+        if constexpr (U * W == 1) {
+            if (lpc && mf) { hipLaunchKernelGGL((analyze_pow2_kernel<U, true, true, false, SP_ANALYZE, W>), grid, block, lds, s, a); return; }
+            if (mf) { hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, false, SP_ANALYZE, W>), grid, block, lds, s, a); return; }
         }
-        if (lpc) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, false, false>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, false>), grid, block, lds, s, a);
-    } else if (lpc && mf) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, true, true>), grid, block, lds, s, a);
-    else if (lpc) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, false, true>), grid, block, lds, s, a);
-    else if (mf) hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, true>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, true>), grid, block, lds, s, a);
+        if (lpc) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, false, false, SP_ANALYZE, W>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, false, SP_ANALYZE, W>), grid, block, lds, s, a);
+    } else if (lpc && mf) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, true, true, SP_ANALYZE, W>), grid, block, lds, s, a);
+    else if (lpc) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, false, true, SP_ANALYZE, W>), grid, block, lds, s, a);
+    else if (mf) hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, true, SP_ANALYZE, W>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, true, SP_ANALYZE, W>), grid, block, lds, s, a);
 }
 
 
