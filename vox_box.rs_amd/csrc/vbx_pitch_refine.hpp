@@ -519,10 +519,21 @@ __device__ __forceinline__ double first_eval_bound(const double *ys, const doubl
         double dl = cos_0_pi(hl * (phil + 1.0)) - cl, dr = cos_0_pi(hr * (phir + 1.0)) - cr;
         const double sl = sin_poly(0.5 * hl), sr = sin_poly(0.5 * hr);
         const double kl = 4.0 * sl * sl, kr = 4.0 * sr * sr;
-        for (int m = 0; m < nh; m++) {
+        // the 2 nh samples first, all in flight together: read where they are used, every term waited a full LDS latency
+        // for its own sample (16 dependent waits per candidate pass; same operations on the same values)
+        double yl[BOUND_HEAD], yr[BOUND_HEAD];
+#pragma unroll
+        for (int m = 0; m < BOUND_HEAD; m++) {
+            const bool in = m < nh;
+            yl[m] = y_at_padded(ys, nvalid, in ? offset + nr - m : 0);
+            yr[m] = y_at_padded(ys, nvalid, in ? offset + nl + m : 0);
+        }
+#pragma unroll
+        for (int m = 0; m < BOUND_HEAD; m++) {
+            if (m >= nh) break;
             const double pl = phil + (double)m, pr = phir + (double)m;
-            const double tl = y_at_padded(ys, nvalid, offset + nr - m) * rcp_nr1(pl) * fma(0.5, cl, 0.5);
-            const double tr = y_at_padded(ys, nvalid, offset + nl + m) * rcp_nr1(pr) * fma(0.5, cr, 0.5);
+            const double tl = yl[m] * rcp_nr1(pl) * fma(0.5, cl, 0.5);
+            const double tr = yr[m] * rcp_nr1(pr) * fma(0.5, cr, 0.5);
             const double t = tl + tr;
             head += (m & 1) ? -t : t;
             cl += dl; dl = fma(-kl, cl, dl);
