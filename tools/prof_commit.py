@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copies the judged evidence of one tools/prof_r03.sh run from gpurun_out/prof_<tag>/ into profiles/ (tracked):
+"""Copies the judged evidence of one tools/prof_round.sh run from gpurun_out/prof_<tag>/ into profiles/ (tracked):
 kernel-stats CSVs, the bench lines printed under the profiler, the per-kernel PMC averages, and
 profiles/pmc_traffic.json -- per kernel: measured HBM bytes per frame (bench.py reads it for roofline.traffic) and, where
 an SQ pass exists, vector instructions per frame and the share of SIMD time the vector ALU is issuing (roofline.issue_frac).
@@ -44,9 +44,9 @@ def bench_line(run):
 KEYS = {
     "analyze": ("pipeline", ["void analyze_kernel<true, true, true, 0,"], "frame"),
     "pitch": ("config3", ["void analyze_kernel<false, false, true, 0,"], "frame"),
-    "analyze_2048": ("pipeline_2048", ["void analyze_pow2_kernel<2, true, true, true, 0>"], "frame"),     # --frame-len 2048 --hop 1024
-    "pitch_2048": ("config3_2048", ["void analyze_pow2_kernel<2, false, false, true, 0>"], "frame"),
-    "pitch_1024": ("config3_1024", ["void analyze_pow2_kernel<1, false, false, true, 0>"], "frame"),
+    "analyze_2048": ("pipeline_2048", ["void analyze_pow2_kernel<2, true, true, true, 0,"], "frame"),     # --frame-len 2048 --hop 1024
+    "pitch_2048": ("config3_2048", ["void analyze_pow2_kernel<2, false, false, true, 0,"], "frame"),
+    "pitch_1024": ("config3_1024", ["void analyze_pow2_kernel<1, false, false, true, 0,"], "frame"),
     # Burg = the one-pass form (k_burg_fast.hip): lag sums, recursion, and the direct recursion on the frames its guard sent on
     "burg_lags_512": ("config4", ["void burg_lags_kernel<8, 12, double"], "frame"),
     "burg_lags": ("pipeline", ["void burg_lags_kernel<20, 12, double"], "frame"),

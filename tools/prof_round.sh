@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-3 evidence run (one MI355X): rocprofv3 kernel trace + stats of the bench commands, then PMC passes in SEPARATE
+# Evidence run of a round (rounds 3 and 4) (one MI355X): rocprofv3 kernel trace + stats of the bench commands, then PMC passes in SEPARATE
 # runs (HBM traffic: FETCH_SIZE / WRITE_SIZE, one counter per pass; one SQ pass per workload).  Everything lands in
 # gpurun_out/prof_<tag>/; tools/prof_summary.py + tools/prof_commit.py turn it into the files committed under profiles/.
-# usage: tools/prof_r03.sh [tag] [quick]       (run on the GPU box from the repo root; "quick" skips the other frame shapes)
-TAG=${1:-r03a}
+# usage: tools/prof_round.sh [tag] [quick]       (run on the GPU box from the repo root; "quick" skips the other frame shapes)
+TAG=${1:-r04c}
 QUICK=${2:-}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}

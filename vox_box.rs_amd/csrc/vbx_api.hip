@@ -1512,8 +1512,9 @@ static int analyze_frames_impl(vbx_ctx *ctx, const char *fn, const double *x, co
                                h_seg_start, n_segments, est, h_p->n_est, (vbx_resonance *)(out_records + c_form), record_ld,
                                nullptr, nullptr, nullptr, st_form, pcm_native ? pcm16 : nullptr);
         if (rc != VBX_SUCCESS) return rc;
-    } else if (st_form) {
-        VBX_HIP(ctx, hipMemsetAsync(st_form, 0, n_frames * sizeof(int32_t), side));
+    } else {
+        ctx->last_track.res = nullptr;                        // no tracks in these records: nothing for vbx_track_stitch_f64 to continue
+        if (st_form) VBX_HIP(ctx, hipMemsetAsync(st_form, 0, n_frames * sizeof(int32_t), side));
     }
     if (fused && h_p->lpc_order && !fused_lpc) {
         rc = run_autocorr_lpc(ctx, side, x, n_frames, frame_len, stride, hann, h_p->lpc_order, 0, nullptr,
