@@ -362,7 +362,16 @@ __global__ __launch_bounds__(64) void tracker_kernel(const res_t *__restrict__ r
 #ifndef VBX_TRK_ROUNDS
 #define VBX_TRK_ROUNDS 3
 #endif
-constexpr int TRK_CHUNK = VBX_TRK_CHUNK, TRK_WARM = VBX_TRK_WARM, TRK_ROUNDS = VBX_TRK_ROUNDS;
+#ifndef VBX_TRK_ROUNDS_LONG
+#define VBX_TRK_ROUNDS_LONG 8
+#endif
+// Check + redo rounds before the sweep.  The sweep redoes what is left SERIALLY, one wavefront per utterance: with thousands of
+// utterances in a batch the leftovers of three rounds are spread over thousands of wavefronts (0.3 ms); with ONE utterance
+// (round 4: the default of the bench, and what a file is) they queue up in a single wavefront -- which, beside the pipeline's
+// analyze kernel, ran 45x slower than alone (a long straight-line step under a thrashed instruction cache): 13.3 ms per
+// 1.44 M frames, 52 ms per 4.5 M.  Every further round costs ~0.16 ms and is parallel: after six the sweep took 0.33 ms, after
+// ten 8 us (nothing left).  Batches whose utterances average more than 8192 frames take eight rounds.
+constexpr int TRK_CHUNK = VBX_TRK_CHUNK, TRK_WARM = VBX_TRK_WARM, TRK_ROUNDS = VBX_TRK_ROUNDS, TRK_ROUNDS_LONG = VBX_TRK_ROUNDS_LONG;
 
 struct trk_in_t {
     const res_t *res; long n_frames; int n_res; const int32_t *res_count; const int64_t *seg_start; long n_seg;
@@ -375,6 +384,7 @@ struct trk_spec_t {               // per chunk g
     int32_t *exact;               // [G]: the entry state is not a guess
     int32_t *redo;                // [G]: check -> repair
     int64_t *stop;                // [G]: first utterance start inside the chunk (rows from there on are exact), or the chunk's end
+    unsigned long long *mask;     // [ceil(G / 64)]: the redo flags of 64 consecutive chunks as one word (check -> sweep)
 };
 
 __device__ __forceinline__ bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
@@ -468,9 +478,8 @@ __global__ __launch_bounds__(64) void tracker_spec_kernel(const trk_in_t in, con
 template <int NE>
 __global__ __launch_bounds__(64) void tracker_check_kernel(const trk_in_t in, const trk_spec_t sp, long n_chunks) {
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_chunks) return;
     int redo = 0;
-    if (g > 0 && !sp.exact[g]) {
+    if (g < n_chunks && g > 0 && !sp.exact[g]) {
         double tf[NS], tb[NS];
         trk_load_row<NE>(in, g * TRK_CHUNK - 1, tf, tb);
         bool same = true;
@@ -482,7 +491,11 @@ __global__ __launch_bounds__(64) void tracker_check_kernel(const trk_in_t in, co
             for (int e = 0; e < NS; e++) { sp.want[g * 2 * NS + 2 * e] = tf[e]; sp.want[g * 2 * NS + 2 * e + 1] = tb[e]; }
         }
     }
-    sp.redo[g] = redo;
+    if (g < n_chunks) sp.redo[g] = redo;
+    // the same flags, 64 chunks to a word (this wavefront's chunks are [64 blockIdx.x, 64 blockIdx.x + 64)): the sweep reads
+    // 4096 chunks per step instead of 64 -- a 12.5-hour utterance has 140,000 chunks, and one wavefront walks them all
+    const unsigned long long m = __ballot(redo != 0);
+    if (threadIdx.x == 0) sp.mask[blockIdx.x] = m;
 }
 
 // redo the flagged chunks from the state the check saw, each inside its own rows
@@ -517,9 +530,18 @@ __global__ __launch_bounds__(64) void tracker_sweep_kernel(const trk_in_t in, co
     const long g_end = (s1 + TRK_CHUNK - 1) / TRK_CHUNK;       // chunks g with g * TRK_CHUNK < s1
     long g = s0 / TRK_CHUNK + 1;                               // the first chunk that starts inside the utterance
     while (g < g_end) {
-        const long mine = g + lane;
-        const unsigned long long mask = __ballot(mine < g_end && sp.redo[mine] != 0);
-        if (mask == 0ull) { g += 64; continue; }
+        // lane l looks at the word of chunks [64 (g / 64 + l), + 64), cut to [g, g_end): 4096 chunks per step
+        const long w0 = g >> 6, wi = w0 + lane;
+        unsigned long long word = (wi * 64 < g_end) ? sp.mask[wi] : 0ull;
+        if (wi == w0) word &= ~0ull << (g & 63);
+        if ((wi + 1) * 64 > g_end) { const long keep = g_end - wi * 64; word &= (keep <= 0) ? 0ull : ((keep >= 64) ? ~0ull : ((1ull << keep) - 1ull)); }
+        const unsigned long long any = __ballot(word != 0ull);
+        if (any == 0ull) { g = (w0 + 64) * 64; continue; }
+        const int wl = __builtin_ctzll(any);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(word & 0xffffffffull), wl);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(word >> 32), wl);
+        const unsigned long long mask = ((unsigned long long)hi << 32) | lo;
+        g = (w0 + wl) * 64;                                    // `first` below = g + ctz(mask)
         const long first = g + __builtin_ctzll(mask);
         long f = first * TRK_CHUNK;
         if (lane == 0) {
@@ -583,7 +605,7 @@ static int tracker_general() { const char *e = getenv("VBX_TRACKER_GENERAL"); re
 
 size_t tracker_chunked_workspace_bytes(long F) {
     const size_t G = (size_t)((F + TRK_CHUNK - 1) / TRK_CHUNK);
-    return G * (2 * 2 * NS * sizeof(double) + 2 * sizeof(int32_t) + sizeof(int64_t)) + 64;
+    return G * (2 * 2 * NS * sizeof(double) + 2 * sizeof(int32_t) + sizeof(int64_t)) + ((G + 63) / 64 + 1) * sizeof(unsigned long long) + 64;
 }
 
 // The same result as launch_tracker (whole segments), for batches with long utterances.  ws: tracker_chunked_workspace_bytes(F).
@@ -598,13 +620,15 @@ void launch_tracker_chunked(hipStream_t s, const res_t *res, long F, int n_res, 
     sp.entry = reinterpret_cast<double *>(w); w += (size_t)G * 2 * NS * sizeof(double);
     sp.want = reinterpret_cast<double *>(w); w += (size_t)G * 2 * NS * sizeof(double);
     sp.stop = reinterpret_cast<int64_t *>(w); w += (size_t)G * sizeof(int64_t);
+    sp.mask = reinterpret_cast<unsigned long long *>(w); w += (size_t)((G + 63) / 64 + 1) * sizeof(unsigned long long);
     sp.exact = reinterpret_cast<int32_t *>(w); w += (size_t)G * sizeof(int32_t);
     sp.redo = reinterpret_cast<int32_t *>(w);
     const dim3 block(64), grid_c((unsigned)((G + 63) / 64)), grid_s((unsigned)in.n_seg);
+    const int rounds = (F / (in.n_seg > 0 ? in.n_seg : 1) > 8192) ? TRK_ROUNDS_LONG : TRK_ROUNDS;
 #define VBX_TRK_CH(NE)                                                                             \
     do {                                                                                           \
         hipLaunchKernelGGL(tracker_spec_kernel<NE>, grid_c, block, 0, s, in, sp, G);               \
-        for (int r = 0; r < TRK_ROUNDS; r++) {                                                     \
+        for (int r = 0; r < rounds; r++) {                                                         \
             hipLaunchKernelGGL(tracker_check_kernel<NE>, grid_c, block, 0, s, in, sp, G);          \
             hipLaunchKernelGGL(tracker_repair_kernel<NE>, grid_c, block, 0, s, in, sp, G);         \
         }                                                                                          \
