@@ -62,7 +62,9 @@ extern "C" {
 
 #define VBX_MAX_RESONANCES 32       /* MAX_RESONANCES, src/lib.rs:26 */
 #define VBX_FORMANT_SLOTS 6         /* FormantSlots, src/spectrum.rs:228 */
-#define VBX_MAX_LPC_ORDER 30        /* 2*order resonances must fit the tracker's fixed arrays */
+#define VBX_MAX_LPC_ORDER 62        /* order of lpc / lpc_praat / find_formants: its at most order / 2 resonances fit the reference's
+                                       MAX_RESONANCES, its polynomial (order + 1 coefficients) the root finder's VBX_MAX_POLY_LEN */
+#define VBX_MAX_POLY_LEN 64         /* coefficients of a polynomial of vbx_find_roots_* / vbx_laguerre_* / vbx_div_polynomial_* */
 #define VBX_MAX_FRAME_LEN 4096      /* frames up to here live in registers / LDS (the fast kernels); the f32 instantiation
                                        (vbx_*_f32, vbx_*_f32_wide) takes no longer ones */
 #define VBX_MAX_LONG_FRAME_LEN 67108864 /* 2^26: every f64 frame-batch entry point takes frames up to this length -- the reference's

@@ -34,7 +34,7 @@ def test_misuse_is_reported_not_fatal(vb, pkg):
     assert rc == -1 and "frame_len" in msg
     rc, msg = _rc(vb, L.vbx_pitch_f64, x.ptr, 1, 5000, 5000, None, 48000.0, 0.2, 75.0, 600.0, 2000, out.ptr, None, None)   # kmax > 5000 / 4 + 2
     assert rc == -1 and "kmax" in msg
-    rc, msg = _rc(vb, L.vbx_lpc_burg_f64, x.ptr, 4, 512, 512, None, 31, out.ptr, None)       # order > 30
+    rc, msg = _rc(vb, L.vbx_lpc_burg_f64, x.ptr, 4, 512, 512, None, 63, out.ptr, None)       # order > 62
     assert rc == -1
     rc, msg = _rc(vb, L.vbx_pitch_f64, x.ptr, 4, 512, 512, None, 48000.0, 0.2, 75.0, 600.0, 1027, out.ptr, None, None)
     assert rc == -1 and "kmax" in msg

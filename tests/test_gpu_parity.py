@@ -152,7 +152,7 @@ def test_lpc_kat(vb, oracle):
 
 
 @pytest.mark.parametrize("n,p,norm", [(512, 12, False), (512, 12, True), (1200, 12, False), (256, 8, False),
-                                      (700, 16, True), (512, 10, False), (300, 20, False)])
+                                      (700, 16, True), (512, 10, False), (300, 20, False), (1024, 46, False), (512, 62, True)])
 def test_autocorr_lpc(vb, oracle, n, p, norm):
     rng = np.random.default_rng(n + p)
     t = np.arange(n)
@@ -179,7 +179,8 @@ def test_lpc_praat_kat(vb, oracle):
 
 
 @pytest.mark.parametrize("n,p", [(512, 12), (1200, 12), (1024, 10), (100, 5), (2049, 13), (4096, 8), (30, 4), (513, 30),
-                                 (64, 20), (128, 16), (200, 17), (2000, 30), (1025, 1), (40, 30)])   # every lane-group shape
+                                 (64, 20), (128, 16), (200, 17), (2000, 30), (1025, 1), (40, 30),    # every lane-group shape
+                                 (1024, 46), (600, 33), (2048, 62), (400, 62), (5000, 46)])           # orders above 30 (44.1 kHz material: sr / 1000 + 2)
 def test_lpc_praat(vb, oracle, n, p):
     rng = np.random.default_rng(n * 31 + p)
     t = np.arange(n)

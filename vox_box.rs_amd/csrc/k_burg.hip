@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64) void burg_kernel(
     int p, T *__restrict__ out, int32_t *__restrict__ status, const frame_map_t map,
     const int32_t *__restrict__ list = nullptr, const int32_t *__restrict__ list_count = nullptr) {
     constexpr int NG = 64 / G;
-    static_assert(G >= VBX_MAX_LPC_ORDER_K || G == 16, "one coefficient per lane of the group");
+    static_assert(G == 16 || G == 32 || G == 64, "one coefficient per lane of the group: orders up to G (the launchers choose)");
     const int lane = lane_id();
     const int gid = lane / G, lig = lane % G;
     // one-frame workgroups of a hop-strided view: neighbouring frames on the same XCD (vbx_device.hpp, xcd_item)
@@ -191,8 +191,9 @@ bool burg_supported(int n, int p) {
     return n >= 2 && n <= 64 * 64 && p >= 1 && p <= VBX_MAX_LPC_ORDER_K;
 }
 
-// orders above 16 need more than 16 lanes per frame (one coefficient per lane)
+// orders above 16 need more than 16 lanes per frame (one coefficient per lane), orders above 32 all 64
 static bool burg_small_groups_ok(int p) { return p <= 16; }
+static bool burg_half_wave_ok(int p) { return p <= 32; }
 
 template <typename T>
 static void launch_burg_t(hipStream_t s, const T *x, long F, int n, long stride, const T *window,
@@ -206,7 +207,7 @@ static void launch_burg_t(hipStream_t s, const T *x, long F, int n, long stride,
     if (g16 && n <= 16 * 8) VBX_BURG(16, 8);
     else if (g16 && n <= 16 * 16) VBX_BURG(16, 16);
     else if (g16 && n <= 16 * 32) VBX_BURG(16, 32);
-    else if (n <= 32 * 32) VBX_BURG(32, 32);
+    else if (n <= 32 * 32 && burg_half_wave_ok(p)) VBX_BURG(32, 32);
     else if (n <= 64 * 20) VBX_BURG(64, 20);
     else if (n <= 64 * 32) VBX_BURG(64, 32);
     else VBX_BURG(64, 64);
@@ -226,7 +227,7 @@ void launch_burg_pcm16(hipStream_t s, const int16_t *x, long F, int n, long stri
                        x, F, n, stride, window, p, out, status, map)
     const bool g16 = burg_small_groups_ok(p);
     if (g16 && n <= 16 * 32) VBX_BURG16(16, 32);
-    else if (n <= 32 * 32) VBX_BURG16(32, 32);
+    else if (n <= 32 * 32 && burg_half_wave_ok(p)) VBX_BURG16(32, 32);
     else if (n <= 64 * 20) VBX_BURG16(64, 20);
     else if (n <= 64 * 32) VBX_BURG16(64, 32);
     else VBX_BURG16(64, 64);
@@ -244,7 +245,7 @@ static void launch_burg_list_t(hipStream_t s, const TIN *x, long F, int n, long 
                        x, F, n, stride, window, p, out, status, map, list, count)
     const bool g16 = burg_small_groups_ok(p);
     if (g16 && n <= 16 * 32) VBX_BURGL(16, 32);
-    else if (n <= 32 * 32) VBX_BURGL(32, 32);
+    else if (n <= 32 * 32 && burg_half_wave_ok(p)) VBX_BURGL(32, 32);
     else if (n <= 64 * 20) VBX_BURGL(64, 20);
     else if (n <= 64 * 32) VBX_BURGL(64, 32);
     else VBX_BURGL(64, 64);

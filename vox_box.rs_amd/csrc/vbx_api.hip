@@ -904,7 +904,7 @@ int vbx_lpc_burg_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t fram
     int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride, VBX_MAX_LONG_FRAME_LEN);
     if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
     VBX_REQUIRE(ctx, out != nullptr, "null output");
-    VBX_REQUIRE(ctx, burg_order_ok(frame_len, n_coeffs), "frame_len must be >= 2, order in [1, 30]");
+    VBX_REQUIRE(ctx, burg_order_ok(frame_len, n_coeffs), "frame_len must be >= 2, order in [1, 62]");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     rc = run_burg(ctx, ctx->stream, x, nullptr, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_coeffs, out, status);
     if (rc != VBX_SUCCESS) return rc;
@@ -917,7 +917,7 @@ int vbx_find_roots_c64(vbx_ctx *ctx, vbx_complex *polys, size_t n_polys, size_t 
     VBX_REQUIRE(ctx, ctx != nullptr, "null context");
     if (n_polys == 0) return VBX_SUCCESS;
     VBX_REQUIRE(ctx, polys != nullptr, "null polynomials");
-    VBX_REQUIRE(ctx, len >= 1 && len <= 2 * VBX_MAX_LPC_ORDER + 4, "len must be in [1, 64]");
+    VBX_REQUIRE(ctx, len >= 1 && len <= VBX_MAX_POLY_LEN, "len must be in [1, 64]");
     VBX_REQUIRE(ctx, n_polys <= 0x7fffffffull, "too many polynomials");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     { Prof p(ctx, "find_roots"); launch_find_roots(ctx->stream, (cplx_t *)polys, (long)n_polys, (int)len, status); }
@@ -929,7 +929,7 @@ int vbx_laguerre_c64(vbx_ctx *ctx, const vbx_complex *polys, size_t n_polys, siz
     VBX_REQUIRE(ctx, ctx != nullptr, "null context");
     if (n_polys == 0) return VBX_SUCCESS;
     VBX_REQUIRE(ctx, polys && out, "null argument");
-    VBX_REQUIRE(ctx, len >= 2 && len <= 2 * VBX_MAX_LPC_ORDER + 4, "len must be in [2, 64]");
+    VBX_REQUIRE(ctx, len >= 2 && len <= VBX_MAX_POLY_LEN, "len must be in [2, 64]");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     cplx_t s; s.re = start.re; s.im = start.im;
     { Prof p(ctx, "laguerre"); launch_laguerre(ctx->stream, (const cplx_t *)polys, (long)n_polys, (int)len, s, (cplx_t *)out); }
@@ -941,7 +941,7 @@ int vbx_div_polynomial_c64(vbx_ctx *ctx, vbx_complex *polys, const vbx_complex *
     VBX_REQUIRE(ctx, ctx != nullptr, "null context");
     if (n_polys == 0) return VBX_SUCCESS;
     VBX_REQUIRE(ctx, polys && others && rem, "null argument");
-    VBX_REQUIRE(ctx, len >= 1 && len <= 2 * VBX_MAX_LPC_ORDER + 4, "len must be in [1, 64]");
+    VBX_REQUIRE(ctx, len >= 1 && len <= VBX_MAX_POLY_LEN, "len must be in [1, 64]");
     VBX_REQUIRE(ctx, n_polys <= 0x7fffffffull, "too many polynomials");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     { Prof p(ctx, "div_polynomial"); launch_div_polynomial(ctx->stream, (cplx_t *)polys, (const cplx_t *)others, (long)n_polys, (int)len, (cplx_t *)rem, status); }
@@ -952,7 +952,7 @@ int vbx_find_roots_c32(vbx_ctx *ctx, vbx_complex32 *polys, size_t n_polys, size_
     VBX_REQUIRE(ctx, ctx != nullptr, "null context");
     if (n_polys == 0) return VBX_SUCCESS;
     VBX_REQUIRE(ctx, polys != nullptr, "null polynomials");
-    VBX_REQUIRE(ctx, len >= 1 && len <= 2 * VBX_MAX_LPC_ORDER + 4, "len must be in [1, 64]");
+    VBX_REQUIRE(ctx, len >= 1 && len <= VBX_MAX_POLY_LEN, "len must be in [1, 64]");
     VBX_REQUIRE(ctx, n_polys <= 0x7fffffffull, "too many polynomials");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     { Prof p(ctx, "find_roots_f32"); launch_find_roots_f32(ctx->stream, (cplx32_t *)polys, (long)n_polys, (int)len, status); }
@@ -964,7 +964,7 @@ int vbx_laguerre_c32(vbx_ctx *ctx, const vbx_complex32 *polys, size_t n_polys, s
     VBX_REQUIRE(ctx, ctx != nullptr, "null context");
     if (n_polys == 0) return VBX_SUCCESS;
     VBX_REQUIRE(ctx, polys && out, "null argument");
-    VBX_REQUIRE(ctx, len >= 2 && len <= 2 * VBX_MAX_LPC_ORDER + 4, "len must be in [2, 64]");
+    VBX_REQUIRE(ctx, len >= 2 && len <= VBX_MAX_POLY_LEN, "len must be in [2, 64]");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     cplx32_t s; s.re = start.re; s.im = start.im;
     { Prof p(ctx, "laguerre_f32"); launch_laguerre_f32(ctx->stream, (const cplx32_t *)polys, (long)n_polys, (int)len, s, (cplx32_t *)out); }
@@ -1095,7 +1095,7 @@ static int run_find_formants(vbx_ctx *ctx, hipStream_t stm, const double *x, siz
                              vbx_resonance *out_formants, size_t formants_ld, vbx_resonance *out_res, int32_t *out_res_count,
                              double *out_coeffs, int32_t *status, const int16_t *pcm = nullptr /* the frames as 16-bit PCM instead of x */) {
     VBX_REQUIRE(ctx, h_est_init && out_formants, "null argument");
-    VBX_REQUIRE(ctx, burg_order_ok(frame_len, n_coeffs), "frame_len must be >= 2, order in [1, 30]");
+    VBX_REQUIRE(ctx, burg_order_ok(frame_len, n_coeffs), "frame_len must be >= 2, order in [1, 62]");
     VBX_REQUIRE(ctx, n_est >= 1 && n_est <= VBX_FORMANT_SLOTS, "n_est must be in [1, 6]");
     VBX_REQUIRE(ctx, formants_ld >= 2 * n_est && formants_ld % 2 == 0, "formant rows must be 16-byte aligned and hold n_est entries");
     const long F = (long)n_frames; const int p = (int)n_coeffs;
@@ -1691,7 +1691,7 @@ int vbx_lpc_burg_f32_wide(vbx_ctx *ctx, const float *x, size_t n_frames, size_t 
     int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
     if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
     VBX_REQUIRE(ctx, out != nullptr, "null output");
-    VBX_REQUIRE(ctx, burg_supported((int)frame_len, (int)n_coeffs), "frame_len must be in [2, 4096], order in [1, 30]");
+    VBX_REQUIRE(ctx, burg_supported((int)frame_len, (int)n_coeffs), "frame_len must be in [2, 4096], order in [1, 62]");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     { Prof p(ctx, "burg_f32"); launch_burg_f32(ctx->stream, x, (long)n_frames, (int)frame_len, (long)stride, window, (int)n_coeffs, out, status); }
     return check_launch(ctx, __func__);
@@ -1795,7 +1795,7 @@ int vbx_lpc_burg_f32(vbx_ctx *ctx, const float *x, size_t n_frames, size_t frame
     int rc = check_frames(ctx, __func__, x, n_frames, frame_len, stride);
     if (rc != VBX_SUCCESS) return rc < 0 ? rc : VBX_SUCCESS;
     VBX_REQUIRE(ctx, out != nullptr, "null output");
-    VBX_REQUIRE(ctx, burg_supported((int)frame_len, (int)n_coeffs), "frame_len must be in [2, 4096], order in [1, 30]");
+    VBX_REQUIRE(ctx, burg_supported((int)frame_len, (int)n_coeffs), "frame_len must be in [2, 4096], order in [1, 62]");
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     // one lane per frame, b1 / b2 in a context-owned scratch: launches of at most `chunk` frames keep it under 256 MB
     long chunk = (long)((256ull << 20) / (8ull * frame_len)) & ~63L;

@@ -4,7 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define VBX_MAX_LPC_ORDER_K 30   // == VBX_MAX_LPC_ORDER (include/voxbox_hip.h)
+#define VBX_MAX_LPC_ORDER_K 62   // == VBX_MAX_LPC_ORDER (include/voxbox_hip.h)
 #define VBX_MAX_FRAME_LEN_K 4096
 #define VBX_MAX_RESONANCES_K 32
 #define VBX_FORMANT_SLOTS_K 6
