@@ -710,7 +710,11 @@ static int launch_spectral(vbx_ctx *ctx, hipStream_t st, spectral_launch_t &L, c
     { Prof p(ctx, prof_name, st); launch_analyze(st, L); }
     {
         Prof p(ctx, "pitch_direct_fallback", st);
-        const int grid = ctx->cu_count > 0 ? ctx->cu_count * 4 : 1024;
+        // a fixed grid over a count only the device knows (almost always zero).  Every workgroup of this kernel allocates the
+        // frame's LDS image + refinement state before it can look at the count: ~70 KB at 3000 samples -- 1024 of them took
+        // 4 ms to come and go with nothing to do, beside 13.5 ms of the analysis itself.  One per CU where the state is large.
+        const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+        const int grid = pitch_lds_bytes(L.n) > 24 * 1024 ? cus : cus * 4;
         launch_pitch_list(st, L.unsure_list, L.unsure_count, grid, L.x, L.n, L.stride, L.window, L.lag_window,
                           L.sample_rate, L.threshold, L.fmin, L.fmax, L.kmax, L.out_cand, L.cand_ld, L.out_count,
                           L.pitch_status, L.work, L.pcm);
