@@ -1284,12 +1284,20 @@ static int run_mfcc(vbx_ctx *ctx, hipStream_t stm, const double *x, size_t n_fra
     // frame, k_mfcc_czt.hip) instead of evaluating them bin by bin on the vector ALU.  Measured, MFCC alone / the whole
     // pipeline, M frames/s: 1103: 28.9 -> 61.9 / 15.2 -> 20.3; 2500: 7.4 -> 15.0 / 3.2 -> 4.0; 3000: 2.8 -> 15.2 / 1.8 -> 3.9.
     // Where the matrix-core kernel has a plan it stays (1000, 1102, 1800: it is the faster one; 1500, 1600: within 5 %).
-    if (!mp.ok) {
-        const int top = hb.back();
-        const int cplan = (nb >= 1 && hb.front() >= 0 && num_coeffs <= 64) ? mfcc_czt_plan((int)frame_len, top) : SPECTRAL_PLAN_NONE;
+    const int czt_top = hb.back();
+    const int czt_plan = (nb >= 1 && hb.front() >= 0 && num_coeffs <= 64) ? mfcc_czt_plan((int)frame_len, czt_top) : SPECTRAL_PLAN_NONE;
+    // ... and from 1400 samples up to what the 2048-point transform holds, where the matrix-core kernel HAS a plan: inside the
+    // pipeline its 512-thread workgroups with ~100 KB of LDS keep the analyze kernel's wavefronts out, the chirp-z kernel's
+    // one-wavefront workgroups interleave with them (pipeline at 1500 / 1600 samples: 15.6 -> 16.2, 15.1 -> 16.8 M frames/s;
+    // below 1400 and on the 4096-point transform the matrix-core kernel wins: 1280: 19.6 against 17.6, 1800: 14.8 against 12.5)
+    const bool czt_over_mfma = mp.ok && czt_plan == SPECTRAL_PLAN_2048 && frame_len >= 1400 && ctx->mfcc_czt == -1 &&
+                               !(ctx->mfcc_force_goertzel || ctx->mfcc_force_dft2 || ctx->mfcc_force_mfma);
+    if (!mp.ok || czt_over_mfma) {
+        const int top = czt_top;
+        const int cplan = czt_plan;
         const bool forced = ctx->mfcc_force_goertzel || ctx->mfcc_force_dft2 || ctx->mfcc_force_mfma;
         // (below ~600 samples the Goertzel kernel's n * nb products cost less than two 1024-point transforms)
-        const bool want = ctx->mfcc_czt == 1 || (ctx->mfcc_czt == -1 && !forced && frame_len >= 600);
+        const bool want = ctx->mfcc_czt == 1 || czt_over_mfma || (ctx->mfcc_czt == -1 && !forced && frame_len >= 600);
         if (cplan != SPECTRAL_PLAN_NONE && want) {
             const double *tab = nullptr, *chirp = nullptr, *bhat = nullptr;
             rc = get_spectral_tab(ctx, cplan, &tab); if (rc != VBX_SUCCESS) return rc;
