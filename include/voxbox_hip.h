@@ -507,7 +507,9 @@ int vbx_gather_records_f64(vbx_ctx *ctx, vbx_comm *comm, const double *local, co
  * previous rank's last formant row when h_plan->continues_prev (it sends it after its own stitch: the ranks of one utterance
  * form a chain of 2 n_est doubles each over the direct xGMI links), corrects this rank's rows, and sends this rank's last row
  * on when h_plan->continues_next.  n_frames = hi - lo + warm rows as in vbx_track_stitch_f64.  Queue the record gather after
- * it with the same `slot`: vbx_comm_wait(slot) then covers both. */
+ * it with the same `slot`: vbx_comm_wait(slot) then covers both.  A rank that receives makes the context's stream wait (on
+ * the device) until its stitch is through: the repair reads the resonance rows the context holds, which the context's next
+ * call overwrites. */
 int vbx_comm_stitch_tracks_f64(vbx_ctx *ctx, vbx_comm *comm, vbx_resonance *formants, size_t n_frames, size_t formants_ld,
                                const vbx_shard_plan_t *h_plan, int32_t *d_changed, int slot);
 /* The transfer list of that gather as one rank sees it, on the host (no GPU, no RCCL: what vbx_gather_records_f64 posts,

@@ -27,6 +27,7 @@ struct vbx_comm {
     hipStream_t stream = nullptr;                    // transfers run here, beside the context's kernels
     hipEvent_t ready = nullptr;                      // "the records are written" (recorded on the context's stream)
     hipEvent_t done[VBX_COMM_SLOTS] = {nullptr};     // "the gather that used slot s has finished"
+    hipEvent_t stitched = nullptr;                   // "the stitch has read the context's resonance rows"
     bool used[VBX_COMM_SLOTS] = {false};
 };
 
@@ -76,6 +77,7 @@ int vbx_comm_create(vbx_ctx *ctx, const void *h_id, int world, int rank, vbx_com
     if (r != ncclSuccess) { delete c; return fail(ctx, VBX_E_RUNTIME, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->stitched, hipEventDisableTiming);
     for (int s = 0; s < VBX_COMM_SLOTS && e == hipSuccess; s++) e = hipEventCreateWithFlags(&c->done[s], hipEventDisableTiming);
     if (e != hipSuccess) { vbx_comm_destroy(c); return fail(ctx, VBX_E_RUNTIME, std::string("vbx_comm_create: ") + hipGetErrorString(e)); }
     *out = c;
@@ -90,6 +92,7 @@ void vbx_comm_destroy(vbx_comm *c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->nccl) ncclCommDestroy(c->nccl);
     if (c->ready) hipEventDestroy(c->ready);
+    if (c->stitched) hipEventDestroy(c->stitched);
     for (int s = 0; s < VBX_COMM_SLOTS; s++) if (c->done[s]) hipEventDestroy(c->done[s]);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -155,6 +158,11 @@ int vbx_comm_stitch_tracks_f64(vbx_ctx *ctx, vbx_comm *c, vbx_resonance *formant
         VBXC_NCCL(ctx, ncclRecv(state, (size_t)(2 * n_est), ncclDouble, c->rank - 1, c->nccl, c->stream));
         int rc = vbx_internal_track_stitch(ctx, (void *)c->stream, formants, n_frames, formants_ld, h_plan->warm, h_plan->stop, state, d_changed);
         if (rc != VBX_SUCCESS) return rc;
+        // the repair reads the resonance rows in the CONTEXT's scratch, which the context's next find_formants / analyze call
+        // overwrites: that call must not start before the stitch is through (a wait on the device; it costs the chain's
+        // latency -- one tiny message and kernel per rank ahead -- once per step)
+        VBXC_HIP(ctx, hipEventRecord(c->stitched, c->stream));
+        VBXC_HIP(ctx, hipStreamWaitEvent(main, c->stitched, 0));
     } else if (d_changed) {
         VBXC_HIP(ctx, hipMemsetAsync(d_changed, 0, sizeof(int32_t), c->stream));
     }
