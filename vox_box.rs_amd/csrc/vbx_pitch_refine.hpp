@@ -6,6 +6,7 @@
 // Reference: src/periodic.rs:29-87 (interpolate_sinc), :103-188 (brent_maximize), :192-229 (improve_extremum),
 //            :362-375 (local_maxima), :413-455 (pitch, after the lag window division).  Quirks Q4-Q10 reproduced.
 #pragma once
+#include <type_traits>
 
 #include "vbx_device.hpp"
 #include "vbx_kernels.hpp"
@@ -76,8 +77,8 @@ __device__ __forceinline__ double y_at_padded(const double *y, int nvalid, int i
 // clamps.  Even lanes of a group take "left" terms, odd lanes "right" terms.  No cross-lane ops.
 template <int G>
 __device__ __forceinline__ double sinc_terms_general(const double *y, int nvalid, int ylen, int offset, int nl, int nr,
-                                                     double phil, double phir, int max_depth) {
-    const int lig = lane_id() & (G - 1);
+                                                     double phil, double phir, int max_depth, int lig = -1) {
+    if (lig < 0) lig = lane_id() & (G - 1);    // (the two-lanes-in-one form passes the lane it stands in for)
     const int side = lig & 1;
     const double ph = side ? phir : phil;
     const double s0 = sinpi(ph);               // sin(pi*(ph+n)) = (-1)^n * s0
@@ -106,64 +107,115 @@ __device__ __forceinline__ double sinc_terms_general(const double *y, int nvalid
 //                             d += -kappa*C; C += d  (kappa = 4 sin^2(delta/2)) replaces the cosine
 //   1/(ph+n)                = four terms share ONE v_rcp_f64 (+ a Newton step): 1/(p0 p1 p2 p3), then products
 // Returns the lane's partial sum already scaled (sum over the group = interpolate_sinc).
+// One lane's share of that sum as a stream: the terms n = n0, n0 + NSTEP, ... of one side (left: indices descend from
+// ibase_l - n0, right: ascend from ibase_r + n0).
+struct sinc_stream_t {
+    double pn, C, d, kappa, acc0, acc1;                        // ph + n; cos(theta_j), C_j - C_{j-1}; sum t, sum t*C  (t = y/(ph+n))
+    const double *yp;
+};
+
+template <int NSTEP>
+__device__ __forceinline__ void sinc_stream_init(sinc_stream_t &s, const double *y, int side, int n0, int ibase_l, int ibase_r,
+                                                 double phil, double phir, int max_depth) {
+    constexpr double S = (double)NSTEP;
+    const double ph = side ? phir : phil;
+    const double h2 = M_PI * rcp_nr2(ph + (double)max_depth); // theta = h2 * (ph + n)  in [0, pi]
+    s.pn = ph + (double)n0;
+    // cosine recurrence state: C = cos(theta_j), d = C_j - C_{j-1}
+    const double theta0 = h2 * s.pn, delta = h2 * S;
+    s.C = cos_0_pi(theta0);
+    s.d = cos_0_pi(theta0 + delta) - s.C;                      // only used when the lane has >= 2 terms
+    const double sh = sin_poly(0.5 * delta);
+    s.kappa = 4.0 * sh * sh;
+    s.yp = y + (side ? (ibase_r + n0) : (ibase_l - n0));
+    s.acc0 = 0.0; s.acc1 = 0.0;
+}
+
+// four terms; step = +-NSTEP (the side's direction)
+template <int NSTEP>
+__device__ __forceinline__ void sinc_stream_block4(sinc_stream_t &s, const int step) {
+    constexpr double S = (double)NSTEP;
+    const double y0 = s.yp[0], y1 = s.yp[step], y2 = s.yp[2 * step], y3 = s.yp[3 * step];
+    const double p0 = s.pn, p1 = s.pn + S, p2 = s.pn + 2.0 * S, p3 = s.pn + 3.0 * S;
+    const double q01 = p0 * p1, q23 = p2 * p3;
+    const double r = rcp_nr1(q01 * q23);
+    const double r01 = r * q23, r23 = r * q01;
+    const double t0 = y0 * (r01 * p1), t1 = y1 * (r01 * p0), t2 = y2 * (r23 * p3), t3 = y3 * (r23 * p2);
+    s.acc0 += t0; s.acc1 = fma(t0, s.C, s.acc1);
+    s.C += s.d; s.d = fma(-s.kappa, s.C, s.d);                 // after the first step d_1 was preset: see above
+    s.acc0 += t1; s.acc1 = fma(t1, s.C, s.acc1);
+    s.C += s.d; s.d = fma(-s.kappa, s.C, s.d);
+    s.acc0 += t2; s.acc1 = fma(t2, s.C, s.acc1);
+    s.C += s.d; s.d = fma(-s.kappa, s.C, s.d);
+    s.acc0 += t3; s.acc1 = fma(t3, s.C, s.acc1);
+    s.C += s.d; s.d = fma(-s.kappa, s.C, s.d);
+    s.pn += 4.0 * S;
+    s.yp += 4 * step;
+}
+
+// 1..3 terms left: one more block, padded with zero-weight terms
+template <int NSTEP>
+__device__ __forceinline__ void sinc_stream_tail(sinc_stream_t &s, const int step, const int rem) {
+    constexpr double S = (double)NSTEP;
+    const double y0 = s.yp[0], y1 = (rem > 1) ? s.yp[step] : 0.0, y2 = (rem > 2) ? s.yp[2 * step] : 0.0;
+    const double p0 = s.pn, p1 = s.pn + S, p2 = s.pn + 2.0 * S;
+    const double q01 = p0 * p1;
+    const double r = rcp_nr1(q01 * p2);
+    const double r01 = r * p2;
+    const double t0 = y0 * (r01 * p1), t1 = y1 * (r01 * p0), t2 = y2 * (r * q01);
+    s.acc0 += t0; s.acc1 = fma(t0, s.C, s.acc1);
+    s.C += s.d; s.d = fma(-s.kappa, s.C, s.d);
+    s.acc0 += t1; s.acc1 = fma(t1, s.C, s.acc1);
+    s.C += s.d;
+    s.acc0 += t2; s.acc1 = fma(t2, s.C, s.acc1);
+}
+
+// the lane's partial sum, scaled and ROUNDED before the cross-lane sum (vbx_device.hpp); k = sin(pi*ph) / pi * 0.5 (the taper's)
+__device__ __forceinline__ double sinc_stream_result(const sinc_stream_t &s, int n0, double k) {
+    const double acc = s.acc0 + s.acc1;
+    return rounded(((n0 & 1) ? -acc : acc) * k);
+}
+
 template <int G>
 __device__ __forceinline__ double sinc_terms_fast(const double *y, int ibase_l, int ibase_r,
                                                   double phil, double phir, int max_depth) {
     constexpr int NSTEP = G / 2;
-    constexpr double S = (double)NSTEP;
     const int lig = lane_id() & (G - 1);
     const int side = lig & 1;
     const int n0 = lig >> 1;
-    const double ph = side ? phir : phil;
     const double s0 = sin_poly(M_PI * fmin(phil, phir));      // sin(pi*phil) == sin(pi*phir)
-    const double h2 = M_PI * rcp_nr2(ph + (double)max_depth); // theta = h2 * (ph + n)  in [0, pi]
-    double pn = ph + (double)n0;
     const int nterms = (n0 <= max_depth) ? (max_depth - n0) / NSTEP + 1 : 0;
-    // cosine recurrence state: C = cos(theta_j), d = C_j - C_{j-1}
-    const double theta0 = h2 * pn, delta = h2 * S;
-    double C = cos_0_pi(theta0);
-    double d = cos_0_pi(theta0 + delta) - C;                   // only used when the lane has >= 2 terms
-    const double sh = sin_poly(0.5 * delta);
-    const double kappa = 4.0 * sh * sh;
+    sinc_stream_t s;
+    sinc_stream_init<NSTEP>(s, y, side, n0, ibase_l, ibase_r, phil, phir, max_depth);
     const int step = side ? NSTEP : -NSTEP;
-    const double *yp = y + (side ? (ibase_r + n0) : (ibase_l - n0));
-    double acc0 = 0.0, acc1 = 0.0;                             // sum t, sum t*C   (t = y/(ph+n))
     int j = 0;
-    for (; j + 4 <= nterms; j += 4) {
-        const double y0 = yp[0], y1 = yp[step], y2 = yp[2 * step], y3 = yp[3 * step];
-        const double p0 = pn, p1 = pn + S, p2 = pn + 2.0 * S, p3 = pn + 3.0 * S;
-        const double q01 = p0 * p1, q23 = p2 * p3;
-        const double r = rcp_nr1(q01 * q23);
-        const double r01 = r * q23, r23 = r * q01;
-        const double t0 = y0 * (r01 * p1), t1 = y1 * (r01 * p0), t2 = y2 * (r23 * p3), t3 = y3 * (r23 * p2);
-        acc0 += t0; acc1 = fma(t0, C, acc1);
-        C += d; d = fma(-kappa, C, d);                         // after the first step d_1 was preset: see below
-        acc0 += t1; acc1 = fma(t1, C, acc1);
-        C += d; d = fma(-kappa, C, d);
-        acc0 += t2; acc1 = fma(t2, C, acc1);
-        C += d; d = fma(-kappa, C, d);
-        acc0 += t3; acc1 = fma(t3, C, acc1);
-        C += d; d = fma(-kappa, C, d);
-        pn += 4.0 * S;
-        yp += 4 * step;
-    }
-    if (j < nterms) {      // 1..3 terms left: one more block, padded with zero-weight terms
-        const int rem = nterms - j;
-        const double y0 = yp[0], y1 = (rem > 1) ? yp[step] : 0.0, y2 = (rem > 2) ? yp[2 * step] : 0.0;
-        const double p0 = pn, p1 = pn + S, p2 = pn + 2.0 * S;
-        const double q01 = p0 * p1;
-        const double r = rcp_nr1(q01 * p2);
-        const double r01 = r * p2;
-        const double t0 = y0 * (r01 * p1), t1 = y1 * (r01 * p0), t2 = y2 * (r * q01);
-        acc0 += t0; acc1 = fma(t0, C, acc1);
-        C += d; d = fma(-kappa, C, d);
-        acc0 += t1; acc1 = fma(t1, C, acc1);
-        C += d;
-        acc0 += t2; acc1 = fma(t2, C, acc1);
-    }
-    const double k = s0 * (0.5 * 0.31830988618379067154);     // sin(pi*ph) / pi, and the 0.5 of the taper
-    const double acc = acc0 + acc1;
-    return rounded(((n0 & 1) ? -acc : acc) * k);       // rounded before the cross-lane sum (vbx_device.hpp)
+    for (; j + 4 <= nterms; j += 4) sinc_stream_block4<NSTEP>(s, step);
+    if (j < nterms) sinc_stream_tail<NSTEP>(s, step, nterms - j);
+    return sinc_stream_result(s, n0, s0 * (0.5 * 0.31830988618379067154));
+}
+
+// The same sum with each lane standing in for TWO lanes of a group of VG: lane p of a group of VG / 2 runs the left stream
+// (lane 2p of the VG) and the right stream (lane 2p + 1) of n0 = p side by side and adds the two results -- the first level of
+// group_sum<VG>'s tree, whose other levels are group_sum<VG / 2> over the half-sized group (quad_xor1, quad_rev,
+// row_half_mirror there pair the same partial sums as quad_rev, row_half_mirror, row_mirror here; every level's addition
+// is commutative).  Same operations on the same values: group_sum<VG / 2> of this is bit for bit group_sum<VG> of
+// sinc_terms_fast<VG>.  What it buys: the per-evaluation work that is NOT the terms (the Brent bookkeeping, the early-outs)
+// is shared by twice as many candidates per wavefront.
+template <int VG>
+__device__ __forceinline__ double sinc_terms_fast_dual(const double *y, int ibase_l, int ibase_r,
+                                                       double phil, double phir, int max_depth) {
+    constexpr int NSTEP = VG / 2;
+    const int n0 = lane_id() & (VG / 2 - 1);
+    const double s0 = sin_poly(M_PI * fmin(phil, phir));
+    const int nterms = (n0 <= max_depth) ? (max_depth - n0) / NSTEP + 1 : 0;
+    sinc_stream_t sl, sr;
+    sinc_stream_init<NSTEP>(sl, y, 0, n0, ibase_l, ibase_r, phil, phir, max_depth);
+    sinc_stream_init<NSTEP>(sr, y, 1, n0, ibase_l, ibase_r, phil, phir, max_depth);
+    int j = 0;
+    for (; j + 4 <= nterms; j += 4) { sinc_stream_block4<NSTEP>(sl, -NSTEP); sinc_stream_block4<NSTEP>(sr, NSTEP); }
+    if (j < nterms) { sinc_stream_tail<NSTEP>(sl, -NSTEP, nterms - j); sinc_stream_tail<NSTEP>(sr, NSTEP, nterms - j); }
+    const double k = s0 * (0.5 * 0.31830988618379067154);
+    return sinc_stream_result(sl, n0, k) + sinc_stream_result(sr, n0, k);
 }
 
 // interpolate_sinc (src/periodic.rs:29-87), cooperative over groups of G lanes; the arguments are
@@ -174,7 +226,8 @@ __device__ __forceinline__ double sinc_terms_fast(const double *y, int ibase_l, 
 // trusted: sinc_bracket_trusted() has shown that EVERY abscissa of the caller's bracket takes the clamp-free sum or one of
 // the two exact-integer early-outs with readable indices; the range tests of :38-40 and the index checks are then skipped
 // (they cannot fire), the arithmetic is the same.
-template <int G>
+// DUAL: G lanes stand in for a group of 2G (sinc_terms_fast_dual): the value is bit for bit sinc_interp<2G>'s.
+template <int G, bool DUAL = false>
 __device__ __forceinline__ double sinc_interp(const double *y, int nvalid, int ylen, int offset, int nx,
                                               double x, int max_depth, bool active, int &st,
                                               unsigned *terms = nullptr, bool trusted = false) {
@@ -228,8 +281,17 @@ __device__ __forceinline__ double sinc_interp(const double *y, int nvalid, int y
     double acc = 0.0;
     if (terms != nullptr && summed) *terms += 2u * (unsigned)(max_depth + 1);
     if (summed) {
-        if (fast) acc = sinc_terms_fast<G>(y, offset + nr, offset + nl, phil, phir, max_depth);
-        else acc = sinc_terms_general<G>(y, nvalid, ylen, offset, nl, nr, phil, phir, max_depth);
+        if constexpr (DUAL) {
+            if (fast) acc = sinc_terms_fast_dual<2 * G>(y, offset + nr, offset + nl, phil, phir, max_depth);
+            else {
+                const int p = lane_id() & (G - 1);
+                acc = rounded(sinc_terms_general<2 * G>(y, nvalid, ylen, offset, nl, nr, phil, phir, max_depth, 2 * p)) +
+                      rounded(sinc_terms_general<2 * G>(y, nvalid, ylen, offset, nl, nr, phil, phir, max_depth, 2 * p + 1));
+            }
+        } else {
+            if (fast) acc = sinc_terms_fast<G>(y, offset + nr, offset + nl, phil, phir, max_depth);
+            else acc = sinc_terms_general<G>(y, nvalid, ylen, offset, nl, nr, phil, phir, max_depth);
+        }
     }
     const double total = group_sum<G>(acc);
     return summed ? total : special;
@@ -441,6 +503,10 @@ constexpr int GROUP_PATH_MIN_CAND = 32;         // pitch frames with more candid
 #define VBX_EXP_GROUP_KMAX 4                    // kmax from which frames with few candidates take the group path too
 #endif
 constexpr int RG = VBX_EXP_RG;                  // lanes per candidate on the group path of pitch_refine_store
+#ifndef VBX_EXP_DUAL_MIN_CAND
+#define VBX_EXP_DUAL_MIN_CAND 6
+#endif
+constexpr int DUAL_MIN_CAND = VBX_EXP_DUAL_MIN_CAND;   // unpruned frames with at least this many candidates: 8 groups, two lanes in one
 
 __device__ __forceinline__ void cand_from_peak(const double *ys, int kk, double sample_rate, int offset,
                                                double &freq, double &nn, const bool f32 = false) {
@@ -762,7 +828,10 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
 
     // a') first-evaluation bounds.  p16: prefix sums of |y| over blocks of PB; keys[c]: upper bound of candidate c's
     // strength, stored as a float rounded UP (still an upper bound; the whole frame then fits 12 wavefronts per CU)
-    {
+    // (not when nothing can be pruned -- the whole Vec, a list that never fills, T = f32: the candidates are then taken in
+    // index order, below)
+    const bool in_order = full != nullptr || kmax > ncand || f32;
+    if (!in_order) {
         // lane l owns the consecutive blocks [l*per, (l+1)*per): local sums, one scan over the lanes, prefix written back
         const int per = (nblk + 63) >> 6;
         double tot = 0.0;
@@ -852,11 +921,20 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
     // sinc terms (64 or 16 lanes): lists returned for kmax in {1, 2, 3} are bit for bit the head of one another, and so are
     // the lists for every kmax >= 4; between the two classes a candidate agrees within the Brent iteration's own scatter
     // (~1e-7 relative in Hz), counts and statuses exactly (tests/test_gpu_parity.py::test_pitch_topk_is_the_prefix...).
+    // Nothing can be pruned (in_order: the whole Vec, or fewer candidates than the caller keeps): every candidate is refined
+    // to the end whatever the others do, so the order is free, and it is the order of DESCENDING lag: a candidate at lag k sums 2 (k + 2) sinc terms per evaluation (:46-52 clamp the depth to
+    // the samples on its left), 160 .. 1,200 over the searched lags.  The four groups of a wavefront step through their
+    // evaluations together, so each round lasts as long as its longest sum: with neighbours in lag side by side the four
+    // sums are within a few per cent of one another (taken by bound, i.e. in no particular order of lag, the longest of four
+    // is ~1.45x the mean), and with the longest first the frame's tail -- groups idle because the list has run out -- is
+    // made of the shortest.
+    int next_full = ncand - 1;
     unsigned nterms = 0, nevals = 0;                // group path: work executed (group leaders' counts are summed)
+    int group_lanes = RG;
     if (ncand <= GROUP_PATH_MIN_CAND && !(kmax >= VBX_EXP_GROUP_KMAX && ncand >= 4)) {
         for (;;) {
             const double bar = VBX_BAR();
-            const int c = (kmax > ncand) ? pick_best(keys, ncand, bar, lane) : pick_best_pred(keys, cand_list, ys, ncand, bar, lane);
+            const int c = in_order ? next_full-- : pick_best_pred(keys, cand_list, ys, ncand, bar, lane);
             if (c < 0) break;
             double freq, nn, xmid, ymid;
             cand_from_peak(ys, cand_list[c], sample_rate, offset, freq, nn, f32);
@@ -878,23 +956,54 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
             insert(xm, ym, c);
         }
     } else {
+      // PG lanes per candidate; DUAL: each of them stands in for two lanes of a group of 2 PG (sinc_terms_fast_dual)
+      auto run_groups = [&](auto pg_tag, auto dual_tag) {
+        constexpr int PG = decltype(pg_tag)::value;
+        constexpr bool DUAL = decltype(dual_tag)::value;
         bool exhausted = false;
-        const int gid = lane / RG;
+        const int gid = lane / PG;
         int ci = -1, it = 0;
         bool special = false, safe = false, trusted = false;
         double ba = 0., bb = 0., v = 0., w = 0., x = 0., fv = 0., fw = 0., fx = 0., xmid = 0., ymid = 0.;
-        constexpr unsigned long long LEADERS = (RG == 16) ? 0x0001000100010001ull : (RG == 8) ? 0x0101010101010101ull
-                                             : (RG == 32) ? 0x0000000100000001ull : (RG == 4) ? 0x1111111111111111ull : 1ull;
+        constexpr unsigned long long LEADERS = (PG == 16) ? 0x0001000100010001ull : (PG == 8) ? 0x0101010101010101ull
+                                             : (PG == 32) ? 0x0000000100000001ull : (PG == 4) ? 0x1111111111111111ull : 1ull;
+        const double golden = 1. - 0.6180339887498948482045868343656381177203091798057628621;
+        const double sqrt_epsilon = 1.4901161193847656e-08, eps = 2.220446049250313e-16, tol = 1e-10;
         for (;;) {
 #pragma clang fp contract(off)   // the scalar Brent arithmetic stays bit-identical to the unfused CPU arithmetic
-            {   // hand the best remaining candidates to the idle groups, in group order
+            // 1. which groups' candidates have converged (:131-137)?  They enter the list and their groups take new candidates
+            // in the SAME round: a group never sits through a round of the others' sinc sums without one of its own.
+            bool finished = false;
+            double range = 0., middle_range = 0., tol_act = 0.;
+            if (ci >= 0) {
+                if (special) finished = true;
+                else if (it > 0) {
+                    range = bb - ba;
+                    middle_range = (ba + bb) * 0.5;
+                    tol_act = sqrt_epsilon * fabs(x) + tol / 3.;
+                    if (it > 60 || fabs(x - middle_range) + range * 0.5 <= 2. * tol_act) { finished = true; xmid = x; ymid = fx; }
+                }
+            }
+            if (__any(finished)) {                               // finished candidates -> sorted list
+                unsigned long long fm = __ballot(finished) & LEADERS;
+                double xm = xmid + (double)offset;                                // :445
+                double ym = ymid;
+                if (ym > 1.) ym = 1. / ym;                                        // :446
+                double cf = sample_rate / (f32 ? (double)(float)xm : xm), cs = ym;   // :447-448
+                if (f32) { cf = (double)(float)cf; cs = (double)(float)cs; }      // Pitch<f32>
+                while (fm) {
+                    const int ld = __builtin_ctzll(fm);
+                    fm &= fm - 1;
+                    insert(readlane_f64(cf, ld), readlane_f64(cs, ld), __builtin_amdgcn_readlane(ci, ld));
+                }
+                if (finished) ci = -1;
+            }
+            {   // 2. hand the next candidates to the idle groups, in group order
                 unsigned long long im = __ballot(ci < 0) & LEADERS;
                 while (im != 0ull && !exhausted) {
-                    // (the order only matters while a bar can rise: with kmax > ncand every candidate is refined to the end)
-                    const int c = (kmax > ncand) ? pick_best(keys, ncand, VBX_BAR(), lane)
-                                                 : pick_best_pred(keys, cand_list, ys, ncand, VBX_BAR(), lane);
+                    const int c = in_order ? next_full-- : pick_best_pred(keys, cand_list, ys, ncand, VBX_BAR(), lane);
                     if (c < 0) { exhausted = true; break; }
-                    const int g = __builtin_ctzll(im) / RG;
+                    const int g = __builtin_ctzll(im) / PG;
                     im &= im - 1ull;
                     if (gid == g) {
                         ci = c;
@@ -913,42 +1022,36 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
             if (!__any(ci >= 0)) break;
             const double bar = VBX_BAR();
 
-            const double golden = 1. - 0.6180339887498948482045868343656381177203091798057628621;
-            const double sqrt_epsilon = 1.4901161193847656e-08, eps = 2.220446049250313e-16, tol = 1e-10;
-            bool finished = false, need = false, pruned = false;
+            // 3. every group's next abscissa (:138-155; a candidate that came in above starts at the golden section, :114), the
+            // sinc sums of all groups together, and the bookkeeping of :157-186.  (A candidate of :193-194 takes no
+            // evaluation; it is entered in the next round's step 1.)
+            bool need = false;
             double t = 0.;
-            if (ci >= 0) {
-                if (special) finished = true;
-                else if (it == 0) { v = ba + golden * (bb - ba); t = v; need = true; }
+            if (ci >= 0 && !special) {
+                if (it == 0) { v = ba + golden * (bb - ba); t = v; }
                 else {
-                    const double range = bb - ba;
-                    const double middle_range = (ba + bb) * 0.5;
-                    const double tol_act = sqrt_epsilon * fabs(x) + tol / 3.;
-                    if (it > 60 || fabs(x - middle_range) + range * 0.5 <= 2. * tol_act) { finished = true; xmid = x; ymid = fx; }
-                    else {
-                        double new_step = (x < middle_range) ? golden * (bb - x) : golden * (ba - x);
-                        if (fabs(x - w) >= tol_act) {
-                            const double tt = (x - w) * (fx - fv);
-                            double q = (x - v) * (fx - fw);
-                            double pp = (x - v) * q - (x - w) * tt;
-                            q = 2. * q - tt;
-                            if (q > 0.) pp = -pp; else q = -q;
-                            if (fabs(pp) < fabs(new_step * q) && pp > q * (ba - x + 2. * tol_act) && pp < q * (bb - x - 2. * tol_act))
-                                new_step = pp / q;
-                        }
-                        if (fabs(new_step) < tol_act) new_step = (new_step > 0.) ? tol_act : -tol_act;
-                        t = x + new_step;
-                        need = true;
+                    double new_step = (x < middle_range) ? golden * (bb - x) : golden * (ba - x);
+                    if (fabs(x - w) >= tol_act) {
+                        const double tt = (x - w) * (fx - fv);
+                        double q = (x - v) * (fx - fw);
+                        double pp = (x - v) * q - (x - w) * tt;
+                        q = 2. * q - tt;
+                        if (q > 0.) pp = -pp; else q = -q;
+                        if (fabs(pp) < fabs(new_step * q) && pp > q * (ba - x + 2. * tol_act) && pp < q * (bb - x - 2. * tol_act))
+                            new_step = pp / q;
                     }
+                    if (fabs(new_step) < tol_act) new_step = (new_step > 0.) ? tol_act : -tol_act;
+                    t = x + new_step;
                 }
+                need = true;
             }
-            const double ft = sinc_interp<RG>(ys, nvalid, ylen, offset, nx, t, 1200, need, st, &nterms, trusted);
+            const double ft = sinc_interp<PG, DUAL>(ys, nvalid, ylen, offset, nx, t, 1200, need, st, &nterms, trusted);
             nevals += need ? 1u : 0u;
             if (need) {
                 if (it == 0) {
                     x = v; w = v; fv = ft; fx = ft; fw = ft; it = 1;
                     const double ub = (ft <= 1.) ? ft : 1.;          // NaN -> 1: never pruned
-                    if (ub < bar && safe) { finished = true; pruned = true; }
+                    if (ub < bar && safe) ci = -1;                   // pruned: it cannot be among the entries returned
                 } else {
                     if (ft <= fx) {
                         if (t < x) bb = x; else ba = x;
@@ -966,25 +1069,16 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
                     }
                     it++;
                     // the final strength is <= the current fx (:162): strictly below the bar it cannot be returned
-                    if (safe && fx < bar) { finished = true; pruned = true; }
+                    if (safe && fx < bar) ci = -1;
                 }
-            }
-            // finished candidates -> sorted list
-            if (__any(finished)) {
-                unsigned long long fm = __ballot(finished && !pruned) & LEADERS;
-                double xm = xmid + (double)offset;                                // :445
-                double ym = ymid;
-                if (ym > 1.) ym = 1. / ym;                                        // :446
-                double cf = sample_rate / (f32 ? (double)(float)xm : xm), cs = ym;   // :447-448
-                if (f32) { cf = (double)(float)cf; cs = (double)(float)cs; }      // Pitch<f32>
-                while (fm) {
-                    const int ld = __builtin_ctzll(fm);
-                    fm &= fm - 1;
-                    insert(readlane_f64(cf, ld), readlane_f64(cs, ld), __builtin_amdgcn_readlane(ci, ld));
-                }
-                if (finished) ci = -1;
             }
         }
+      };
+      // Nothing can be pruned and there are candidates for more than four groups: eight groups of RG / 2 lanes, each lane
+      // standing in for two -- bit for bit the sums of the RG-lane groups (so the lists of every kmax >= 4 stay the head of
+      // one another), with the bookkeeping of a round shared by eight candidates instead of four.
+      if (RG == 16 && in_order && ncand >= DUAL_MIN_CAND) { run_groups(std::integral_constant<int, RG / 2>{}, std::true_type{}); group_lanes = RG / 2; }
+      else run_groups(std::integral_constant<int, RG>{}, std::false_type{});
     }
 #undef VBX_BAR
     const int total_cand = ncand + 1;
@@ -1029,7 +1123,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
         if (status != nullptr) status[f] = code;
     }
     if (work != nullptr) {                          // profiling only: frames, candidates, sinc evaluations, sinc terms
-        const bool leader = (lane & (RG - 1)) == 0;
+        const bool leader = (lane & (group_lanes - 1)) == 0;
         unsigned long long te = leader ? nterms : 0u, ev = leader ? nevals : 0u;
         for (int o = 32; o > 0; o >>= 1) { te += __shfl_xor(te, o, 64); ev += __shfl_xor(ev, o, 64); }
         if (lane == 0) {
