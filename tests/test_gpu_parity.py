@@ -997,6 +997,40 @@ def test_pitch_fft_path_and_direct_path_agree(pkg, oracle, audio, monkeypatch, n
     assert not np.array_equal(A, B)                                                              # two kernels really ran
 
 
+@pytest.mark.parametrize("n,hop", [(2048, 1024), (4096, 2048), (3000, 1200), (1600, 640), (4000, 1000)])
+@pytest.mark.parametrize("kmax", [1, 8, 0])
+def test_pitch_cut_lag_curve_changes_nothing(vb, pkg, oracle, audio, monkeypatch, n, hop, kmax):
+    """The power-of-two FFT kernels keep only the lags the refinement can read (peak scan: [0, n/2]; sinc terms of candidates
+    that pass the frequency filter: < 2 sample_rate / fmin + 4) -- pitch_curve_entries, vbx_pitch_refine.hpp.  With
+    VBX_PITCH_CURVE_CUT=0 the whole curve is stored: every output must be BIT FOR BIT the same, for the settings that cut
+    (fmin 75 Hz), for an fmin just high enough to cut at all, and for one so low that nothing is cut.  kmax 0: the whole Vec."""
+    rng = np.random.default_rng(n + kmax)
+    F = pkg.frame_count(audio.size, n, hop)
+    w = oracle.window("hanning", n)
+    x = _frames(audio, n, hop, list(range(0, F, max(3, F // 150)))) * w
+    t = np.arange(n) / SR
+    odd = np.array([rng.standard_normal(n), np.sin(2 * np.pi * 76.0 * t), np.sin(2 * np.pi * 30.0 * t), np.sign(np.sin(2 * np.pi * 80 * t)),
+                    0.5 + 0.01 * rng.standard_normal(n)]) * w
+    X = np.concatenate([x, odd])
+    km = pkg.pitch_max_candidates(n) if kmax == 0 else kmax
+    fmin_edge = 2.0 * SR / (n - 40)                   # the reach 2 ceil(sr / fmin) + 16 just below n
+    res = {}
+    for name, val in (("cut", None), ("whole", "0")):
+        if val:
+            monkeypatch.setenv("VBX_PITCH_CURVE_CUT", val)
+        v = pkg.VoxBox(0)
+        if val:
+            monkeypatch.delenv("VBX_PITCH_CURVE_CUT")
+        try:
+            res[name] = [v.pitch(X, SR, 0.2, fmin, 600.0, kmax=km) for fmin in (75.0, fmin_edge, 20.0)]
+        finally:
+            v.close()
+    for (ca, ka, sa), (cb, kb, sb) in zip(res["cut"], res["whole"]):
+        assert np.array_equal(ka, kb) and np.array_equal(sa, sb) and np.array_equal(ca, cb)
+    if kmax == 8:
+        assert _check_pitch(vb, oracle, X[::4], SR, 0.2, 75.0, 600.0, 8, label=f"cut curve, N={n}") == 0
+
+
 def test_pitch_fft_path_defers_undecidable_frames(vb, oracle):
     """Frames whose strict 3-point peak test lies inside the transforms' rounding error (a lag curve that is exactly zero
     or flat over a stretch: a few impulses, a constant) are not decided by the FFT kernel: they are listed and redone by

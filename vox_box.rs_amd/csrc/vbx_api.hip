@@ -51,6 +51,7 @@ struct vbx_ctx {
     std::map<std::pair<size_t, int>, std::pair<double *, double *>> dft2_tabs;   // (n, n1) -> (stage-1 table, twiddles)
     std::map<std::tuple<size_t, int, int>, std::array<double *, 4>> mfma_tabs;   // (n, n1, k2) -> ctab, twd, twm, wm
     std::map<std::tuple<size_t, int, int>, std::pair<double *, double *>> czt_tabs;   // (n, top, L) -> (chirp, FFT of the chirp)
+    bool pitch_whole_curve = false;                       // VBX_PITCH_CURVE_CUT=0: the pow2 kernels keep every lag of the curve in LDS (tests)
     int mfcc_czt = -1;                                    // VBX_MFCC_CZT=0 / 1: never / wherever it fits (tests); -1: the measured choice
     std::map<std::tuple<size_t, size_t, double, double, double>, int32_t *> bins_cache;
     std::map<std::tuple<size_t, size_t, double, double, double>, double *> slopes_cache;   // [nb][2] i/up, i/down per bin
@@ -442,6 +443,7 @@ int vbx_ctx_create(vbx_ctx **out, int device, void *hip_stream) {
     { const char *e = std::getenv("VBX_MFCC_DFT2"); ctx->mfcc_force_dft2 = e && e[0] == '1'; }
     { const char *e = std::getenv("VBX_MFCC_MFMA"); ctx->mfcc_force_mfma = e && e[0] == '1'; }
     { const char *e = std::getenv("VBX_MFCC_CZT"); ctx->mfcc_czt = e ? (e[0] == '1' ? 1 : 0) : -1; }
+    { const char *e = std::getenv("VBX_PITCH_CURVE_CUT"); ctx->pitch_whole_curve = e != nullptr && e[0] == '0'; }
     { const char *e = std::getenv("VBX_PITCH_MFMA"); ctx->pitch_force_mfma = e && e[0] == '1'; }
     if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->owns_stream = false; }
     else {
@@ -772,6 +774,7 @@ static int run_pitch(vbx_ctx *ctx, hipStream_t st, const double *x, size_t n_fra
         if (rc != VBX_SUCCESS) return rc;
         L.x = x; L.F = (long)n_frames; L.stride = (long)stride; L.window = window; L.lag_window = lagw; L.tab = tab;
         L.sample_rate = sample_rate; L.threshold = threshold; L.fmin = fmin; L.fmax = fmax; L.kmax = (int)kmax;
+        L.whole_curve = ctx->pitch_whole_curve;
         L.out_cand = (pitch_t *)out_cand; L.cand_ld = (long)cand_ld; L.out_count = out_count; L.pitch_status = status;
         L.work = ctx->prof ? ctx->pitch_work : nullptr;
         return launch_spectral(ctx, st, L, "pitch");
@@ -1572,6 +1575,7 @@ static int analyze_frames_impl(vbx_ctx *ctx, const char *fn, const double *x, co
         L.sample_rate = h_p->sample_rate; L.threshold = h_p->pitch_threshold; L.fmin = h_p->pitch_fmin; L.fmax = h_p->pitch_fmax;
         L.kmax = 1;
         L.pcm = pcm_native;
+        L.whole_curve = ctx->pitch_whole_curve;
         L.out_cand = (pitch_t *)out_records; L.cand_ld = (long)record_ld; L.out_count = nullptr; L.pitch_status = st_pitch;
         L.work = ctx->prof ? ctx->pitch_work : nullptr;
         if (fused_lpc) { L.out_lpc = out_records + c_lpc; L.lpc_ld = (long)record_ld; }

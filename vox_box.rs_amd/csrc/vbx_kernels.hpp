@@ -159,6 +159,7 @@ struct spectral_launch_t {
     bool mfcc_only;                                              // MFCC::mfcc alone (n == the plan's Nc): no pitch, no LPC
     double *out_r; int n_lags;                                   // non-NULL: Autocorrelate::autocorrelate(n_lags) alone, [F, n_lags]
     bool pcm;                                                    // x points to int16 PCM samples (n == 1200 only)
+    bool whole_curve;                                            // keep every lag of the curve in LDS (VBX_PITCH_CURVE_CUT=0; tests)
 };
 bool spectral_supported(int n, int lpc_order, int mfcc_nb, int mfcc_b_lo, int num_coeffs);
 void launch_analyze(hipStream_t s, const spectral_launch_t &L);

@@ -730,11 +730,30 @@ __device__ __forceinline__ int pick_best_pred(float *keys, const cand_t *cand_li
 
 // LDS of the refinement, in this order from `ys`:  y[n + Y_PAD] | p16[nblk + 1 (+pad)] | keys[n/4 + 8] (float) |
 // candidate list (uint16).  pitch_refine_lds_doubles(n) is that footprint in doubles (rounded up).
-__host__ __device__ constexpr int pitch_refine_lds_bytes(int n) {
-    return (n + Y_PAD + ((((n + PB - 1) / PB) + 2) & ~1)) * 8 + (n / 4 + 8) * (int)(sizeof(float) + sizeof(cand_t));
+// nst: lags of the curve that are stored (pitch_curve_entries; 0 = all n)
+__host__ __device__ constexpr int pitch_refine_lds_bytes(int n, int nst = 0) {
+    const int m = (nst > 0) ? nst : n;
+    return (m + Y_PAD + ((((m + PB - 1) / PB) + 2) & ~1)) * 8 + (n / 4 + 8) * (int)(sizeof(float) + sizeof(cand_t));
 }
 
-struct pitch_params_t { double sample_rate, threshold, fmin, fmax; int kmax; int full_off; int f32 = 0; };   // full_off: byte offset of
+// How much of the lag curve the refinement can read, when that is less than all of it (0 = all n lags).  The peak scan looks
+// at lags [0, n/2] (src/periodic.rs:416-419).  A candidate passes the frequency filter (:439) with a parabolic lag below
+// sample_rate / fmin; its Brent bracket reaches one lag further, its sinc sum as deep as the samples on its left (:46-52):
+// the right-most lag of any term is < 2 sample_rate / fmin + 4.  (A candidate of :194 reads lag nx - 1 = n for an even n:
+// past the data, zero, like everything from the cut on.)  For long frames at speech settings this is half of the curve:
+// at 4,096 samples / 48 kHz / fmin 75 Hz lags [0, 2050), and the frame state in LDS shrinks from 46 KB to what the transform's
+// exchange buffer needs anyway (35 KB: four frames per CU instead of three); at 2,048 from 22.9 to 17.4 KB (eight per CU, 7).
+inline int pitch_curve_entries(int n, double sample_rate, double fmin) {
+    if ((n & 1) || !(fmin > 0.0) || !(sample_rate > 0.0)) return 0;          // an odd n reads its last lag (:194); NaN: all
+    const double reach = 2.0 * ceil(sample_rate / fmin) + 16.0;
+    if (!(reach < (double)n)) return 0;
+    int m = (int)reach;
+    if (m < n / 2 + 2) m = n / 2 + 2;
+    m = (m + 1) & ~1;
+    return (m < n) ? m : 0;
+}
+
+struct pitch_params_t { double sample_rate, threshold, fmin, fmax; int kmax; int full_off; int f32 = 0; int ncurve = 0; };   // full_off: byte offset of
                                                                                                 // the full-list region in the
                                                                                                 // dynamic LDS, 0 = none, < 0 =
                                                                                                 // the frame's output row
@@ -768,15 +787,16 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
     const double sample_rate = pp.sample_rate, threshold = pp.threshold, fmin = pp.fmin, fmax = pp.fmax;
     const int kmax = pp.kmax;
     const bool f32 = pp.f32 != 0;
-    const int nblk = (n + PB - 1) / PB;              // blocks of PB lags for the |y| prefix sums
-    double *p16 = ys + n + Y_PAD;
+    const int nst = (pp.ncurve > 0) ? pp.ncurve : n;   // lags stored (pitch_curve_entries): zeros from there on, as past n
+    const int nblk = (nst + PB - 1) / PB;            // blocks of PB lags for the |y| prefix sums
+    double *p16 = ys + nst + Y_PAD;
     float *keys = reinterpret_cast<float *>(p16 + ((nblk + 2) & ~1));
     cand_t *cand_list = reinterpret_cast<cand_t *>(keys + (n / 4 + 8));
     const int b = (int)floor(0.5 * (double)n);      // brent_ixmax, :414
     const int offset = -b - 1;                      // :429
     const int nx = b - offset;                      // :430
     const int ylen = 2 * n;                         // :411
-    const int nvalid = n + Y_PAD;
+    const int nvalid = nst + Y_PAD;
 
     // a) peaks -> filtered candidate list.  Two passes so that the two divisions of the frequency filter run once per
     // 64 PEAKS, not once per 64 lags: first every strict local maximum is compacted (index order), then the filter.

@@ -472,27 +472,28 @@ void analyze_pow2_kernel(const spectral_args_t a) {
     }
     const double scale = 1.0 / amax;                         // normalize (:404), then / lag window (:406-408)
     double *ys = smem;
+    const int nst = (a.pp.ncurve > 0) ? a.pp.ncurve : n;     // lags the refinement can read (pitch_curve_entries; even when < n)
     pow2_sync<W>();                                          // every thread is done with the exchange buffer
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const int i = 2 * jj[s];
-        if (i + 1 < n) {
+        if (i + 1 < nst) {
             const double2 lw = *reinterpret_cast<const double2 *>(a.lag_window + i);
             double2 y;
             y.x = (r_e[s] * scale) / lw.x;
             y.y = (r_o[s] * scale) / lw.y;
             *reinterpret_cast<double2 *>(ys + i) = y;
-        } else if (i < n) {                                  // the last lag of an odd n
+        } else if (i < nst) {                                // the last lag of an odd n
             ys[i] = (r_e[s] * scale) / a.lag_window[i];
         }
     }
-    if (tid < Y_PAD) ys[n + tid] = 0.0;
+    if (tid < Y_PAD) ys[nst + tid] = 0.0;
     if constexpr (W > 1) {
         __syncthreads();                                     // the curve is complete in LDS: the refinement is one wavefront's work
         if (wave != 0) return;
     }
 #ifndef VBX_EXP_NO_EXACT_TAIL
-    if (!FULL) spectral_exact_tail(ys, n, xf, a.window, a.lag_window, x0, scale, lane);
+    if (!FULL && nst == n) spectral_exact_tail(ys, n, xf, a.window, a.lag_window, x0, scale, lane);
 #endif
     wave_sync();
     const double unc_tol = SP_UNC_EPS * fabs(s0) * scale;
@@ -503,8 +504,8 @@ void analyze_pow2_kernel(const spectral_args_t a) {
 }
 
 template <int U, int W = 1>
-inline size_t pow2_lds_bytes(int n, int nb) {
-    size_t need = (size_t)pitch_refine_lds_bytes(n);
+inline size_t pow2_lds_bytes(int n, int nb, int nst = 0) {
+    size_t need = (size_t)pitch_refine_lds_bytes(n, nst);
     const size_t exch = (size_t)pow2_geom<U, W>::EX * sizeof(double);
     const size_t mel = (size_t)(2 * ((nb + 1) & ~1) + 64) * sizeof(double);
     if (exch > need) need = exch;
@@ -515,7 +516,8 @@ inline size_t pow2_lds_bytes(int n, int nb) {
 template <int U, int W = 1>
 void launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a) {
     const dim3 grid((unsigned)L.F), block(64 * W);
-    const size_t base = pow2_lds_bytes<U, W>(L.n, L.nb), extra = pitch_full_list_bytes(L.n, L.kmax);
+    a.pp.ncurve = (!L.whole_curve && L.out_r == nullptr && !L.mfcc_only) ? pitch_curve_entries(L.n, L.sample_rate, L.fmin) : 0;
+    const size_t base = pow2_lds_bytes<U, W>(L.n, L.nb, a.pp.ncurve), extra = pitch_full_list_bytes(L.n, L.kmax);
     a.pp.full_off = extra ? (int)base : 0;
     const size_t lds = base + extra;
     const size_t lds_mfcc = pow2_lds_bytes<U, W>(0, L.nb), lds_ac = pow2_lds_bytes<U, W>(0, 0);
