@@ -666,6 +666,25 @@ def test_pitch_topk_is_the_prefix_of_the_full_list(vb, oracle, audio, pkg, thr):
     assert _check_pitch(vb, oracle, x[::9], SR, thr, 75.0, 600.0, 8) == 0
 
 
+def test_roctx_ranges_do_not_change_results(pkg, oracle, audio, monkeypatch):
+    """VBX_ROCTX=1: every kernel group is also a roctx range (rocprofv3 --marker-trace shows which entry point a kernel belongs
+    to).  Without a profiler attached the ranges go nowhere; the outputs are the same bits."""
+    x = _frames(audio, N48, H48, list(range(0, 400, 7))) * oracle.window("hanning", N48)
+    res = []
+    for on in (False, True):
+        if on:
+            monkeypatch.setenv("VBX_ROCTX", "1")
+        v = pkg.VoxBox(0)
+        if on:
+            monkeypatch.delenv("VBX_ROCTX")
+        try:
+            res.append((v.pitch(x, SR, 0.2, 75.0, 600.0, kmax=4), v.mfcc(x, 13, (100.0, 8000.0), SR)))
+        finally:
+            v.close()
+    (pa, ma), (pb, mb) = res
+    assert all(np.array_equal(a, b) for a, b in zip(pa, pb)) and all(np.array_equal(a, b) for a, b in zip(ma, mb))
+
+
 def test_pitch_work_counters(vb, oracle, audio, pkg):
     """vbx_profile_pitch_work reports the work the refine kernel executed (bench.py's FP64 roofline uses it)."""
     F = pkg.frame_count(audio.size, N48, H48)

@@ -12,6 +12,7 @@
 #include <array>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
 #include <string>
 #include <tuple>
@@ -59,6 +60,10 @@ struct vbx_ctx {
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool prof = false;
+    // VBX_ROCTX=1: every kernel group of an entry point (the names vbx_profile_* reports) is also a roctx range, so that a
+    // `rocprofv3 --marker-trace --kernel-trace` timeline shows which call a kernel belongs to
+    int (*roctx_push)(const char *) = nullptr;
+    int (*roctx_pop)() = nullptr;
     std::vector<ProfRec> recs;
     std::map<std::string, std::pair<double, long>> prof_acc;
     double *spectral_tab[SPECTRAL_PLANS] = {};             // twiddles of k_spectral*.hip, by plan
@@ -111,10 +116,12 @@ int check_launch(vbx_ctx *ctx, const char *what) {
 struct Prof {
     vbx_ctx *ctx; const char *name; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
     Prof(vbx_ctx *c, const char *n, hipStream_t stream = nullptr) : ctx(c), name(n), st(stream ? stream : c->stream) {
+        if (ctx->roctx_push) ctx->roctx_push(name);
         if (ctx->prof) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, st); }
     }
     ~Prof() {
         if (ctx->prof) { hipEventRecord(b, st); ctx->recs.push_back({name, a, b, st}); }
+        if (ctx->roctx_pop) ctx->roctx_pop();
     }
 };
 
@@ -444,6 +451,15 @@ int vbx_ctx_create(vbx_ctx **out, int device, void *hip_stream) {
     { const char *e = std::getenv("VBX_MFCC_MFMA"); ctx->mfcc_force_mfma = e && e[0] == '1'; }
     { const char *e = std::getenv("VBX_MFCC_CZT"); ctx->mfcc_czt = e ? (e[0] == '1' ? 1 : 0) : -1; }
     { const char *e = std::getenv("VBX_PITCH_CURVE_CUT"); ctx->pitch_whole_curve = e != nullptr && e[0] == '0'; }
+    if (const char *e = std::getenv("VBX_ROCTX"); e != nullptr && e[0] == '1') {
+        void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h == nullptr) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h != nullptr) {
+            ctx->roctx_push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+            ctx->roctx_pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (ctx->roctx_push == nullptr || ctx->roctx_pop == nullptr) { ctx->roctx_push = nullptr; ctx->roctx_pop = nullptr; }
+        }
+    }
     { const char *e = std::getenv("VBX_PITCH_MFMA"); ctx->pitch_force_mfma = e && e[0] == '1'; }
     if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->owns_stream = false; }
     else {
