@@ -1097,7 +1097,12 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
       // Nothing can be pruned and there are candidates for more than four groups: eight groups of RG / 2 lanes, each lane
       // standing in for two -- bit for bit the sums of the RG-lane groups (so the lists of every kmax >= 4 stay the head of
       // one another), with the bookkeeping of a round shared by eight candidates instead of four.
-      if (RG == 16 && in_order && ncand >= DUAL_MIN_CAND) { run_groups(std::integral_constant<int, RG / 2>{}, std::true_type{}); group_lanes = RG / 2; }
+#ifdef VBX_EXP_DUAL_PRUNED
+      const bool dual_ok = ncand >= VBX_EXP_DUAL_PRUNED && kmax >= 8;
+#else
+      const bool dual_ok = in_order;
+#endif
+      if (RG == 16 && dual_ok && ncand >= DUAL_MIN_CAND) { run_groups(std::integral_constant<int, RG / 2>{}, std::true_type{}); group_lanes = RG / 2; }
       else run_groups(std::integral_constant<int, RG>{}, std::false_type{});
     }
 #undef VBX_BAR
