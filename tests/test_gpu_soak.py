@@ -244,6 +244,55 @@ def test_soak_reference_orders(vb, oracle, pkg, order, n, hop):
     assert not any(cls.values()), cls
 
 
+@pytest.mark.parametrize("n,hop,frames", [(1200, 480, 3000), (2048, 1024, 600), (4096, 2048, 300)])
+def test_soak_whole_vec(vb, oracle, pkg, n, hop, frames):
+    """The reference's literal return value -- the WHOLE sorted candidate Vec of every frame (src/periodic.rs:452-454) -- on
+    consecutive frames of the bench's recording (voiced glides and noise-only stretches: 10 to ~175 candidates per frame)
+    against the oracle: status and candidate COUNT exact; every candidate's frequency within 1e-4 relative (compared as sets
+    ordered by frequency: strengths closer than the Brent iteration's scatter may permute), strengths within 1e-4 except
+    "flips" (a refinement that ended on the other side of the integer-lag discontinuity: same frequency, other strength),
+    bounded at 1 per 1,000 candidates; the GPU's list sorted by descending strength.  This is the path of DESIGN section 3's
+    `refine` row, round 4: descending-lag order, eight groups per wavefront with two lanes in one (1200), and the cut lag
+    curve of the power-of-two kernels (2048, 4096)."""
+    from concurrent.futures import ThreadPoolExecutor
+    audio_d = vb.synth_speech((frames - 1) * hop + n, sample_offset=3 * 48000)
+    audio = audio_d.numpy()
+    win = vb.window(pkg.WINDOW_HANNING, n)
+    kfull = pkg.pitch_max_candidates(n)
+    cand, cnt, st = vb.pitch(audio_d, SR, 0.2, 75.0, 600.0, kmax=kfull, frame_len=n, stride=hop, n_frames=frames, window=win)
+    audio_d.free()
+    w = oracle.window("hanning", n)
+
+    def one(f):
+        return oracle.pitch(audio[f * hop:f * hop + n] * w, SR, 0.2, 75.0, 600.0)
+    try:
+        workers = max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        workers = 4
+    with ThreadPoolExecutor(workers) as ex:
+        exp = list(ex.map(one, range(frames)))
+    n_cand = n_flip = n_freq_bad = n_count_bad = n_order_bad = 0
+    for f, (es, ec, en) in enumerate(exp):
+        if st[f] != es or cnt[f] != (en if es == 0 else 0):
+            n_count_bad += 1
+            continue
+        if es != 0:
+            continue
+        g = cand[f, :en]
+        n_order_bad += int(np.any(np.diff(g[:, 1]) > 0.0)) + int(np.any(cand[f, en:] != 0.0))
+        g = g[np.argsort(g[:, 0], kind="stable")]
+        e = ec[np.argsort(ec[:, 0], kind="stable")]
+        n_freq_bad += int(np.sum(np.abs(g[:, 0] - e[:, 0]) > 1e-4 * np.abs(e[:, 0])))
+        n_flip += int(np.sum(np.abs(g[:, 1] - e[:, 1]) > 1e-4))
+        n_cand += en
+    cls = {"status_or_count": n_count_bad, "frequency": n_freq_bad, "order": n_order_bad, "strength_flips": n_flip}
+    REPORT["whole_vec_%d_%d" % (n, hop)] = {"frames": frames, "candidates": n_cand, "max_count": int(cnt.max()), "disagreements": cls}
+    print("\nsoak whole Vec at %d / %d: %d candidates," % (n, hop, n_cand), cls)
+    assert n_count_bad == 0 and n_freq_bad == 0 and n_order_bad == 0, cls
+    assert n_flip <= max(1, n_cand // 1000), cls
+    assert cnt.max() > 64                                  # the stretch holds frames that need the LDS-resident list
+
+
 def test_zz_soak_report():
     """Writes what the soak tests counted to gpurun_out/soak_report.json (copied to profiles/ by the builder)."""
     import json

@@ -1097,11 +1097,9 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
       // Nothing can be pruned and there are candidates for more than four groups: eight groups of RG / 2 lanes, each lane
       // standing in for two -- bit for bit the sums of the RG-lane groups (so the lists of every kmax >= 4 stay the head of
       // one another), with the bookkeeping of a round shared by eight candidates instead of four.
-#ifdef VBX_EXP_DUAL_PRUNED
-      const bool dual_ok = ncand >= VBX_EXP_DUAL_PRUNED && kmax >= 8;
-#else
-      const bool dual_ok = in_order;
-#endif
+      // (also where the bar can rise, from kmax = 8 and twelve candidates on: a few more evaluations are started on candidates
+      // the bar then retires, 248 -> 259 per frame at kmax = 8, and the rounds are still cheaper: 6.41 -> 6.50, kmax 64: 3.15 -> 3.28 M)
+      const bool dual_ok = in_order || (kmax >= 8 && ncand >= 12);
       if (RG == 16 && dual_ok && ncand >= DUAL_MIN_CAND) { run_groups(std::integral_constant<int, RG / 2>{}, std::true_type{}); group_lanes = RG / 2; }
       else run_groups(std::integral_constant<int, RG>{}, std::false_type{});
     }
