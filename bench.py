@@ -607,7 +607,9 @@ def run_rank(args):
         seg_all = None if UTT <= 0 else np.arange(0, world * F, UTT, dtype=np.int64)
         plan = pkg.shard_plan(world * F, world, rank, seg_all)
         lo, hi, warm = plan.lo, plan.hi, plan.warm
-        assert hi - lo == F
+        if hi - lo != F:         # a cut that moved to a nearby utterance start (vbx_shard_range): shards of unequal length
+            raise SystemExit(f"bench.py: --utterance-frames {UTT} moves the shard cuts ({hi - lo} frames on rank {rank}, not {F}); "
+                             "weak scaling wants equal shards: pass a length that divides the per-GPU frame count, or 0")
         seg = pkg.shard_local_segments(plan, seg_all)                         # utterance starts of frames [lo - warm, hi)
         s0, s1 = pkg.shard_samples(lo - warm, hi, N, H)                       # includes the frame_len - hop halo
     else:

@@ -855,7 +855,8 @@ def test_mfcc_four_kernels_agree(pkg, oracle, audio, monkeypatch):
 @pytest.mark.parametrize("n,k,lo,hi,sr", [(1103, 13, 100.0, 8000.0, 44100.0), (3000, 13, 100.0, 8000.0, 48000.0), (2500, 13, 100.0, 8000.0, 48000.0),
                                           (997, 20, 50.0, 6000.0, 22050.0), (2049, 26, 133.0, 6855.0, 22050.0), (3301, 13, 100.0, 8000.0, 48000.0),
                                           (601, 13, 100.0, 8000.0, 48000.0), (1200, 13, 100.0, 8000.0, 48000.0), (700, 40, 0.0, 10000.0, 48000.0),
-                                          (64, 5, 300.0, 3000.0, 8000.0), (1601, 64, 0.0, 8000.0, 16000.0)])
+                                          (64, 5, 300.0, 3000.0, 8000.0), (1601, 64, 0.0, 8000.0, 16000.0),
+                                          (4000, 13, 100.0, 8000.0, 48000.0), (3601, 13, 100.0, 8000.0, 44100.0), (4095, 20, 0.0, 11000.0, 48000.0)])
 def test_mfcc_chirp_z_kernel(pkg, oracle, audio, monkeypatch, n, k, lo, hi, sr):
     """Frame lengths with no transform and no matrix-core factorisation of their own (1103 = 25 ms at 44.1 kHz is prime; 2500 and
     3000 need more bins than the two-stage kernel's tiles hold) take the chirp-z kernel (k_mfcc_czt.hip) by default;
@@ -880,10 +881,42 @@ def test_mfcc_chirp_z_kernel(pkg, oracle, audio, monkeypatch, n, k, lo, hi, sr):
             assert np.all(rel_close(res[mode][0][f], em, 1e-6)), (mode, f, np.max(np.abs(res[mode][0][f] - em)))
     if n != 1200:                                              # (a frame that IS a transform's keeps the FFT kernel either way)
         assert not np.array_equal(res["1"][0], res["0"][0])
-    if n in (1103, 3000, 2500, 997, 2049, 3301, 601):
+    if n in (1103, 3000, 2500, 997, 2049, 3301, 601, 4000, 3601, 4095):   # (the last three: too long for one transform, split in two)
         assert np.array_equal(res[None][0], res["1"][0])       # the default IS the chirp-z kernel here
     if n in (1200, 64):
         assert np.array_equal(res[None][0], res["0"][0])       # ... and is not here (its own transform; too short)
+
+
+@pytest.mark.parametrize("n,k,lo,hi,sr", [(1103, 13, 100.0, 8000.0, 44100.0), (997, 20, 50.0, 6000.0, 22050.0), (2500, 13, 100.0, 8000.0, 48000.0),
+                                          (64, 5, 300.0, 3000.0, 8000.0), (1601, 64, 0.0, 8000.0, 16000.0), (4000, 13, 100.0, 8000.0, 48000.0)])
+def test_mfcc_chirp_z_split_in_two_blocks(pkg, oracle, audio, monkeypatch, n, k, lo, hi, sr):
+    """A frame too long for one transform (frame_len + top_bin - 1 > 4096) goes through the chirp-z kernel in two halves, each
+    convolved with its own segment of the chirp, the complex results summed before the magnitude (vbx_mfcc_czt.hpp).
+    VBX_MFCC_CZT_SPLIT=1 takes that form wherever it fits -- odd lengths (halves of unequal length), short ones, many
+    coefficients: against the oracle at the MFCC tolerance, and against the one-block form within 1e-9 (same bins, another
+    summation)."""
+    x = _frames(audio, n, 977, range(0, 40, 4)) * oracle.window("hanning", n) * 40.0
+    res = {}
+    for name, split in (("one", None), ("two", "1")):
+        monkeypatch.setenv("VBX_MFCC_CZT", "1")
+        if split:
+            monkeypatch.setenv("VBX_MFCC_CZT_SPLIT", split)
+        v = pkg.VoxBox(0)
+        monkeypatch.delenv("VBX_MFCC_CZT")
+        if split:
+            monkeypatch.delenv("VBX_MFCC_CZT_SPLIT")
+        try:
+            res[name] = v.mfcc(x, k, (lo, hi), sr)
+        finally:
+            v.close()
+    for f in range(x.shape[0]):
+        es, em = oracle.mfcc(x[f], k, lo, hi, sr)
+        for name in res:
+            assert res[name][1][f] == es
+            assert np.all(rel_close(res[name][0][f], em, 1e-6)), (name, f, np.max(np.abs(res[name][0][f] - em)))
+    assert np.all(rel_close(res["one"][0], res["two"][0], 1e-9))
+    if n in (1103, 997, 2500):                                 # (4000 is split either way; 64 and 1601: top_bin > frame_len / 2, no split)
+        assert not np.array_equal(res["one"][0], res["two"][0])
 
 
 def test_mfcc_and_formants_odd_signals(vb, oracle):

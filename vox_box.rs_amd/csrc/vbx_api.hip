@@ -53,6 +53,7 @@ struct vbx_ctx {
     std::map<std::tuple<size_t, int, int>, std::array<double *, 4>> mfma_tabs;   // (n, n1, k2) -> ctab, twd, twm, wm
     std::map<std::tuple<size_t, int, int>, std::pair<double *, double *>> czt_tabs;   // (n, top, L) -> (chirp, FFT of the chirp)
     bool pitch_whole_curve = false;                       // VBX_PITCH_CURVE_CUT=0: the pow2 kernels keep every lag of the curve in LDS (tests)
+    bool mfcc_czt_split = false;                          // VBX_MFCC_CZT_SPLIT=1: the two-block form of the chirp-z kernel wherever it fits (tests)
     int mfcc_czt = -1;                                    // VBX_MFCC_CZT=0 / 1: never / wherever it fits (tests); -1: the measured choice
     std::map<std::tuple<size_t, size_t, double, double, double>, int32_t *> bins_cache;
     std::map<std::tuple<size_t, size_t, double, double, double>, double *> slopes_cache;   // [nb][2] i/up, i/down per bin
@@ -271,12 +272,13 @@ int get_mfcc_mfma_dev(vbx_ctx *ctx, size_t n, const mfcc_mplan_t &pl, const doub
 }
 
 // tables of the chirp-z MFCC kernel (k_mfcc_czt.hip)
-int get_czt_dev(vbx_ctx *ctx, size_t n, int top, int L, const double **chirp, const double **bhat) {
-    auto key = std::make_tuple(n, top, L);
+int get_czt_dev(vbx_ctx *ctx, size_t n, int top, int L, int n1, const double **chirp, const double **bhat) {
+    auto key = std::make_tuple(n, top, L + 8192 * n1);     // (L <= 4096: the split length rides in the same key field)
     auto it = ctx->czt_tabs.find(key);
     if (it == ctx->czt_tabs.end()) {
-        std::vector<double> hc(2 * n), hb(2 * (size_t)L);
-        mfcc_czt_fill_tabs((int)n, top, L, hc.data(), hb.data());
+        const size_t nblk = (n1 > 0 && (size_t)n1 < n) ? (n + n1 - 1) / n1 : 1;
+        std::vector<double> hc(2 * n), hb(2 * (size_t)L * nblk);
+        mfcc_czt_fill_tabs((int)n, top, L, n1, hc.data(), hb.data());
         double *dc = nullptr, *db = nullptr;
         VBX_HIP(ctx, hipMalloc((void **)&dc, hc.size() * sizeof(double)));
         VBX_HIP(ctx, hipMalloc((void **)&db, hb.size() * sizeof(double)));
@@ -450,6 +452,7 @@ int vbx_ctx_create(vbx_ctx **out, int device, void *hip_stream) {
     { const char *e = std::getenv("VBX_MFCC_DFT2"); ctx->mfcc_force_dft2 = e && e[0] == '1'; }
     { const char *e = std::getenv("VBX_MFCC_MFMA"); ctx->mfcc_force_mfma = e && e[0] == '1'; }
     { const char *e = std::getenv("VBX_MFCC_CZT"); ctx->mfcc_czt = e ? (e[0] == '1' ? 1 : 0) : -1; }
+    { const char *e = std::getenv("VBX_MFCC_CZT_SPLIT"); ctx->mfcc_czt_split = e != nullptr && e[0] == '1'; }
     { const char *e = std::getenv("VBX_PITCH_CURVE_CUT"); ctx->pitch_whole_curve = e != nullptr && e[0] == '0'; }
     if (const char *e = std::getenv("VBX_ROCTX"); e != nullptr && e[0] == '1') {
         void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
@@ -1304,12 +1307,21 @@ static int run_mfcc(vbx_ctx *ctx, hipStream_t stm, const double *x, size_t n_fra
     // pipeline, M frames/s: 1103: 28.9 -> 61.9 / 15.2 -> 20.3; 2500: 7.4 -> 15.0 / 3.2 -> 4.0; 3000: 2.8 -> 15.2 / 1.8 -> 3.9.
     // Where the matrix-core kernel has a plan it stays (1000, 1102, 1800: it is the faster one; 1500, 1600: within 5 %).
     const int czt_top = hb.back();
-    const int czt_plan = (nb >= 1 && hb.front() >= 0 && num_coeffs <= 64) ? mfcc_czt_plan((int)frame_len, czt_top) : SPECTRAL_PLAN_NONE;
+    int czt_plan = (nb >= 1 && hb.front() >= 0 && num_coeffs <= 64) ? mfcc_czt_plan((int)frame_len, czt_top) : SPECTRAL_PLAN_NONE;
+    // too long for one transform (frame_len + top - 1 > 4096: 3,431..4,095 samples at these settings), or VBX_MFCC_CZT_SPLIT=1
+    // (tests): the frame in two halves, each with its own chirp segment, the complex results summed (vbx_mfcc_czt.hpp) -- four
+    // 4096-point transforms per frame instead of frame_len x bins products (pipeline at 4000 / 2000: 1.4 -> M frames/s)
+    int czt_n1 = 0;
+    if (nb >= 1 && hb.front() >= 0 && num_coeffs <= 64 && (czt_plan == SPECTRAL_PLAN_NONE || ctx->mfcc_czt_split)) {
+        int n1 = 0;
+        const int p2 = mfcc_czt_split_plan((int)frame_len, czt_top, &n1);
+        if (p2 != SPECTRAL_PLAN_NONE) { czt_plan = p2; czt_n1 = n1; }
+    }
     // ... and from 1400 samples up to what the 2048-point transform holds, where the matrix-core kernel HAS a plan: inside the
     // pipeline its 512-thread workgroups with ~100 KB of LDS keep the analyze kernel's wavefronts out, the chirp-z kernel's
     // one-wavefront workgroups interleave with them (pipeline at 1500 / 1600 samples: 15.6 -> 16.2, 15.1 -> 16.8 M frames/s;
     // below 1400 and on the 4096-point transform the matrix-core kernel wins: 1280: 19.6 against 17.6, 1800: 14.8 against 12.5)
-    const bool czt_over_mfma = mp.ok && czt_plan == SPECTRAL_PLAN_2048 && frame_len >= 1400 && ctx->mfcc_czt == -1 &&
+    const bool czt_over_mfma = mp.ok && czt_plan == SPECTRAL_PLAN_2048 && czt_n1 == 0 && frame_len >= 1400 && ctx->mfcc_czt == -1 &&
                                !(ctx->mfcc_force_goertzel || ctx->mfcc_force_dft2 || ctx->mfcc_force_mfma);
     if (!mp.ok || czt_over_mfma) {
         const int top = czt_top;
@@ -1320,11 +1332,11 @@ static int run_mfcc(vbx_ctx *ctx, hipStream_t stm, const double *x, size_t n_fra
         if (cplan != SPECTRAL_PLAN_NONE && want) {
             const double *tab = nullptr, *chirp = nullptr, *bhat = nullptr;
             rc = get_spectral_tab(ctx, cplan, &tab); if (rc != VBX_SUCCESS) return rc;
-            rc = get_czt_dev(ctx, frame_len, top, spectral_plan_nc(cplan), &chirp, &bhat); if (rc != VBX_SUCCESS) return rc;
+            rc = get_czt_dev(ctx, frame_len, top, spectral_plan_nc(cplan), czt_n1, &chirp, &bhat); if (rc != VBX_SUCCESS) return rc;
             void *cw = nullptr;
-            rc = ws_get(ctx, vbx_ctx::WS_CZT, 2 * (size_t)spectral_plan_nc(cplan) * sizeof(double), &cw); if (rc != VBX_SUCCESS) return rc;
+            rc = ws_get(ctx, vbx_ctx::WS_CZT, (czt_n1 ? 4 : 2) * (size_t)spectral_plan_nc(cplan) * sizeof(double), &cw); if (rc != VBX_SUCCESS) return rc;
             { Prof p(ctx, "mfcc", stm);
-              launch_mfcc_czt(stm, cplan, x, (long)n_frames, (int)frame_len, (long)stride, window, tab, chirp, bhat, d_bins, slopes, dct,
+              launch_mfcc_czt(stm, cplan, x, (long)n_frames, (int)frame_len, czt_n1, (long)stride, window, tab, chirp, bhat, d_bins, slopes, dct,
                               (int)num_coeffs, nb, out, (long)out_ld, status, (double *)cw); }
             return check_launch(ctx, "vbx_mfcc_f64");
         }

@@ -207,12 +207,16 @@ void launch_mfcc(hipStream_t s, const double *x, long F, int n, long stride, con
                  const double *slopes /* [nb][2] */, const double *dct_table /* [K][K] */,
                  int num_coeffs, double *out, long out_ld, int32_t *status, int nb /* bins[K+1]-bins[0] */);
 // k_mfcc_czt.hip: the needed bins of the n-point DFT by the chirp-z identity on the power-of-two FFT (any n with
-// n + top - 1 <= 4096: frame lengths that are not a transform's and do not divide one)
+// n + top - 1 <= 4096: frame lengths that are not a transform's and do not divide one; longer ones up to 4096 samples split
+// into two blocks of n1 samples whose complex results add up, n1 + top - 1 <= 4096)
 int mfcc_czt_plan(int n, int top /* b_lo + nb */);              // SPECTRAL_PLAN_1024 / _2048 / _4096, or SPECTRAL_PLAN_NONE
-void mfcc_czt_fill_tabs(int n, int top, int L, double *h_chirp /* [2 n] */, double *h_bhat /* [2 L] */);
-void launch_mfcc_czt(hipStream_t s, int plan, const double *x, long F, int n, long stride, const double *window,
+int mfcc_czt_split_plan(int n, int top, int *n1);               // the same for a frame split in two (n1 = samples per block)
+// n1 <= 0 or >= n: one block, h_bhat [2 L]; else ceil(n / n1) blocks, h_bhat [blocks][2 L]
+void mfcc_czt_fill_tabs(int n, int top, int L, int n1, double *h_chirp /* [2 n] */, double *h_bhat);
+void launch_mfcc_czt(hipStream_t s, int plan, const double *x, long F, int n, int n1, long stride, const double *window,
                      const double *tab /* the plan's twiddles */, const double *chirp, const double *bhat, const int32_t *bins,
-                     const double *slopes, const double *dct, int num_coeffs, int nb, double *out, long out_ld, int32_t *status, double *cw_scratch);
+                     const double *slopes, const double *dct, int num_coeffs, int nb, double *out, long out_ld, int32_t *status,
+                     double *cw_scratch /* [blocks][2 L] */);
 void launch_fill_rows(hipStream_t s, double *out, long rows, int n, long ld, double value, int32_t *status, int32_t code);
 void launch_dct_rows(hipStream_t s, const double *in, long rows, int n, const double *dct_table, double *out);
 
