@@ -546,7 +546,7 @@ def sub_benchmarks(vb, torch, dev, pkg, audio48, F48):
 
 
 PIPELINE_SHAPES = ((400, 160), (512, 256), (600, 240), (800, 320), (1024, 512), (1102, 441), (1103, 441), (1200, 480), (1600, 640),
-                   (2048, 1024), (3000, 1200), (4096, 2048))
+                   (2048, 1024), (3000, 1200), (4000, 2000), (4096, 2048))
 
 
 def pipeline_shapes(vb, torch, dev, pkg, audio48, hours=1.0, shapes=PIPELINE_SHAPES):

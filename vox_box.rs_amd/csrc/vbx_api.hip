@@ -1310,7 +1310,7 @@ static int run_mfcc(vbx_ctx *ctx, hipStream_t stm, const double *x, size_t n_fra
     int czt_plan = (nb >= 1 && hb.front() >= 0 && num_coeffs <= 64) ? mfcc_czt_plan((int)frame_len, czt_top) : SPECTRAL_PLAN_NONE;
     // too long for one transform (frame_len + top - 1 > 4096: 3,431..4,095 samples at these settings), or VBX_MFCC_CZT_SPLIT=1
     // (tests): the frame in two halves, each with its own chirp segment, the complex results summed (vbx_mfcc_czt.hpp) -- four
-    // 4096-point transforms per frame instead of frame_len x bins products (pipeline at 4000 / 2000: 1.4 -> M frames/s)
+    // 4096-point transforms per frame instead of frame_len x bins products (pipeline at 4000 / 2000: 1.4 -> 5.7 M frames/s)
     int czt_n1 = 0;
     if (nb >= 1 && hb.front() >= 0 && num_coeffs <= 64 && (czt_plan == SPECTRAL_PLAN_NONE || ctx->mfcc_czt_split)) {
         int n1 = 0;
