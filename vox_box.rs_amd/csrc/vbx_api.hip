@@ -51,7 +51,7 @@ struct vbx_ctx {
     std::map<size_t, double *> dct_tables;                // K -> [K][K]
     std::map<std::pair<size_t, int>, std::pair<double *, double *>> dft2_tabs;   // (n, n1) -> (stage-1 table, twiddles)
     std::map<std::tuple<size_t, int, int>, std::array<double *, 4>> mfma_tabs;   // (n, n1, k2) -> ctab, twd, twm, wm
-    std::map<std::tuple<size_t, int, int>, std::pair<double *, double *>> czt_tabs;   // (n, top, L) -> (chirp, FFT of the chirp)
+    std::map<std::tuple<size_t, int, int, int>, std::pair<double *, double *>> czt_tabs;   // (n, top, L, split length or 0) -> (chirp, FFT of the chirp segment(s))
     bool pitch_whole_curve = false;                       // VBX_PITCH_CURVE_CUT=0: the pow2 kernels keep every lag of the curve in LDS (tests)
     bool mfcc_czt_split = false;                          // VBX_MFCC_CZT_SPLIT=1: the two-block form of the chirp-z kernel wherever it fits (tests)
     int mfcc_czt = -1;                                    // VBX_MFCC_CZT=0 / 1: never / wherever it fits (tests); -1: the measured choice
@@ -273,7 +273,7 @@ int get_mfcc_mfma_dev(vbx_ctx *ctx, size_t n, const mfcc_mplan_t &pl, const doub
 
 // tables of the chirp-z MFCC kernel (k_mfcc_czt.hip)
 int get_czt_dev(vbx_ctx *ctx, size_t n, int top, int L, int n1, const double **chirp, const double **bhat) {
-    auto key = std::make_tuple(n, top, L + 8192 * n1);     // (L <= 4096: the split length rides in the same key field)
+    auto key = std::make_tuple(n, top, L, n1);
     auto it = ctx->czt_tabs.find(key);
     if (it == ctx->czt_tabs.end()) {
         const size_t nblk = (n1 > 0 && (size_t)n1 < n) ? (n + n1 - 1) / n1 : 1;
