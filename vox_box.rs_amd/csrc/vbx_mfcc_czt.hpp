@@ -61,80 +61,80 @@ void mfcc_czt_kernel(const double *x, long n_frames, int n, int n1, int nblk, lo
     // buffer, touched by its owner alone.
     double xr[TQ][R], xi[TQ][R];
     for (int blk = 0; blk < (SPLIT ? nblk : 1); blk++) {
-    const int s_b = blk * n1;
-    const int n_b = (n - s_b < n1) ? n - s_b : n1;
-    const double2 *cwb = chirp + (long)blk * NC;
-    const double2 *bh = bhat + (long)blk * NC;
-    // (the twiddle table's address is opaque in every pass: as loop-invariant loads its entries would be hoisted out of the
-    // block loop and held in registers across both transforms -- 100 registers spilled against none)
-    const double2 *tabb = tab;
-    if constexpr (SPLIT) asm volatile("" : "+s"(tabb));
-    // a_j = x_{s_b + j} * cw_j in the transform's stage-1 layout (lane l, unit u, slot q holds index 16R q + l + 64 u); cw = the
-    // caller's window times conj(w), folded once per call (czt_fold_kernel): three doubles in flight per sample, not four
-    double re[U][16], im[U][16];
+        const int s_b = blk * n1;
+        const int n_b = (n - s_b < n1) ? n - s_b : n1;
+        const double2 *cwb = chirp + (long)blk * NC;
+        const double2 *bh = bhat + (long)blk * NC;
+        // (the twiddle table's address is opaque in every pass: as loop-invariant loads its entries would be hoisted out of the
+        // block loop and held in registers across both transforms -- 100 registers spilled against none)
+        const double2 *tabb = tab;
+        if constexpr (SPLIT) asm volatile("" : "+s"(tabb));
+        // a_j = x_{s_b + j} * cw_j in the transform's stage-1 layout (lane l, unit u, slot q holds index 16R q + l + 64 u); cw = the
+        // caller's window times conj(w), folded once per call (czt_fold_kernel): three doubles in flight per sample, not four
+        double re[U][16], im[U][16];
 #pragma unroll
-    for (int u = 0; u < U; u++)
+        for (int u = 0; u < U; u++)
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            double v[8]; double2 c[8];
+            for (int h = 0; h < 2; h++) {
+                double v[8]; double2 c[8];
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int i = 16 * R * (8 * h + q) + tid + NT * u;
-                v[q] = xf[s_b + ((i < n_b) ? i : n_b - 1)];
-                c[q] = cwb[i];
+                for (int q = 0; q < 8; q++) {
+                    const int i = 16 * R * (8 * h + q) + tid + NT * u;
+                    v[q] = xf[s_b + ((i < n_b) ? i : n_b - 1)];
+                    c[q] = cwb[i];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) { re[u][8 * h + q] = v[q] * c[q].x; im[u][8 * h + q] = v[q] * c[q].y; }
             }
-#pragma unroll
-            for (int q = 0; q < 8; q++) { re[u][8 * h + q] = v[q] * c[q].x; im[u][8 * h + q] = v[q] * c[q].y; }
-        }
-    fft_pow2<U, W>(re, im, xr, xi, ex, tabb);
+        fft_pow2<U, W>(re, im, xr, xi, ex, tabb);
 
-    // times FFT_L(chirp), conjugated for the inverse, back to the stage-1 layout through the exchange buffer: the real parts,
-    // then the imaginary parts (the table is read again rather than kept: registers)
+        // times FFT_L(chirp), conjugated for the inverse, back to the stage-1 layout through the exchange buffer: the real parts,
+        // then the imaginary parts (the table is read again rather than kept: registers)
 #pragma unroll
-    for (int t = 0; t < TQ; t++) {
-#pragma unroll
-        for (int kc = 0; kc < R; kc++) {
-            const int k = tid + NT * t + 256 * kc;
-            const double2 b = bh[k];
-            ex[k] = fma(xr[t][kc], b.x, -(xi[t][kc] * b.y));
-        }
-    }
-    pow2_sync<W>();
-#pragma unroll
-    for (int u = 0; u < U; u++)
-#pragma unroll
-        for (int q = 0; q < 16; q++) re[u][q] = ex[16 * R * q + tid + NT * u];
-    pow2_sync<W>();
-#pragma unroll
-    for (int t = 0; t < TQ; t++) {
-#pragma unroll
-        for (int kc = 0; kc < R; kc++) {
-            const int k = tid + NT * t + 256 * kc;
-            const double2 b = bh[k];
-            ex[k] = -fma(xr[t][kc], b.y, xi[t][kc] * b.x);
-        }
-    }
-    pow2_sync<W>();
-#pragma unroll
-    for (int u = 0; u < U; u++)
-#pragma unroll
-        for (int q = 0; q < 16; q++) im[u][q] = ex[16 * R * q + tid + NT * u];
-    pow2_sync<W>();
-    fft_pow2<U, W>(re, im, xr, xi, ex, tabb);                // = conj(L * conv): |conv[k]|^2 = (xr^2 + xi^2) / L^2
-    if constexpr (SPLIT) {
-        const int b_lo = bins[0];
-        double *accr = smem + G::EX, *acci = accr + ((nb + 1) & ~1);
-#pragma unroll
-        for (int t = 0; t < TQ; t++)
+        for (int t = 0; t < TQ; t++) {
 #pragma unroll
             for (int kc = 0; kc < R; kc++) {
-                const int b1 = tid + NT * t + 256 * kc - b_lo;
-                if (b1 >= 0 && b1 < nb) {
-                    if (blk > 0) { xr[t][kc] += accr[b1]; xi[t][kc] += acci[b1]; }
-                    if (blk + 1 < nblk) { accr[b1] = xr[t][kc]; acci[b1] = xi[t][kc]; }
-                }
+                const int k = tid + NT * t + 256 * kc;
+                const double2 b = bh[k];
+                ex[k] = fma(xr[t][kc], b.x, -(xi[t][kc] * b.y));
             }
-    }
+        }
+        pow2_sync<W>();
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) re[u][q] = ex[16 * R * q + tid + NT * u];
+        pow2_sync<W>();
+#pragma unroll
+        for (int t = 0; t < TQ; t++) {
+#pragma unroll
+            for (int kc = 0; kc < R; kc++) {
+                const int k = tid + NT * t + 256 * kc;
+                const double2 b = bh[k];
+                ex[k] = -fma(xr[t][kc], b.y, xi[t][kc] * b.x);
+            }
+        }
+        pow2_sync<W>();
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) im[u][q] = ex[16 * R * q + tid + NT * u];
+        pow2_sync<W>();
+        fft_pow2<U, W>(re, im, xr, xi, ex, tabb);                // = conj(L * conv): |conv[k]|^2 = (xr^2 + xi^2) / L^2
+        if constexpr (SPLIT) {
+            const int b_lo = bins[0];
+            double *accr = smem + G::EX, *acci = accr + ((nb + 1) & ~1);
+#pragma unroll
+            for (int t = 0; t < TQ; t++)
+#pragma unroll
+                for (int kc = 0; kc < R; kc++) {
+                    const int b1 = tid + NT * t + 256 * kc - b_lo;
+                    if (b1 >= 0 && b1 < nb) {
+                        if (blk > 0) { xr[t][kc] += accr[b1]; xi[t][kc] += acci[b1]; }
+                        if (blk + 1 < nblk) { accr[b1] = xr[t][kc]; acci[b1] = xi[t][kc]; }
+                    }
+                }
+        }
     }
 
     const int b_lo = bins[0];
