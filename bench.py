@@ -573,6 +573,38 @@ def pipeline_shapes(vb, torch, dev, pkg, audio48, hours=1.0, shapes=PIPELINE_SHA
     return rows
 
 
+def cross_rank_check(vb, torch, dev, pkg, params, REC, rows_all, frame_len, stride, cuts, reach=4096, settle=1024):
+    """Rank 0, after the timed steps, outside the timed region: the frames on either side of every shard cut, analysed AGAIN on
+    this GPU alone as one stretch of the recording, against the rows the ranks produced and the gather delivered.  The stretch
+    starts `reach` frames before the cut; its own tracker has forgotten its start long before `settle` frames (64 suffice
+    almost always), so rows [cut - reach + settle, cut + reach) must be BIT FOR BIT the gathered ones -- every column: pitch,
+    LPC, MFCC (per-frame) and the formant tracks (carried across the cut by warm-up + state hand-off).  Returns counts; never
+    raises (a failure of the CHECK must not cost the measurement)."""
+    out = {"cuts": [int(c) for c in cuts], "rows_compared": 0, "rows_different": 0}
+    try:
+        total = int(rows_all.shape[0])
+        for c in cuts:
+            lo, hi = max(0, int(c) - reach), min(total, int(c) + reach)
+            ns = (hi - lo - 1) * stride + frame_len
+            a = torch.empty(ns, dtype=torch.float64, device=dev)
+            vb.synth_speech(ns, sample_offset=lo * stride, sample_rate=SR, out=a)
+            r = torch.empty((hi - lo, REC), dtype=torch.float64, device=dev)
+            st = torch.empty((3, hi - lo), dtype=torch.int32, device=dev)
+            vb.analyze_frames(a, params, frame_len=frame_len, stride=stride, n_frames=hi - lo, out=r, record_ld=REC, status=st)
+            vb.sync()
+            first = 0 if lo == 0 else settle
+            mine, theirs = r[first:], rows_all[lo + first:hi]
+            # bit patterns, not values: NaN == NaN, -0.0 != 0.0
+            diff = (mine.view(torch.int64) != theirs.view(torch.int64)).any(dim=1)
+            out["rows_compared"] += int(diff.numel())
+            out["rows_different"] += int(diff.sum().item())
+            del a, r, st
+        out["verdict"] = "bit-identical" if out["rows_different"] == 0 else "DIFFERENT"
+    except Exception as e:  # noqa: BLE001
+        out["error"] = repr(e)[:300]
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 def run_rank(args):
     import torch
@@ -792,6 +824,16 @@ def run_rank(args):
             # one) -- so besides the dominant kernel's line: the whole config against both roofs (4264 B and
             # ~135 kflop per frame)
             out["whole_config"] = config4_whole(F, dt / args.steps, kernels, args.steps)
+        # N > 1 (or VBX_BENCH_SELFCHECK=1 at N = 1, a rehearsal of the same code against an interior "cut"): are the gathered rows
+        # around every shard cut what ONE GPU computes for the same stretch of the recording?
+        if wl == "pipeline" and args.utterance_frames <= 0 and (world > 1 or os.environ.get("VBX_BENCH_SELFCHECK")):
+            vb.sync()
+            if comm is not None:
+                comm.sync()
+            b_last = (args.warmup + args.steps - 1) % len(rec)
+            rows_all = gathered[b_last] if world > 1 else rec[b_last]
+            cuts = [r * F for r in range(1, world)] if world > 1 else [F // 2]
+            out["cross_rank_check"] = cross_rank_check(vb, torch, dev, pkg, params, REC, rows_all, frame_len, stride, cuts)
         if wl == "pipeline" and default_shape and world == 1 and not args.no_sub:
             del rec, gathered                                                 # the records' HBM back before the dense batches
             out["sub_benchmarks"] = sub_benchmarks(vb, torch, dev, pkg, audio, F)

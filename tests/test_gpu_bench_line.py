@@ -12,8 +12,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(*args):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600)
+def _bench(*args, env=None):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600,
+                       env=None if env is None else dict(os.environ, **env))
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
@@ -55,6 +56,17 @@ def test_config_workloads_pick_the_measured_dominant_kernel():
     assert "whole_config" in d and d["whole_config"]["fp64_frac"] > 0
     d = _bench("--workload", "config3", "--frame-len", "2048", "--hop", "1024", "--hours", "0.25", "--steps", "2", "--warmup", "1", "--no-cpu")
     assert "2048-sample frames" in d["metric"] and d["config"]["frame_len"] == 2048 and d["roofline"]["kernel"] == "pitch"
+
+
+def test_cross_rank_check_rehearsal_on_one_gpu():
+    """At N > 1 rank 0 re-analyses the frames around every shard cut on its own GPU and compares them, bit for bit, with the rows
+    the ranks produced and the gather delivered (`cross_rank_check` in the bench line).  VBX_BENCH_SELFCHECK=1 runs the same code
+    at N = 1 against an interior "cut": the check itself is exercised on every one-GPU box."""
+    d = _bench("--hours", "0.5", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-sub", env={"VBX_BENCH_SELFCHECK": "1"})
+    c = d["cross_rank_check"]
+    assert "error" not in c, c
+    assert c["rows_compared"] >= 7000 and c["rows_different"] == 0 and c["verdict"] == "bit-identical", c
+    assert "cross_rank_check" not in _bench("--hours", "0.25", "--steps", "1", "--warmup", "1", "--no-cpu", "--no-sub")
 
 
 def test_two_ranks_without_a_second_gpu_fail_loudly_and_never_fall_back():
