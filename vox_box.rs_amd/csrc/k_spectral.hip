@@ -83,14 +83,42 @@ __device__ __forceinline__ void dft20(double (&re)[20], double (&im)[20]) {
 // Complex FFT of length 1200.  In: lane n' < 60 holds z[60 a + n'] in (re[a], im[a]).  Out: lane l holds
 // X[l + 64 t + 400 kc] in (xr[t][kc], xi[t][kc]) for l + 64 t < 400 (KC = 3: every output; KC = 2: kc = 0, 1 only).
 // ex: LDS exchange buffer (>= 20 * SP_S1 doubles).  tab: twiddle table.
-template <int KC>
+// The twenty twiddle products of a stage in batches of FIVE, each batch finished before the next one's loads may start: the
+// products are pinned (an empty asm with the value as in/out operand) and the loads fenced (a compiler memory barrier).  Left
+// alone the compiler requests all twenty twiddles at once -- 80 registers -- right after the 20-point DFT, whose results it
+// spills to make room (the 168-register instance: ~100 scratch round trips per transform).
+__device__ __forceinline__ void twiddle_tight(double (&re)[20], double (&im)[20], const double2 *tw_row) {
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+        double2 tw[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) tw[k] = tw_row[5 * h + k];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            if (5 * h + k == 0) continue;
+            const int s = dft20_slot(5 * h + k);
+            const double a = re[s], b = im[s];
+            re[s] = fma(a, tw[k].x, -(b * tw[k].y));
+            im[s] = fma(a, tw[k].y, b * tw[k].x);
+            asm volatile("" : "+v"(re[s]), "+v"(im[s]));
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
+// TIGHT (the instance compiled for three wavefronts per SIMD, 168 registers): the scheduler may not move the twiddle loads
+// above the 20-point DFT they follow -- hoisted there to hide their latency they hold 40..80 registers while the DFT needs
+// them, and the DFT's own values spill (scratch round trips inside both transforms).
+template <int KC, bool TIGHT = false>
 __device__ __forceinline__ void fft1200(double (&re)[20], double (&im)[20], double (&xr)[7][3], double (&xi)[7][3],
-                                        double *ex, const double2 *__restrict__ tab) {
+                                        double *ex, const double2 *tab) {
     const int lane = lane_id();
     const int np = (lane < 60) ? lane : 59;                 // lanes 60..63 shadow lane 59 (they never write)
     const bool act = lane < 60;
     // stage 1 (the twiddles arrive in two batches of ten: the 20-point DFT needs the registers)
     dft20(re, im);
+    if constexpr (TIGHT) twiddle_tight(re, im, tab + SP_T1 + np * 20);
+    else {
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         double2 tw[10];
@@ -104,6 +132,7 @@ __device__ __forceinline__ void fft1200(double (&re)[20], double (&im)[20], doub
             re[s] = fma(a, tw[k].x, -(b * tw[k].y));
             im[s] = fma(a, tw[k].y, b * tw[k].x);
         }
+    }
     }
     // exchange 1: [ka][n'] -> lane (ka2, c2) = (lane % 20, lane / 20) reads n' = 3 b + c2
     const int ka2 = np % 20, c2 = np / 20;
@@ -122,6 +151,8 @@ __device__ __forceinline__ void fft1200(double (&re)[20], double (&im)[20], doub
     for (int b = 0; b < 20; b++) bi[b] = ex[ka2 * SP_S1 + 3 * b + c2];
     // stage 2
     dft20(br, bi);
+    if constexpr (TIGHT) twiddle_tight(br, bi, tab + SP_T2 + c2 * 20);
+    else {
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         double2 tw[10];
@@ -135,6 +166,7 @@ __device__ __forceinline__ void fft1200(double (&re)[20], double (&im)[20], doub
             br[s] = fma(a, tw[k].x, -(b * tw[k].y));
             bi[s] = fma(a, tw[k].y, b * tw[k].x);
         }
+    }
     }
     // exchange 2: [c][ka + 20 kb] -> lane l reads q = l + 64 t for c = 0..2
     double vr[7][3], vi[7][3];
@@ -237,7 +269,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
 
     // ---- forward transform of the packed frame ----
     double xr[7][3], xi[7][3];
-    fft1200<3>(re, im, xr, xi, ex, a.tab);
+    fft1200<3, (WAVES >= 3)>(re, im, xr, xi, ex, a.tab);
 
     // ---- exchange 3: natural order, then each lane takes the pairs (m, N - m), m = lane + 64 t <= 600 ----
     double ar[10], ai[10], br[10], bi[10];
@@ -352,7 +384,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
     if constexpr (!PITCH) return;
 
     // ---- second transform: Y = FFT(G);  S[2j] = Re Y[j] / M, S[2j+1] = -Im Y[j] / M, j < 600 only ----
-    fft1200<2>(re, im, xr, xi, ex, a.tab);
+    fft1200<2, (WAVES >= 3)>(re, im, xr, xi, ex, a.tab);
 
     // r[lag] = (S[lag] - x0 x[lag]) + x0 (Q1), lane l: j = l + 64 t (kc = 0) and j = 400 + l + 64 t < 600 (kc = 1)
     constexpr double INV_M = 1.0 / (double)SP_M;
@@ -554,20 +586,29 @@ void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
         else hipLaunchKernelGGL((analyze_kernel<false, false, false, SP_AC_ONLY>), grid, block, spectral_lds_bytes(0), s, a);
         return;
     }
-    // several candidates per frame and no full-list region in LDS (12 wavefronts of 13.5 KB fit the CU): the form compiled
-    // for three wavefronts per SIMD (pitch alone; the fused frame loop keeps kmax = 1)
-    const bool w3 = !lpc && !mf && L.kmax >= 2 && extra == 0 && 12 * lds <= 160 * 1024;
+    // Three wavefronts per SIMD (twelve frames of 13.5 KB fill the CU's LDS; 168 registers) wherever the frame state allows it,
+    // i.e. no full-list region in LDS.  Round 3 had it for pitch alone from kmax = 2 (the refinement is a chain of dependent
+    // operations that two wavefronts do not cover); at kmax = 1 and in the fused loop the transforms' ~55 spilled registers
+    // cost more than the third wavefront brought.  Round 4: with the twiddle products in pinned batches (twiddle_tight) the
+    // 168-register instances spill 12-29 registers instead of 146-171, and three wavefronts win everywhere: pitch at kmax = 1
+    // 33.7 -> 37.8 M frames/s, the fused loop (the headline) 30.0 -> 33.5 M.  VBX_SPECTRAL_W3=0: two wavefronts as before (A/B).
+    static const bool want3 = [] { const char *e = getenv("VBX_SPECTRAL_W3"); return e == nullptr || atoi(e) != 0; }();
+    const bool w3 = want3 && extra == 0 && 12 * lds <= 160 * 1024;
+#define VBX_SP_LAUNCH(LPC_, MF_, FULL_)                                                                              \
+    do {                                                                                                              \
+        if (w3) hipLaunchKernelGGL((analyze_kernel<LPC_, MF_, FULL_, SP_ANALYZE, 3>), grid, block, lds, s, a);        \
+        else hipLaunchKernelGGL((analyze_kernel<LPC_, MF_, FULL_>), grid, block, lds, s, a);                          \
+    } while (0)
     if (L.n != SP_N) {                                       // a padded frame; MFCC joins when its length divides 2400
-        if (lpc && mf) hipLaunchKernelGGL((analyze_kernel<true, true, false>), grid, block, lds, s, a);
-        else if (mf) hipLaunchKernelGGL((analyze_kernel<false, true, false>), grid, block, lds, s, a);
-        else if (lpc) hipLaunchKernelGGL((analyze_kernel<true, false, false>), grid, block, lds, s, a);
-        else if (w3) hipLaunchKernelGGL((analyze_kernel<false, false, false, SP_ANALYZE, 3>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((analyze_kernel<false, false, false>), grid, block, lds, s, a);
-    } else if (lpc && mf) hipLaunchKernelGGL((analyze_kernel<true, true, true>), grid, block, lds, s, a);
-    else if (lpc) hipLaunchKernelGGL((analyze_kernel<true, false, true>), grid, block, lds, s, a);
-    else if (mf) hipLaunchKernelGGL((analyze_kernel<false, true, true>), grid, block, lds, s, a);
-    else if (w3) hipLaunchKernelGGL((analyze_kernel<false, false, true, SP_ANALYZE, 3>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((analyze_kernel<false, false, true>), grid, block, lds, s, a);
+        if (lpc && mf) VBX_SP_LAUNCH(true, true, false);
+        else if (mf) VBX_SP_LAUNCH(false, true, false);
+        else if (lpc) VBX_SP_LAUNCH(true, false, false);
+        else VBX_SP_LAUNCH(false, false, false);
+    } else if (lpc && mf) VBX_SP_LAUNCH(true, true, true);
+    else if (lpc) VBX_SP_LAUNCH(true, false, true);
+    else if (mf) VBX_SP_LAUNCH(false, true, true);
+    else VBX_SP_LAUNCH(false, false, true);
+#undef VBX_SP_LAUNCH
 }
 
 }  // namespace vbx
