@@ -23,6 +23,9 @@
 
 namespace vbx {
 
+#ifndef VBX_POW2_U1_WAVES
+#define VBX_POW2_U1_WAVES 3                     // Nc = 1024, the fused analysis: three wavefronts per SIMD (168 registers, pinned twiddle batches)
+#endif
 #ifndef VBX_POW2_U2_WAVES
 #define VBX_POW2_U2_WAVES 2
 #endif
@@ -115,7 +118,28 @@ template <int W> __device__ __forceinline__ void pow2_sync() { if constexpr (W =
 
 // Complex FFT of length Nc.  In: thread i holds z[16R a + i + NT u] in (re[u][a], im[u][a]).  Out: thread i holds
 // X[i + NT t + 256 kc] in (xr[t][kc], xi[t][kc]).  ex: LDS exchange buffer (pow2_geom<U, W>::EX doubles).
-template <int U, int W = 1>
+// The sixteen twiddle products of a unit in batches of FOUR, each batch finished before the next one's loads may start (the
+// products pinned by an empty asm, the loads fenced by a compiler memory barrier): left alone the compiler requests every
+// twiddle of the stage right after the 16-point DFTs and spills their results to make room (k_spectral.hip, twiddle_tight).
+__device__ __forceinline__ void twiddle_tight16(double (&re)[16], double (&im)[16], const double2 *tw_row) {
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+        double2 w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = tw_row[4 * h + k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (4 * h + k == 0) continue;
+            const int s = dft16_slot(4 * h + k);
+            rot(re[s], im[s], w[k].x, w[k].y);
+            asm volatile("" : "+v"(re[s]), "+v"(im[s]));
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
+// TIGHT: twiddle_tight16 (the instances that are short of registers: three wavefronts per SIMD at Nc = 1024, and Nc = 2048)
+template <int U, int W = 1, bool TIGHT = false>
 __device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16], double (&xr)[4 / W][4 * U * W],
                                          double (&xi)[4 / W][4 * U * W], double *ex, const double2 *__restrict__ tab) {
     using G = pow2_geom<U, W>;
@@ -126,6 +150,7 @@ __device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16
     for (int u = 0; u < U; u++) {
         dft16(re[u], im[u]);
         const double2 *tw = tab + G::T1 + (tid + NT * u) * 16;
+        if constexpr (TIGHT) { twiddle_tight16(re[u], im[u], tw); continue; }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             double2 w[8];
@@ -167,6 +192,7 @@ __device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16
     for (int u = 0; u < U; u++) {
         dft16(br[u], bi[u]);
         const double2 *tw = tab + G::T2 + (c2 + CW * u) * 16;
+        if constexpr (TIGHT) { twiddle_tight16(br[u], bi[u], tw); continue; }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             double2 w[8];
@@ -219,9 +245,11 @@ __device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16
 // MODE (vbx_spectral.hpp): SP_ANALYZE the fused analysis; SP_MFCC_ONLY MFCC::mfcc alone (the forward transform and the mel / DCT
 // tail only); SP_AC_ONLY Autocorrelate::autocorrelate alone (both transforms, the fold seed, the lag sums stored).
 template <int U, bool LPC, bool MFCC, bool FULL, int MODE = SP_ANALYZE, int W = 1>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(U == 4 ? 1 : (U == 2 && MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? VBX_POW2_U2_WAVES : 2,
-                                                                     U == 4 ? ((MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? 1 : 2) : (MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? 2 : 4)))
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu((U == 1 && W == 1 && MODE == SP_ANALYZE) ? VBX_POW2_U1_WAVES : U == 4 ? 1 : (U == 2 && MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? VBX_POW2_U2_WAVES : 2,
+                                                                     (U == 1 && W == 1 && MODE == SP_ANALYZE) ? VBX_POW2_U1_WAVES : U == 4 ? ((MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? 1 : 2) : (MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? 2 : 4)))
 void analyze_pow2_kernel(const spectral_args_t a) {
+    // pinned twiddle batches where registers are short: Nc = 1024 at three wavefronts per SIMD, Nc = 2048 at two
+    constexpr bool POW2_TIGHT = MODE == SP_ANALYZE && W == 1 && ((U == 1 && VBX_POW2_U1_WAVES >= 3) || U == 2);
     static_assert((MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) || (MFCC && FULL && !LPC), "the MFCC-only forms need the full frame and have no lag sums");
     static_assert(MODE != SP_AC_ONLY || (!MFCC && !LPC), "the autocorrelation-only form");
     constexpr bool PITCH = MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF;   // the second transform runs
@@ -277,7 +305,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
 
     // ---- forward transform of the packed frame ----
     double xr[TQ][R], xi[TQ][R];
-    fft_pow2<U, W>(re, im, xr, xi, ex, a.tab);
+    fft_pow2<U, W, POW2_TIGHT>(re, im, xr, xi, ex, a.tab);
 
     // ---- exchange 3: natural order, then each lane takes the pairs (m, Nc - m), m = lane + 64 t <= Nc / 2 ----
     double ar[TP], ai[TP], br[TP], bi[TP];
@@ -396,7 +424,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
     if constexpr (!PITCH) return;
 
     // ---- second transform: Y = FFT(G);  S[2j] = Re Y[j] / M, S[2j+1] = -Im Y[j] / M, j = lane + 64 t + 256 kc < Nc / 2 ----
-    fft_pow2<U, W>(re, im, xr, xi, ex, a.tab);
+    fft_pow2<U, W, POW2_TIGHT>(re, im, xr, xi, ex, a.tab);
 
     constexpr int NS = TQ * (R / 2);                         // slots per thread: t < TQ, kc < R / 2
     constexpr double INV_M = 1.0 / (double)(2 * NC);
