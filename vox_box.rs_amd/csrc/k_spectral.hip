@@ -87,16 +87,20 @@ __device__ __forceinline__ void dft20(double (&re)[20], double (&im)[20]) {
 // products are pinned (an empty asm with the value as in/out operand) and the loads fenced (a compiler memory barrier).  Left
 // alone the compiler requests all twenty twiddles at once -- 80 registers -- right after the 20-point DFT, whose results it
 // spills to make room (the 168-register instance: ~100 scratch round trips per transform).
+#ifndef VBX_EXP_TWB
+#define VBX_EXP_TWB 5
+#endif
+constexpr int TWB = VBX_EXP_TWB;
 __device__ __forceinline__ void twiddle_tight(double (&re)[20], double (&im)[20], const double2 *tw_row) {
 #pragma unroll
-    for (int h = 0; h < 4; h++) {
-        double2 tw[5];
+    for (int h = 0; h < 20 / TWB; h++) {
+        double2 tw[TWB];
 #pragma unroll
-        for (int k = 0; k < 5; k++) tw[k] = tw_row[5 * h + k];
+        for (int k = 0; k < TWB; k++) tw[k] = tw_row[TWB * h + k];
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            if (5 * h + k == 0) continue;
-            const int s = dft20_slot(5 * h + k);
+        for (int k = 0; k < TWB; k++) {
+            if (TWB * h + k == 0) continue;
+            const int s = dft20_slot(TWB * h + k);
             const double a = re[s], b = im[s];
             re[s] = fma(a, tw[k].x, -(b * tw[k].y));
             im[s] = fma(a, tw[k].y, b * tw[k].x);
