@@ -83,12 +83,13 @@ __device__ __forceinline__ void dft20(double (&re)[20], double (&im)[20]) {
 // Complex FFT of length 1200.  In: lane n' < 60 holds z[60 a + n'] in (re[a], im[a]).  Out: lane l holds
 // X[l + 64 t + 400 kc] in (xr[t][kc], xi[t][kc]) for l + 64 t < 400 (KC = 3: every output; KC = 2: kc = 0, 1 only).
 // ex: LDS exchange buffer (>= 20 * SP_S1 doubles).  tab: twiddle table.
-// The twenty twiddle products of a stage in batches of FIVE, each batch finished before the next one's loads may start: the
+// The twenty twiddle products of a stage in batches of TWB (two), each batch finished before the next one's loads may start: the
 // products are pinned (an empty asm with the value as in/out operand) and the loads fenced (a compiler memory barrier).  Left
 // alone the compiler requests all twenty twiddles at once -- 80 registers -- right after the 20-point DFT, whose results it
-// spills to make room (the 168-register instance: ~100 scratch round trips per transform).
+// spills to make room (the 168-register instance: ~100 scratch round trips per transform).  Batches of 2 / 5 / 10: 0 / 12 / 9
+// spilled registers in the fused kernel, 34.1 / 34.3 / 34.6 M frames/s -- two it is: no scratch traffic at all.
 #ifndef VBX_EXP_TWB
-#define VBX_EXP_TWB 5
+#define VBX_EXP_TWB 2
 #endif
 constexpr int TWB = VBX_EXP_TWB;
 __device__ __forceinline__ void twiddle_tight(double (&re)[20], double (&im)[20], const double2 *tw_row) {
