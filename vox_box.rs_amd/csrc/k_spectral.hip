@@ -206,9 +206,9 @@ __device__ __forceinline__ void fft1200(double (&re)[20], double (&im)[20], doub
     }
 }
 
-// Two wavefronts per SIMD: the two transforms need ~230 registers.  At three (168 registers) 55 of them spill, which the
-// refinement's arithmetic hides in time (measured: the same frames/s) but which costs 36 KB of scratch traffic per
-// frame -- 46 KB against 10 KB of HBM traffic per frame (profiles/r02*_pmc_counters.json).
+// WAVES: wavefronts per SIMD the instance is compiled for.  Two: the transforms take ~230 registers.  Three (168 registers, what
+// launch_analyze picks since the end of round 4): with the twiddle products in pinned batches (twiddle_tight) nothing spills in
+// the fused kernel; before that ~55 registers did and the third wavefront cost more than it brought.
 #ifndef VBX_SPECTRAL_WAVES
 #define VBX_SPECTRAL_WAVES 2
 #endif

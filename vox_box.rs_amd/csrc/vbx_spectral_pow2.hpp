@@ -238,7 +238,8 @@ __device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16
 // complex values per lane) the kernel took 512 registers + ~150 spilled at one wavefront per SIMD, three frames = three
 // wavefronts per CU (the frame state is 46 KB of LDS): 5.7 M frames/s at 4096 / 2048.  The second wavefront leaves when the lag
 // curve is in LDS; the first runs the refinement as in every other kernel.
-// U = 1, 2 with W = 1: two wavefronts per SIMD.  U = 1 (Nc = 1024) needs ~210 registers.  U = 2 (Nc = 2048: 32 complex values per lane, 17
+// U = 1 (Nc = 1024): three wavefronts per SIMD since the end of round 4 (168 registers with the twiddle products in pinned
+// batches, twiddle_tight16; ~210 registers at two).  U = 2 with W = 1: two wavefronts per SIMD.  U = 2 (Nc = 2048: 32 complex values per lane, 17
 // spectrum pairs) needs ~290: at 256 a dozen to fifty of them spill, and the frame state (23 KB of LDS) admits six frames
 // per CU.  Measured at n = 2048: 25.2 M frames/s against 18.6 M with one wavefront per SIMD and no spills.
 // FULL: the frame fills the transform (n == Nc, the bounds tests fold away); otherwise n < Nc (MFCC joins when n divides M).
