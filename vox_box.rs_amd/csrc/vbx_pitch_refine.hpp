@@ -491,7 +491,18 @@ __device__ __forceinline__ bool improve_extremum_sinc_wave(const double *y, int 
 //  b, c) refinement (improve_extremum_sinc) and the sorted candidate list, see pitch_refine_store.
 // ------------------------------------------------------------------------------------------
 constexpr int Y_PAD = 16;                       // zeros kept after y[n) (stand for the head of resize(2N, 0))
-constexpr int PB = 5;                           // lags per block of the |y| prefix sums
+#ifndef VBX_EXP_PB
+#define VBX_EXP_PB 5
+#endif
+constexpr int PB = VBX_EXP_PB;                  // lags per block of the |y| prefix sums (<= Y_PAD + 1: the last block reads on into the zeros)
+// sum of |y| over one block (the same association wherever it is taken)
+__device__ __forceinline__ double block_abs_sum(const double *yp) {
+    double s = fabs(yp[0]) + fabs(yp[1]);
+#pragma unroll
+    for (int i = 2; i + 1 < PB; i += 2) s += fabs(yp[i]) + fabs(yp[i + 1]);
+    if (PB & 1) s += fabs(yp[PB - 1]);
+    return s;
+}
 typedef unsigned short cand_t;                  // candidate lags (< 2048)
 constexpr int PG = 16;                          // lanes per query point (sinc_points / extremum_points kernels)
 constexpr int PNG = 64 / PG;                    // points per wavefront
@@ -857,7 +868,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
         double tot = 0.0;
         for (int q = 0; q < per; q++) {
             const int j = lane * per + q;
-            if (j < nblk) { const double *yp = ys + PB * j; tot += ((fabs(yp[0]) + fabs(yp[1])) + (fabs(yp[2]) + fabs(yp[3]))) + fabs(yp[4]); }   // entries past n are zero
+            if (j < nblk) tot += block_abs_sum(ys + PB * j);   // entries past n are zero
         }
         double incl = tot;                                   // inclusive scan over the lanes
         for (int o = 1; o < 64; o <<= 1) { const double up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
@@ -866,8 +877,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
         for (int q = 0; q < per; q++) {
             const int j = lane * per + q;
             if (j < nblk) {
-                const double *yp = ys + PB * j;
-                run += ((fabs(yp[0]) + fabs(yp[1])) + (fabs(yp[2]) + fabs(yp[3]))) + fabs(yp[4]);
+                run += block_abs_sum(ys + PB * j);
                 p16[j + 1] = run;
             }
         }
