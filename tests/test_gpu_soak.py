@@ -174,7 +174,7 @@ def test_soak_pipeline_shard(vb, oracle, pkg):
     # the runner-up of an unvoiced frame is a noise candidate: <= 0.5 % of those refinements end on the other side of the
     # lag discontinuity (same frequency, another strength) -- _check_pitch in test_gpu_parity.py
     # classifies them candidate by candidate, here they are only bounded (1 % of the frames)
-    # allowances = what rounds 2-4 observed on this stretch, plus one event (profiles/r03l_soak_report.json: every class 0 but
+    # allowances = what rounds 2-4 observed on this stretch, plus one event (profiles/archive/r03l_soak_report.json: every class 0 but
     # the Levinson rows): a single refinement whose chaotic tail lands elsewhere after a change of summation order must not turn
     # the suite red, anything systematic must
     allowed = {"pitch_top_tie_swap": 1, "fused_pitch_top_tie_swap": 1,
