@@ -578,8 +578,9 @@ def cross_rank_check(vb, torch, dev, pkg, params, REC, rows_all, frame_len, stri
     this GPU alone as one stretch of the recording, against the rows the ranks produced and the gather delivered.  The stretch
     starts `reach` frames before the cut; its own tracker has forgotten its start long before `settle` frames (64 suffice
     almost always), so rows [cut - reach + settle, cut + reach) must be BIT FOR BIT the gathered ones -- every column: pitch,
-    LPC, MFCC (per-frame) and the formant tracks (carried across the cut by warm-up + state hand-off).  Returns counts; never
-    raises (a failure of the CHECK must not cost the measurement)."""
+    LPC, MFCC (per-frame) and the formant tracks (carried across the cut by warm-up + state hand-off).  Returns counts and a
+    verdict; the caller prints the line and then FAILS the run (exit code 3, `valid: false`) on anything but "bit-identical":
+    a headline number over rows that are not the single-GPU rows is not a measurement of this path."""
     out = {"cuts": [int(c) for c in cuts], "rows_compared": 0, "rows_different": 0}
     try:
         total = int(rows_all.shape[0])
@@ -613,6 +614,7 @@ def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dry = bool(os.environ.get("VBX_BENCH_DRY_RUN"))      # tests/test_shard_cpu.py: the launcher's plumbing without a GPU
+    rc_final = 0                                         # 3: the line was printed but its cross-rank check failed
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -833,7 +835,12 @@ def run_rank(args):
             b_last = (args.warmup + args.steps - 1) % len(rec)
             rows_all = gathered[b_last] if world > 1 else rec[b_last]
             cuts = [r * F for r in range(1, world)] if world > 1 else [F // 2]
-            out["cross_rank_check"] = cross_rank_check(vb, torch, dev, pkg, params, REC, rows_all, frame_len, stride, cuts)
+            chk = cross_rank_check(vb, torch, dev, pkg, params, REC, rows_all, frame_len, stride, cuts)
+            out["cross_rank_check"] = chk
+            if chk.get("verdict") != "bit-identical" or "error" in chk:
+                out["valid"] = False
+                out["invalid_because"] = "cross_rank_check: the gathered rows around a shard cut are not the single-GPU rows"
+                rc_final = 3
         if wl == "pipeline" and default_shape and world == 1 and not args.no_sub:
             del rec, gathered                                                 # the records' HBM back before the dense batches
             out["sub_benchmarks"] = sub_benchmarks(vb, torch, dev, pkg, audio, F)
@@ -846,7 +853,7 @@ def run_rank(args):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    return 0
+    return rc_final
 
 
 def main():

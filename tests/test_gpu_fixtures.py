@@ -321,6 +321,22 @@ def test_mfcc_long_frames(vb, oracle, pkg, golden_dir, n, k, lo, hi):
         assert np.all(rel_close(m[t], em)), (t, np.max(np.abs(m[t] - em)))
 
 
+def test_mfcc_long_frames_more_than_65535(vb, oracle, pkg, golden_dir):
+    """A batch of more long frames than a grid's y dimension holds (round-4 advisor finding: the frame index was on
+    gridDim.y): 70,001 frames of 4,097 samples, hop 1, out of the 44.1 kHz recording; a sample of them against the oracle,
+    the last one included."""
+    samples, sr = _read_wav16(os.path.join(golden_dir, "sample-two_vowels.wav"))
+    n, hop, F = 4097, 1, 70001
+    assert samples.size >= (F - 1) * hop + n
+    w = oracle.window("hanning", n)
+    han = vb.window(pkg.WINDOW_HANNING, n)
+    m, st = vb.mfcc(samples, 13, (100.0, 8000.0), sr, frame_len=n, stride=hop, n_frames=F, window=han)
+    assert m.shape[0] == F and np.all(st == 0)
+    for t in (0, 1, 65534, 65535, 65536, 69999, F - 1):
+        es, em = oracle.mfcc(samples[t * hop:t * hop + n] * w, 13, 100.0, 8000.0, sr)
+        assert es == 0 and np.all(rel_close(m[t], em)), (t, np.max(np.abs(m[t] - em)))
+
+
 def test_analyze_frames_long(vb, oracle, pkg, golden_dir):
     """The fused frame loop on 5,000-sample frames: every column of the record against the oracle."""
     samples, sr = _read_wav16(os.path.join(golden_dir, "sample-two_vowels.wav"))

@@ -2,7 +2,7 @@
 * the oracle (oracle/libvbx_oracle_asan.so, `make -C oracle asan`): its known-answer tests and the soak walker's tests re-run
   on the instrumented build;
 * the library's host-only entry points (csrc/vbx_host.cpp -> lib/libvbx_host_asan.so, `make -C vox_box.rs_amd host_asan`):
-  tools/host_property_test.py -- random worlds / rows / segment lists / table sizes / mel geometries and misuse.
+  tools/host_property_check.py -- random worlds / rows / segment lists / table sizes / mel geometries and misuse.
 The GPU kernels cannot run under a sanitizer on this pool (no GPU ASan / XNACK); these are the parts that can."""
 import os
 import subprocess
@@ -53,7 +53,7 @@ def test_oracle_asan_build_is_the_one_loaded():
 def test_host_entry_points_under_asan_ubsan(seed):
     env = _asan_env()
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "vox_box.rs_amd"), "-s", "host_asan"])
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_property_test.py"), str(seed)], env=env, capture_output=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_property_check.py"), str(seed)], env=env, capture_output=True,
                        text=True, timeout=900)
     out = r.stdout + r.stderr
     _clean(out)

@@ -482,9 +482,9 @@ constexpr int ML_BPL = 4;
 __global__ __launch_bounds__(64) void mfcc_long_bins_kernel(const double *__restrict__ x, long n_frames, long n, long stride,
                                                             const double *__restrict__ window, const double *__restrict__ kappa_sigma,
                                                             const double *__restrict__ slopes, int nb, long nbp, double *__restrict__ pupd) {
-    const long f = blockIdx.y;
+    const long f = blockIdx.x;                       // frames on x (no 65,535 cap), blocks of 256 bins on y
     const int lane = lane_id();
-    const int p0 = blockIdx.x * 64 * ML_BPL;
+    const int p0 = blockIdx.y * 64 * ML_BPL;
     const double *xf = x + f * stride;
     double kap[ML_BPL], sig[ML_BPL], sv[ML_BPL], dv[ML_BPL];
 #pragma unroll
@@ -541,7 +541,7 @@ void launch_mfcc_long(hipStream_t s, const double *x, long F, long n, long strid
                       const int32_t *bins, const double *slopes, const double *dct, int num_coeffs, int nb, double *out, long out_ld,
                       int32_t *status, double *ws) {
     const long nbp = (nb + 1) & ~1;
-    hipLaunchKernelGGL(mfcc_long_bins_kernel, dim3((unsigned)((nb + 64 * ML_BPL - 1) / (64 * ML_BPL)), (unsigned)F), dim3(64), 0, s, x, F, n, stride,
+    hipLaunchKernelGGL(mfcc_long_bins_kernel, dim3((unsigned)F, (unsigned)((nb + 64 * ML_BPL - 1) / (64 * ML_BPL))), dim3(64), 0, s, x, F, n, stride,
                        window, kappa_sigma, slopes, nb, nbp, ws);
     hipLaunchKernelGGL(mfcc_long_tail_kernel, dim3((unsigned)F), dim3(64), 0, s, F, (const double *)ws, nbp, bins, dct, num_coeffs, out, out_ld, status);
 }

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(ROOTS_BLOCK) void formant_resonances_kernel(
     for (int j = 0; j < p; j++) co.set(j, cmk(a[p - 1 - j], 0.0));
     co.set(p, cmk(1.0, 0.0));
     res_t *row = out_res + fr * (long)VBX_MAX_RESONANCES_K;    // idle lanes shadow the last frame (same values)
-    int count = 0;
+    int count = 0, total = 0;
     int rst = 0;
     if (st == 0) {
         // every root goes straight through Resonance::from_root (im > 0 only, src/lib.rs:94-104); the
@@ -142,11 +142,14 @@ __global__ __launch_bounds__(ROOTS_BLOCK) void formant_resonances_kernel(
         // frequencies are > 50, so that is a sorted insertion.  No root array is kept.
         rst = find_roots_emit(co, len, [&](int, c64 z) {
             res_t v;
-            if (z.im > 0.0 && count < VBX_MAX_RESONANCES_K && resonance_from_root(z, sample_rate, v)) {
-                if (active) res_insert_sorted(row, count, v);
-                count++;
+            if (z.im > 0.0 && resonance_from_root(z, sample_rate, v)) {
+                if (count < VBX_MAX_RESONANCES_K) { if (active) res_insert_sorted(row, count, v); count++; }
+                total++;
             }
         });
+        // the 33rd resonance: resonances[count] out of bounds in the reference (src/lib.rs:97-99; reachable from order 34 on,
+        // when roots that are real in exact arithmetic come out with tiny positive imaginary parts)
+        if (rst == 0 && total > VBX_MAX_RESONANCES_K) rst = 4;   // VBX_FRAME_ERR_PANIC
     }
     if (!active) return;
     if (rst != 0) count = 0;

@@ -131,6 +131,7 @@ __global__ __launch_bounds__(64) void formant_resonances_fast_kernel(
     bool bad = run && rst == 0 && !finite;                   // -> the reference-faithful kernel
     int m = (run && rst == 0 && !bad) ? P : 0;
     double rf[NR], rb[NR];                                   // the frame's resonances, sorted by frequency
+    bool direct_row = false;                                 // a lane redone by the reference's iteration writes its row itself
 #pragma unroll
     for (int j = 0; j < NR; j++) { rf[j] = 0.0; rb[j] = 0.0; }
     int count = 0;
@@ -230,31 +231,34 @@ __global__ __launch_bounds__(64) void formant_resonances_fast_kernel(
 #pragma unroll
         for (int j = 0; j <= P; j++) co.set(j, cmk(c0[j], 0.0));
         if (bad) {
-#pragma unroll
-            for (int j = 0; j < NR; j++) { rf[j] = 0.0; rb[j] = 0.0; }
+            // the row goes straight to memory, all VBX_MAX_RESONANCES slots of it: an iteration that has not converged can
+            // leave more than P / 2 roots above the real axis (the reference takes up to 32 and panics on the 33rd,
+            // src/lib.rs:97-99: resonances[count] out of bounds)
             count = 0;
+            int total = 0;
+            res_t *rowd = out_res + fr * (long)VBX_MAX_RESONANCES_K;
             rst = find_roots_emit(co, P + 1, [&](int, c64 z) {
                 res_t v;
-                if (z.im > 0.0 && count < NR && resonance_from_root(z, sample_rate, v)) {
-                    bool placed = false;
-                    double cf = v.frequency, cb = v.bandwidth;
-#pragma unroll
-                    for (int j = 0; j < NR; j++) {
-                        if (!placed && (j >= count || rf[j] > cf)) placed = true;
-                        if (placed) { const double tf = rf[j], tb = rb[j]; rf[j] = cf; rb[j] = cb; cf = tf; cb = tb; }
-                    }
-                    count++;
+                if (z.im > 0.0 && resonance_from_root(z, sample_rate, v)) {
+                    if (count < VBX_MAX_RESONANCES_K) { if (active) res_insert_sorted(rowd, count, v); count++; }
+                    total++;
                 }
             });
+            if (rst == 0 && total > VBX_MAX_RESONANCES_K) rst = 4;   // VBX_FRAME_ERR_PANIC
+            direct_row = true;
             if (active && redo_count != nullptr) atomicAdd(redo_count, 1);
         }
     }
     if (!active) return;
     if (rst != 0 || st != 0) count = 0;
     res_t *row = out_res + f * (long)VBX_MAX_RESONANCES_K;
+    if (direct_row) {
+        for (int j = count; j < VBX_MAX_RESONANCES_K; j++) { row[j].frequency = 0.0; row[j].bandwidth = 0.0; }
+    } else {
 #pragma unroll
-    for (int j = 0; j < NR; j++) { row[j].frequency = (j < count) ? rf[j] : 0.0; row[j].bandwidth = (j < count) ? rb[j] : 0.0; }
-    for (int j = NR; j < VBX_MAX_RESONANCES_K; j++) { row[j].frequency = 0.0; row[j].bandwidth = 0.0; }
+        for (int j = 0; j < NR; j++) { row[j].frequency = (j < count) ? rf[j] : 0.0; row[j].bandwidth = (j < count) ? rb[j] : 0.0; }
+        for (int j = NR; j < VBX_MAX_RESONANCES_K; j++) { row[j].frequency = 0.0; row[j].bandwidth = 0.0; }
+    }
     if (out_count != nullptr) out_count[f] = count;
     if (status != nullptr && st == 0 && rst != 0) status[f] = rst;
 }

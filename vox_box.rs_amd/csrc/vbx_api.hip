@@ -1244,6 +1244,16 @@ double *vbx_internal_stitch_state(vbx_ctx *ctx) {
     return ctx->stitch_state;
 }
 int vbx_internal_last_track_n_est(vbx_ctx *ctx) { return ctx ? ctx->last_track.n_est : 0; }
+// every host-side condition of a stitch / hand-off on these rows, for callers that must know BEFORE they enqueue anything
+// a peer waits for (vbx_comm.hip: an early return between ncclRecv and ncclSend would leave the next rank blocked)
+int vbx_internal_track_check(vbx_ctx *ctx, const vbx_resonance *formants, size_t n_frames, size_t formants_ld) {
+    VBX_REQUIRE(ctx, ctx != nullptr, "null context");
+    const auto &lt = ctx->last_track;
+    VBX_REQUIRE(ctx, lt.res != nullptr && lt.n_est >= 1, "no tracks on this context: the last call produced none");
+    VBX_REQUIRE(ctx, formants && lt.out == (const res_t *)formants && lt.F == (long)n_frames && lt.out_ld == (long)formants_ld,
+                "the formant rows are not the ones the last find_formants / analyze_frames call on this context wrote");
+    return VBX_SUCCESS;
+}
 
 // ---- spectrum.rs: MFCC --------------------------------------------------------------------
 
@@ -1557,6 +1567,7 @@ static int analyze_frames_impl(vbx_ctx *ctx, const char *fn, const double *x, co
         if (rc != VBX_SUCCESS) return rc;
     } else {
         ctx->last_track.res = nullptr;                        // no tracks in these records: nothing for vbx_track_stitch_f64 to continue
+        ctx->last_track.n_est = 0;                            // ... and no row for a communicator to send on
         if (st_form) VBX_HIP(ctx, hipMemsetAsync(st_form, 0, n_frames * sizeof(int32_t), side));
     }
     if (fused && h_p->lpc_order && !fused_lpc) {

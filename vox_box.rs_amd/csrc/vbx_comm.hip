@@ -20,6 +20,7 @@ extern "C" int vbx_internal_track_stitch(vbx_ctx *ctx, void *stream, vbx_resonan
                                          size_t first, size_t stop, const double *d_state_in, int32_t *d_changed);
 extern "C" double *vbx_internal_stitch_state(vbx_ctx *ctx);
 extern "C" int vbx_internal_last_track_n_est(vbx_ctx *ctx);
+extern "C" int vbx_internal_track_check(vbx_ctx *ctx, const vbx_resonance *formants, size_t n_frames, size_t formants_ld);
 
 struct vbx_comm {
     ncclComm_t nccl = nullptr;
@@ -147,13 +148,22 @@ int vbx_comm_stitch_tracks_f64(vbx_ctx *ctx, vbx_comm *c, vbx_resonance *formant
     if ((recv || send) && (!formants || n_frames != h_plan->hi - h_plan->lo + h_plan->warm || h_plan->stop > n_frames))
         return fail(ctx, VBX_E_INVALID, "vbx_comm_stitch_tracks_f64: the rows are not the plan's frames [lo - warm, hi)");
     VBXC_HIP(ctx, hipSetDevice(c->device));
+    // every host-side check BEFORE the first event or NCCL call (round-4 advisor finding): a return between this rank's
+    // ncclRecv and its ncclSend would leave the next rank blocked in its matching ncclRecv.  Send-only ranks too: the row
+    // they send must be the last call's.
+    double *state = nullptr;
+    if (recv || send) {
+        int rc = vbx_internal_track_check(ctx, formants, n_frames, formants_ld);
+        if (rc != VBX_SUCCESS) return rc;
+        if (h_plan->warm > h_plan->stop) return fail(ctx, VBX_E_INVALID, "vbx_comm_stitch_tracks_f64: need warm <= stop");
+        if (recv && !(state = vbx_internal_stitch_state(ctx)))
+            return fail(ctx, VBX_E_RUNTIME, "vbx_comm_stitch_tracks_f64: no tracker state buffer on this context");
+    }
     hipStream_t main = (hipStream_t)vbx_internal_stream(ctx);
     VBXC_HIP(ctx, hipEventRecord(c->ready, main));                       // the shard's own scan is done
     VBXC_HIP(ctx, hipStreamWaitEvent(c->stream, c->ready, 0));
     const int n_est = vbx_internal_last_track_n_est(ctx);
     if (recv) {
-        double *state = vbx_internal_stitch_state(ctx);
-        if (!state || n_est < 1) return fail(ctx, VBX_E_RUNTIME, "vbx_comm_stitch_tracks_f64: no tracker state on this context");
         // the row the previous rank ends with: 2 n_est doubles over the direct link from rank - 1 (it sends after ITS stitch)
         VBXC_NCCL(ctx, ncclRecv(state, (size_t)(2 * n_est), ncclDouble, c->rank - 1, c->nccl, c->stream));
         int rc = vbx_internal_track_stitch(ctx, (void *)c->stream, formants, n_frames, formants_ld, h_plan->warm, h_plan->stop, state, d_changed);
@@ -167,7 +177,6 @@ int vbx_comm_stitch_tracks_f64(vbx_ctx *ctx, vbx_comm *c, vbx_resonance *formant
         VBXC_HIP(ctx, hipMemsetAsync(d_changed, 0, sizeof(int32_t), c->stream));
     }
     if (send) {
-        if (n_est < 1) return fail(ctx, VBX_E_RUNTIME, "vbx_comm_stitch_tracks_f64: no tracker state on this context");
         const double *last = (const double *)formants + (n_frames - 1) * formants_ld;
         VBXC_NCCL(ctx, ncclSend(last, (size_t)(2 * n_est), ncclDouble, c->rank + 1, c->nccl, c->stream));
     }

@@ -257,7 +257,11 @@ def mfcc_bins(frame_len, num_coeffs, lo_hz, hi_hz, sample_rate):
 
 
 def shard_range(n_frames, world, rank, seg_start=None):
-    """vbx_shard_range: frames [lo, hi) of `rank`; with seg_start the cuts fall on utterance boundaries."""
+    """vbx_shard_range: frames [lo, hi) of `rank` -- the EVEN split.  With seg_start a cut moves to an utterance start only
+    when one lies within 1/32 of a shard after it; otherwise it stays INSIDE the utterance (ABI 4; up to ABI 3 every cut
+    moved to a boundary).  A caller that analyses [lo, hi) per rank on its own therefore restarts the tracker in the middle
+    of an utterance: use shard_plan + shard_local_segments + Comm.stitch_tracks ("From ABI 3 to ABI 4"),
+    or shard.segment_aligned_ranges for cuts on boundaries only."""
     lo, hi = C.c_size_t(), C.c_size_t()
     seg = None if seg_start is None else np.ascontiguousarray(seg_start, dtype=np.int64)
     rc = load_library().vbx_shard_range(n_frames, world, rank, None if seg is None else seg.ctypes.data,
