@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define VBX_ABI_VERSION 4
+#define VBX_ABI_VERSION 5
 
 /* API return codes */
 #define VBX_SUCCESS 0
@@ -119,6 +119,11 @@ int vbx_timer_end(vbx_ctx *ctx, float *h_ms);
 int vbx_profile_enable(vbx_ctx *ctx, int on);
 int vbx_profile_reset(vbx_ctx *ctx);
 int vbx_profile_get(vbx_ctx *ctx, const char *kernel_name, double *h_total_ms, long *h_launches);
+/* ABI 5.  The stream the kernel's last profiled launch ran on: 0 = the context's stream (the critical path of a call),
+ * 1 = the side stream of the fused frame loop (the formant chain / an unfused MFCC beside the spectral kernel),
+ * 2 = the tracker's time-slice stream; -1 = not profiled.  Event times of kernels on streams 1 and 2 include the time
+ * they spend co-resident with the context stream's kernel: a bench must not call them "dominant" by that number. */
+int vbx_profile_stream(vbx_ctx *ctx, const char *kernel_name, int *h_stream);
 /* Work the pitch refine kernel executed while profiling was enabled (since the last
  * vbx_profile_reset): h_out4 = { frames, candidates found, sinc evaluations, sinc terms }.
  * Feeds bench.py's FP64 roofline with the work actually done, not the reference's. */

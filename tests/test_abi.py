@@ -15,7 +15,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert len(names) >= 35
     for n in names:
         assert hasattr(lib, n), f"libvoxbox_hip.so lacks {n}"
-    assert lib.vbx_abi_version() == 4
+    assert lib.vbx_abi_version() == 5
 
 
 def test_no_cpu_fallback(pkg):

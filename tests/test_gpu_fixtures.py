@@ -201,7 +201,7 @@ def test_formant_extraction_example(vb, oracle, pkg, golden_dir):
             assert not np.all(np.abs(e2 - est) <= 1e-6 * np.abs(est)), (t, ff["formants"][t], est)
             n_unstable += 1
             est = ff["formants"][t].copy()               # follow the GPU's track from here (the state is carried)
-    assert n_pitch_top_tie <= 1 and n_unstable <= F // 100, (n_pitch_top_tie, n_unstable)
+    assert n_pitch_top_tie <= 1 and n_unstable <= 1, (n_pitch_top_tie, n_unstable)      # observed: 0 and 0
     REPORT["formant_extraction_example"] = dict(frames=F, pitch_top_ties=n_pitch_top_tie, oracle_unstable_frames=n_unstable,
                                                 burg_direct=n_direct_burg, roots_direct=n_direct_roots)
 

@@ -67,6 +67,7 @@ struct vbx_ctx {
     int (*roctx_pop)() = nullptr;
     std::vector<ProfRec> recs;
     std::map<std::string, std::pair<double, long>> prof_acc;
+    std::map<std::string, int> prof_stream;               // name -> 0: the context's stream, 1: the side stream, 2: the tracker's
     double *spectral_tab[SPECTRAL_PLANS] = {};             // twiddles of k_spectral*.hip, by plan
     bool pitch_force_mfma = false;                        // test hook: VBX_PITCH_MFMA=1 keeps the matrix-core pitch kernel on 1200-sample frames
     bool mfcc_force_goertzel = false;                     // test hooks: VBX_MFCC_GOERTZEL=1 / VBX_MFCC_DFT2=1 keep the
@@ -578,6 +579,7 @@ static int prof_flush(vbx_ctx *ctx) {
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             auto &acc = ctx->prof_acc[r.name];
             acc.first += ms; acc.second += 1;
+            ctx->prof_stream[r.name] = (r.stream == ctx->stream) ? 0 : (r.stream == ctx->side) ? 1 : 2;
         }
         hipEventDestroy(r.a); hipEventDestroy(r.b);
     }
@@ -594,6 +596,7 @@ int vbx_profile_reset(vbx_ctx *ctx) {
     VBX_REQUIRE(ctx, ctx != nullptr, "null context");
     int rc = prof_flush(ctx);
     ctx->prof_acc.clear();
+    ctx->prof_stream.clear();
     if (ctx->pitch_work)
         VBX_HIP(ctx, hipMemsetAsync(ctx->pitch_work, 0, PITCH_WORK_SLOTS * 4 * sizeof(unsigned long long), ctx->stream));
     return rc;
@@ -615,6 +618,14 @@ int vbx_profile_get(vbx_ctx *ctx, const char *kernel_name, double *h_total_ms, l
     auto it = ctx->prof_acc.find(kernel_name);
     if (h_total_ms) *h_total_ms = (it == ctx->prof_acc.end()) ? 0.0 : it->second.first;
     if (h_launches) *h_launches = (it == ctx->prof_acc.end()) ? 0 : it->second.second;
+    return VBX_SUCCESS;
+}
+int vbx_profile_stream(vbx_ctx *ctx, const char *kernel_name, int *h_stream) {
+    VBX_REQUIRE(ctx, ctx && kernel_name && h_stream, "null argument");
+    int rc = prof_flush(ctx);
+    if (rc != VBX_SUCCESS) return rc;
+    auto it = ctx->prof_stream.find(kernel_name);
+    *h_stream = (it == ctx->prof_stream.end()) ? -1 : it->second;
     return VBX_SUCCESS;
 }
 int vbx_profile_names(vbx_ctx *ctx, char *h_buf, size_t cap) {

@@ -129,6 +129,7 @@ def load_library():
         "vbx_profile_enable": (C.c_int, [vp, i32]),
         "vbx_profile_reset": (C.c_int, [vp]),
         "vbx_profile_get": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+        "vbx_profile_stream": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_int)]),
         "vbx_profile_names": (C.c_int, [vp, C.c_char_p, sz]),
         "vbx_profile_pitch_work": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         "vbx_window_table_f64": (C.c_int, [i32, sz, vp]),
@@ -508,6 +509,15 @@ class VoxBox:
             ms, cnt = C.c_double(), C.c_long()
             self._check(self.L.vbx_profile_get(self.ctx, name.encode(), C.byref(ms), C.byref(cnt)))
             out[name] = (ms.value, cnt.value)
+        return out
+
+    def profile_streams(self):
+        """name -> 0 (the context's stream: the critical path), 1 (side stream), 2 (tracker time slices)."""
+        out = {}
+        for name in self.profile_report():
+            sid = C.c_int()
+            self._check(self.L.vbx_profile_stream(self.ctx, name.encode(), C.byref(sid)))
+            out[name] = sid.value
         return out
 
     def _frames(self, x, frame_len=None, stride=None, n_frames=None):
