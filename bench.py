@@ -557,7 +557,41 @@ def sub_benchmarks(vb, torch, dev, pkg, audio48, F48):
                 "recording at other frame shapes: 25 ms / 10 ms at 16, 24, 32, 44.1 kHz-like sample counts, the reference's own "
                 "1024 / 512 (tests/lib.rs:56-57) and 2048 / 1024 (examples/pitch_detection.rs:23), and 4096 / 2048 (benches/periodic.rs:22-25)",
                 "unit": "frames/s", "steps": 2, "warmup": 1, "shapes": pipeline_shapes(vb, torch, dev, pkg, audio48)})
+    out.append(config5_whole_on_one_gpu(vb, torch, dev, pkg))
     return out
+
+
+def config5_whole_on_one_gpu(vb, torch, dev, pkg, hours=100.0, steps=3, warmup=1):
+    """BASELINE config 5 WHOLE on one GPU: 100 h = 36,000,000 frames, 138 GB of f64 audio resident beside the headline's shard
+    (288 GB of HBM hold both), ONE utterance, one vbx_analyze_frames_f64 call per step.  Skipped (and says so) if the
+    allocation fails."""
+    F = int(hours * 3600 * 100)
+    ns = (F - 1) * H48 + N48
+    est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+    params = pkg.AnalysisParams.make(SR, pitch=(0.2, 75.0, 600.0), lpc_order=P, formant_order=P, est_init=est0, mfcc=(13, 100.0, 8000.0))
+    REC = int(vb.L.vbx_record_doubles(params))
+    name = "config5_100h_1gpu"
+    try:
+        audio = torch.empty(ns, dtype=torch.float64, device=dev)
+        rec = torch.empty((F, REC), dtype=torch.float64, device=dev)
+        st3 = torch.empty((3, F), dtype=torch.int32, device=dev)
+    except RuntimeError as e:                                   # out of memory on a smaller part: not a measurement
+        return {"name": name, "skipped": repr(e)[:200]}
+    vb.synth_speech(ns, sample_offset=0, sample_rate=SR, out=audio)
+
+    def step(i):
+        vb.analyze_frames(audio, params, frame_len=N48, stride=H48, n_frames=F, out=rec, record_ld=REC, status=st3)
+    dt, prof, work = timed(vb, torch, step, warmup, steps)
+    roof, hbm, kms, _ = roofline_for("pipeline", prof, work, F, N48, H48, steps)
+    bad = int((st3 != 0).sum().item())
+    r = {"name": name, "workload": f"BASELINE config 5 whole on ONE GPU: {hours:g} h synthetic 48 kHz = {F} frames, 25 ms / 10 ms hop, "
+         "pitch + LPC + formants + MFCC, the whole recording one utterance, audio resident (138 GB)",
+         "value": F * steps / dt, "unit": "frames/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "frames": F,
+         "frame_len": N48, "hop": H48, "frames_with_nonzero_status": bad, "roofline": roof, "kernels_ms": kms}
+    if hbm is not None:
+        r["roofline_hbm"] = {k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes_per_frame")}
+    del audio, rec, st3
+    return r
 
 
 PIPELINE_SHAPES = ((400, 160), (512, 256), (600, 240), (800, 320), (1024, 512), (1102, 441), (1103, 441), (1200, 480), (1600, 640),

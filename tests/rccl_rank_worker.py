@@ -1,4 +1,4 @@
-"""One rank process of tests/test_gpu_shard.py::test_two_rank_processes_stitch_and_gather_over_rccl (started as a child,
+"""One rank process of tests/test_gpu_shard.py::test_rank_processes_stitch_and_gather_over_rccl (started as a child,
 RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* in the environment).  Control plane: gloo; data plane: the library's RCCL
 communicator (the state hand-off of the formant tracker and the record gather)."""
 import json

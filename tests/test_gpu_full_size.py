@@ -271,5 +271,32 @@ def test_pipeline_shard_twelve_and_a_half_hours(vb, oracle, pkg):
         fr = audio.numpy_slice(t * H, N)
         s_, est, _, _ = oracle.find_formants(fr, SR, P, est)
         assert s_ == 0 and np.all(np.abs(est[:, 0] - fo[t, :, 0]) <= 1e-4 * np.abs(est[:, 0])), t
-    for d in (audio, rec, st3):
+    del R, S3, pit, fo
+    # ---- the bench's DEFAULT mode: the whole shard is ONE utterance (bench.py --utterance-frames 0; what the reference's
+    # loop over a file is, tests/lib.rs:75-79).  (1) the fused call's formant columns are vbx_find_formants_f64's tracks bit
+    # for bit; (2) ALL 4,500,000 resonance rows of the GPU through the oracle's C estimate_formants, in order, on the host:
+    # the tracks of the chunked scan (one utterance = 140,625 chunks of 32 frames, eight check + redo rounds, a sweep) are
+    # the sequential scan's, bit for bit, on every frame of the configuration the driver times.
+    vb.analyze_frames(audio, params, frame_len=N, stride=H, n_frames=F, out=rec, record_ld=REC, status=st3)
+    R1 = rec.numpy()
+    assert np.all(st3.numpy() == 0) and np.all(np.isfinite(R1))
+    fo1 = np.ascontiguousarray(R1[:, cols["formants"][0]:cols["formants"][1]]).reshape(F, 4, 2)
+    per_frame = [c for k, (a, b) in cols.items() if k != "formants" for c in range(a, b)]
+    rec.free()
+    ff = vb.find_formants(audio, SR, P, est0, frame_len=N, stride=H, n_frames=F, want=("formants", "res", "status"))
+    assert np.all(ff["status"] == 0)
+    assert np.array_equal(ff["formants"], fo1)
+    trk = oracle.soak_track(ff["res"], ff["status"], est0)
+    bad = np.flatnonzero(np.any(trk != ff["formants"], axis=(1, 2)))
+    assert bad.size == 0, (bad.size, bad[:5])
+    del ff, trk
+    # the per-frame columns do not depend on how the recording is cut into utterances (the first launch's rows again)
+    rec1k = vb.empty((F, REC))
+    vb.analyze_frames(audio, params, seg_start=seg, frame_len=N, stride=H, n_frames=F, out=rec1k, record_ld=REC, status=st3)
+    R2 = rec1k.numpy()
+    assert np.array_equal(R2[:, per_frame], R1[:, per_frame])
+    # ... and the tracks differ only after an utterance start of the 1,000-frame cut, never before the first one
+    fo2 = R2[:, cols["formants"][0]:cols["formants"][1]].reshape(F, 4, 2)
+    assert np.array_equal(fo2[:1000], fo1[:1000])
+    for d in (audio, rec1k, st3):
         d.free()

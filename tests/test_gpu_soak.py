@@ -97,13 +97,19 @@ def _formant_classes(oracle, gpu, s, est0, seg):
     return cls
 
 
-def test_soak_pipeline_shard(vb, oracle, pkg):
+_ORACLE_WALK = {}      # the oracle's walk of the stretch, shared by the two utterance layouts (its per-frame part is the same)
+
+
+@pytest.mark.parametrize("utterances", ["one", "of_1000_frames"])
+def test_soak_pipeline_shard(vb, oracle, pkg, utterances):
+    """utterances = "one": bench.py's DEFAULT mode (--utterance-frames 0): the stretch is one utterance, the tracker's state
+    runs through all of it (what the driver times); "of_1000_frames": the tracker restarts every 1,000 frames."""
     F = SOAK_PIPELINE - SOAK_PIPELINE % SEG
     ns = (F - 1) * H48 + N48
     audio_d = vb.synth_speech(ns, sample_offset=0)            # rank 0's recording starts at sample 0 (bench.py)
     audio = audio_d.numpy()
     est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
-    seg = np.arange(0, F, SEG, dtype=np.int64)
+    seg = None if utterances == "one" else np.arange(0, F, SEG, dtype=np.int64)
     params = pkg.AnalysisParams.make(SR, pitch=(0.2, 75.0, 600.0), lpc_order=P, formant_order=P, est_init=est0,
                                      mfcc=(13, 100.0, 8000.0))
     cols = params.columns()
@@ -115,7 +121,9 @@ def test_soak_pipeline_shard(vb, oracle, pkg):
 
     t0 = time.time()
     what = oracle.SOAK_PITCH | oracle.SOAK_LPC | oracle.SOAK_MFCC | oracle.SOAK_FORMANTS
-    s = oracle.soak(audio, N48, H48, 0, F, P, SR, what)
+    if F not in _ORACLE_WALK:                                 # per-frame results only: the tracks are scanned below, per layout
+        _ORACLE_WALK[F] = oracle.soak(audio, N48, H48, 0, F, P, SR, what)
+    s = _ORACLE_WALK[F]
     wall = time.time() - t0
 
     cls = {}
@@ -168,9 +176,9 @@ def test_soak_pipeline_shard(vb, oracle, pkg):
     cls["fused_vs_standalone_formant_bits"] = int(np.sum(np.any(rec[:, f0:f0 + fn] != ff["formants"].reshape(F, -1), axis=1)))
 
     voiced = int(np.sum(e_top[:, 0] > 0))
-    REPORT["pipeline"] = {"frames": F, "voiced": voiced, "unvoiced": F - voiced, "oracle_seconds": round(wall, 1),
+    REPORT["pipeline_" + utterances] = {"frames": F, "voiced": voiced, "unvoiced": F - voiced, "oracle_seconds": round(wall, 1),
                           "oracle_threads": oracle.usable_cores(), "disagreements": cls, "lpc_ill_conditioned_rows": lpc_note}
-    print("\nsoak pipeline:", REPORT["pipeline"])
+    print("\nsoak pipeline:", utterances, REPORT["pipeline_" + utterances])
     # the runner-up of an unvoiced frame is a noise candidate: <= 0.5 % of those refinements end on the other side of the
     # lag discontinuity (same frequency, another strength) -- _check_pitch in test_gpu_parity.py
     # classifies them candidate by candidate, here they are only bounded (1 % of the frames)
