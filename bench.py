@@ -90,6 +90,11 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="wall budget of the CPU baseline leg (both legs together)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-sub", action="store_true", help="skip the sub_benchmarks of the default run (configs 2, 3, 4)")
+    ap.add_argument("--signal", default="synthetic", choices=["synthetic", "speech"], help="speech: the pipeline on a recording of REAL "
+                    "speech (tests/golden/sample-two_vowels.wav, 44.1 kHz, tiled with per-tile gains and a -70 dB dither) at the "
+                    "shapes a 44.1 kHz caller uses (1103 / 441 = 25 ms / 10 ms; 1024 / 512 = tests/lib.rs:56-57), order 13 "
+                    "(examples/formant_extraction/src/main.rs:53), beside the synthetic signal at the same shapes; its own metric "
+                    "name, never the headline")
     ap.add_argument("--host-fed", action="store_true", help="pipeline only: the recording starts in pinned HOST memory as 16-bit PCM "
                     "and crosses PCIe inside the timed region, in chunks, double-buffered against the kernels (vbx_analyze_frames_pcm16); "
                     "reported under its own metric name, never as the headline `value`")
@@ -557,8 +562,58 @@ def sub_benchmarks(vb, torch, dev, pkg, audio48, F48):
                 "recording at other frame shapes: 25 ms / 10 ms at 16, 24, 32, 44.1 kHz-like sample counts, the reference's own "
                 "1024 / 512 (tests/lib.rs:56-57) and 2048 / 1024 (examples/pitch_detection.rs:23), and 4096 / 2048 (benches/periodic.rs:22-25)",
                 "unit": "frames/s", "steps": 2, "warmup": 1, "shapes": pipeline_shapes(vb, torch, dev, pkg, audio48)})
+    out.append(bench_speech(vb, torch, dev, pkg))
     out.append(config5_whole_on_one_gpu(vb, torch, dev, pkg))
     return out
+
+
+SPEECH_WAV = os.path.join(ROOT, "tests", "golden", "sample-two_vowels.wav")
+SPEECH_SHAPES = ((1103, 441), (1024, 512))
+
+
+def bench_speech(vb, torch, dev, pkg, hours=1.0, steps=2, warmup=1, shapes=SPEECH_SHAPES, order=13):
+    """The full pipeline on REAL speech: what the reference's callers feed it (tests/lib.rs:60-83,
+    examples/formant_extraction/src/main.rs:36-47 read WAV files).  Per shape: frames/s on the speech recording and on the
+    synthetic signal with the same parameters, and the share of frames the one-pass Burg's guard / the conjugate-pair root
+    finder's check hand to the reference's own recursions (`burg_direct`, `roots_direct`): the fast paths' coverage is a
+    property of the material, so it is measured on material."""
+    import wave
+    from importlib import import_module
+    with wave.open(SPEECH_WAV, "rb") as w:
+        sr = float(w.getframerate())
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+    ns = int(hours * 3600 * sr)
+    syn = import_module(pkg.__name__ + ".synth")
+    speech = syn.speech_recording(torch, dev, pcm, ns)
+    synth = torch.empty(ns, dtype=torch.float64, device=dev)
+    vb.synth_speech(ns, sample_offset=0, sample_rate=sr, out=synth)
+    est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+    params = pkg.AnalysisParams.make(sr, pitch=(0.2, 75.0, 600.0), lpc_order=P, formant_order=order, est_init=est0,
+                                     mfcc=(13, 100.0, 8000.0))
+    REC = int(vb.L.vbx_record_doubles(params))
+    rows = []
+    for n, hop in shapes:
+        F = pkg.frame_count(ns, n, hop)
+        rec = torch.empty((F, REC), dtype=torch.float64, device=dev)
+        st3 = torch.empty((3, F), dtype=torch.int32, device=dev)
+        row = {"frame_len": n, "hop": hop, "frames": F}
+        for name, audio in (("speech", speech), ("synthetic", synth)):
+            def step(i, audio=audio, n=n, hop=hop, F=F, rec=rec, st3=st3):
+                vb.analyze_frames(audio, params, frame_len=n, stride=hop, n_frames=F, out=rec, record_ld=REC, status=st3)
+            dt, prof, _ = timed(vb, torch, step, warmup, steps)
+            kms = {k: round(ms / max(c, 1), 3) for k, (ms, c) in prof.items()}
+            row[name] = {"value": F * steps / dt, "ms_per_step": dt / steps * 1e3,
+                         "burg_direct": vb.last_burg_direct_count() / F, "roots_direct": vb.last_roots_direct_count() / F,
+                         "frames_with_nonzero_status": int((st3 != 0).any(dim=0).sum().item()),
+                         "dominant_kernel": dominant_kernel(prof), "kernels_ms": kms}
+        row["speech_over_synthetic"] = row["speech"]["value"] / row["synthetic"]["value"]
+        rows.append(row)
+        del rec, st3
+    del speech, synth
+    return {"name": "speech_44k", "workload": f"the full pipeline (pitch + LPC + formants order {order} + MFCC, one utterance) on "
+            f"{hours:g} h of real speech at {sr:g} Hz (tests/golden/sample-two_vowels.wav tiled: per-tile gain in [0.5, 1), -70 dB "
+            "dither) and on the synthetic signal with the same parameters", "unit": "frames/s", "steps": steps, "warmup": warmup,
+            "sample_rate": sr, "formant_order": order, "shapes": rows}
 
 
 def config5_whole_on_one_gpu(vb, torch, dev, pkg, hours=100.0, steps=3, warmup=1):
@@ -740,6 +795,18 @@ def run_rank(args):
     f64 = torch.float64
     if wl == "frontend":
         return bench_frontend(args, torch, dev, vb, pkg)
+    if args.signal == "speech":
+        if wl != "pipeline" or world != 1:
+            raise SystemExit("bench.py --signal speech: the pipeline on one GPU only")
+        r = bench_speech(vb, torch, dev, pkg, hours=min(args.hours, 2.0) if args.hours != 12.5 else 1.0, steps=args.steps, warmup=args.warmup)
+        head = r["shapes"][0]
+        print(json.dumps({"metric": "frames/sec (pipeline on real 44.1 kHz speech, 1103-sample frames / 441-sample hop, order 13)",
+                          "value": head["speech"]["value"], "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": head["speech"]["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f64", "data": "real speech (committed WAV fixture, tiled)", "config": {"workload": r["workload"]},
+                          "speech": r}), flush=True)
+        vb.close()
+        return 0
     if args.host_fed:
         if wl != "pipeline" or world != 1 or (N, H) != (N48, H48):
             raise SystemExit("bench.py --host-fed: the default pipeline shape on one GPU only")

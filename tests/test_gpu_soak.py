@@ -252,6 +252,99 @@ def test_soak_reference_orders(vb, oracle, pkg, order, n, hop):
     assert not any(cls.values()), cls
 
 
+@pytest.mark.parametrize("n,hop", [(1103, 441), (1024, 512)])
+def test_soak_real_speech_44k(vb, oracle, pkg, golden_dir, n, hop):
+    """20,000 consecutive frames of REAL speech -- the reference's callers read WAV files (tests/lib.rs:60-83,
+    examples/formant_extraction/src/main.rs:36-47) -- through the fused frame loop as ONE utterance, order 13
+    (examples/formant_extraction/src/main.rs:53), every column against the oracle's walk: the 44.1 kHz fixture tiled with
+    per-tile gains under a -70 dB dither (vox_box.rs_amd/synth.py speech_recording; bench.py --signal speech times the same
+    recording).  On this material the one-pass Burg's guard hands most frames to the direct recursion (oversampled speech:
+    an ill-conditioned covariance matrix); the counts are recorded.  A resonance row that leaves the oracle's is a
+    disagreement only where the oracle's own row is stable under a 1e-13 perturbation of the frame (an order-13 polynomial
+    of such a frame can carry a near-multiple root cluster: neither side has digits there)."""
+    import wave
+    import torch
+    from importlib import import_module
+    F, order = 20000, 13
+    with wave.open(os.path.join(golden_dir, "sample-two_vowels.wav"), "rb") as w:
+        sr = float(w.getframerate())
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+    syn = import_module(pkg.__name__ + ".synth")
+    ns = (F - 1) * hop + n
+    audio_t = syn.speech_recording(torch, "cuda:0", pcm, ns)
+    torch.cuda.synchronize()
+    audio = audio_t.cpu().numpy()
+    audio_d = vb.to_device(audio)                              # the library's own buffer: the same bits
+    del audio_t
+    est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+    params = pkg.AnalysisParams.make(sr, pitch=(0.2, 75.0, 600.0), lpc_order=order, formant_order=order, est_init=est0,
+                                     mfcc=(13, 100.0, 8000.0))
+    cols = params.columns()
+    rec, st3 = vb.analyze_frames(audio_d, params, frame_len=n, stride=hop, n_frames=F)
+    nb_fused, nr_fused = vb.last_burg_direct_count(), vb.last_roots_direct_count()
+    ff = vb.find_formants(audio_d, sr, order, est0, frame_len=n, stride=hop, n_frames=F)
+    nb, nr = vb.last_burg_direct_count(), vb.last_roots_direct_count()
+    audio_d.free()
+    what = oracle.SOAK_PITCH | oracle.SOAK_LPC | oracle.SOAK_MFCC | oracle.SOAK_FORMANTS
+    s = oracle.soak(audio, n, hop, 0, F, order, sr, what)
+    cls = {}
+    # pitch: status exact, PitchExtractor output within 1e-4 (or a tie of the oracle's two best)
+    c0 = cols["pitch"][0]
+    g, e_top, e_run = rec[:, c0:c0 + 2], s["pitch_top"][:, 0], s["pitch_top"][:, 1]
+    okst = s["pitch_status"] == 0
+    cls["pitch_status"] = int(np.sum(st3[0] != s["pitch_status"]))
+    close = (np.abs(g[:, 0] - e_top[:, 0]) <= 1e-4 * np.abs(e_top[:, 0])) & (np.abs(g[:, 1] - e_top[:, 1]) <= 1e-4)
+    gap = np.where(s["pitch_count"] > 1, np.abs(e_top[:, 1] - e_run[:, 1]), np.inf)
+    is_runner = (np.abs(g[:, 0] - e_run[:, 0]) <= 1e-4 * np.abs(e_run[:, 0])) & (np.abs(g[:, 1] - e_run[:, 1]) <= 1e-3)
+    swap = okst & ~close & (gap < 1e-3) & is_runner
+    cls["pitch_top_bad"] = int(np.sum(okst & ~close & ~swap))
+    cls["pitch_top_tie_swap"] = int(np.sum(swap))
+    # LPC (Levinson on the Hanning frame's autocorrelation), MFCC
+    l0, ln = cols["lpc"]; m0, mn = cols["mfcc"]
+    lpc_rows = _rows_bad(rec[:, l0:l0 + ln], s["a"])
+    wh = oracle.window("hanning", n)
+    beyond, wg, wo = _lpc_adjudicate(lambda t: audio[t * hop:t * hop + n] * wh, rec[:, l0:l0 + ln], s["a"], lpc_rows[:200])
+    cls["lpc_beyond_oracle_rounding"] = beyond
+    cls["mfcc_status"] = int(np.sum(st3[2] != s["mfcc_status"]))
+    cls["mfcc_1e-6"] = int(_rows_bad(rec[:, m0:m0 + mn], s["mfcc"]).size)
+    # formants: Burg coefficients, rows, tracks
+    ok = s["ff_status"] == 0
+    cls["formant_status"] = int(np.sum(ff["status"] != s["ff_status"])) + int(np.sum(st3[1] != s["ff_status"]))
+    cls["burg_1e-6"] = int(_rows_bad(ff["coeffs"][ok], s["burg"][ok]).size)
+    e, gr = s["res"], ff["res"]
+    row_ok = np.all(np.abs(gr - e) <= 1e-4 * np.abs(e) + 1e-9, axis=(1, 2)) & (ff["count"] == s["res_count"])
+    suspects = np.flatnonzero(ok & ~row_ok)
+    unstable = 0
+    for t in suspects[:500]:
+        fr = audio[t * hop:t * hop + n]
+        _, _, r1, _ = oracle.find_formants(fr * (1.0 + 1e-13), sr, order, est0)
+        if np.all(np.abs(r1 - e[t]) <= 1e-6 * np.abs(e[t]) + 1e-9):
+            cls["res_rows_1e-4"] = cls.get("res_rows_1e-4", 0) + 1       # the oracle has digits here and the GPU left them
+        else:
+            unstable += 1
+    cls.setdefault("res_rows_1e-4", 0)
+    cls["res_rows_unchecked"] = max(0, int(suspects.size) - 500)
+    # the tracker: the GPU's tracks are the sequential scan of the GPU's own rows, bit for bit (one utterance of 20,000 frames)
+    trk_g = oracle.soak_track(ff["res"], ff["status"], est0)
+    cls["track_on_gpu_rows_exact"] = int(np.sum(np.any(ff["formants"] != trk_g, axis=(1, 2))))
+    f0, fn = cols["formants"]
+    cls["fused_vs_standalone_formant_bits"] = int(np.sum(np.any(rec[:, f0:f0 + fn] != ff["formants"].reshape(F, -1), axis=1)))
+    if unstable == 0:
+        trk = oracle.soak_track(s["res"], s["ff_status"], est0)
+        cls["track_1e-4"] = int(np.sum(~np.all(np.abs(ff["formants"] - trk) <= 1e-4 * np.abs(trk), axis=(1, 2))))
+    voiced = int(np.sum(e_top[:, 0] > 0))
+    REPORT["real_speech_%d_%d" % (n, hop)] = {
+        "frames": F, "voiced": voiced, "levinson_rows_beyond_1e-6": int(lpc_rows.size),
+        "levinson_worst_gpu_vs_long_double": wg, "levinson_worst_oracle_vs_long_double": wo,
+        "burg_direct": nb, "roots_direct": nr, "burg_direct_fused": nb_fused, "roots_direct_fused": nr_fused,
+        "oracle_unstable_resonance_rows": unstable, "disagreements": cls}
+    print("\nsoak real speech at %d / %d:" % (n, hop), REPORT["real_speech_%d_%d" % (n, hop)])
+    allowed = {"pitch_top_tie_swap": 2}
+    bad = {k: v for k, v in cls.items() if v > allowed.get(k, 0)}
+    assert not bad, f"disagreements with the oracle over {F} consecutive frames of real speech: {bad} (all classes: {cls})"
+    assert voiced > F // 10
+
+
 @pytest.mark.parametrize("n,hop,frames", [(1200, 480, 3000), (2048, 1024, 600), (4096, 2048, 300)])
 def test_soak_whole_vec(vb, oracle, pkg, n, hop, frames):
     """The reference's literal return value -- the WHOLE sorted candidate Vec of every frame (src/periodic.rs:452-454) -- on

@@ -44,3 +44,27 @@ def synth_speech(n_samples, sample_offset=0, sample_rate=48000.0, seed=SEED):
         acc += (g / h) * s_cur
         s_prev, s_cur = s_cur, two_c * s_cur - s_prev
     return np.where(unvoiced, 0.05 * noise, 0.25 * acc + 0.0025 * noise)
+
+
+
+def speech_recording(torch, device, pcm16, n_samples, seed=0x5EED0044, dither_db=-70.0):
+    """A long recording of REAL speech for benches and soaks, built on `device` with torch (plumbing): the 16-bit samples of
+    a WAV fixture (what a reader hands the reference's callers, tests/lib.rs:15-19) tiled to n_samples -- every tile with its
+    own gain in [0.5, 1) (the golden ratio's multiples mod 1) and the whole under a uniform dither at dither_db re full scale,
+    so that no two frames are the same bits -- as f64 in [-1, 1]: `sample / 32767` first, exactly as the reference's test
+    converts.  The dither comes from torch's generator on that device (seeded): a test that needs the samples on the host
+    copies them back, both sides then see identical input."""
+    f64 = torch.float64
+    base = torch.as_tensor(np.asarray(pcm16, dtype=np.float64) / 32767.0, dtype=f64, device=device)
+    L = int(base.numel())
+    tiles = -(-int(n_samples) // L)
+    gains = torch.as_tensor(0.5 + 0.5 * np.modf(0.6180339887498949 * np.arange(1, tiles + 1))[0], dtype=f64, device=device)
+    out = (gains[:, None] * base[None, :]).reshape(-1)[:n_samples].contiguous()
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    amp = 10.0 ** (dither_db / 20.0)
+    step = 1 << 26
+    for s0 in range(0, int(n_samples), step):
+        m = min(step, int(n_samples) - s0)
+        out[s0:s0 + m] += amp * (2.0 * torch.rand(m, generator=gen, dtype=f64, device=device) - 1.0)
+    return out
