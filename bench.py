@@ -600,9 +600,14 @@ def bench_speech(vb, torch, dev, pkg, hours=1.0, steps=2, warmup=1, shapes=SPEEC
         for name, audio in (("speech", speech), ("synthetic", synth)):
             def step(i, audio=audio, n=n, hop=hop, F=F, rec=rec, st3=st3):
                 vb.analyze_frames(audio, params, frame_len=n, stride=hop, n_frames=F, out=rec, record_ld=REC, status=st3)
-            dt, prof, _ = timed(vb, torch, step, warmup, steps)
+            dt, prof, work = timed(vb, torch, step, warmup, steps)
             kms = {k: round(ms / max(c, 1), 3) for k, (ms, c) in prof.items()}
+            frames_w, cand_w, evals_w, terms_w = work
             row[name] = {"value": F * steps / dt, "ms_per_step": dt / steps * 1e3,
+                         # what the pitch refinement did (device counters): the material decides it -- a recording that is
+                         # voiced throughout refines a candidate in (nearly) every frame, the synthetic one in four of five
+                         "sinc_evals_per_frame": evals_w / max(frames_w, 1), "sinc_terms_per_frame": terms_w / max(frames_w, 1),
+                         "candidates_per_frame": cand_w / max(frames_w, 1),
                          "burg_direct": vb.last_burg_direct_count() / F, "roots_direct": vb.last_roots_direct_count() / F,
                          "frames_with_nonzero_status": int((st3 != 0).any(dim=0).sum().item()),
                          "dominant_kernel": dominant_kernel(prof), "kernels_ms": kms}

@@ -201,9 +201,9 @@ int vbx_improve_extremum_ex_f64(vbx_ctx *ctx, const double *y, size_t ylen, long
  * Bit identity across kmax: the lists returned for kmax in {1, 2, 3} are bit for bit the head of one another, and so are
  * the lists for every kmax >= 4 (from 4 on, few-candidate frames refine four candidates at a time, which changes the last
  * bits of a candidate's sinc sums); between the two classes a candidate agrees to ~1e-7 relative in Hz.
- * Which shapes are fast (one MI355X, kmax = 1, frames/s): 512..1024 samples 33-53 M, 1025..1200 30-33 M, 1201..2048
- * 27-28 M (that kernel spills a few registers: ~1.8x its algorithmic HBM traffic), 2049..4096 7-8 M, below 512 samples the
- * direct lag sums on the matrix cores 40-70 M.  kmax 2 / 8 / 64 / whole Vec at 1200: 13.6 / 5.6 / 2.7 / 1.9 M. */
+ * Which shapes are fast (one MI355X, kmax = 1, frames/s; the table in DESIGN.md section 4 is kept current): 512..1024 samples
+ * 44-56 M, 1025..1200 38-40 M, 1201..2048 29 M, 2049..4096 14 M, below 512 samples the direct lag sums on the matrix cores
+ * 50-70 M.  kmax 2 / 8 / 64 / whole Vec at 1200: 13.5 / 6.5 / 3.25 / 2.7 M. */
 int vbx_pitch_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
                   const double *window, double sample_rate, double threshold, double fmin, double fmax,
                   size_t kmax, vbx_pitch *out_cand, int32_t *out_count, int32_t *status);
@@ -231,10 +231,15 @@ int vbx_autocorr_lpc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t 
  * Orders 8, 10, 12, 13, 14, 16 on frames of 256..2048 samples (also inside vbx_find_formants_f64 and vbx_analyze_frames_*): one pass over
  * the frame -- its p + 1 lag sums and first / last p + 1 samples, then an O(p^2) recursion per frame that yields the reference's
  * reflection coefficients (csrc/k_burg_fast.hip).  That recursion is exact in real arithmetic but amplifies the lag sums'
- * rounding by the frame's conditioning (~1e-11 of the row's largest coefficient on speech), so the kernel bounds its own
- * error per frame: a row is written only if the bound is inside 5e-7 in the parity metric
- * |d| <= 1e-6 max(|a_j|, 1e-6 max|a|); every other frame (about 1 % of speech frames, every pure tone / DC / silent / NaN
- * frame) is computed by the reference's own per-order sums, as all frames of every other order and length are.
+ * rounding by the frame's conditioning, so the kernel bounds its own error per frame: a row is written only if the bound
+ * is inside 5e-7 in the parity metric |d| <= 1e-6 max(|a_j|, 1e-6 max|a|); every other frame is computed by the reference's
+ * own per-order sums, as all frames of every other order and length are.  HOW MANY frames that is depends on the material:
+ * ~1 % of the bench's synthetic 48 kHz signal at order 12; 40 % of a real 44.1 kHz recording at order 13 (68 % without a
+ * -70 dB dither: oversampled speech has almost no energy above 8 kHz, its covariance matrix is ill conditioned, and there the
+ * one-pass recursion's error is real -- 14 % of such frames are off by more than 1e-7, 5 % by more than 5e-7,
+ * tools/experiments/burg_guard_vs_error.py); every pure tone / DC / silent / NaN frame.  The results are the direct
+ * recursion's either way; the cost is its speed on those frames (about 4x the one-pass form's instructions per frame;
+ * bench.py --signal speech: the pipeline on such a recording runs within 4 % of what the same material would without it).
  * Environment: VBX_BURG_DIRECT=1 (read per call) takes the per-order sums for every frame. */
 int vbx_lpc_burg_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
                      size_t stride, const double *window, size_t n_coeffs, double *out, int32_t *status);

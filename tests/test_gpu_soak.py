@@ -47,30 +47,46 @@ def _rows_bad(got, exp, rtol=1e-6):
     return np.nonzero(~np.all(ok, axis=1))[0]
 
 
+def _levinson_ld(rl, p):
+    """src/spectrum.rs:63-84 in long double"""
+    al = np.zeros(p + 1, dtype=np.longdouble); al[0] = 1; err = rl[0]
+    for i in range(1, p + 1):
+        kk = -(rl[i] + sum(al[j] * rl[i - j] for j in range(1, i))) / err
+        tl = al.copy(); al[i] = kk
+        for j in range(1, i):
+            al[j] = tl[j] + kk * tl[i - j]
+        err = err * (1 - kk * kk)
+    return al
+
+
 def _lpc_adjudicate(frames_windowed, got, exp, rows):
     """Rows where the GPU's Levinson coefficients and the oracle's differ by more than 1e-6 in the parity metric: who is
     right?  Order-12 Levinson on the autocorrelation of a 48 kHz speech frame is ill-conditioned (the recursion divides by
-    the prediction error, ~1e-5 of r[0] here), so BOTH f64 results carry rounding of their own lag sums amplified by 1e5 and
-    more, and a coefficient that happens to be tiny against the row's largest is held to an absolute 1e-12 by the metric.
-    The same recursion in long double (x87 80-bit) on long-double lag sums of the same frame is the arbiter: a row counts
-    as a GPU error only if the GPU is further from it than 1e-6 AND than twice the oracle's own distance.
-    Returns (rows beyond the oracle's own rounding, worst GPU distance / worst oracle distance over the rows)."""
+    the prediction error, ~1e-5 of r[0] here; order 13 on 44.1 kHz speech: down to 1e-10), so BOTH f64 results carry rounding
+    of their own lag sums amplified by 1e5 and more, and a coefficient that happens to be tiny against the row's largest is
+    held to an absolute 1e-12 by the metric.  The same recursion in long double (x87 80-bit) on long-double lag sums of the
+    same frame is the arbiter, and the row's own conditioning the yardstick: `amp` = how far (in the parity metric) the
+    arbiter's row moves per unit of relative perturbation of its lag sums (three random perturbations of 1e-13, the largest
+    answer).  Lag sums of ~1000 products carry a rounding of a few eps of r[0] under ANY summation order (the oracle's
+    sequential fold ~2 eps observed, the GPU's two transforms < 8 eps).  A row counts as a GPU error only if
+    the GPU is further from the arbiter than 1e-6 AND than twice the oracle's own distance AND than what 16 eps of
+    perturbation of the lag sums explains.
+    Returns (rows beyond all three, worst GPU distance, worst oracle distance over the rows)."""
     beyond, worst_g, worst_o = 0, 0.0, 0.0
+    rng = np.random.default_rng(2025)
     for t in rows:
         xl = frames_windowed(t).astype(np.longdouble)
         n, p = xl.size, got.shape[1] - 1
         rl = np.array([xl[0] + np.sum(xl[1:n - k] * xl[1 + k:n]) for k in range(p + 1)])     # src/periodic.rs:284: seeded with x[0]
-        al = np.zeros(p + 1, dtype=np.longdouble); al[0] = 1; err = rl[0]
-        for i in range(1, p + 1):                                                              # src/spectrum.rs:63-84
-            kk = -(rl[i] + sum(al[j] * rl[i - j] for j in range(1, i))) / err
-            tl = al.copy(); al[i] = kk
-            for j in range(1, i):
-                al[j] = tl[j] + kk * tl[i - j]
-            err = err * (1 - kk * kk)
+        al = _levinson_ld(rl, p)
         dev = lambda v: float(np.max(np.abs(v - al) / np.maximum(np.abs(al), 1e-6 * np.max(np.abs(al)))))
         dg, do = dev(got[t]), dev(exp[t])
+        amp = 0.0
+        for _ in range(3):
+            pert = rl + 1e-13 * np.abs(rl[0]) * rng.uniform(-1.0, 1.0, p + 1).astype(np.longdouble)
+            amp = max(amp, dev(_levinson_ld(pert, p)) / 1e-13)
         worst_g, worst_o = max(worst_g, dg), max(worst_o, do)
-        beyond += int(dg > max(1e-6, 2.0 * do))
+        beyond += int(dg > max(1e-6, 2.0 * do, 16.0 * 2.220446049250313e-16 * amp))
     return beyond, worst_g, worst_o
 
 
