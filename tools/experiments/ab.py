@@ -37,6 +37,10 @@ REC = int(vb.L.vbx_record_doubles(params))
 rec = vb.empty((F, REC)); st3 = vb.empty((3, F), np.int32)
 seg = np.arange(0, F, 1000, dtype=np.int64)
 t("analyze_ms", lambda: vb.analyze_frames(audio, params, seg_start=seg, frame_len=N, stride=H, n_frames=F, out=rec, record_ld=REC, status=st3))
+p2 = pkg.AnalysisParams.make(SR, pitch=(0.2, 75.0, 600.0), lpc_order=12, formant_order=0, mfcc=(13, 100.0, 8000.0))
+REC2 = int(vb.L.vbx_record_doubles(p2))
+rec2 = vb.empty((F, REC2))
+t("analyze_noformants_ms", lambda: vb.analyze_frames(audio, p2, frame_len=N, stride=H, n_frames=F, out=rec2, record_ld=REC2, status=st3))
 np.save(%(save)r, np.concatenate([top.reshape(F, 2), cnt.reshape(F, 1).astype(np.float64)], axis=1))
 print("AB_RESULT " + json.dumps(res))
 '''
@@ -68,8 +72,8 @@ def main():
             bad = int(np.sum((np.abs(cur[:, 0] - ref[:, 0]) > 1e-4 * np.abs(ref[:, 0])) | (np.abs(cur[:, 1] - ref[:, 1]) > 1e-4) | (cur[:, 2] != ref[:, 2])))
             same = f"{nd} frames differ bitwise, {bad} beyond 1e-4 / count"
         F = r["frames"]
-        print("%-44s pitch %8.3f ms (%6.2f M/s)  fft-only %7.3f  k64(F/8) %8.3f  analyze %8.3f ms (%6.2f M/s)  | %s" % (
+        print("%-44s pitch %8.3f ms (%6.2f M/s)  fft-only %7.3f  k64(F/8) %8.3f  analyze %8.3f ms (%6.2f M/s)  no-formants %7.3f  | %s" % (
             os.path.basename(lib) + (":" + envs if envs else ""), r["pitch_ms"], F / r["pitch_ms"] / 1e3, r["fft_only_ms"], r["pitch_k64_ms"], r["analyze_ms"],
-            F / r["analyze_ms"] / 1e3, same), flush=True)
+            F / r["analyze_ms"] / 1e3, r.get("analyze_noformants_ms", 0.0), same), flush=True)
 
 main()

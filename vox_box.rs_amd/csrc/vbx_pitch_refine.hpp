@@ -194,6 +194,32 @@ __device__ __forceinline__ double sinc_terms_fast(const double *y, int ibase_l, 
     return sinc_stream_result(s, n0, s0 * (0.5 * 0.31830988618379067154));
 }
 
+// sinc_terms_fast<64> with what depends on the abscissa's unit cell alone handed in (improve_extremum_sinc_wave keeps it
+// across the evaluations of a Brent run): yp0 = the lane's first sample, nterms its term count, dmd = (double)max_depth.
+// Every floating-point operation is sinc_terms_fast<64>'s, in its order.
+__device__ __forceinline__ double sinc_terms_fast_cell(const double *yp0, int side, int n0, int nterms, double dmd,
+                                                       double phil, double phir) {
+    constexpr int NSTEP = 32;
+    constexpr double S = (double)NSTEP;
+    const double s0 = sin_poly(M_PI * fmin(phil, phir));      // sin(pi*phil) == sin(pi*phir)
+    sinc_stream_t s;
+    const double ph = side ? phir : phil;
+    const double h2 = M_PI * rcp_nr2(ph + dmd);               // theta = h2 * (ph + n)  in [0, pi]
+    s.pn = ph + (double)n0;
+    const double theta0 = h2 * s.pn, delta = h2 * S;
+    s.C = cos_0_pi(theta0);
+    s.d = cos_0_pi(theta0 + delta) - s.C;
+    const double sh = sin_poly(0.5 * delta);
+    s.kappa = 4.0 * sh * sh;
+    s.yp = yp0;
+    s.acc0 = 0.0; s.acc1 = 0.0;
+    const int step = side ? NSTEP : -NSTEP;
+    int j = 0;
+    for (; j + 4 <= nterms; j += 4) sinc_stream_block4<NSTEP>(s, step);
+    if (j < nterms) sinc_stream_tail<NSTEP>(s, step, nterms - j);
+    return sinc_stream_result(s, n0, s0 * (0.5 * 0.31830988618379067154));
+}
+
 // The same sum with each lane standing in for TWO lanes of a group of VG: lane p of a group of VG / 2 runs the left stream
 // (lane 2p of the VG) and the right stream (lane 2p + 1) of n0 = p side by side and adds the two results -- the first level of
 // group_sum<VG>'s tree, whose other levels are group_sum<VG / 2> over the half-sized group (quad_xor1, quad_rev,
@@ -419,18 +445,39 @@ __device__ __forceinline__ bool improve_extremum_sinc_wave(const double *y, int 
     if (__any(ixmid == 0. || ixmid >= (double)nx || !(ixmid - 1. < ixmid + 1.))) return false;   // :193-194, :113
     double a = ixmid - 1., b = ixmid + 1.;
     if (!__any(sinc_bracket_trusted(a, b, nvalid, ylen, offset, nx, depth))) return false;
-    // one evaluation of the interpolant at a trusted abscissa (sinc_interp<64>'s trusted arm, decisions as scalar branches)
+    // one evaluation of the interpolant at a trusted abscissa (sinc_interp<64>'s trusted arm, decisions as scalar branches).
+    // Round 5, same operations on the same values with fewer instructions around them:
+    //  * the two exact-integer tests of :41-42 read phil / phir: x - (double)nl IS phil (x - floor(x) is exact), and
+    //    (double)nr - x is 1 - phil exactly wherever it could be below 1e-10 (phil >= 0.5: Sterbenz);
+    //  * everything that depends on the unit CELL of x alone -- the clamped depth, each lane's term count and first sample's
+    //    address, the terms counter's increment -- is kept from the previous evaluation: a Brent run converges inside one or
+    //    two cells (the bracket is two lags wide), so these ~18 integer instructions run once or twice per candidate
+    //    instead of once per evaluation.
+    const int lane = lane_id();
+    const int side = lane & 1, n0 = lane >> 1;
+    int cell = -0x7fffffff, md = 0, nterms = 0;
+    unsigned tinc = 0u;
+    double dmd = 0.0;
+    const double *yp0 = y;
     auto eval = [&](double x) -> double {
         const double fl = floor(x);
-        const int nl = (int)fl, nr = nl + 1;
+        const int nl = (int)fl;
         const double phil = x - fl, phir = 1.0 - phil;
-        if (__any(fabs(x - (double)nl) < 1.0e-10)) return y[offset + nl];                        // :41
-        if (__any(fabs(x - (double)nr) < 1.0e-10)) return y[offset + nr];                        // :42
-        int md = depth;
-        if ((offset + nr) < md) md = offset + nr;                                                // :46-52 (offset + nr >= 1 here)
-        if ((offset + nl + md) >= nx) md = nx - offset + nl - 1;                                 // :55-57
-        terms += 2u * (unsigned)(md + 1);
-        return group_sum<64>(sinc_terms_fast<64>(y, offset + nr, offset + nl, phil, phir, md));
+        if (__any(phil < 1.0e-10)) return y[offset + nl];                                        // :41
+        if (__any(phir < 1.0e-10)) return y[offset + nl + 1];                                    // :42
+        if (__any(nl != cell)) {
+            cell = nl;
+            const int nr = nl + 1;
+            md = depth;
+            if ((offset + nr) < md) md = offset + nr;                                            // :46-52 (offset + nr >= 1 here)
+            if ((offset + nl + md) >= nx) md = nx - offset + nl - 1;                             // :55-57
+            tinc = 2u * (unsigned)(md + 1);
+            dmd = (double)md;
+            nterms = (n0 <= md) ? (md - n0) / 32 + 1 : 0;
+            yp0 = y + (side ? (offset + nl + n0) : (offset + nr - n0));
+        }
+        terms += tinc;
+        return group_sum<64>(sinc_terms_fast_cell(yp0, side, n0, nterms, dmd, phil, phir));
     };
     double v = a + golden * (b - a);
     double fv = eval(v);
@@ -453,8 +500,10 @@ __device__ __forceinline__ bool improve_extremum_sinc_wave(const double *y, int 
             double p = (x - v) * q - (x - w) * t;
             q = 2. * q - t;
             if (__any(q > 0.)) p = -p; else q = -q;
-            if (__any(fabs(p) < fabs(new_step * q) && p > q * (a - x + 2. * tol_act) && p < q * (b - x - 2. * tol_act)))
-                new_step = p / q;
+            if (__any(fabs(p) < fabs(new_step * q) && p > q * (a - x + 2. * tol_act) && p < q * (b - x - 2. * tol_act))) {
+                asm volatile("" ::: "memory");   // a real branch: the IEEE division runs when the step is taken (a quarter of
+                new_step = p / q;                // the iterations), not speculated on every one and then selected
+            }
         }
         if (__any(fabs(new_step) < tol_act)) new_step = __any(new_step > 0.) ? tol_act : -tol_act;
         const double t = x + new_step;
