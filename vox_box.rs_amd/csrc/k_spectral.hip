@@ -41,6 +41,9 @@ constexpr int SP_T1 = 0;                     // twiddle table (complex entries):
 constexpr int SP_T2 = SP_T1 + 60 * 20;       //                                  T2[3][20]  = W_60^(c kb)
 constexpr int SP_TM = SP_T2 + 3 * 20;        //                                  WM[601]    = W_2400^m
 static_assert(SP_TM + 601 == SPECTRAL_TAB_COMPLEX, "table layout");
+// LDS: [0, 9760) exchange buffer (later the lag curve), [0, 10144) the mel sums between the transforms, then the copy of T2
+constexpr int SP_T2_LDS_OFFSET = (2 * 602 + 64) * 8;
+static_assert(SP_T2_LDS_OFFSET >= (20 * SP_S1 > 3 * SP_S2 ? 20 * SP_S1 : 3 * SP_S2) * 8 && SP_T2_LDS_OFFSET % 16 == 0, "T2 behind both");
 
 __device__ __forceinline__ void dft5(double &r0, double &i0, double &r1, double &i1, double &r2, double &i2,
                                      double &r3, double &i3, double &r4, double &i4) {
@@ -92,6 +95,7 @@ __device__ __forceinline__ void dft20(double (&re)[20], double (&im)[20]) {
 #define VBX_EXP_TWB 2
 #endif
 constexpr int TWB = VBX_EXP_TWB;
+template <int TWB = vbx::TWB>
 __device__ __forceinline__ void twiddle_tight(double (&re)[20], double (&im)[20], const double2 *tw_row) {
 #pragma unroll
     for (int h = 0; h < 20 / TWB; h++) {
@@ -114,9 +118,13 @@ __device__ __forceinline__ void twiddle_tight(double (&re)[20], double (&im)[20]
 // TIGHT (the instance compiled for three wavefronts per SIMD, 168 registers): the scheduler may not move the twiddle loads
 // above the 20-point DFT they follow -- hoisted there to hide their latency they hold 40..80 registers while the DFT needs
 // them, and the DFT's own values spill (scratch round trips inside both transforms).
+// t2: the stage-2 twiddles T2[3][20] (960 B) in LDS (analyze_kernel copies them there once per frame, into a region that only
+// the refinement uses later): ten dependent round trips to the L1 / L2 per transform become LDS reads.  (Round 5: s_memtime
+// at the phase boundaries showed a wavefront spending 23 % of its life in the two transforms and the split between them
+// for 16 % of its instructions -- twenty batches of two twiddle loads per transform, each waited for.)
 template <int KC, bool TIGHT = false>
 __device__ __forceinline__ void fft1200(double (&re)[20], double (&im)[20], double (&xr)[7][3], double (&xi)[7][3],
-                                        double *ex, const double2 *tab) {
+                                        double *ex, const double2 *tab, const double2 *t2) {
     const int lane = lane_id();
     const int np = (lane < 60) ? lane : 59;                 // lanes 60..63 shadow lane 59 (they never write)
     const bool act = lane < 60;
@@ -156,13 +164,13 @@ __device__ __forceinline__ void fft1200(double (&re)[20], double (&im)[20], doub
     for (int b = 0; b < 20; b++) bi[b] = ex[ka2 * SP_S1 + 3 * b + c2];
     // stage 2
     dft20(br, bi);
-    if constexpr (TIGHT) twiddle_tight(br, bi, tab + SP_T2 + c2 * 20);
+    if constexpr (TIGHT) twiddle_tight<4>(br, bi, t2 + c2 * 20);
     else {
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         double2 tw[10];
 #pragma unroll
-        for (int k = 0; k < 10; k++) tw[k] = tab[SP_T2 + c2 * 20 + 10 * h + k];
+        for (int k = 0; k < 10; k++) tw[k] = t2[c2 * 20 + 10 * h + k];
 #pragma unroll
         for (int k = 0; k < 10; k++) {
             if (10 * h + k == 0) continue;
@@ -234,6 +242,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
     const int n = FULL ? SP_N : a.n;                         // frame length, <= SP_N (shorter: longer zero padding)
     double *ex = smem;                                       // exchange buffer, later the lag curve y
     const double *xf = a.frames + f * a.stride;
+    // stage-2 twiddles into LDS, behind the exchange buffer and the mel sums (fft1200; ordered by the first exchange's wave_sync)
+    double2 *t2 = reinterpret_cast<double2 *>(reinterpret_cast<char *>(smem) + SP_T2_LDS_OFFSET);
+    if (lane < 60) t2[lane] = a.tab[SP_T2 + lane];
+    VBX_PHASE_INIT();
 
     // ---- load: z[60 a + n'] = (xw[120 a + 2 n'], xw[120 a + 2 n' + 1]), a < 10 (the rest is the zero padding) ----
     double re[20], im[20];
@@ -271,10 +283,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
         for (int q = 10; q < 20; q++) { re[q] = 0.0; im[q] = 0.0; }
     }
     const double x0 = readlane_f64(re[0], 0);               // x_w[0], for the fold seed (Q1)
+    VBX_PHASE(a.work, f, 0);
 
     // ---- forward transform of the packed frame ----
     double xr[7][3], xi[7][3];
-    fft1200<3, (WAVES >= 3)>(re, im, xr, xi, ex, a.tab);
+    fft1200<3, (WAVES >= 3)>(re, im, xr, xi, ex, a.tab, t2);
+    VBX_PHASE(a.work, f, 1);
 
     // ---- exchange 3: natural order, then each lane takes the pairs (m, N - m), m = lane + 64 t <= 600 ----
     double ar[10], ai[10], br[10], bi[10];
@@ -354,6 +368,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
         wave_sync();
     }
 
+    VBX_PHASE(a.work, f, 2);
     // ---- MFCC::mfcc from the powers: the frame's n-point DFT bin k' is X_M[q k'], q = M / n (2 for the full frame; a
     //      shorter frame whose length divides M = 2400 -- 800, 600 -- is zero padded and its bins are every q-th one): bin m / q
     //      from P[m] and bin n/2 - m / q from P[N - m] ----
@@ -386,10 +401,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
         wave_sync();
     }
 
+    VBX_PHASE(a.work, f, 3);
     if constexpr (!PITCH) return;
 
     // ---- second transform: Y = FFT(G);  S[2j] = Re Y[j] / M, S[2j+1] = -Im Y[j] / M, j < 600 only ----
-    fft1200<2, (WAVES >= 3)>(re, im, xr, xi, ex, a.tab);
+    fft1200<2, (WAVES >= 3)>(re, im, xr, xi, ex, a.tab, t2);
+    VBX_PHASE(a.work, f, 4);
 
     // r[lag] = (S[lag] - x0 x[lag]) + x0 (Q1), lane l: j = l + 64 t (kc = 0) and j = 400 + l + 64 t < 600 (kc = 1)
     constexpr double INV_M = 1.0 / (double)SP_M;
@@ -475,6 +492,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
     if (!FULL) spectral_exact_tail(ys, n, xf, a.window, a.lag_window, x0, scale, lane);
 #endif
     wave_sync();
+    VBX_PHASE(a.work, f, 5);
     // Rounding error of the two transforms: a few ulp of S[0] per lag (measured: < 8 eps S[0]); y = r * scale / w_lag
     // with w_lag >= 1/6 on the searched half.  SP_UNC_EPS bounds the error of a DIFFERENCE of two entries with a wide
     // margin; frames with a peak decision inside it go to the direct-sum kernel (launch_pitch_list).
@@ -488,10 +506,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
 
 static size_t spectral_lds_bytes(int n) {
     size_t need = (size_t)pitch_refine_lds_bytes(n);
-    const size_t exch = (size_t)(20 * SP_S1 > 3 * SP_S2 ? 20 * SP_S1 : 3 * SP_S2) * sizeof(double);
-    const size_t mel = (size_t)(2 * 602 + 64) * sizeof(double);
-    if (exch > need) need = exch;
-    if (mel > need) need = mel;
+    const size_t t2_end = (size_t)SP_T2_LDS_OFFSET + 60 * sizeof(double2);     // exchange buffer | mel sums | T2 copy
+    if (t2_end > need) need = t2_end;
     return (need + 15) & ~(size_t)15;
 }
 

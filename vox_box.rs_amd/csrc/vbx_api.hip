@@ -598,7 +598,7 @@ int vbx_profile_reset(vbx_ctx *ctx) {
     ctx->prof_acc.clear();
     ctx->prof_stream.clear();
     if (ctx->pitch_work)
-        VBX_HIP(ctx, hipMemsetAsync(ctx->pitch_work, 0, PITCH_WORK_SLOTS * 4 * sizeof(unsigned long long), ctx->stream));
+        VBX_HIP(ctx, hipMemsetAsync(ctx->pitch_work, 0, PITCH_WORK_WORDS * sizeof(unsigned long long), ctx->stream));
     return rc;
 }
 int vbx_profile_pitch_work(vbx_ctx *ctx, uint64_t *h_out4) {
@@ -609,6 +609,16 @@ int vbx_profile_pitch_work(vbx_ctx *ctx, uint64_t *h_out4) {
     VBX_HIP(ctx, hipMemcpyAsync(h, ctx->pitch_work, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     VBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int s = 0; s < PITCH_WORK_SLOTS; s++) for (int i = 0; i < 4; i++) h_out4[i] += h[4 * s + i];
+#ifdef VBX_EXP_PHASES
+    {   // experiment build: the phase clock sums, to stderr
+        unsigned long long ph[PITCH_WORK_SLOTS * PHASE_SLOTS], tot[PHASE_SLOTS] = {0};
+        VBX_HIP(ctx, hipMemcpy(ph, ctx->pitch_work + PITCH_WORK_SLOTS * 4, sizeof ph, hipMemcpyDeviceToHost));
+        for (int s = 0; s < PITCH_WORK_SLOTS; s++) for (int k = 0; k < PHASE_SLOTS; k++) tot[k] += ph[s * PHASE_SLOTS + k];
+        fprintf(stderr, "VBX_PHASES frames %llu cycles", (unsigned long long)h_out4[0]);
+        for (int k = 0; k < PHASE_SLOTS; k++) fprintf(stderr, " %llu", tot[k]);
+        fprintf(stderr, "\n");
+    }
+#endif
     return VBX_SUCCESS;
 }
 int vbx_profile_get(vbx_ctx *ctx, const char *kernel_name, double *h_total_ms, long *h_launches) {
@@ -791,7 +801,7 @@ static int run_pitch(vbx_ctx *ctx, hipStream_t st, const double *x, size_t n_fra
     VBX_REQUIRE(ctx, pitch_lds_bytes((int)frame_len) + pitch_full_list_bytes((int)frame_len, (int)kmax) + 16 <= 160 * 1024,
                 "frame does not fit the LDS");
     if (ctx->prof && !ctx->pitch_work) {
-        const size_t wb = PITCH_WORK_SLOTS * 4 * sizeof(unsigned long long);
+        const size_t wb = PITCH_WORK_WORDS * sizeof(unsigned long long);
         VBX_HIP(ctx, hipMalloc((void **)&ctx->pitch_work, wb));
         VBX_HIP(ctx, hipMemsetAsync(ctx->pitch_work, 0, wb, st));
     }
@@ -1615,7 +1625,7 @@ static int analyze_frames_impl(vbx_ctx *ctx, const char *fn, const double *x, co
             if (rc != VBX_SUCCESS) return rc;
         }
         if (ctx->prof && !ctx->pitch_work) {
-            const size_t wb = PITCH_WORK_SLOTS * 4 * sizeof(unsigned long long);
+            const size_t wb = PITCH_WORK_WORDS * sizeof(unsigned long long);
             VBX_HIP(ctx, hipMalloc((void **)&ctx->pitch_work, wb));
             VBX_HIP(ctx, hipMemsetAsync(ctx->pitch_work, 0, wb, ctx->stream));
         }

@@ -111,6 +111,26 @@ constexpr int PITCH_LIST_LANES = 64;
 size_t pitch_full_list_bytes(int n, int kmax);
 // profiling counters of the refine kernel: [PITCH_WORK_SLOTS][4] = frames, candidates, sinc evaluations, sinc terms
 constexpr int PITCH_WORK_SLOTS = 64;
+// experiment builds (-DVBX_EXP_PHASES, tools/experiments/phases.sh): behind the counters, [PITCH_WORK_SLOTS][PHASE_SLOTS] sums of
+// shader-clock cycles a wavefront spent in each phase of the fused kernel (s_memtime at the phase boundaries, after a
+// wait for everything outstanding).  A CU holds a fixed number of frames (LDS), so frames/s = frames in flight / a frame's
+// time in the kernel: the phase that holds a wavefront longest is the one to shorten, whatever its instruction count.
+constexpr int PHASE_SLOTS = 16;
+constexpr int PITCH_WORK_WORDS = PITCH_WORK_SLOTS * 4 + PITCH_WORK_SLOTS * PHASE_SLOTS;
+#ifdef VBX_EXP_PHASES
+#define VBX_PHASE_INIT() unsigned long long _tp = __builtin_readcyclecounter()
+#define VBX_PHASE(work_, f_, k_)                                                                                   \
+    do {                                                                                                            \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                 \
+        const unsigned long long _t = __builtin_readcyclecounter();                                                 \
+        if ((work_) != nullptr && lane_id() == 0)                                                                   \
+            atomicAdd((work_) + PITCH_WORK_SLOTS * 4 + ((f_) & (PITCH_WORK_SLOTS - 1)) * PHASE_SLOTS + (k_), _t - _tp); \
+        _tp = _t;                                                                                                   \
+    } while (0)
+#else
+#define VBX_PHASE_INIT() do { } while (0)
+#define VBX_PHASE(work_, f_, k_) do { } while (0)
+#endif
 void launch_pitch(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                   const double *lag_window, double sample_rate, double threshold, double fmin, double fmax,
                   int kmax, pitch_t *out_cand, long cand_ld /* doubles per output row, >= 2*kmax, even */,

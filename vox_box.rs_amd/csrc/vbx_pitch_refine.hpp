@@ -201,6 +201,7 @@ __device__ __forceinline__ double sinc_terms_fast_cell(const double *yp0, int si
                                                        double phil, double phir) {
     constexpr int NSTEP = 32;
     constexpr double S = (double)NSTEP;
+    const int step = side ? NSTEP : -NSTEP;
     const double s0 = sin_poly(M_PI * fmin(phil, phir));      // sin(pi*phil) == sin(pi*phir)
     sinc_stream_t s;
     const double ph = side ? phir : phil;
@@ -213,7 +214,6 @@ __device__ __forceinline__ double sinc_terms_fast_cell(const double *yp0, int si
     s.kappa = 4.0 * sh * sh;
     s.yp = yp0;
     s.acc0 = 0.0; s.acc1 = 0.0;
-    const int step = side ? NSTEP : -NSTEP;
     int j = 0;
     for (; j + 4 <= nterms; j += 4) sinc_stream_block4<NSTEP>(s, step);
     if (j < nterms) sinc_stream_tail<NSTEP>(s, step, nterms - j);
@@ -455,29 +455,41 @@ __device__ __forceinline__ bool improve_extremum_sinc_wave(const double *y, int 
     //    instead of once per evaluation.
     const int lane = lane_id();
     const int side = lane & 1, n0 = lane >> 1;
-    int cell = -0x7fffffff, md = 0, nterms = 0;
-    unsigned tinc = 0u;
-    double dmd = 0.0;
-    const double *yp0 = y;
+    // two cells are kept: the iteration closes in on an integer lag -- a jump of the mirrored interpolant (Q6) -- from BOTH
+    // sides, so its abscissae alternate between the two cells next to it
+    struct cell_t { int nl, nterms; unsigned tinc; double dmd; const double *yp0; };
+    cell_t ca{-0x7fffffff, 0, 0u, 0.0, y}, cb{-0x7fffffff, 0, 0u, 0.0, y};
+    bool a_is_older = true;
+    auto fill = [&](cell_t &c, int nl) {
+        c.nl = nl;
+        const int nr = nl + 1;
+        int md = depth;
+        if ((offset + nr) < md) md = offset + nr;                                                // :46-52 (offset + nr >= 1 here)
+        if ((offset + nl + md) >= nx) md = nx - offset + nl - 1;                                 // :55-57
+        c.tinc = 2u * (unsigned)(md + 1);
+        c.dmd = (double)md;
+        c.nterms = (n0 <= md) ? (md - n0) / 32 + 1 : 0;
+        c.yp0 = y + (side ? (offset + nl + n0) : (offset + nr - n0));
+    };
     auto eval = [&](double x) -> double {
         const double fl = floor(x);
         const int nl = (int)fl;
         const double phil = x - fl, phir = 1.0 - phil;
         if (__any(phil < 1.0e-10)) return y[offset + nl];                                        // :41
         if (__any(phir < 1.0e-10)) return y[offset + nl + 1];                                    // :42
-        if (__any(nl != cell)) {
-            cell = nl;
-            const int nr = nl + 1;
-            md = depth;
-            if ((offset + nr) < md) md = offset + nr;                                            // :46-52 (offset + nr >= 1 here)
-            if ((offset + nl + md) >= nx) md = nx - offset + nl - 1;                             // :55-57
-            tinc = 2u * (unsigned)(md + 1);
-            dmd = (double)md;
-            nterms = (n0 <= md) ? (md - n0) / 32 + 1 : 0;
-            yp0 = y + (side ? (offset + nl + n0) : (offset + nr - n0));
+        if (__any(nl == ca.nl)) {
+            a_is_older = false;
+            terms += ca.tinc;
+            return group_sum<64>(sinc_terms_fast_cell(ca.yp0, side, n0, ca.nterms, ca.dmd, phil, phir));
         }
-        terms += tinc;
-        return group_sum<64>(sinc_terms_fast_cell(yp0, side, n0, nterms, dmd, phil, phir));
+        if (__any(nl != cb.nl)) {
+            if (a_is_older) { fill(ca, nl); a_is_older = false; terms += ca.tinc;
+                              return group_sum<64>(sinc_terms_fast_cell(ca.yp0, side, n0, ca.nterms, ca.dmd, phil, phir)); }
+            fill(cb, nl);
+        }
+        a_is_older = true;
+        terms += cb.tinc;
+        return group_sum<64>(sinc_terms_fast_cell(cb.yp0, side, n0, cb.nterms, cb.dmd, phil, phir));
     };
     double v = a + golden * (b - a);
     double fv = eval(v);
@@ -858,6 +870,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
     const int ylen = 2 * n;                         // :411
     const int nvalid = nst + Y_PAD;
 
+    VBX_PHASE_INIT();
     // a) peaks -> filtered candidate list.  Two passes so that the two divisions of the frequency filter run once per
     // 64 PEAKS, not once per 64 lags: first every strict local maximum is compacted (index order), then the filter.
     int npeak = 0;
@@ -877,6 +890,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
     }
     wave_sync();
     if (unc_tol > 0.0 && __any(unsure)) return false;
+    VBX_PHASE(work, f, 6);
     unsure = false;
     int ncand = 0;
     for (int base = 0; base < npeak; base += 64) {  // in place: the write position never passes the read position
@@ -905,6 +919,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
     }
 
     if (unc_tol > 0.0 && __any(unsure)) return false;         // a frequency within the curve's error of fmin / fmax
+    VBX_PHASE(work, f, 7);
 
     // a') first-evaluation bounds.  p16: prefix sums of |y| over blocks of PB; keys[c]: upper bound of candidate c's
     // strength, stored as a float rounded UP (still an upper bound; the whole frame then fits 12 wavefronts per CU)
@@ -956,6 +971,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
         wave_sync();
     }
 
+    VBX_PHASE(work, f, 8);
     int st = 0;
     int kept = 0;
     double lf = 0.0, ls = 0.0;                      // lane j holds sorted candidate j
@@ -1163,6 +1179,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
       else run_groups(std::integral_constant<int, RG>{}, std::false_type{});
     }
 #undef VBX_BAR
+    VBX_PHASE(work, f, 9);
     const int total_cand = ncand + 1;
     st = __any(st & 4) ? 4 : 0;
     if (total_cand > 1 && (any_nan || threshold != threshold)) st |= 8;   // partial_cmp().unwrap() panics (Q10)
