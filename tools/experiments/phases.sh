@@ -4,7 +4,7 @@ VBX_LIB_PATH=$R/vox_box.rs_amd/lib/libvoxbox_hip_phases.so python3 tools/experim
 python3 - <<'PY'
 import os,re
 R=os.environ.get("GRAFT_REPO_ROOT","/root/repo")
-names=["load","fft_fwd","split","mfcc","fft_inv","normalise","peak_scan","filter","bounds","refine"]
+names=["load","fft_fwd","split","mfcc_rest","fft_inv","normalise","peak_scan","filter","bounds","refine","mfcc_sums","mfcc_log","mfcc_dct","mfcc_products"]
 lab=None
 for l in open(R+"/gpurun_out/phases.err"):
     if l.startswith("VBX_PHASES_LABEL"): lab=l.split()[1:]; continue

@@ -338,11 +338,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
 
     if constexpr (PITCH) {
         // ---- exchange 4: G in natural order -> stage-1 layout of the second transform ----
+        // (the ten twiddles W_M^m requested together and without a condition -- index 0 stands in past m = 600 --, not one
+        // by one behind `if (m <= 600)`: a load inside a branch cannot be moved out of it, and each waited for its own)
+        double2 wm[10];
+    #pragma unroll
+        for (int t = 0; t < 10; t++) { const int m = lane + 64 * t; wm[t] = a.tab[SP_TM + ((m <= 600) ? m : 0)]; }
     #pragma unroll
         for (int t = 0; t < 10; t++) {
             const int m = lane + 64 * t;
             if (m <= 600) {
-                const double2 w = a.tab[SP_TM + m];
+                const double2 w = wm[t];
                 const double sm = pk[t] + pn[t], d = pk[t] - pn[t];
                 ex[m] = fma(d, w.y, sm);
                 if (m >= 1 && m < 600) ex[SP_N - m] = fma(-d, w.y, sm);
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
         for (int t = 0; t < 10; t++) {
             const int m = lane + 64 * t;
             if (m <= 600) {
-                const double2 w = a.tab[SP_TM + m];
+                const double2 w = wm[t];
                 const double gi = -((pk[t] - pn[t]) * w.x);
                 ex[m] = gi;
                 if (m >= 1 && m < 600) ex[SP_N - m] = gi;
@@ -376,26 +381,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
         const int nbp = (a.nb + 1) & ~1;
         const int q = FULL ? 2 : a.mfcc_q, half = FULL ? SP_N / 2 : a.n / 2;
         double *pu = ex, *pd = ex + nbp, *en = ex + 2 * nbp; // the exchange buffer is free between the two transforms
+        constexpr int MB = 2;     // slots per batch (five: 24 registers spilled in the three-wavefront instance)
+        // (the slope pairs of a few slots requested together, without a condition -- pair 0 stands in for a slot
+        // without a bin --, then the products: behind `if (bin in range)` each load waited for its own round trip)
 #pragma unroll
-        for (int t = 0; t < 10; t++) {
-            const int m = lane + 64 * t;
-            if (m <= 600 && (FULL ? (m & 1) == 0 : m % q == 0)) {
+        for (int h = 0; h < 10 / MB; h++) {
+            double2 s1[MB], s2[MB];
+            int c1[MB], c2[MB];
+#pragma unroll
+            for (int u = 0; u < MB; u++) {
+                const int t = MB * h + u, m = lane + 64 * t;
+                const bool on = m <= 600 && (FULL ? (m & 1) == 0 : m % q == 0);
                 const int mq = FULL ? (m >> 1) : m / q;
                 const int b1 = mq - b_lo, b2 = (half - mq) - b_lo;
-                if (b1 >= 0 && b1 < a.nb) {
-                    const double2 sl = *reinterpret_cast<const double2 *>(a.slopes + 2 * b1);
-                    pu[b1] = fabs(pk[t]) * sl.x;             // norm_sqr * multiplier (src/spectrum.rs:426-428)
-                    pd[b1] = fabs(sqrt(pk[t])) * sl.y;       // norm * multiplier (:432-434)
+                c1[u] = (on && b1 >= 0 && b1 < a.nb) ? b1 : -1;
+                c2[u] = (on && b2 >= 0 && b2 < a.nb && b2 != b1) ? b2 : -1;
+                s1[u] = *reinterpret_cast<const double2 *>(a.slopes + 2 * (c1[u] < 0 ? 0 : c1[u]));
+                s2[u] = *reinterpret_cast<const double2 *>(a.slopes + 2 * (c2[u] < 0 ? 0 : c2[u]));
+            }
+#pragma unroll
+            for (int u = 0; u < MB; u++) {
+                const int t = MB * h + u;
+                if (c1[u] >= 0) {
+                    pu[c1[u]] = fabs(pk[t]) * s1[u].x;       // norm_sqr * multiplier (src/spectrum.rs:426-428)
+                    pd[c1[u]] = fabs(sqrt(pk[t])) * s1[u].y; // norm * multiplier (:432-434)
                 }
-                if (b2 >= 0 && b2 < a.nb && b2 != b1) {
-                    const double2 sl = *reinterpret_cast<const double2 *>(a.slopes + 2 * b2);
-                    pu[b2] = fabs(pn[t]) * sl.x;
-                    pd[b2] = fabs(sqrt(pn[t])) * sl.y;
+                if (c2[u] >= 0) {
+                    pu[c2[u]] = fabs(pn[t]) * s2[u].x;
+                    pd[c2[u]] = fabs(sqrt(pn[t])) * s2[u].y;
                 }
             }
         }
         wave_sync();
-        if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
+        VBX_PHASE(a.work, f, 13);
+        if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld, a.work, f);
         else mfcc_tail_m(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
         if (a.mfcc_status != nullptr && lane == 0) a.mfcc_status[f] = 0;
         wave_sync();
@@ -474,11 +493,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
     const double scale = 1.0 / amax;                         // normalize (:404), then / lag window (:406-408)
     double *ys = smem;
     wave_sync();                                             // every lane is done with the exchange buffer
+    // (the lag window's entries requested together, without a condition: entry 0 stands in for a slot without lags)
+    double2 lwv[11];
+#pragma unroll
+    for (int s = 0; s < 11; s++) {
+        const int i = 2 * jj[s];
+        lwv[s] = *reinterpret_cast<const double2 *>(a.lag_window + ((jj[s] >= 0 && i + 1 < n) ? i : 0));
+    }
 #pragma unroll
     for (int s = 0; s < 11; s++) {
         const int i = 2 * jj[s];
         if (jj[s] >= 0 && i + 1 < n) {
-            const double2 lw = *reinterpret_cast<const double2 *>(a.lag_window + i);
+            const double2 lw = lwv[s];
             double2 y;
             y.x = (r_e[s] * scale) / lw.x;
             y.y = (r_o[s] * scale) / lw.y;

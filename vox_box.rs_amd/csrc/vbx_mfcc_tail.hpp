@@ -3,6 +3,7 @@
 #pragma once
 
 #include "vbx_device.hpp"
+#include "vbx_kernels.hpp"
 
 namespace vbx {
 
@@ -44,26 +45,51 @@ __device__ __forceinline__ void mfcc_tail_m(const double *pu, const double *pd, 
 // Must be called from converged code.
 __device__ __forceinline__ void mfcc_tail_q(const double *pu, const double *pd, double *en, const int32_t *bins,
                                             const double *dct_table, int num_coeffs, int b_lo, int lane,
-                                            double *out_row) {
+                                            double *out_row, unsigned long long *work = nullptr, long f = 0) {
+    VBX_PHASE_INIT();
     const int w = lane >> 2, sub = lane & 3;
     const bool have = w < num_coeffs;
     double up_sum = 0.0, down_sum = 0.0;
+    // Round 5: the same sums in the same order with the loads of four steps (and of the whole DCT row) requested together --
+    // one element per trip, each addition waited for its own LDS read (20 trips for the widest filter), each DCT term for its own
+    // load from memory.  A step past the filter's end adds +0.0 to a sum of non-negative terms: the same bits.
     if (have) {
         const int w0 = bins[w] - b_lo, w1 = bins[w + 1] - b_lo, w2 = bins[w + 2] - b_lo;
-        for (int b = w0 + sub; b < w1; b += 4) up_sum += pu[b];
-        for (int b = w1 + sub; b < w2; b += 4) down_sum += pd[b];
+        for (int b = w0 + sub; b < w1; b += 16) {
+            double v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = (b + 4 * j < w1) ? pu[b + 4 * j] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) up_sum += v[j];
+        }
+        for (int b = w1 + sub; b < w2; b += 16) {
+            double v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = (b + 4 * j < w2) ? pd[b + 4 * j] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) down_sum += v[j];
+        }
     }
+    VBX_PHASE(work, f, 10);
     const double tot = group_sum<4>(up_sum + down_sum);
     if (have && sub == 0) {
         const double lg = log10(tot);
         en[w] = (lg != lg || lg < 1.0e-10) ? 1.0e-10 : lg;    // f64::max(1e-10): NaN yields the other operand
     }
+    VBX_PHASE(work, f, 11);
+    // the lane's DCT row, requested before the log above is needed (num_coeffs <= 16)
+    double drow[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++)                          // (no condition on the loads: clamped indices)
+        drow[j] = dct_table[((lane < num_coeffs) ? lane : num_coeffs - 1) * num_coeffs + ((j < num_coeffs) ? j : num_coeffs - 1)];
     wave_sync();
     if (lane < num_coeffs) {                              // dct (:391-397)
         double acc = 0.0;
-        for (int j = 0; j < num_coeffs; j++) acc = acc + en[j] * dct_table[lane * num_coeffs + j];
+#pragma unroll
+        for (int j = 0; j < 16; j++) if (j < num_coeffs) acc = acc + en[j] * drow[j];
         out_row[lane] = 2.0 * acc;
     }
+    VBX_PHASE(work, f, 12);
 }
 
 }  // namespace vbx
