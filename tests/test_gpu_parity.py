@@ -56,6 +56,7 @@ def test_lane_helpers(vb):
         col = gsum[:, j].reshape(64 // g, g)
         assert np.allclose(col[:, 0], v.reshape(64 // g, g).sum(axis=1), rtol=1e-13), g
         assert np.all(col == col[:, :1]), g
+    assert np.allclose(gsum[:, 5], np.cumsum(v), rtol=1e-14), "DPP inclusive scan"
 
 
 def test_synth_matches_host_statement(vb, pkg, audio):

@@ -67,6 +67,26 @@ __device__ __forceinline__ double wave_sum(double v) {
     return (a + b) + (c + d);
 }
 
+// Inclusive prefix sum over the 64 lanes, all on the vector ALU (no LDS crossbar: six ds_bpermute round trips otherwise): a
+// row-level scan by row_shr:1, 2, 4, 8 (a lane without a source adds 0), then the totals of the rows before -- lane 15 of a
+// row into the next row (rows 1 and 3), lane 31 into rows 2 and 3.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64_or_zero(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);   // rows outside ROW_MASK, lanes without a source: 0
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_inclusive_scan(double v) {
+    v += dpp_f64<0x111>(v);                      // row_shr:1
+    v += dpp_f64<0x112>(v);                      // row_shr:2
+    v += dpp_f64<0x114>(v);                      // row_shr:4
+    v += dpp_f64<0x118>(v);                      // row_shr:8
+    v += dpp_f64_or_zero<DPP_ROW_BCAST15, 0xA>(v);
+    v += dpp_f64_or_zero<DPP_ROW_BCAST31, 0xC>(v);
+    return v;
+}
+
 __device__ __forceinline__ double wave_max(double v) {
     v = fmax(v, dpp_f64<DPP_ROW_ROR8>(v));
     v = fmax(v, dpp_f64<DPP_ROW_ROR4>(v));

@@ -934,8 +934,7 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
             const int j = lane * per + q;
             if (j < nblk) tot += block_abs_sum(ys + PB * j);   // entries past n are zero
         }
-        double incl = tot;                                   // inclusive scan over the lanes
-        for (int o = 1; o < 64; o <<= 1) { const double up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+        const double incl = wave_inclusive_scan(tot);        // inclusive scan over the lanes (DPP: no LDS round trips)
         double run = incl - tot;
         if (lane == 0) p16[0] = 0.0;
         for (int q = 0; q < per; q++) {
