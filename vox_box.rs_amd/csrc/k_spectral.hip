@@ -244,7 +244,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
     const double *xf = a.frames + f * a.stride;
     // stage-2 twiddles into LDS, behind the exchange buffer and the mel sums (fft1200; ordered by the first exchange's wave_sync)
     double2 *t2 = reinterpret_cast<double2 *>(reinterpret_cast<char *>(smem) + SP_T2_LDS_OFFSET);
-    if (lane < 60) t2[lane] = a.tab[SP_T2 + lane];
     VBX_PHASE_INIT();
 
     // ---- load: z[60 a + n'] = (xw[120 a + 2 n'], xw[120 a + 2 n' + 1]), a < 10 (the rest is the zero padding) ----
@@ -283,6 +282,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
         for (int q = 10; q < 20; q++) { re[q] = 0.0; im[q] = 0.0; }
     }
     const double x0 = readlane_f64(re[0], 0);               // x_w[0], for the fold seed (Q1)
+    if (lane < 60) t2[lane] = a.tab[SP_T2 + lane];          // (here, not before the frame's loads: the registers are fewest)
     VBX_PHASE(a.work, f, 0);
 
     // ---- forward transform of the packed frame ----

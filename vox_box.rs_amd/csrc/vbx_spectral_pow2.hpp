@@ -121,36 +121,44 @@ template <int W> __device__ __forceinline__ void pow2_sync() { if constexpr (W =
 // The sixteen twiddle products of a unit in batches of FOUR, each batch finished before the next one's loads may start (the
 // products pinned by an empty asm, the loads fenced by a compiler memory barrier): left alone the compiler requests every
 // twiddle of the stage right after the 16-point DFTs and spills their results to make room (k_spectral.hip, twiddle_tight).
+// (batches of FOUR for the two-wavefront form of Nc = 4096; batches of TWO for one wavefront per frame -- with them and the
+// per-call table pointer below the fused Nc = 2048 kernel spills nothing (round 4: 9 registers = 2.5 KB of scratch per frame,
+// the "1.31x traffic" of the round-4 review), the Nc = 1024 kernels 0-2 registers instead of 3-7)
+template <int B>
 __device__ __forceinline__ void twiddle_tight16(double (&re)[16], double (&im)[16], const double2 *tw_row) {
 #pragma unroll
-    for (int h = 0; h < 4; h++) {
-        double2 w[4];
+    for (int h = 0; h < 16 / B; h++) {
+        double2 w[B];
 #pragma unroll
-        for (int k = 0; k < 4; k++) w[k] = tw_row[4 * h + k];
+        for (int k = 0; k < B; k++) w[k] = tw_row[B * h + k];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (4 * h + k == 0) continue;
-            const int s = dft16_slot(4 * h + k);
+        for (int k = 0; k < B; k++) {
+            if (B * h + k == 0) continue;
+            const int s = dft16_slot(B * h + k);
             rot(re[s], im[s], w[k].x, w[k].y);
             asm volatile("" : "+v"(re[s]), "+v"(im[s]));
         }
         asm volatile("" ::: "memory");
     }
 }
-
 // TIGHT: twiddle_tight16 (the instances that are short of registers: three wavefronts per SIMD at Nc = 1024, and Nc = 2048)
 template <int U, int W = 1, bool TIGHT = false>
 __device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16], double (&xr)[4 / W][4 * U * W],
-                                         double (&xi)[4 / W][4 * U * W], double *ex, const double2 *__restrict__ tab) {
+                                         double (&xi)[4 / W][4 * U * W], double *ex, const double2 *tab) {
     using G = pow2_geom<U, W>;
     constexpr int R = G::R, NT = G::NT, CW = G::CW, TQ = G::TQ;
     const int tid = pow2_tid<W>();
+    // the table pointer is made opaque per call: the two transforms of a kernel would otherwise SHARE the per-lane twiddle
+    // row addresses -- computed in the first, kept (spilled: five 64-bit values per lane at Nc = 2048, 2.5 KB of scratch
+    // written and read back per frame) for the second.  Recomputing them costs a few integer instructions.
+    if constexpr (W == 1) asm volatile("" : "+s"(tab));
+    constexpr int TB = (W == 1) ? 2 : 4;
     // stage 1
 #pragma unroll
     for (int u = 0; u < U; u++) {
         dft16(re[u], im[u]);
         const double2 *tw = tab + G::T1 + (tid + NT * u) * 16;
-        if constexpr (TIGHT) { twiddle_tight16(re[u], im[u], tw); continue; }
+        if constexpr (TIGHT) { twiddle_tight16<TB>(re[u], im[u], tw); continue; }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             double2 w[8];
@@ -192,7 +200,7 @@ __device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16
     for (int u = 0; u < U; u++) {
         dft16(br[u], bi[u]);
         const double2 *tw = tab + G::T2 + (c2 + CW * u) * 16;
-        if constexpr (TIGHT) { twiddle_tight16(br[u], bi[u], tw); continue; }
+        if constexpr (TIGHT) { twiddle_tight16<TB>(br[u], bi[u], tw); continue; }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             double2 w[8];
