@@ -1,5 +1,5 @@
 #!/bin/bash
-# Evidence run of a round (rounds 3 and 4) (one MI355X): rocprofv3 kernel trace + stats of the bench commands, then PMC passes in SEPARATE
+# Evidence run of a round (rounds 3 to 5) (one MI355X): rocprofv3 kernel trace + stats of the bench commands, then PMC passes in SEPARATE
 # runs (HBM traffic: FETCH_SIZE / WRITE_SIZE, one counter per pass; one SQ pass per workload).  Everything lands in
 # gpurun_out/prof_<tag>/; tools/prof_summary.py + tools/prof_commit.py turn it into the files committed under profiles/.
 # usage: tools/prof_round.sh [tag] [quick]       (run on the GPU box from the repo root; "quick" skips the other frame shapes)
@@ -23,7 +23,10 @@ if [ -z "$QUICK" ]; then
   run trace_pipeline_2048 --kernel-trace --stats --output-format csv -d $O/trace_pipeline_2048 -- python3 bench.py --frame-len 2048 --hop 1024 --hours 2 --steps 3 --warmup 1 $B
   run trace_config3_2048 --kernel-trace --stats --output-format csv -d $O/trace_config3_2048 -- python3 bench.py --workload config3 --frame-len 2048 --hop 1024 --hours 2 --steps 3 --warmup 1 $B
   run trace_config3_1024 --kernel-trace --stats --output-format csv -d $O/trace_config3_1024 -- python3 bench.py --workload config3 --frame-len 1024 --hop 512 --hours 2 --steps 3 --warmup 1 $B
-  for w in pipeline_2048:pipeline:2048:1024 config3_2048:config3:2048:1024 config3_1024:config3:1024:512; do
+  # the reference's bench frame (benches/periodic.rs:22-25: 4096 samples; hop 2048)
+  run trace_pipeline_4096 --kernel-trace --stats --output-format csv -d $O/trace_pipeline_4096 -- python3 bench.py --frame-len 4096 --hop 2048 --hours 2 --steps 3 --warmup 1 $B
+  run trace_config3_4096 --kernel-trace --stats --output-format csv -d $O/trace_config3_4096 -- python3 bench.py --workload config3 --frame-len 4096 --hop 2048 --hours 2 --steps 3 --warmup 1 $B
+  for w in pipeline_2048:pipeline:2048:1024 config3_2048:config3:2048:1024 config3_1024:config3:1024:512 pipeline_4096:pipeline:4096:2048 config3_4096:config3:4096:2048; do
     IFS=: read name wl fl hop <<< "$w"
     run pmc_fetch_$name --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$name -- python3 bench.py --workload $wl --frame-len $fl --hop $hop --hours 0.5 --steps 1 --warmup 0 $B
     run pmc_write_$name --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$name -- python3 bench.py --workload $wl --frame-len $fl --hop $hop --hours 0.5 --steps 1 --warmup 0 $B
