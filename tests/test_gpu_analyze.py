@@ -127,6 +127,23 @@ def test_analyze_frames_parts_can_be_skipped_and_rows_can_be_padded(vb, pkg, aud
     assert r0.shape == (0, 36)
 
 
+def test_profile_says_which_stream_a_kernel_ran_on(vb, pkg, audio_d):
+    """vbx_profile_stream (ABI 5): the fused call's spectral kernel runs on the context's stream (0), the formant chain beside
+    it on the side stream (1); a kernel that was not profiled reports -1.  bench.py ranks its dominant kernel among stream 0."""
+    import ctypes as C
+    F = pkg.frame_count(6 * 48000, N, H)
+    est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+    params = pkg.AnalysisParams.make(SR, pitch=(0.2, 75.0, 600.0), lpc_order=P, formant_order=P, est_init=est0, mfcc=(13, 100.0, 8000.0))
+    vb.profile_reset(); vb.profile(True)
+    vb.analyze_frames(audio_d, params, frame_len=N, stride=H, n_frames=F)
+    streams = vb.profile_streams()
+    vb.profile(False)
+    assert streams["analyze"] == 0, streams
+    assert streams["burg_lags"] == 1 and streams["formant_resonances"] == 1, streams
+    sid = C.c_int(7)
+    assert vb.L.vbx_profile_stream(vb.ctx, b"no_such_kernel", C.byref(sid)) == 0 and sid.value == -1
+
+
 def test_rccl_record_gather_single_rank(vb, pkg):
     """The library's RCCL path on one GPU: communicator of world 1, loopback ncclSend/ncclRecv self-test, and the
     gather entry point (own rows in place / copied, slots, device-side wait)."""

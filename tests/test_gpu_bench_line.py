@@ -40,7 +40,15 @@ def test_default_workload_line():
     # sub-benchmarks: BASELINE configs 2, 3, 4 driver-timed in the default run, each with its own roofline; config 2 is the
     # HBM-bound one and carries its measured traffic (= the algorithmic 4304 B/frame)
     sub = {s["name"]: s for s in d["sub_benchmarks"]}
-    assert {"config2", "config3_kmax1", "config3_kmax8", "config4"} <= set(sub)
+    assert {"config2", "config3_kmax1", "config3_kmax8", "config4", "pipeline_shapes", "speech_44k", "config5_100h_1gpu"} <= set(sub)
+    # round 5: BASELINE config 5 WHOLE on this GPU (36 M frames, 138 GB resident) and the pipeline on real 44.1 kHz speech
+    c5 = sub["config5_100h_1gpu"]
+    assert "skipped" in c5 or (c5["frames"] == 36_000_000 and c5["value"] > 1e6 and c5["frames_with_nonzero_status"] == 0)
+    for row in sub["speech_44k"]["shapes"]:
+        assert row["speech"]["value"] > 1e6 and row["synthetic"]["value"] > 1e6 and row["speech"]["frames_with_nonzero_status"] == 0
+        assert 0.0 <= row["speech"]["burg_direct"] <= 1.0 and row["speech"]["roots_direct"] >= 0.0
+        assert row["speech"]["dominant_kernel"] == "analyze"        # the critical stream's kernel, not a co-resident one's event time
+    assert all(r["dominant_kernel"] in ("analyze", "pitch") for r in sub["pipeline_shapes"]["shapes"])
     c2 = sub["config2"]["roofline"]
     assert c2["bound"] == "hbm" and c2["kernel"] == "autocorr_lpc" and 0.4 < c2["frac"] < 1.0
     assert c2["traffic"] is not None and abs(c2["traffic"] / sub["config2"]["frames"] - 4304) < 0.05 * 4304
@@ -56,6 +64,18 @@ def test_config_workloads_pick_the_measured_dominant_kernel():
     assert "whole_config" in d and d["whole_config"]["fp64_frac"] > 0
     d = _bench("--workload", "config3", "--frame-len", "2048", "--hop", "1024", "--hours", "0.25", "--steps", "2", "--warmup", "1", "--no-cpu")
     assert "2048-sample frames" in d["metric"] and d["config"]["frame_len"] == 2048 and d["roofline"]["kernel"] == "pitch"
+
+
+def test_speech_mode_line():
+    """bench.py --signal speech: the pipeline on the tiled 44.1 kHz fixture under its own metric name, with the fast paths'
+    fallback shares and the refinement's work counters beside the synthetic signal at the same shapes."""
+    d = _bench("--signal", "speech", "--hours", "0.1", "--steps", "1", "--warmup", "1", "--no-cpu")
+    assert "real 44.1 kHz speech" in d["metric"] and d["data"].startswith("real speech") and d["value"] > 1e6
+    rows = d["speech"]["shapes"]
+    assert [(r["frame_len"], r["hop"]) for r in rows] == [(1103, 441), (1024, 512)]
+    for r in rows:
+        assert r["speech"]["sinc_evals_per_frame"] > 5 and r["synthetic"]["sinc_evals_per_frame"] > 5
+        assert 0.2 < r["speech_over_synthetic"] < 2.0 and r["speech"]["burg_direct"] > r["synthetic"]["burg_direct"]
 
 
 def test_cross_rank_check_rehearsal_on_one_gpu():
