@@ -49,6 +49,12 @@ struct pow2_geom {
     static constexpr int TAB = TM + NC / 2 + 1;
     static constexpr int TP = NC / (2 * NT) + 1;       // pairs (m, Nc - m), m = tid + NT t <= Nc / 2, per thread
     static constexpr int EX = (16 * S1 > R * S2) ? 16 * S1 : R * S2;   // doubles of the exchange buffer
+    // round 5: the stage-2 twiddles T2[R][16] live in LDS behind the exchange buffer (the mel sums between the transforms never
+    // reach past it: 2 (Nc / 2) + 64 <= EX), in a region only the refinement uses later: eight to sixteen dependent round trips
+    // to the L1 / L2 per transform become LDS reads, and the kernel no longer carries the rows' 64-bit addresses
+    static constexpr int T2_LDS_OFFSET = ((EX * 8 + 15) / 16) * 16;    // bytes
+    static constexpr int T2_LDS_BYTES = R * 16 * 16;
+    static_assert(NC + 64 <= EX, "the mel sums stay inside the exchange buffer");
 };
 
 // 16-point DFT in place, radix 4 x 4.  Input index a sits in slot a; output index k is left in slot dft16_slot(k).
@@ -144,7 +150,7 @@ __device__ __forceinline__ void twiddle_tight16(double (&re)[16], double (&im)[1
 // TIGHT: twiddle_tight16 (the instances that are short of registers: three wavefronts per SIMD at Nc = 1024, and Nc = 2048)
 template <int U, int W = 1, bool TIGHT = false>
 __device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16], double (&xr)[4 / W][4 * U * W],
-                                         double (&xi)[4 / W][4 * U * W], double *ex, const double2 *tab) {
+                                         double (&xi)[4 / W][4 * U * W], double *ex, const double2 *tab, const double2 *t2 = nullptr /* T2 in LDS, or from the table */) {
     using G = pow2_geom<U, W>;
     constexpr int R = G::R, NT = G::NT, CW = G::CW, TQ = G::TQ;
     const int tid = pow2_tid<W>();
@@ -199,7 +205,7 @@ __device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16
 #pragma unroll
     for (int u = 0; u < U; u++) {
         dft16(br[u], bi[u]);
-        const double2 *tw = tab + G::T2 + (c2 + CW * u) * 16;
+        const double2 *tw = (t2 != nullptr ? t2 : tab + G::T2) + (c2 + CW * u) * 16;
         if constexpr (TIGHT) { twiddle_tight16<TB>(br[u], bi[u], tw); continue; }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -275,6 +281,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
     const int n = HALF ? 2 * NC : FULL ? NC : a.n;           // frame length, <= NC (SP_MFCC_HALF: 2 NC)
     double *ex = smem;                                       // exchange buffer, later the lag curve y
     const double *xf = a.frames + f * a.stride;
+    double2 *t2 = reinterpret_cast<double2 *>(reinterpret_cast<char *>(smem) + G::T2_LDS_OFFSET);
 
     // ---- load: z[16R a + n'] = (xw[32R a + 2 n'], xw[.. + 1]), a < 8 (the rest is the zero padding), 0 past the frame ----
     double re[U][16], im[U][16];
@@ -306,6 +313,10 @@ void analyze_pow2_kernel(const spectral_args_t a) {
         }
     }
     double x0 = readlane_f64(re[0][0], 0);                  // x_w[0], for the fold seed (Q1)
+    if constexpr (W == 1) {                                  // (two wavefronts per frame: measured slower, the table stays in memory)
+#pragma unroll
+        for (int i = tid; i < R * 16; i += NT) t2[i] = a.tab[G::T2 + i];  // ordered before its first use by the first exchange's barriers
+    }
     if constexpr (W > 1) {
         if (tid == 0) bcast[0] = x0;
         __syncthreads();
@@ -314,7 +325,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
 
     // ---- forward transform of the packed frame ----
     double xr[TQ][R], xi[TQ][R];
-    fft_pow2<U, W, POW2_TIGHT>(re, im, xr, xi, ex, a.tab);
+    fft_pow2<U, W, POW2_TIGHT>(re, im, xr, xi, ex, a.tab, W == 1 ? t2 : nullptr);
 
     // ---- exchange 3: natural order, then each lane takes the pairs (m, Nc - m), m = lane + 64 t <= Nc / 2 ----
     double ar[TP], ai[TP], br[TP], bi[TP];
@@ -433,7 +444,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
     if constexpr (!PITCH) return;
 
     // ---- second transform: Y = FFT(G);  S[2j] = Re Y[j] / M, S[2j+1] = -Im Y[j] / M, j = lane + 64 t + 256 kc < Nc / 2 ----
-    fft_pow2<U, W, POW2_TIGHT>(re, im, xr, xi, ex, a.tab);
+    fft_pow2<U, W, POW2_TIGHT>(re, im, xr, xi, ex, a.tab, W == 1 ? t2 : nullptr);
 
     constexpr int NS = TQ * (R / 2);                         // slots per thread: t < TQ, kc < R / 2
     constexpr double INV_M = 1.0 / (double)(2 * NC);
@@ -547,6 +558,8 @@ inline size_t pow2_lds_bytes(int n, int nb, int nst = 0) {
     const size_t mel = (size_t)(2 * ((nb + 1) & ~1) + 64) * sizeof(double);
     if (exch > need) need = exch;
     if (mel > need) need = mel;
+    const size_t t2_end = (size_t)pow2_geom<U, W>::T2_LDS_OFFSET + pow2_geom<U, W>::T2_LDS_BYTES;
+    if (t2_end > need) need = t2_end;
     return (need + 15) & ~(size_t)15;
 }
 
