@@ -909,7 +909,25 @@ def run_rank(args):
             vb.pitch(audio.data_ptr() + warm * stride * 8, SR, 0.2, 75.0, 600.0, kmax=args.kmax, frame_len=frame_len, stride=stride,
                      n_frames=F, window=win, out=(o_cand, o_cnt, o_pst))
 
+    # N > 1 has never run on hardware in this build's rounds: a collective that never completes must not hang the node.  A
+    # watchdog ends THIS rank (exit code 5, a message on stderr) if warm-up + the timed steps take absurdly long; the launcher
+    # (or torchrun) then ends the others.
+    watchdog = None
+    if world > 1:
+        import threading
+        limit = float(os.environ.get("VBX_BENCH_WATCHDOG_S", "0")) or max(300.0, 30.0 * (args.warmup + args.steps) * args.hours / 12.5)
+
+        def _bark():
+            sys.stderr.write(f"bench.py rank {rank}: warm-up + {args.steps} steps did not finish within {limit:.0f} s -- a collective of the "
+                             "N > 1 path (tracker hand-off chain or record gather) is stuck; aborting this rank\n")
+            sys.stderr.flush()
+            os._exit(5)
+        watchdog = threading.Timer(limit, _bark)
+        watchdog.daemon = True
+        watchdog.start()
     dt, prof, work = timed(vb, torch, step, args.warmup, args.steps, barrier if world > 1 else None)
+    if watchdog is not None:
+        watchdog.cancel()
     if world > 1:
         tt = torch.tensor([dt], dtype=f64)                                   # CPU tensor: gloo
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
