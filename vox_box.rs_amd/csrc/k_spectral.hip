@@ -233,7 +233,9 @@ template <bool LPC, bool MFCC, bool FULL, int MODE = SP_ANALYZE, int WAVES = VBX
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_MFCC_ONLY ? 2 : WAVES, MODE == SP_MFCC_ONLY ? 4 : WAVES))) void analyze_kernel(const spectral_args_t a) {
     static_assert(MODE != SP_MFCC_ONLY || (MFCC && FULL && !LPC), "the MFCC-only form needs the full frame and has no lag sums");
     static_assert(MODE != SP_AC_ONLY || (!MFCC && !LPC), "the autocorrelation-only form");
+    static_assert(MODE != SP_ANALYZE_INTERP || (MFCC && !FULL), "interpolated bins: a padded frame's MFCC");
     constexpr bool PITCH = MODE != SP_MFCC_ONLY;             // the second transform runs
+    constexpr bool INTERP = MODE == SP_ANALYZE_INTERP;       // MFCC's bins lie between the transform's (mfcc_interp_t, vbx_kernels.hpp)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const long f = xcd_item(blockIdx.x, a.n_frames);            // neighbouring frames on the same XCD: their overlap hits its L2
     if (f >= a.n_frames) return;
@@ -324,6 +326,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
     //   the inverse's input G[m] = S - i D w, G[N - m] = S - i D conj(w)   (S = P[m] + P[N-m], D = P[m] - P[N-m], w = W_M^m)
     const int b_lo = MFCC ? a.bins[0] : 0;
     double pk[10], pn[10];                                   // P[m], P[N - m]
+    double2 *zc = reinterpret_cast<double2 *>(ex);           // INTERP: Z[j - jmin] = X_M[j] e^{2 pi i j c / M}, Z[-j] = conj Z[j]
 #pragma unroll
     for (int t = 0; t < 10; t++) {
         const int m = lane + 64 * t;
@@ -334,6 +337,55 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
         const double pr = er + tr, pi = ei + ti, qr = er - tr, qi = ei - ti;
         pk[t] = fma(pr, pr, pi * pi);
         pn[t] = fma(qr, qr, qi * qi);
+        if constexpr (INTERP) {                              // (every lane is past exchange 3's last read: the buffer is free)
+            asm volatile("" : "+v"(pk[t]), "+v"(pn[t]));     // the powers NOW: two values wait for exchange 4, not the four they are made of
+            const double2 rt = reinterpret_cast<const double2 *>(a.ip.rot)[(m <= 600) ? m : 0];
+            const double zr = fma(pr, rt.x, -(pi * rt.y)), zi = fma(pr, rt.y, pi * rt.x);
+            if (m >= a.ip.jmin && m <= a.ip.jmax) zc[m - a.ip.jmin] = double2{zr, zi};
+            if (m >= 1 && -m >= a.ip.jmin) zc[-m - a.ip.jmin] = double2{zr, -zi};
+        }
+    }
+
+    // ---- MFCC::mfcc at a length that does not divide the transform: each of the frame's DFT bins from MFCC_INTERP_TAPS of the
+    //      transform's (lane l: bins b_lo + l + 64 u), BEFORE exchange 4 takes the buffer; then the same products and tail ----
+    if constexpr (INTERP) {
+        wave_sync();
+        const int nbp = (a.nb + 1) & ~1;
+        double *pu = ex + a.ip.pu_off, *pd = pu + nbp, *en = pd + nbp;
+        const double2 *cf = reinterpret_cast<const double2 *>(a.ip.coef) + lane;
+        constexpr int HT = MFCC_INTERP_TAPS / 2;
+        for (int u = 0; u * 64 < a.nb; u++) {
+            const int b = lane + 64 * u;
+            const double2 *zp = zc + a.ip.j0[u * 64 + lane];
+            const double2 sl = *reinterpret_cast<const double2 *>(a.slopes + 2 * ((b < a.nb) ? b : 0));
+            double ar0 = 0.0, ai0 = 0.0, ar1 = 0.0, ai1 = 0.0;
+            // (batches of eight taps, pinned: all of a bin's loads at once are 192 registers)
+#pragma unroll
+            for (int tb = 0; tb < HT; tb += 4) {
+                double2 c[4], z0[4], z1[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { c[i] = cf[(u * HT + tb + i) * 64]; z0[i] = zp[2 * (tb + i)]; z1[i] = zp[2 * (tb + i) + 1]; }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    ar0 = fma(c[i].x, z0[i].x, ar0); ai0 = fma(c[i].x, z0[i].y, ai0);
+                    ar1 = fma(c[i].y, z1[i].x, ar1); ai1 = fma(c[i].y, z1[i].y, ai1);
+                }
+                asm volatile("" : "+v"(ar0), "+v"(ai0), "+v"(ar1), "+v"(ai1));
+                asm volatile("" ::: "memory");
+            }
+            const double vr = ar0 + ar1, vi = ai0 + ai1;
+            const double pw = fma(vr, vr, vi * vi);
+            if (b < a.nb) {
+                pu[b] = fabs(pw) * sl.x;                     // norm_sqr * multiplier (src/spectrum.rs:426-428)
+                pd[b] = fabs(sqrt(pw)) * sl.y;               // norm * multiplier (:432-434)
+            }
+        }
+        wave_sync();
+        if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld, a.work, f);
+        else mfcc_tail_m(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
+        if (a.mfcc_status != nullptr && lane == 0) a.mfcc_status[f] = 0;
+        wave_sync();
+        if (lane < 60) t2[lane] = a.tab[SP_T2 + lane];       // the products may have lain over the stage-2 twiddles
     }
 
     if constexpr (PITCH) {
@@ -377,7 +429,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
     // ---- MFCC::mfcc from the powers: the frame's n-point DFT bin k' is X_M[q k'], q = M / n (2 for the full frame; a
     //      shorter frame whose length divides M = 2400 -- 800, 600 -- is zero padded and its bins are every q-th one): bin m / q
     //      from P[m] and bin n/2 - m / q from P[N - m] ----
-    if (MFCC) {
+    if constexpr (MFCC && !INTERP) {
         const int nbp = (a.nb + 1) & ~1;
         const int q = FULL ? 2 : a.mfcc_q, half = FULL ? SP_N / 2 : a.n / 2;
         double *pu = ex, *pd = ex + nbp, *en = ex + 2 * nbp; // the exchange buffer is free between the two transforms
@@ -598,6 +650,67 @@ bool spectral_supported_plan(int plan, int n, int lpc_order, int mfcc_nb, int mf
     return true;
 }
 
+// ---- tables of the interpolated MFCC bins (mfcc_interp_t, vbx_kernels.hpp), host side, in long double ----
+size_t mfcc_interp_table_bytes(int plan) {
+    const size_t quarter = (size_t)spectral_plan_nc(plan) / 2;                                 // M / 4
+    return (quarter + 1) * 16 + (size_t)MFCC_INTERP_SLOTS * (MFCC_INTERP_TAPS / 2) * 64 * 16 + (size_t)MFCC_INTERP_SLOTS * 64 * 4;
+}
+
+bool mfcc_interp_fill(int plan, int n, int b_lo, int nb, void *h_table, mfcc_interp_t *d) {
+    if (plan != SPECTRAL_PLAN_1200) return false;                                              // (the power-of-two kernels: not yet)
+    const long M = 2L * spectral_plan_nc(plan), quarter = M / 4;
+    constexpr int W = MFCC_INTERP_TAPS, HT = W / 2, SL = MFCC_INTERP_SLOTS;
+    if (n < 2 || 2L * n > M || M % n == 0 || nb < 1 || nb > 64 * SL || b_lo < 0) return false;
+    const long double pi = 3.141592653589793238462643383279502884L;
+    const long double tau = 0.5L - (long double)n / (2.0L * (long double)M);                   // the bump's half-width
+    const long double beta = pi * tau * (long double)W;
+    auto sinhc = [](long double s) { return s < 1e-6L ? 1.0L + s * s / 6.0L : sinhl(s) / s; };
+    const long double norm = sinhc(beta);
+    char *base = static_cast<char *>(h_table);
+    double *rot = reinterpret_cast<double *>(base);
+    double *coef = reinterpret_cast<double *>(base + (quarter + 1) * 16);
+    int32_t *j0t = reinterpret_cast<int32_t *>(base + (quarter + 1) * 16 + (size_t)SL * HT * 64 * 16);
+    for (long j = 0; j <= quarter; j++) {                                                      // e^{2 pi i j c / M}, c = (n - 1) / 2
+        const long double ang = 2.0L * pi * (long double)((j * (long)(n - 1)) % (2 * M)) / (long double)(2 * M);
+        rot[2 * j] = (double)cosl(ang); rot[2 * j + 1] = (double)sinl(ang);
+    }
+    long jmin = 1L << 40, jmax = -(1L << 40);
+    for (int i = 0; i < nb; i++) {
+        const long first = ((long)(b_lo + i) * M) / n - W / 2 + 1;
+        if (first < jmin) jmin = first;
+        if (first + W - 1 > jmax) jmax = first + W - 1;
+    }
+    if (jmax > quarter || jmin < -quarter) return false;
+    for (int i = 0; i < 64 * SL; i++) {
+        const int u = i / 64, lane = i % 64;
+        const long k = b_lo + i;
+        const long first = (i < nb) ? (k * M) / n - W / 2 + 1 : jmin;
+        j0t[i] = (int32_t)(first - jmin);
+        for (int t = 0; t < W; t++) {
+            long double c = 0.0L;
+            if (i < nb) {
+                const long num = k * M - (first + t) * (long)n;                                // nu = num / n, |nu| <= W / 2
+                if (num == 0) c = 1.0L;
+                else {
+                    const long double nu = (long double)num / (long double)n;
+                    long r = num % (2L * n); if (r < 0) r += 2L * n;                           // sin(pi nu) from the reduced numerator
+                    const long double sn = sinl(pi * (long double)r / (long double)n);
+                    const long double arg = beta * beta - (2.0L * pi * tau * nu) * (2.0L * pi * tau * nu);
+                    const long double bump = sinhc(arg > 0.0L ? sqrtl(arg) : 0.0L) / norm;
+                    c = sn / (pi * nu) * bump;
+                }
+            }
+            coef[(((size_t)u * HT + t / 2) * 64 + lane) * 2 + (t & 1)] = (double)c;
+        }
+    }
+    const int zn = (int)(jmax - jmin + 1), nbp = (nb + 1) & ~1;
+    d->jmin = (int)jmin; d->jmax = (int)jmax;
+    d->pu_off = 2 * zn;
+    d->lds_bytes = (2 * zn + 2 * nbp + 64) * 8;
+    d->rot = nullptr; d->coef = nullptr; d->j0 = nullptr;                                      // the caller's: device addresses
+    return d->lds_bytes <= (160 * 1024) / 12;                                                  // twelve frames per CU or not at all
+}
+
 void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
     spectral_args_t a;
     a.frames = L.x; a.n_frames = L.F; a.stride = L.stride; a.window = L.window; a.lag_window = L.lag_window;
@@ -613,6 +726,7 @@ void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
     a.out_r = L.out_r; a.n_lags = L.n_lags;
     a.pcm = (L.pcm && L.n == SP_N) ? 1 : 0;                  // the host side only asks for it on full 1200-sample frames
     a.mfcc_q = (L.plan != SPECTRAL_PLAN_NONE && L.n > 0) ? (2 * spectral_plan_nc(L.plan)) / L.n : 2;
+    a.ip = mfcc_interp_t{};
     if (L.plan != SPECTRAL_PLAN_1200) { launch_analyze_pow2(s, L, a); return; }
     const dim3 grid((unsigned)L.F), block(64);
     const size_t base = spectral_lds_bytes(L.n);
@@ -646,7 +760,15 @@ void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
         if (w3) hipLaunchKernelGGL((analyze_kernel<LPC_, MF_, FULL_, SP_ANALYZE, 3>), grid, block, lds, s, a);        \
         else hipLaunchKernelGGL((analyze_kernel<LPC_, MF_, FULL_>), grid, block, lds, s, a);                          \
     } while (0)
-    if (L.n != SP_N) {                                       // a padded frame; MFCC joins when its length divides 2400
+    if (L.interp && mf && L.n != SP_N) {                     // a padded frame whose MFCC bins are interpolated from the transform's
+        a.ip = L.ip;
+        const size_t li = lds > (size_t)L.ip.lds_bytes ? lds : (((size_t)L.ip.lds_bytes + 15) & ~(size_t)15);
+        const bool w3i = want3 && extra == 0 && 12 * li <= 160 * 1024;
+        if (lpc) { if (w3i) hipLaunchKernelGGL((analyze_kernel<true, true, false, SP_ANALYZE_INTERP, 3>), grid, block, li, s, a);
+                   else hipLaunchKernelGGL((analyze_kernel<true, true, false, SP_ANALYZE_INTERP>), grid, block, li, s, a); }
+        else { if (w3i) hipLaunchKernelGGL((analyze_kernel<false, true, false, SP_ANALYZE_INTERP, 3>), grid, block, li, s, a);
+               else hipLaunchKernelGGL((analyze_kernel<false, true, false, SP_ANALYZE_INTERP>), grid, block, li, s, a); }
+    } else if (L.n != SP_N) {                                // a padded frame; MFCC joins when its length divides 2400
         if (lpc && mf) VBX_SP_LAUNCH(true, true, false);
         else if (mf) VBX_SP_LAUNCH(false, true, false);
         else if (lpc) VBX_SP_LAUNCH(true, false, false);

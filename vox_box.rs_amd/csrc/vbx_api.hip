@@ -57,6 +57,8 @@ struct vbx_ctx {
     int mfcc_czt = -1;                                    // VBX_MFCC_CZT=0 / 1: never / wherever it fits (tests); -1: the measured choice
     std::map<std::tuple<size_t, size_t, double, double, double>, int32_t *> bins_cache;
     std::map<std::tuple<size_t, size_t, double, double, double>, double *> slopes_cache;   // [nb][2] i/up, i/down per bin
+    std::map<std::tuple<int, int, int, int>, std::pair<void *, mfcc_interp_t>> interp_cache;   // (plan, n, b_lo, nb) -> tables of the interpolated MFCC bins (first == nullptr: no such form)
+    int mfcc_interp = -1;                                 // VBX_MFCC_INTERP=0: never (the chirp-z kernel beside the fused one, as before round 5; tests, A/B)
     std::map<std::pair<size_t, double>, std::pair<int32_t *, double *>> resample_tabs;   // (n, ratio) -> (index, fraction)
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -307,6 +309,33 @@ int get_dct_dev(vbx_ctx *ctx, size_t k, const double **out) {
     return VBX_SUCCESS;
 }
 
+// tables of the MFCC bins interpolated inside the fused kernel (mfcc_interp_t); *ok = false: the shape has no such form
+int get_interp_dev(vbx_ctx *ctx, int plan, int n, int b_lo, int nb, mfcc_interp_t *out, bool *ok) {
+    auto key = std::make_tuple(plan, n, b_lo, nb);
+    auto it = ctx->interp_cache.find(key);
+    if (it == ctx->interp_cache.end()) {
+        mfcc_interp_t d{};
+        void *dev = nullptr;
+        if (plan == SPECTRAL_PLAN_1200) {
+            const size_t bytes = mfcc_interp_table_bytes(plan);
+            std::vector<char> h(bytes, 0);
+            if (mfcc_interp_fill(plan, n, b_lo, nb, h.data(), &d)) {
+                VBX_HIP(ctx, hipMalloc(&dev, bytes));
+                VBX_HIP(ctx, hipMemcpy(dev, h.data(), bytes, hipMemcpyHostToDevice));
+                const size_t quarter = (size_t)spectral_plan_nc(plan) / 2;
+                char *b = static_cast<char *>(dev);
+                d.rot = reinterpret_cast<const double *>(b);
+                d.coef = reinterpret_cast<const double *>(b + (quarter + 1) * 16);
+                d.j0 = reinterpret_cast<const int32_t *>(b + (quarter + 1) * 16 + (size_t)MFCC_INTERP_SLOTS * (MFCC_INTERP_TAPS / 2) * 64 * 16);
+            }
+        }
+        it = ctx->interp_cache.emplace(key, std::make_pair(dev, d)).first;
+    }
+    *ok = it->second.first != nullptr;
+    *out = it->second.second;
+    return VBX_SUCCESS;
+}
+
 // twiddles of the fused spectral kernels (k_spectral.hip, k_spectral_pow2.hip), one table per plan
 int get_spectral_tab(vbx_ctx *ctx, int plan, const double **out) {
     if (!ctx->spectral_tab[plan]) {
@@ -453,6 +482,7 @@ int vbx_ctx_create(vbx_ctx **out, int device, void *hip_stream) {
     { const char *e = std::getenv("VBX_MFCC_DFT2"); ctx->mfcc_force_dft2 = e && e[0] == '1'; }
     { const char *e = std::getenv("VBX_MFCC_MFMA"); ctx->mfcc_force_mfma = e && e[0] == '1'; }
     { const char *e = std::getenv("VBX_MFCC_CZT"); ctx->mfcc_czt = e ? (e[0] == '1' ? 1 : 0) : -1; }
+    { const char *e = std::getenv("VBX_MFCC_INTERP"); ctx->mfcc_interp = e ? (e[0] == '0' ? 0 : 1) : -1; }
     { const char *e = std::getenv("VBX_MFCC_CZT_SPLIT"); ctx->mfcc_czt_split = e != nullptr && e[0] == '1'; }
     { const char *e = std::getenv("VBX_PITCH_CURVE_CUT"); ctx->pitch_whole_curve = e != nullptr && e[0] == '0'; }
     if (const char *e = std::getenv("VBX_ROCTX"); e != nullptr && e[0] == '1') {
@@ -494,6 +524,7 @@ void vbx_ctx_destroy(vbx_ctx *ctx) {
     for (auto &kv : ctx->czt_tabs) { hipFree(kv.second.first); hipFree(kv.second.second); }
     for (auto &kv : ctx->bins_cache) hipFree(kv.second);
     for (auto &kv : ctx->slopes_cache) hipFree(kv.second);
+    for (auto &kv : ctx->interp_cache) if (kv.second.first) hipFree(kv.second.first);
     for (auto &kv : ctx->resample_tabs) { hipFree(kv.second.first); hipFree(kv.second.second); }
     for (auto &r : ctx->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
@@ -1550,8 +1581,16 @@ static int analyze_frames_impl(vbx_ctx *ctx, const char *fn, const double *x, co
         const int pm = spectral_plan_mfcc((int)frame_len);
         if (spectral_supported_plan(pm, (int)frame_len, 0, nb, hb.front(), (int)h_p->mfcc_coeffs)) plan = pm;
     }
-    const bool fused_mfcc = fused && !bad_bins && h_p->mfcc_coeffs &&
-                            spectral_supported_plan(plan, (int)frame_len, 0, nb, hb.front(), (int)h_p->mfcc_coeffs);
+    bool fused_mfcc = fused && !bad_bins && h_p->mfcc_coeffs &&
+                      spectral_supported_plan(plan, (int)frame_len, 0, nb, hb.front(), (int)h_p->mfcc_coeffs);
+    // ... and at the other lengths of the 1200-point plan by interpolating the frame's DFT bins from the transform's (mfcc_interp_t)
+    bool interp_mfcc = false;
+    mfcc_interp_t ip{};
+    if (fused && !fused_mfcc && !bad_bins && h_p->mfcc_coeffs && ctx->mfcc_interp != 0 && plan == SPECTRAL_PLAN_1200 && nb >= 1 && hb.front() >= 0) {
+        rc = get_interp_dev(ctx, plan, (int)frame_len, hb.front(), nb, &ip, &interp_mfcc);
+        if (rc != VBX_SUCCESS) return rc;
+        fused_mfcc = interp_mfcc;
+    }
     // 16-bit PCM frames: the fused kernel of full 1200-sample frames, the pitch fallback and Burg read them directly;
     // anything that would send another kernel over the samples takes one widening pass into a context-owned f64 copy
     const bool pcm_native = pcm16 != nullptr && fused && frame_len == (size_t)SPECTRAL_N &&
@@ -1642,6 +1681,7 @@ static int analyze_frames_impl(vbx_ctx *ctx, const char *fn, const double *x, co
         if (fused_mfcc) {
             L.out_mfcc = out_records + c_mfcc; L.mfcc_ld = (long)record_ld; L.mfcc_status = st_mfcc;
             L.bins = d_bins; L.slopes = slopes; L.dct = dct; L.num_coeffs = (int)h_p->mfcc_coeffs; L.nb = nb;
+            L.interp = interp_mfcc; L.ip = ip;
         }
         rc = launch_spectral(ctx, ctx->stream, L, "analyze");
     } else {

@@ -167,6 +167,29 @@ int spectral_tab_complex(int plan);                             // complex entri
 void spectral_fill_tab(int plan, double *h_out);                // the table, host side: [2 * spectral_tab_complex(plan)]
 int spectral_pow2_tab_complex(int plan);
 void spectral_pow2_fill_tab(int plan, double *h_out);
+// MFCC::mfcc inside the fused kernel at a frame length n that does not divide the transform's M (src/spectrum.rs:401-441 wants
+// the n-point DFT: bin k is the frame's DTFT at k / n, between the transform's bins).  The frame occupies n of the transform's M >= 2 n
+// samples, so its DTFT is a band-limited function of the bin index sampled at more than twice its rate: with c = (n - 1) / 2
+//     X(k / n) e^{i w c} = sum_j  Z[j] K0(k M / n - j),      Z[j] = X_M[j] e^{2 pi i j c / M},
+// exactly, for any real K0 whose transform is 1 on |t| <= n / 2M and 0 on |t - m| <= n / 2M, m != 0.  K0 = sinc * (the transform of a
+// Kaiser-Bessel bump of half-width 1/2 - n / 2M) cut to MFCC_INTERP_TAPS taps: the cut's error is < 2e-13 of the largest |X| nearby at
+// every M / n >= 2 (tools/experiments/mfcc_interp_design.py; tests/test_gpu_analyze.py holds the bins to that) -- the size of the transform's
+// own rounding.  The phase factor drops out of |X|^2.  ~600 vector instructions per frame instead of a chirp-z kernel of two more
+// transforms.  Host tables: rot[j] = e^{2 pi i j c / M} (j <= M / 4), per bin its first tap's index and its taps.
+constexpr int MFCC_INTERP_TAPS = 32;
+constexpr int MFCC_INTERP_SLOTS = 4;                            // bins per lane (nb <= 256)
+struct mfcc_interp_t {
+    const double *rot;                                          // complex [M / 4 + 1]
+    const double *coef;                                         // double2 [SLOTS][TAPS / 2][64]: taps 2 t, 2 t + 1 of bin 64 u + lane
+    const int32_t *j0;                                          // [SLOTS][64]: index of the bin's first tap MINUS jmin
+    int jmin, jmax;                                             // the transform's bins the taps read: Z[jmin .. jmax] (jmin may be < 0)
+    int pu_off;                                                 // doubles from the exchange buffer's start to the filter products
+    int lds_bytes;                                              // Z + products + mel sums
+};
+size_t mfcc_interp_table_bytes(int plan);
+// false: the shape has no interpolated form (bins beyond M / 4, more than 256 bins, too much LDS)
+bool mfcc_interp_fill(int plan, int n, int b_lo, int nb, void *h_table, mfcc_interp_t *h_desc /* offsets in the pointer fields */);
+
 struct spectral_launch_t {
     int plan; int n;                                             // spectral_plan(n), frame length
     const double *x; long F; long stride; const double *window; const double *lag_window; const double *tab;
@@ -180,6 +203,7 @@ struct spectral_launch_t {
     double *out_r; int n_lags;                                   // non-NULL: Autocorrelate::autocorrelate(n_lags) alone, [F, n_lags]
     bool pcm;                                                    // x points to int16 PCM samples (n == 1200 only)
     bool whole_curve;                                            // keep every lag of the curve in LDS (VBX_PITCH_CURVE_CUT=0; tests)
+    bool interp; mfcc_interp_t ip;                               // MFCC by interpolation of the transform's bins (device pointers)
 };
 bool spectral_supported(int n, int lpc_order, int mfcc_nb, int mfcc_b_lo, int num_coeffs);
 void launch_analyze(hipStream_t s, const spectral_launch_t &L);

@@ -12,7 +12,9 @@ namespace vbx {
 
 // what a spectral kernel instantiation computes.  SP_MFCC_HALF (power-of-two kernels): MFCC::mfcc of a frame of 2 Nc samples --
 // the frame itself is the real sequence of the transform (no padding), its bins are the transform's bins
-enum { SP_ANALYZE = 0, SP_MFCC_ONLY = 1, SP_AC_ONLY = 2, SP_MFCC_HALF = 3 };
+enum { SP_ANALYZE = 0, SP_MFCC_ONLY = 1, SP_AC_ONLY = 2, SP_MFCC_HALF = 3, SP_ANALYZE_INTERP = 4 };
+// SP_ANALYZE_INTERP: SP_ANALYZE of a frame whose length does not divide the transform's, with MFCC::mfcc's bins -- samples of
+// the frame's DTFT at k / n, between the transform's bins j / M -- interpolated from the transform (mfcc_interp_t, below).
 
 constexpr double SP_UNC_EPS = 6.0 * 400.0 * 2.220446049250313e-16;   // 1 / min w_lag * margin * eps
 
@@ -41,6 +43,7 @@ struct spectral_args_t {
     int mfcc_q;                                              // the frame's DFT bin k' is the transform's bin mfcc_q * k' (M / n)
     int pcm;                                                 // 1: `frames` points to int16 PCM samples (widened in registers:
                                                              // s / 32767, vbx_device.hpp pcm16_value); full frames only
+    mfcc_interp_t ip;                                        // SP_ANALYZE_INTERP
 };
 
 // The last SP_TAIL lags of the curve.  The lag window falls below 1e-8 there (1e-10 .. 1e-17 over the last twelve lags), so
