@@ -421,7 +421,14 @@ int vbx_pitch_f32_wide(vbx_ctx *ctx, const float *x, size_t n_frames, size_t fra
  *   hanning frame -> mfcc(mfcc_coeffs, (lo, hi), sr)
  * Each part with order / count 0 is skipped.  The library is free to share work between the parts (one pass over
  * the samples, one spectral transform feeding several of them); results obey the same tolerances as the
- * separate entry points.  Output: one record of vbx_record_doubles(params) doubles per frame,
+ * separate entry points.  MFCC shares the pitch path's transform at EVERY frame length from 513 to 4096 samples: where the
+ * length divides the transform's (512, 600, 800, 1024, 1200, 2048, 4096) the frame's DFT bins are bins of the transform; at
+ * the other lengths (25 ms at 44.1 kHz = 1102 / 1103 samples, ...) each bin is interpolated from 24-40 of the transform's --
+ * the frame fills at most half of it, so its spectrum is oversampled twofold and the interpolation's error is a design
+ * parameter: < 6e-13 of the largest bin (tests/test_mfcc_interp_table.py), MFCC values within 1e-9 of vbx_mfcc_f64's.
+ * (Bins above a quarter of the transform -- mfcc_hi_hz beyond ~sample_rate / 4 at a length just below the transform's half --
+ * fall back to vbx_mfcc_f64's kernel beside the fused one; VBX_MFCC_INTERP=0 in the environment forces that everywhere.)
+ * Output: one record of vbx_record_doubles(params) doubles per frame,
  *   [ pitch.frequency, pitch.strength | formants[n_est] {frequency, bandwidth} | mfcc[mfcc_coeffs] | lpc[lpc_order + 1] ]
  * at out_records + f * record_ld (record_ld even, >= the record size; 16-byte aligned base): the fixed-size
  * per-frame record that the multi-GPU gather below moves.  status3 (optional): [3, F] = pitch / formant / mfcc

@@ -44,10 +44,12 @@ def _oracle_records(oracle, pkg, audio, F, seg, N=N, H=H):
 
 # (1200, 480), (1024, 512), (2048, 1024): pitch + LPC + MFCC from one FFT of the frame; (512, 256): the same from the zero-padded
 # frame (512 divides the 1024 plan's 2048 points: its DFT bins are every 4th bin); (800, 320), (600, 240): likewise in the
-# 1200 plan (2400 = 3 * 800 = 4 * 600) instead of the 1024 plan their length would pick; (1103, 441), (1600, 640), (960, 480):
-# pitch + LPC from the FFT, MFCC by its own kernel; (4096, 2048): complex FFT of 4096; (256, 128): no fused kernel
+# 1200 plan (2400 = 3 * 800 = 4 * 600) instead of the 1024 plan their length would pick; (1103, 441), (1199, 480), (1600, 640),
+# (960, 480), (700, 350), (3000, 1200), (4000, 2000): lengths that do not divide their transform -- MFCC's bins interpolated from
+# the transform's inside the fused kernel (round 5; one instance per plan), held here to the chirp-z kernel of vbx_mfcc_f64 and to
+# the oracle; (4096, 2048): complex FFT of 4096; (256, 128): no fused kernel
 @pytest.mark.parametrize("N,H", [(1200, 480), (1024, 512), (2048, 1024), (1103, 441), (1600, 640), (512, 256), (4096, 2048), (256, 128),
-                                 (800, 320), (600, 240), (960, 480)])
+                                 (800, 320), (600, 240), (960, 480), (1199, 480), (700, 350), (3000, 1200), (4000, 2000)])
 def test_analyze_frames_matches_the_oracle_and_the_separate_entry_points(vb, pkg, oracle, audio_d, N, H):
     audio = audio_d.numpy()
     F = pkg.frame_count(audio.size, N, H)
@@ -125,6 +127,39 @@ def test_analyze_frames_parts_can_be_skipped_and_rows_can_be_padded(vb, pkg, aud
     # empty batch
     r0, _ = vb.analyze_frames(audio_d, full, frame_len=N, stride=H, n_frames=0)
     assert r0.shape == (0, 36)
+
+
+@pytest.mark.parametrize("N,H,sr", [(1103, 441, 44100.0), (1102, 441, 44100.0), (1025, 512, 48000.0), (1199, 480, 48000.0), (882, 441, 44100.0),
+                                    (1201, 600, 48000.0), (2047, 1024, 48000.0), (2049, 1024, 48000.0), (4095, 2048, 48000.0)])
+def test_mfcc_inside_the_fused_kernel_at_lengths_that_do_not_divide_the_transform(pkg, monkeypatch, N, H, sr):
+    """MFCC::mfcc (src/spectrum.rs:401-441) of a frame whose length does not divide the fused kernel's transform: the bins are
+    interpolated from the transform's (mfcc_interp_t) instead of coming from a chirp-z kernel beside it.  Same records: the MFCC
+    columns within 1e-9 of the chirp-z form's (VBX_MFCC_INTERP=0: the tables' design error is < 6e-13 of the largest bin,
+    tests/test_mfcc_interp_table.py), every other column and status bit for bit; and the form is really the one that ran."""
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VBX_MFCC_INTERP", mode)
+        ctx = pkg.VoxBox(0)
+        try:
+            audio = ctx.synth_speech(int(8 * sr), sample_offset=int(2 * sr))
+            F = pkg.frame_count(int(8 * sr), N, H)
+            est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+            params = pkg.AnalysisParams.make(sr, pitch=(0.2, 75.0, 600.0), lpc_order=P, formant_order=P, est_init=est0, mfcc=(13, 100.0, 8000.0))
+            ctx.profile_reset(); ctx.profile(True)
+            rec, st = ctx.analyze_frames(audio, params, frame_len=N, stride=H, n_frames=F)
+            names = set(ctx.profile_streams().keys())
+            ctx.profile(False)
+            got[mode] = (rec.copy(), st.copy(), names)
+            audio.free()
+        finally:
+            ctx.close()
+    (r0, s0, n0), (r1, s1, n1) = got["0"], got["1"]
+    assert any(k.startswith("mfcc") for k in n0), n0                      # the chirp-z kernel beside the fused one
+    assert not any(k.startswith("mfcc") for k in n1), n1                  # no MFCC kernel at all: the bins came from the fused kernel
+    assert np.array_equal(s0, s1)
+    assert np.array_equal(r0[:, :10], r1[:, :10]) and np.array_equal(r0[:, 23:], r1[:, 23:])
+    assert np.abs(r0[:, 10:23] - r1[:, 10:23]).max() <= 1e-9
+    assert np.abs(r0[:, 10:23]).max() > 5.0
 
 
 def test_profile_says_which_stream_a_kernel_ran_on(vb, pkg, audio_d):

@@ -15,7 +15,8 @@ def main():
     hours = float(sys.argv[sys.argv.index("--hours") + 1]) if "--hours" in sys.argv else 0.25
     pkg = g.load_package()
     out = {}
-    for (n, hop, sr) in [(1103, 441, 44100.0), (1102, 441, 44100.0), (1103, 441, 48000.0), (1025, 512, 48000.0), (1199, 480, 48000.0), (1100, 440, 44100.0)]:
+    for (n, hop, sr) in [(1103, 441, 44100.0), (1102, 441, 44100.0), (1103, 441, 48000.0), (1025, 512, 48000.0), (1199, 480, 48000.0), (882, 441, 44100.0), (1000, 500, 48000.0),
+                         (700, 350, 48000.0), (1201, 600, 48000.0), (1600, 640, 48000.0), (2047, 1024, 48000.0), (2049, 1024, 48000.0), (3000, 1200, 48000.0), (4000, 2000, 48000.0), (4095, 2048, 48000.0)]:
         res = {}
         for mode in ("0", "1"):
             os.environ["VBX_MFCC_INTERP"] = mode
@@ -35,7 +36,6 @@ def main():
             res[mode] = (rec.numpy().copy(), st3.numpy().copy(), best, F)
             vb.close()
         a, b = res["0"][0], res["1"][0]
-        c_m = 2 + 2 * 4 if False else None
         # columns: pitch 2 | formants 2 n_est | mfcc 13 | lpc 13
         n_est = len(pkg.MALE_FORMANT_ESTIMATES)
         c0 = 2 + 2 * n_est

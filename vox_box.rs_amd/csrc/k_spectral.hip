@@ -346,21 +346,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
         }
     }
 
-    // ---- MFCC::mfcc at a length that does not divide the transform: each of the frame's DFT bins from MFCC_INTERP_TAPS of the
+    // ---- MFCC::mfcc at a length that does not divide the transform: each of the frame's DFT bins from 24 .. 40 of the
     //      transform's (lane l: bins b_lo + l + 64 u), BEFORE exchange 4 takes the buffer; then the same products and tail ----
     if constexpr (INTERP) {
         wave_sync();
         const int nbp = (a.nb + 1) & ~1;
         double *pu = ex + a.ip.pu_off, *pd = pu + nbp, *en = pd + nbp;
         const double2 *cf = reinterpret_cast<const double2 *>(a.ip.coef) + lane;
-        constexpr int HT = MFCC_INTERP_TAPS / 2;
+        const int HT = a.ip.taps >> 1;                       // 12, 16 or 20 pairs of taps (the host's choice for M / n)
         for (int u = 0; u * 64 < a.nb; u++) {
             const int b = lane + 64 * u;
             const double2 *zp = zc + a.ip.j0[u * 64 + lane];
             const double2 sl = *reinterpret_cast<const double2 *>(a.slopes + 2 * ((b < a.nb) ? b : 0));
             double ar0 = 0.0, ai0 = 0.0, ar1 = 0.0, ai1 = 0.0;
             // (batches of eight taps, pinned: all of a bin's loads at once are 192 registers)
-#pragma unroll
+#pragma unroll 1
             for (int tb = 0; tb < HT; tb += 4) {
                 double2 c[4], z0[4], z1[4];
 #pragma unroll
@@ -651,16 +651,43 @@ bool spectral_supported_plan(int plan, int n, int lpc_order, int mfcc_nb, int mf
 }
 
 // ---- tables of the interpolated MFCC bins (mfcc_interp_t, vbx_kernels.hpp), host side, in long double ----
-size_t mfcc_interp_table_bytes(int plan) {
-    const size_t quarter = (size_t)spectral_plan_nc(plan) / 2;                                 // M / 4
-    return (quarter + 1) * 16 + (size_t)MFCC_INTERP_SLOTS * (MFCC_INTERP_TAPS / 2) * 64 * 16 + (size_t)MFCC_INTERP_SLOTS * 64 * 4;
+// threads per frame of the plan's kernel (the bins are dealt to them) and the LDS the interpolation may use: what costs at most one
+// of the twelve / eight frames of a CU (a chirp-z kernel over the same frames costs more), none of the 4096-point plan's four
+static void mfcc_interp_geom(int plan, long *M, int *nt, int *lds_cap) {
+    *M = 2L * spectral_plan_nc(plan);
+    *nt = plan == SPECTRAL_PLAN_4096 ? 128 : 64;
+    *lds_cap = (plan == SPECTRAL_PLAN_1200 || plan == SPECTRAL_PLAN_1024) ? (160 * 1024) / 11 : plan == SPECTRAL_PLAN_2048 ? (160 * 1024) / 7 : (160 * 1024) / 4;
+}
+static int mfcc_interp_slots(int plan, int nb) { long M; int nt, cap; mfcc_interp_geom(plan, &M, &nt, &cap); return (nb + nt - 1) / nt; }
+
+// Taps per bin.  The cut's error falls like e^{-pi tau W} (tau = 1/2 - n / 2M, the Kaiser-Bessel bump's half-width): 32 taps hold it
+// below 5e-13 of the largest |X| down to M / n = 2.16 (1103 samples in 2400: the worst frame, an impulse at its very end, 4e-13), 40
+// from there to M / n = 2, 24 from M / n = 3.6 up (tests/test_mfcc_interp_table.py measures every class against the exact DFT).
+int mfcc_interp_taps(int plan, int n) {
+    long M; int nt, cap; mfcc_interp_geom(plan, &M, &nt, &cap);
+    const double tau = 0.5 - (double)n / (2.0 * (double)M);
+    return tau >= 0.36 ? 24 : tau >= 0.268 ? 32 : MFCC_INTERP_MAX_TAPS;
+}
+
+size_t mfcc_interp_table_bytes(int plan, int nb) {
+    long M; int nt, cap; mfcc_interp_geom(plan, &M, &nt, &cap);
+    const size_t slots = (size_t)mfcc_interp_slots(plan, nb);
+    return (size_t)(M / 4 + 1) * 16 + slots * (MFCC_INTERP_MAX_TAPS / 2) * nt * 16 + slots * nt * 4;
+}
+size_t mfcc_interp_coef_offset(int plan) { return (size_t)(2L * spectral_plan_nc(plan) / 4 + 1) * 16; }
+size_t mfcc_interp_j0_offset(int plan, int nb) {
+    long M; int nt, cap; mfcc_interp_geom(plan, &M, &nt, &cap);
+    return mfcc_interp_coef_offset(plan) + (size_t)mfcc_interp_slots(plan, nb) * (MFCC_INTERP_MAX_TAPS / 2) * nt * 16;
 }
 
 bool mfcc_interp_fill(int plan, int n, int b_lo, int nb, void *h_table, mfcc_interp_t *d) {
-    if (plan != SPECTRAL_PLAN_1200) return false;                                              // (the power-of-two kernels: not yet)
-    const long M = 2L * spectral_plan_nc(plan), quarter = M / 4;
-    constexpr int W = MFCC_INTERP_TAPS, HT = W / 2, SL = MFCC_INTERP_SLOTS;
-    if (n < 2 || 2L * n > M || M % n == 0 || nb < 1 || nb > 64 * SL || b_lo < 0) return false;
+    if (plan == SPECTRAL_PLAN_NONE) return false;
+    long M; int NT, cap;
+    mfcc_interp_geom(plan, &M, &NT, &cap);
+    const long quarter = M / 4;
+    if (n < 2 || 2L * n > M || M % n == 0 || nb < 1 || nb > 4096 || b_lo < 0) return false;
+    const int SL = mfcc_interp_slots(plan, nb);
+    const int W = mfcc_interp_taps(plan, n), HT = W / 2;
     const long double pi = 3.141592653589793238462643383279502884L;
     const long double tau = 0.5L - (long double)n / (2.0L * (long double)M);                   // the bump's half-width
     const long double beta = pi * tau * (long double)W;
@@ -668,8 +695,8 @@ bool mfcc_interp_fill(int plan, int n, int b_lo, int nb, void *h_table, mfcc_int
     const long double norm = sinhc(beta);
     char *base = static_cast<char *>(h_table);
     double *rot = reinterpret_cast<double *>(base);
-    double *coef = reinterpret_cast<double *>(base + (quarter + 1) * 16);
-    int32_t *j0t = reinterpret_cast<int32_t *>(base + (quarter + 1) * 16 + (size_t)SL * HT * 64 * 16);
+    double *coef = reinterpret_cast<double *>(base + mfcc_interp_coef_offset(plan));
+    int32_t *j0t = reinterpret_cast<int32_t *>(base + mfcc_interp_j0_offset(plan, nb));
     for (long j = 0; j <= quarter; j++) {                                                      // e^{2 pi i j c / M}, c = (n - 1) / 2
         const long double ang = 2.0L * pi * (long double)((j * (long)(n - 1)) % (2 * M)) / (long double)(2 * M);
         rot[2 * j] = (double)cosl(ang); rot[2 * j + 1] = (double)sinl(ang);
@@ -681,8 +708,8 @@ bool mfcc_interp_fill(int plan, int n, int b_lo, int nb, void *h_table, mfcc_int
         if (first + W - 1 > jmax) jmax = first + W - 1;
     }
     if (jmax > quarter || jmin < -quarter) return false;
-    for (int i = 0; i < 64 * SL; i++) {
-        const int u = i / 64, lane = i % 64;
+    for (int i = 0; i < NT * SL; i++) {
+        const int u = i / NT, th = i % NT;
         const long k = b_lo + i;
         const long first = (i < nb) ? (k * M) / n - W / 2 + 1 : jmin;
         j0t[i] = (int32_t)(first - jmin);
@@ -700,15 +727,15 @@ bool mfcc_interp_fill(int plan, int n, int b_lo, int nb, void *h_table, mfcc_int
                     c = sn / (pi * nu) * bump;
                 }
             }
-            coef[(((size_t)u * HT + t / 2) * 64 + lane) * 2 + (t & 1)] = (double)c;
+            coef[(((size_t)u * HT + t / 2) * NT + th) * 2 + (t & 1)] = (double)c;
         }
     }
     const int zn = (int)(jmax - jmin + 1), nbp = (nb + 1) & ~1;
-    d->jmin = (int)jmin; d->jmax = (int)jmax;
+    d->jmin = (int)jmin; d->jmax = (int)jmax; d->taps = W;
     d->pu_off = 2 * zn;
     d->lds_bytes = (2 * zn + 2 * nbp + 64) * 8;
     d->rot = nullptr; d->coef = nullptr; d->j0 = nullptr;                                      // the caller's: device addresses
-    return d->lds_bytes <= (160 * 1024) / 12;                                                  // twelve frames per CU or not at all
+    return d->lds_bytes <= cap;
 }
 
 void launch_analyze(hipStream_t s, const spectral_launch_t &L) {

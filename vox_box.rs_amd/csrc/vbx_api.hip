@@ -316,17 +316,16 @@ int get_interp_dev(vbx_ctx *ctx, int plan, int n, int b_lo, int nb, mfcc_interp_
     if (it == ctx->interp_cache.end()) {
         mfcc_interp_t d{};
         void *dev = nullptr;
-        if (plan == SPECTRAL_PLAN_1200) {
-            const size_t bytes = mfcc_interp_table_bytes(plan);
+        {
+            const size_t bytes = mfcc_interp_table_bytes(plan, nb);
             std::vector<char> h(bytes, 0);
             if (mfcc_interp_fill(plan, n, b_lo, nb, h.data(), &d)) {
                 VBX_HIP(ctx, hipMalloc(&dev, bytes));
                 VBX_HIP(ctx, hipMemcpy(dev, h.data(), bytes, hipMemcpyHostToDevice));
-                const size_t quarter = (size_t)spectral_plan_nc(plan) / 2;
                 char *b = static_cast<char *>(dev);
                 d.rot = reinterpret_cast<const double *>(b);
-                d.coef = reinterpret_cast<const double *>(b + (quarter + 1) * 16);
-                d.j0 = reinterpret_cast<const int32_t *>(b + (quarter + 1) * 16 + (size_t)MFCC_INTERP_SLOTS * (MFCC_INTERP_TAPS / 2) * 64 * 16);
+                d.coef = reinterpret_cast<const double *>(b + mfcc_interp_coef_offset(plan));
+                d.j0 = reinterpret_cast<const int32_t *>(b + mfcc_interp_j0_offset(plan, nb));
             }
         }
         it = ctx->interp_cache.emplace(key, std::make_pair(dev, d)).first;
@@ -1307,6 +1306,26 @@ int vbx_internal_track_check(vbx_ctx *ctx, const vbx_resonance *formants, size_t
     return VBX_SUCCESS;
 }
 
+// Host only (no device, no context): the tables of the MFCC bins interpolated inside the fused kernel (mfcc_interp_t) for one shape,
+// for tests that hold the interpolation to the frame's exact DFT.  desc[8] = {M, threads per frame, slots, taps, jmin, jmax,
+// byte offset of the taps, byte offset of the first-tap indices}; *need = bytes of the table (copied to buf when cap >= *need).
+// Returns 1 when the shape has the form, 0 when it has not (its MFCC comes from the chirp-z kernel), < 0 on a bad argument.
+int vbx_internal_mfcc_interp_table(size_t frame_len, int b_lo, int nb, int32_t *desc, void *buf, size_t cap, size_t *need) {
+    if (!desc || !need || frame_len < 2 || frame_len > VBX_MAX_FRAME_LEN || nb < 1 || nb > 4096) return VBX_E_INVALID;
+    const int plan = spectral_plan_mfcc((int)frame_len);                  // (the plan vbx_analyze_frames_f64 picks)
+    if (plan == SPECTRAL_PLAN_NONE || (2 * spectral_plan_nc(plan)) % (int)frame_len == 0) return 0;
+    const size_t bytes = mfcc_interp_table_bytes(plan, nb);
+    *need = bytes;
+    std::vector<char> h(bytes, 0);
+    mfcc_interp_t d{};
+    if (!mfcc_interp_fill(plan, (int)frame_len, b_lo, nb, h.data(), &d)) return 0;
+    const int nt = plan == SPECTRAL_PLAN_4096 ? 128 : 64;
+    desc[0] = 4 * spectral_plan_nc(plan) / 2; desc[1] = nt; desc[2] = (nb + nt - 1) / nt; desc[3] = d.taps;
+    desc[4] = d.jmin; desc[5] = d.jmax; desc[6] = (int32_t)mfcc_interp_coef_offset(plan); desc[7] = (int32_t)mfcc_interp_j0_offset(plan, nb);
+    if (buf && cap >= bytes) std::memcpy(buf, h.data(), bytes);
+    return 1;
+}
+
 // ---- spectrum.rs: MFCC --------------------------------------------------------------------
 
 static int run_mfcc(vbx_ctx *ctx, hipStream_t stm, const double *x, size_t n_frames, size_t frame_len, size_t stride,
@@ -1583,10 +1602,10 @@ static int analyze_frames_impl(vbx_ctx *ctx, const char *fn, const double *x, co
     }
     bool fused_mfcc = fused && !bad_bins && h_p->mfcc_coeffs &&
                       spectral_supported_plan(plan, (int)frame_len, 0, nb, hb.front(), (int)h_p->mfcc_coeffs);
-    // ... and at the other lengths of the 1200-point plan by interpolating the frame's DFT bins from the transform's (mfcc_interp_t)
+    // ... and at the other lengths by interpolating the frame's DFT bins from the transform's (mfcc_interp_t)
     bool interp_mfcc = false;
     mfcc_interp_t ip{};
-    if (fused && !fused_mfcc && !bad_bins && h_p->mfcc_coeffs && ctx->mfcc_interp != 0 && plan == SPECTRAL_PLAN_1200 && nb >= 1 && hb.front() >= 0) {
+    if (fused && !fused_mfcc && !bad_bins && h_p->mfcc_coeffs && ctx->mfcc_interp != 0 && plan != SPECTRAL_PLAN_NONE && nb >= 1 && nb <= 4096 && hb.front() >= 0) {
         rc = get_interp_dev(ctx, plan, (int)frame_len, hb.front(), nb, &ip, &interp_mfcc);
         if (rc != VBX_SUCCESS) return rc;
         fused_mfcc = interp_mfcc;

@@ -172,22 +172,26 @@ void spectral_pow2_fill_tab(int plan, double *h_out);
 // samples, so its DTFT is a band-limited function of the bin index sampled at more than twice its rate: with c = (n - 1) / 2
 //     X(k / n) e^{i w c} = sum_j  Z[j] K0(k M / n - j),      Z[j] = X_M[j] e^{2 pi i j c / M},
 // exactly, for any real K0 whose transform is 1 on |t| <= n / 2M and 0 on |t - m| <= n / 2M, m != 0.  K0 = sinc * (the transform of a
-// Kaiser-Bessel bump of half-width 1/2 - n / 2M) cut to MFCC_INTERP_TAPS taps: the cut's error is < 2e-13 of the largest |X| nearby at
-// every M / n >= 2 (tools/experiments/mfcc_interp_design.py; tests/test_gpu_analyze.py holds the bins to that) -- the size of the transform's
-// own rounding.  The phase factor drops out of |X|^2.  ~600 vector instructions per frame instead of a chirp-z kernel of two more
+// Kaiser-Bessel bump of half-width 1/2 - n / 2M) cut to 24 / 32 / 40 taps by M / n: the cut's error is < 6e-13 of the largest |X| of
+// the transform at every M / n >= 2 (tests/test_mfcc_interp_table.py holds the tables to the exact DFT on the CPU) -- MFCC values
+// within 1e-10 of the chirp-z kernel's on speech.  The phase factor drops out of |X|^2.  ~600 vector instructions per frame instead of a chirp-z kernel of two more
 // transforms.  Host tables: rot[j] = e^{2 pi i j c / M} (j <= M / 4), per bin its first tap's index and its taps.
-constexpr int MFCC_INTERP_TAPS = 32;
-constexpr int MFCC_INTERP_SLOTS = 4;                            // bins per lane (nb <= 256)
+constexpr int MFCC_INTERP_MAX_TAPS = 40;                        // 24, 32 or 40 taps per bin (mfcc_interp_taps: by M / n)
 struct mfcc_interp_t {
     const double *rot;                                          // complex [M / 4 + 1]
-    const double *coef;                                         // double2 [SLOTS][TAPS / 2][64]: taps 2 t, 2 t + 1 of bin 64 u + lane
-    const int32_t *j0;                                          // [SLOTS][64]: index of the bin's first tap MINUS jmin
+    const double *coef;                                         // double2 [slots][TAPS / 2][NT]: taps 2 t, 2 t + 1 of bin NT u + thread (NT threads per frame,
+                                                                // slots = ceil(nb / NT))
+    const int32_t *j0;                                          // [slots][NT]: index of the bin's first tap MINUS jmin
     int jmin, jmax;                                             // the transform's bins the taps read: Z[jmin .. jmax] (jmin may be < 0)
+    int taps;                                                   // per bin (a multiple of 8)
     int pu_off;                                                 // doubles from the exchange buffer's start to the filter products
     int lds_bytes;                                              // Z + products + mel sums
 };
-size_t mfcc_interp_table_bytes(int plan);
-// false: the shape has no interpolated form (bins beyond M / 4, more than 256 bins, too much LDS)
+int mfcc_interp_taps(int plan, int n);
+size_t mfcc_interp_table_bytes(int plan, int nb);
+size_t mfcc_interp_coef_offset(int plan);                      // byte offsets of coef and j0 in the table (rot at 0)
+size_t mfcc_interp_j0_offset(int plan, int nb);
+// false: the shape has no interpolated form (bins beyond M / 4, LDS that would cost a frame per CU)
 bool mfcc_interp_fill(int plan, int n, int b_lo, int nb, void *h_table, mfcc_interp_t *h_desc /* offsets in the pointer fields */);
 
 struct spectral_launch_t {

@@ -260,11 +260,13 @@ __device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16
 // MODE (vbx_spectral.hpp): SP_ANALYZE the fused analysis; SP_MFCC_ONLY MFCC::mfcc alone (the forward transform and the mel / DCT
 // tail only); SP_AC_ONLY Autocorrelate::autocorrelate alone (both transforms, the fold seed, the lag sums stored).
 template <int U, bool LPC, bool MFCC, bool FULL, int MODE = SP_ANALYZE, int W = 1>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu((U == 1 && W == 1 && MODE == SP_ANALYZE) ? VBX_POW2_U1_WAVES : U == 4 ? 1 : (U == 2 && MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? VBX_POW2_U2_WAVES : 2,
-                                                                     (U == 1 && W == 1 && MODE == SP_ANALYZE) ? VBX_POW2_U1_WAVES : U == 4 ? ((MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? 1 : 2) : (MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? 2 : 4)))
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu((U == 1 && W == 1 && (MODE == SP_ANALYZE || MODE == SP_ANALYZE_INTERP)) ? VBX_POW2_U1_WAVES : U == 4 ? 1 : (U == 2 && MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? VBX_POW2_U2_WAVES : 2,
+                                                                     (U == 1 && W == 1 && (MODE == SP_ANALYZE || MODE == SP_ANALYZE_INTERP)) ? VBX_POW2_U1_WAVES : U == 4 ? ((MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? 1 : 2) : (MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? 2 : 4)))
 void analyze_pow2_kernel(const spectral_args_t a) {
     // pinned twiddle batches where registers are short: Nc = 1024 at three wavefronts per SIMD, Nc = 2048 at two
-    constexpr bool POW2_TIGHT = MODE == SP_ANALYZE && W == 1 && ((U == 1 && VBX_POW2_U1_WAVES >= 3) || U == 2);
+    constexpr bool INTERP = MODE == SP_ANALYZE_INTERP;       // MFCC's bins lie between the transform's (mfcc_interp_t, vbx_kernels.hpp)
+    static_assert(!INTERP || (MFCC && !FULL), "interpolated bins: a padded frame's MFCC");
+    constexpr bool POW2_TIGHT = (MODE == SP_ANALYZE || INTERP) && W == 1 && ((U == 1 && VBX_POW2_U1_WAVES >= 3) || U == 2);
     static_assert((MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) || (MFCC && FULL && !LPC), "the MFCC-only forms need the full frame and have no lag sums");
     static_assert(MODE != SP_AC_ONLY || (!MFCC && !LPC), "the autocorrelation-only form");
     constexpr bool PITCH = MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF;   // the second transform runs
@@ -359,6 +361,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
     // ---- spectrum of the real sequence, powers, the inverse transform's input (k_spectral.hip: same formulas) ----
     const int b_lo = MFCC ? a.bins[0] : 0;
     double pk[TP], pn[TP];                                   // P[m], P[Nc - m]
+    double2 *zc = reinterpret_cast<double2 *>(ex);           // INTERP: Z[j - jmin] = X_M[j] e^{2 pi i j c / M}, Z[-j] = conj Z[j]
 #pragma unroll
     for (int t = 0; t < TP; t++) {
         const int m = tid + NT * t;
@@ -369,6 +372,58 @@ void analyze_pow2_kernel(const spectral_args_t a) {
         const double pr = er + tr, pi = ei + ti, qr = er - tr, qi = ei - ti;
         pk[t] = fma(pr, pr, pi * pi);
         pn[t] = fma(qr, qr, qi * qi);
+        if constexpr (INTERP) {                              // (every thread is past exchange 3's last read: the buffer is free)
+            asm volatile("" : "+v"(pk[t]), "+v"(pn[t]));     // the powers NOW: two values wait for exchange 4, not the four they are made of
+            const double2 rt = reinterpret_cast<const double2 *>(a.ip.rot)[(m <= NC / 2) ? m : 0];
+            const double zr = fma(pr, rt.x, -(pi * rt.y)), zi = fma(pr, rt.y, pi * rt.x);
+            if (m >= a.ip.jmin && m <= a.ip.jmax) zc[m - a.ip.jmin] = double2{zr, zi};
+            if (m >= 1 && -m >= a.ip.jmin) zc[-m - a.ip.jmin] = double2{zr, -zi};
+        }
+    }
+
+    // ---- MFCC::mfcc at a length that does not divide the transform (k_spectral.hip: the same block; thread i: bins b_lo + i + NT u) ----
+    if constexpr (INTERP) {
+        pow2_sync<W>();
+        const int nbp = (a.nb + 1) & ~1;
+        double *pu = ex + a.ip.pu_off, *pd = pu + nbp, *en = pd + nbp;
+        const double2 *cf = reinterpret_cast<const double2 *>(a.ip.coef) + tid;
+        const int HT = a.ip.taps >> 1;                       // 12, 16 or 20 pairs of taps (the host's choice for M / n)
+        for (int u = 0; u * NT < a.nb; u++) {
+            const int b = tid + NT * u;
+            const double2 *zp = zc + a.ip.j0[u * NT + tid];
+            const double2 sl = *reinterpret_cast<const double2 *>(a.slopes + 2 * ((b < a.nb) ? b : 0));
+            double ar0 = 0.0, ai0 = 0.0, ar1 = 0.0, ai1 = 0.0;
+#pragma unroll 1
+            for (int tb = 0; tb < HT; tb += 4) {
+                double2 c[4], z0[4], z1[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { c[i] = cf[(u * HT + tb + i) * NT]; z0[i] = zp[2 * (tb + i)]; z1[i] = zp[2 * (tb + i) + 1]; }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    ar0 = fma(c[i].x, z0[i].x, ar0); ai0 = fma(c[i].x, z0[i].y, ai0);
+                    ar1 = fma(c[i].y, z1[i].x, ar1); ai1 = fma(c[i].y, z1[i].y, ai1);
+                }
+                asm volatile("" : "+v"(ar0), "+v"(ai0), "+v"(ar1), "+v"(ai1));
+                asm volatile("" ::: "memory");
+            }
+            const double vr = ar0 + ar1, vi = ai0 + ai1;
+            const double pw = fma(vr, vr, vi * vi);
+            if (b < a.nb) {
+                pu[b] = fabs(pw) * sl.x;                     // norm_sqr * multiplier (src/spectrum.rs:426-428)
+                pd[b] = fabs(sqrt(pw)) * sl.y;               // norm * multiplier (:432-434)
+            }
+        }
+        pow2_sync<W>();
+        if (wave == 0) {
+            if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
+            else mfcc_tail_m(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
+            if (a.mfcc_status != nullptr && lane == 0) a.mfcc_status[f] = 0;
+        }
+        pow2_sync<W>();
+        if constexpr (W == 1) {                              // the products may have lain over the stage-2 twiddles
+#pragma unroll
+            for (int i = tid; i < R * 16; i += NT) t2[i] = a.tab[G::T2 + i];
+        }
     }
 
     if constexpr (PITCH) {
@@ -409,7 +464,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
 
     // ---- MFCC::mfcc from the powers: X_n[k'] = X_M[q k'], q = M / n -- 2 for a frame of Nc samples, 1 for one of 2 Nc (HALF),
     //      4, 8, .. for a shorter frame whose length divides M (512 in the 1024 plan) ----
-    if (MFCC) {
+    if constexpr (MFCC && !INTERP) {
         const int nbp = (a.nb + 1) & ~1;
         const int qm = HALF ? 0 : FULL ? 1 : a.mfcc_q - 1;    // q is a power of two: m % q == 0  <=>  (m & (q - 1)) == 0
         const int qs = HALF ? 0 : FULL ? 1 : 31 - __builtin_clz((unsigned)a.mfcc_q);
@@ -582,6 +637,13 @@ void launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a
     if (L.out_r != nullptr) {                                // autocorrelate(n_lags) alone
         if (L.n == NC) hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, true, SP_AC_ONLY, W>), grid, block, lds_ac, s, a);
         else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, false, SP_AC_ONLY, W>), grid, block, lds_ac, s, a);
+        return;
+    }
+    if (L.interp && mf && L.n != NC) {         // a padded frame whose MFCC bins are interpolated from the transform's
+        a.ip = L.ip;
+        const size_t li = lds > (size_t)L.ip.lds_bytes ? lds : (((size_t)L.ip.lds_bytes + 15) & ~(size_t)15);
+        if (lpc) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, true, false, SP_ANALYZE_INTERP, W>), grid, block, li, s, a);
+        else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, false, SP_ANALYZE_INTERP, W>), grid, block, li, s, a);
         return;
     }
     if (L.n != NC) {                           // a padded frame; MFCC joins when its length divides M (U = 1: 512)
