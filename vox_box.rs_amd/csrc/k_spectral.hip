@@ -28,6 +28,7 @@
 #include "vbx_device.hpp"
 #include "vbx_kernels.hpp"
 #include "vbx_mfcc_tail.hpp"
+#include "vbx_mfcc_interp.hpp"
 #include "vbx_pitch_refine.hpp"
 #include "vbx_spectral.hpp"
 
@@ -327,6 +328,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
     const int b_lo = MFCC ? a.bins[0] : 0;
     double pk[10], pn[10];                                   // P[m], P[N - m]
     double2 *zc = reinterpret_cast<double2 *>(ex);           // INTERP: Z[j - jmin] = X_M[j] e^{2 pi i j c / M}, Z[-j] = conj Z[j]
+    double2 rot_m = double2{1.0, 0.0}, rot_step = double2{1.0, 0.0};
+    if constexpr (INTERP) { rot_m = reinterpret_cast<const double2 *>(a.ip.rot)[lane]; rot_step = reinterpret_cast<const double2 *>(a.ip.rot)[64]; }
 #pragma unroll
     for (int t = 0; t < 10; t++) {
         const int m = lane + 64 * t;
@@ -339,10 +342,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
         pn[t] = fma(qr, qr, qi * qi);
         if constexpr (INTERP) {                              // (every lane is past exchange 3's last read: the buffer is free)
             asm volatile("" : "+v"(pk[t]), "+v"(pn[t]));     // the powers NOW: two values wait for exchange 4, not the four they are made of
-            const double2 rt = reinterpret_cast<const double2 *>(a.ip.rot)[(m <= 600) ? m : 0];
-            const double zr = fma(pr, rt.x, -(pi * rt.y)), zi = fma(pr, rt.y, pi * rt.x);
-            if (m >= a.ip.jmin && m <= a.ip.jmax) zc[m - a.ip.jmin] = double2{zr, zi};
-            if (m >= 1 && -m >= a.ip.jmin) zc[-m - a.ip.jmin] = double2{zr, -zi};
+            mfcc_interp_stage(zc, a.ip, m, pr, pi, rot_m, rot_step);
         }
     }
 
@@ -350,6 +350,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
     //      transform's (lane l: bins b_lo + l + 64 u), BEFORE exchange 4 takes the buffer; then the same products and tail ----
     if constexpr (INTERP) {
         wave_sync();
+        VBX_PHASE(a.work, f, 13);
         const int nbp = (a.nb + 1) & ~1;
         double *pu = ex + a.ip.pu_off, *pd = pu + nbp, *en = pd + nbp;
         const double2 *cf = reinterpret_cast<const double2 *>(a.ip.coef) + lane;
@@ -358,22 +359,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
             const int b = lane + 64 * u;
             const double2 *zp = zc + a.ip.j0[u * 64 + lane];
             const double2 sl = *reinterpret_cast<const double2 *>(a.slopes + 2 * ((b < a.nb) ? b : 0));
-            double ar0 = 0.0, ai0 = 0.0, ar1 = 0.0, ai1 = 0.0;
-            // (batches of eight taps, pinned: all of a bin's loads at once are 192 registers)
-#pragma unroll 1
-            for (int tb = 0; tb < HT; tb += 4) {
-                double2 c[4], z0[4], z1[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) { c[i] = cf[(u * HT + tb + i) * 64]; z0[i] = zp[2 * (tb + i)]; z1[i] = zp[2 * (tb + i) + 1]; }
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    ar0 = fma(c[i].x, z0[i].x, ar0); ai0 = fma(c[i].x, z0[i].y, ai0);
-                    ar1 = fma(c[i].y, z1[i].x, ar1); ai1 = fma(c[i].y, z1[i].y, ai1);
-                }
-                asm volatile("" : "+v"(ar0), "+v"(ai0), "+v"(ar1), "+v"(ai1));
-                asm volatile("" ::: "memory");
-            }
-            const double vr = ar0 + ar1, vi = ai0 + ai1;
+            double vr, vi;
+            mfcc_interp_bin(HT, cf + (u * HT) * 64, 64, zp, vr, vi);
             const double pw = fma(vr, vr, vi * vi);
             if (b < a.nb) {
                 pu[b] = fabs(pw) * sl.x;                     // norm_sqr * multiplier (src/spectrum.rs:426-428)
@@ -381,11 +368,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
             }
         }
         wave_sync();
+        VBX_PHASE(a.work, f, 14);
+        const double2 t2v = a.tab[SP_T2 + np];               // the products may lie over the stage-2 twiddles: requested now, put back after the tail
         if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld, a.work, f);
         else mfcc_tail_m(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
         if (a.mfcc_status != nullptr && lane == 0) a.mfcc_status[f] = 0;
         wave_sync();
-        if (lane < 60) t2[lane] = a.tab[SP_T2 + lane];       // the products may have lain over the stage-2 twiddles
+        if (lane < 60) t2[lane] = t2v;
+        VBX_PHASE(a.work, f, 15);
     }
 
     if constexpr (PITCH) {

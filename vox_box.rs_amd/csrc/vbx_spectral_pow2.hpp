@@ -18,6 +18,7 @@
 #include "vbx_device.hpp"
 #include "vbx_kernels.hpp"
 #include "vbx_mfcc_tail.hpp"
+#include "vbx_mfcc_interp.hpp"
 #include "vbx_pitch_refine.hpp"
 #include "vbx_spectral.hpp"
 
@@ -362,6 +363,8 @@ void analyze_pow2_kernel(const spectral_args_t a) {
     const int b_lo = MFCC ? a.bins[0] : 0;
     double pk[TP], pn[TP];                                   // P[m], P[Nc - m]
     double2 *zc = reinterpret_cast<double2 *>(ex);           // INTERP: Z[j - jmin] = X_M[j] e^{2 pi i j c / M}, Z[-j] = conj Z[j]
+    double2 rot_m = double2{1.0, 0.0}, rot_step = double2{1.0, 0.0};
+    if constexpr (INTERP) { rot_m = reinterpret_cast<const double2 *>(a.ip.rot)[tid]; rot_step = reinterpret_cast<const double2 *>(a.ip.rot)[NT]; }
 #pragma unroll
     for (int t = 0; t < TP; t++) {
         const int m = tid + NT * t;
@@ -374,10 +377,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
         pn[t] = fma(qr, qr, qi * qi);
         if constexpr (INTERP) {                              // (every thread is past exchange 3's last read: the buffer is free)
             asm volatile("" : "+v"(pk[t]), "+v"(pn[t]));     // the powers NOW: two values wait for exchange 4, not the four they are made of
-            const double2 rt = reinterpret_cast<const double2 *>(a.ip.rot)[(m <= NC / 2) ? m : 0];
-            const double zr = fma(pr, rt.x, -(pi * rt.y)), zi = fma(pr, rt.y, pi * rt.x);
-            if (m >= a.ip.jmin && m <= a.ip.jmax) zc[m - a.ip.jmin] = double2{zr, zi};
-            if (m >= 1 && -m >= a.ip.jmin) zc[-m - a.ip.jmin] = double2{zr, -zi};
+            mfcc_interp_stage(zc, a.ip, m, pr, pi, rot_m, rot_step);
         }
     }
 
@@ -392,21 +392,8 @@ void analyze_pow2_kernel(const spectral_args_t a) {
             const int b = tid + NT * u;
             const double2 *zp = zc + a.ip.j0[u * NT + tid];
             const double2 sl = *reinterpret_cast<const double2 *>(a.slopes + 2 * ((b < a.nb) ? b : 0));
-            double ar0 = 0.0, ai0 = 0.0, ar1 = 0.0, ai1 = 0.0;
-#pragma unroll 1
-            for (int tb = 0; tb < HT; tb += 4) {
-                double2 c[4], z0[4], z1[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) { c[i] = cf[(u * HT + tb + i) * NT]; z0[i] = zp[2 * (tb + i)]; z1[i] = zp[2 * (tb + i) + 1]; }
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    ar0 = fma(c[i].x, z0[i].x, ar0); ai0 = fma(c[i].x, z0[i].y, ai0);
-                    ar1 = fma(c[i].y, z1[i].x, ar1); ai1 = fma(c[i].y, z1[i].y, ai1);
-                }
-                asm volatile("" : "+v"(ar0), "+v"(ai0), "+v"(ar1), "+v"(ai1));
-                asm volatile("" ::: "memory");
-            }
-            const double vr = ar0 + ar1, vi = ai0 + ai1;
+            double vr, vi;
+            mfcc_interp_bin(HT, cf + (u * HT) * NT, NT, zp, vr, vi);
             const double pw = fma(vr, vr, vi * vi);
             if (b < a.nb) {
                 pu[b] = fabs(pw) * sl.x;                     // norm_sqr * multiplier (src/spectrum.rs:426-428)
@@ -414,15 +401,20 @@ void analyze_pow2_kernel(const spectral_args_t a) {
             }
         }
         pow2_sync<W>();
+        double2 t2v[(R * 16 + NT - 1) / NT];                 // the products may lie over the stage-2 twiddles (W == 1): requested now, put back after the tail
+        if constexpr (W == 1) {
+#pragma unroll
+            for (int i = 0; i < (R * 16 + NT - 1) / NT; i++) t2v[i] = a.tab[G::T2 + ((tid + NT * i < R * 16) ? tid + NT * i : 0)];
+        }
         if (wave == 0) {
             if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
             else mfcc_tail_m(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
             if (a.mfcc_status != nullptr && lane == 0) a.mfcc_status[f] = 0;
         }
         pow2_sync<W>();
-        if constexpr (W == 1) {                              // the products may have lain over the stage-2 twiddles
+        if constexpr (W == 1) {
 #pragma unroll
-            for (int i = tid; i < R * 16; i += NT) t2[i] = a.tab[G::T2 + i];
+            for (int i = 0; i < (R * 16 + NT - 1) / NT; i++) if (tid + NT * i < R * 16) t2[tid + NT * i] = t2v[i];
         }
     }
 
