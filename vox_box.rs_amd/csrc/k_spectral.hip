@@ -96,6 +96,9 @@ __device__ __forceinline__ void dft20(double (&re)[20], double (&im)[20]) {
 #define VBX_EXP_TWB 2
 #endif
 constexpr int TWB = VBX_EXP_TWB;
+#ifndef VBX_EXP_MB1
+#define VBX_EXP_MB1 3
+#endif
 template <int TWB = vbx::TWB>
 __device__ __forceinline__ void twiddle_tight(double (&re)[20], double (&im)[20], const double2 *tw_row) {
 #pragma unroll
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
         pn[t] = fma(qr, qr, qi * qi);
         if constexpr (INTERP) {                              // (every lane is past exchange 3's last read: the buffer is free)
             asm volatile("" : "+v"(pk[t]), "+v"(pn[t]));     // the powers NOW: two values wait for exchange 4, not the four they are made of
-            mfcc_interp_stage(zc, a.ip, m, pr, pi, rot_m, rot_step);
+            mfcc_interp_stage(zc, a.ip, m, pr, pi, rot_m, rot_step, t == 0);
         }
     }
 
@@ -424,6 +427,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
         const int q = FULL ? 2 : a.mfcc_q, half = FULL ? SP_N / 2 : a.n / 2;
         double *pu = ex, *pd = ex + nbp, *en = ex + 2 * nbp; // the exchange buffer is free between the two transforms
         constexpr int MB = 2;     // slots per batch (five: 24 registers spilled in the three-wavefront instance)
+        // Can a mirrored bin n/2 - m/q (from P[N - m]) be one of the filters' at all?  Only when they reach above a quarter of
+        // the sampling rate (m <= 600: n/2 - m/q >= 600/q).  Below that -- speech settings: 8 kHz of 24 -- only P[m] has bins,
+        // half as many slope pairs are wanted, and five slots' pairs are requested together instead of two: two round trips
+        // to the L2 per frame instead of five (the phase clocks: 8 k cycles of the frame's 170 k for ~100 instructions).
+        const bool two_sided = (half - 600 / q) - b_lo < a.nb;
+        if (!two_sided) {
+            constexpr int MB1 = VBX_EXP_MB1;               // (batches of three: nothing spills, 18.37 ms per 720,000 frames; of five: six registers, 18.45; round 4's form: 18.56)
+#pragma unroll
+            for (int h = 0; h < (10 + MB1 - 1) / MB1; h++) {
+                double2 s1[MB1];
+                int c1[MB1];
+#pragma unroll
+                for (int u = 0; u < MB1; u++) {
+                    const int t = MB1 * h + u, m = lane + 64 * t;
+                    if (t >= 10) { c1[u] = -1; continue; }
+                    const bool on = m <= 600 && (FULL ? (m & 1) == 0 : m % q == 0);
+                    const int b1 = (FULL ? (m >> 1) : m / q) - b_lo;
+                    c1[u] = (on && b1 >= 0 && b1 < a.nb) ? b1 : -1;
+                    s1[u] = *reinterpret_cast<const double2 *>(a.slopes + 2 * (c1[u] < 0 ? 0 : c1[u]));
+                }
+#pragma unroll
+                for (int u = 0; u < MB1; u++) {
+                    const int t = MB1 * h + u;
+                    if (t < 10 && c1[u] >= 0) {
+                        pu[c1[u]] = fabs(pk[t]) * s1[u].x;   // norm_sqr * multiplier (src/spectrum.rs:426-428)
+                        pd[c1[u]] = fabs(sqrt(pk[t])) * s1[u].y;   // norm * multiplier (:432-434)
+                    }
+                }
+            }
+        } else
         // (the slope pairs of a few slots requested together, without a condition -- pair 0 stands in for a slot
         // without a bin --, then the products: behind `if (bin in range)` each load waited for its own round trip)
 #pragma unroll

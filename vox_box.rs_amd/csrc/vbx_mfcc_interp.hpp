@@ -59,10 +59,12 @@ __device__ __forceinline__ void mfcc_interp_bin(int ht, const double2 *cf, int n
 // Z[j - jmin] = X_M[j] e^{2 pi i j c / M} for the thread's bin m of the transform (and its mirror: Z[-j] = conj Z[j]).  rt: the rotation of
 // bin m -- the thread's own table entry rot[tid] advanced by rot[NT] per slot (a recurrence of at most 17 steps, ~2e-15) instead of one
 // table entry per slot: those loads were ten dependent round trips in the middle of the split (measured: 10 k cycles per frame).
-__device__ __forceinline__ void mfcc_interp_stage(double2 *zc, const mfcc_interp_t &ip, int m, double pr, double pi, double2 &rt, double2 step) {
+// mirror: the slot can hold bins whose mirror is read (only the thread's FIRST slot: jmin > -taps / 2 >= -NT)
+__device__ __forceinline__ void mfcc_interp_stage(double2 *zc, const mfcc_interp_t &ip, int m, double pr, double pi, double2 &rt, double2 step,
+                                                  const bool mirror) {
     const double zr = fma(pr, rt.x, -(pi * rt.y)), zi = fma(pr, rt.y, pi * rt.x);
     if (m >= ip.jmin && m <= ip.jmax) zc[m - ip.jmin] = double2{zr, zi};
-    if (m >= 1 && -m >= ip.jmin) zc[-m - ip.jmin] = double2{zr, -zi};
+    if (mirror && m >= 1 && -m >= ip.jmin) zc[-m - ip.jmin] = double2{zr, -zi};
     const double nx = fma(rt.x, step.x, -(rt.y * step.y)), ny = fma(rt.x, step.y, rt.y * step.x);
     rt = double2{nx, ny};
 }

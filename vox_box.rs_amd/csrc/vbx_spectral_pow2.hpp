@@ -377,7 +377,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
         pn[t] = fma(qr, qr, qi * qi);
         if constexpr (INTERP) {                              // (every thread is past exchange 3's last read: the buffer is free)
             asm volatile("" : "+v"(pk[t]), "+v"(pn[t]));     // the powers NOW: two values wait for exchange 4, not the four they are made of
-            mfcc_interp_stage(zc, a.ip, m, pr, pi, rot_m, rot_step);
+            mfcc_interp_stage(zc, a.ip, m, pr, pi, rot_m, rot_step, t == 0);
         }
     }
 
@@ -462,6 +462,33 @@ void analyze_pow2_kernel(const spectral_args_t a) {
         const int qs = HALF ? 0 : FULL ? 1 : 31 - __builtin_clz((unsigned)a.mfcc_q);
         const int half = HALF ? NC : FULL ? NC / 2 : n / 2;
         double *pu = ex, *pd = ex + nbp, *en = ex + 2 * nbp; // the exchange buffer is free between the two transforms
+        // (k_spectral.hip: when no mirrored bin can be one of the filters' -- they end below a quarter of the sampling rate --
+        // only P[m] has bins, and the slope pairs of three slots are requested together, without a condition)
+        const bool two_sided = (half - ((NC / 2) >> qs)) - b_lo < a.nb;
+        if (!two_sided) {
+            constexpr int MB1 = 3;
+#pragma unroll
+            for (int h = 0; h < (TP + MB1 - 1) / MB1; h++) {
+                double2 s1[MB1];
+                int c1[MB1];
+#pragma unroll
+                for (int u = 0; u < MB1; u++) {
+                    const int t = MB1 * h + u, m = tid + NT * t;
+                    if (t >= TP) { c1[u] = -1; continue; }
+                    const int b1 = (m >> qs) - b_lo;
+                    c1[u] = (m <= NC / 2 && (m & qm) == 0 && b1 >= 0 && b1 < a.nb) ? b1 : -1;
+                    s1[u] = *reinterpret_cast<const double2 *>(a.slopes + 2 * (c1[u] < 0 ? 0 : c1[u]));
+                }
+#pragma unroll
+                for (int u = 0; u < MB1; u++) {
+                    const int t = MB1 * h + u;
+                    if (t < TP && c1[u] >= 0) {
+                        pu[c1[u]] = fabs(pk[t]) * s1[u].x;   // norm_sqr * multiplier (src/spectrum.rs:426-428)
+                        pd[c1[u]] = fabs(sqrt(pk[t])) * s1[u].y;   // norm * multiplier (:432-434)
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int t = 0; t < TP; t++) {
             const int m = tid + NT * t;
