@@ -6,22 +6,26 @@
 #include "vbx_device.hpp"
 #include "vbx_kernels.hpp"
 
+#ifndef VBX_EXP_INTERP_CH12
+#define VBX_EXP_INTERP_CH12 4
+#endif
 #ifndef VBX_EXP_INTERP_CH16
-#define VBX_EXP_INTERP_CH16 16
+#define VBX_EXP_INTERP_CH16 4
 #endif
 #ifndef VBX_EXP_INTERP_CH20
-#define VBX_EXP_INTERP_CH20 20
+#define VBX_EXP_INTERP_CH20 4
 #endif
 
 namespace vbx {
 
 // One bin.  cf: the thread's first pair of taps (stride nt double2 between pairs); zp: Z[j0].
-// All of the bin's taps are requested before the first is used (the table lives in L2: 48-200 KB per shape, every frame reads all of
-// it); the Z reads (LDS) follow in groups of two pairs, each group finished before the next one's reads may start (the accumulators
-// pinned, the loads fenced): the powers of exchange 4 wait in 40 registers meanwhile.  Measured (timing builds that skip a part,
-// 720,000 frames of 1199 / 1103 samples): the loop 1.4 / 1.2 ms of 21.8, the staging 0.2, the products + tail + what the instance's
-// 27 spilled registers cost 1.3 / 2.3 -- against 1.26 ms for MFCC from the transform's own bins at 1200.  Chunks of 8 / 10 pairs instead
-// of 16 / 20 (VBX_EXP_INTERP_CH16 / _CH20): the same time.
+// The taps are requested in chunks of CH pairs (the table lives in L2: 48-200 KB per shape, every frame reads all of it); the Z reads
+// (LDS) follow in groups of two pairs, each group finished before the next one's reads may start (the accumulators pinned, the loads
+// fenced): the powers of exchange 4 wait in 40 registers meanwhile.  Measured (timing builds that skip a part, 720,000 frames of
+// 1199 / 1103 samples): the loop 1.4 / 1.2 ms of 21.8, the staging 0.2, the products + tail 1.3 / 2.3 -- against 1.26 ms for MFCC from
+// the transform's own bins at 1200.  Chunks of 4, 8 / 10 or ALL 16 / 20 pairs in flight (VBX_EXP_INTERP_CH*): the same time to 0.1 %
+// -- three wavefronts per SIMD cover the round trips -- but 12, 18 and 27 spilled registers in the 168-register instance (5.4 KB of
+// scratch writes per frame with all in flight): chunks of four.
 template <int HT, int CH = HT>
 __device__ __forceinline__ void mfcc_interp_bin(const double2 *cf, int nt, const double2 *zp, double &vr, double &vi) {
     static_assert(HT % CH == 0 && CH % 2 == 0, "chunks of whole groups");
@@ -53,7 +57,7 @@ __device__ __forceinline__ void mfcc_interp_bin(const double2 *cf, int nt, const
 __device__ __forceinline__ void mfcc_interp_bin(int ht, const double2 *cf, int nt, const double2 *zp, double &vr, double &vi) {
     if (ht == 16) mfcc_interp_bin<16, VBX_EXP_INTERP_CH16>(cf, nt, zp, vr, vi);
     else if (ht == 20) mfcc_interp_bin<20, VBX_EXP_INTERP_CH20>(cf, nt, zp, vr, vi);
-    else mfcc_interp_bin<12>(cf, nt, zp, vr, vi);
+    else mfcc_interp_bin<12, VBX_EXP_INTERP_CH12>(cf, nt, zp, vr, vi);
 }
 
 // Z[j - jmin] = X_M[j] e^{2 pi i j c / M} for the thread's bin m of the transform (and its mirror: Z[-j] = conj Z[j]).  rt: the rotation of
