@@ -162,6 +162,36 @@ def test_mfcc_inside_the_fused_kernel_at_lengths_that_do_not_divide_the_transfor
     assert np.abs(r0[:, 10:23]).max() > 5.0
 
 
+@pytest.mark.parametrize("N,H", [(3000, 1200), (2500, 1000), (4096, 2048), (4000, 2000)])
+def test_the_4096_point_plan_as_two_kernels(pkg, monkeypatch, N, H):
+    """Frames of 2049..4096 samples: the transforms + LPC + MFCC in one kernel, the lag curve through a scratch row, the refinement in
+    a second kernel at three wavefronts per SIMD (SP_ANALYZE_SPLIT; the default up to 3584 samples and from kmax = 2, forced here by
+    VBX_POW2_SPLIT=1) -- bit for bit the fused kernel's records, candidates, counts and statuses (VBX_POW2_SPLIT=0)."""
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VBX_POW2_SPLIT", mode)
+        ctx = pkg.VoxBox(0)
+        try:
+            audio = ctx.synth_speech(20 * 48000, sample_offset=2 * 48000)
+            F = pkg.frame_count(20 * 48000, N, H)
+            est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+            params = pkg.AnalysisParams.make(SR, pitch=(0.2, 75.0, 600.0), lpc_order=P, formant_order=P, est_init=est0, mfcc=(13, 100.0, 8000.0))
+            rec, st = ctx.analyze_frames(audio, params, frame_len=N, stride=H, n_frames=F)
+            split_a = int(ctx.L.vbx_internal_last_spectral_split(ctx.ctx))
+            han = ctx.window(pkg.WINDOW_HANNING, N)
+            c1 = ctx.pitch(audio, SR, 0.2, 75.0, 600.0, kmax=1, frame_len=N, stride=H, n_frames=F, window=han)
+            c8 = ctx.pitch(audio, SR, 0.2, 75.0, 600.0, kmax=8, frame_len=N, stride=H, n_frames=F, window=han)
+            split_p = int(ctx.L.vbx_internal_last_spectral_split(ctx.ctx))
+            got[mode] = ([rec.copy(), st.copy()] + [np.array(x).copy() for x in c1] + [np.array(x).copy() for x in c8], split_a, split_p)
+            audio.free()
+        finally:
+            ctx.close()
+    assert got["0"][1:] == (0, 0) and got["1"][1:] == (1, 1), (got["0"][1:], got["1"][1:])
+    for a, b in zip(got["0"][0], got["1"][0]):
+        assert np.array_equal(a, b)
+    assert np.count_nonzero(got["1"][0][0][:, 0]) > 50                      # voiced frames among them
+
+
 def test_profile_says_which_stream_a_kernel_ran_on(vb, pkg, audio_d):
     """vbx_profile_stream (ABI 5): the fused call's spectral kernel runs on the context's stream (0), the formant chain beside
     it on the side stream (1); a kernel that was not profiled reports -1.  bench.py ranks its dominant kernel among stream 0."""

@@ -766,7 +766,7 @@ bool mfcc_interp_fill(int plan, int n, int b_lo, int nb, void *h_table, mfcc_int
     return d->lds_bytes <= cap;
 }
 
-void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
+int launch_analyze(hipStream_t s, const spectral_launch_t &L) {
     spectral_args_t a;
     a.frames = L.x; a.n_frames = L.F; a.stride = L.stride; a.window = L.window; a.lag_window = L.lag_window;
     a.tab = reinterpret_cast<const double2 *>(L.tab);
@@ -782,7 +782,7 @@ void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
     a.pcm = (L.pcm && L.n == SP_N) ? 1 : 0;                  // the host side only asks for it on full 1200-sample frames
     a.mfcc_q = (L.plan != SPECTRAL_PLAN_NONE && L.n > 0) ? (2 * spectral_plan_nc(L.plan)) / L.n : 2;
     a.ip = mfcc_interp_t{};
-    if (L.plan != SPECTRAL_PLAN_1200) { launch_analyze_pow2(s, L, a); return; }
+    if (L.plan != SPECTRAL_PLAN_1200) return launch_analyze_pow2(s, L, a);
     const dim3 grid((unsigned)L.F), block(64);
     const size_t base = spectral_lds_bytes(L.n);
     size_t extra = pitch_full_list_bytes(L.n, L.kmax);
@@ -795,12 +795,12 @@ void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
     const bool lpc = L.out_lpc != nullptr, mf = L.out_mfcc != nullptr;
     if (L.mfcc_only) {                                       // spectral_supported(): n == SP_N
         hipLaunchKernelGGL((analyze_kernel<false, true, true, SP_MFCC_ONLY>), grid, block, spectral_lds_bytes(0), s, a);
-        return;
+        return 0;
     }
     if (L.out_r != nullptr) {                                // autocorrelate(n_lags) alone
         if (L.n == SP_N) hipLaunchKernelGGL((analyze_kernel<false, false, true, SP_AC_ONLY>), grid, block, spectral_lds_bytes(0), s, a);
         else hipLaunchKernelGGL((analyze_kernel<false, false, false, SP_AC_ONLY>), grid, block, spectral_lds_bytes(0), s, a);
-        return;
+        return 0;
     }
     // Three wavefronts per SIMD (twelve frames of 13.5 KB fill the CU's LDS; 168 registers) wherever the frame state allows it,
     // i.e. no full-list region in LDS.  Round 3 had it for pitch alone from kmax = 2 (the refinement is a chain of dependent
@@ -833,6 +833,7 @@ void launch_analyze(hipStream_t s, const spectral_launch_t &L) {
     else if (mf) VBX_SP_LAUNCH(false, true, true);
     else VBX_SP_LAUNCH(false, false, true);
 #undef VBX_SP_LAUNCH
+    return 0;
 }
 
 }  // namespace vbx

@@ -3,6 +3,6 @@
 
 namespace vbx {
 
-void launch_pow2_u1(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a) { launch_pow2_u<1>(s, L, a); }
+int launch_pow2_u1(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a) { return launch_pow2_u<1>(s, L, a); }
 
 }  // namespace vbx

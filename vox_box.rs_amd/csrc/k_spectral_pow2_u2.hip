@@ -4,9 +4,9 @@
 namespace vbx {
 
 #ifdef VBX_POW2_2048_TWO_WAVES
-void launch_pow2_u2(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a) { launch_pow2_u<1, 2>(s, L, a); }
+int launch_pow2_u2(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a) { return launch_pow2_u<1, 2>(s, L, a); }
 #else
-void launch_pow2_u2(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a) { launch_pow2_u<2>(s, L, a); }
+int launch_pow2_u2(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a) { return launch_pow2_u<2>(s, L, a); }
 #endif
 
 }  // namespace vbx

@@ -39,7 +39,7 @@ struct vbx_ctx {
     std::string arch;
     int cu_count = 0;
     // workspaces (grown on demand, never shrunk)
-    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_UNSURE, WS_F32_IN, WS_F32_OUT, WS_TRK, WS_BURG_LIST, WS_ROOTS_LIST, WS_LONG, WS_LONG2, WS_CZT, WS_N };
+    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_UNSURE, WS_F32_IN, WS_F32_OUT, WS_TRK, WS_BURG_LIST, WS_ROOTS_LIST, WS_LONG, WS_LONG2, WS_CZT, WS_CURVE, WS_N };
     void *ws[WS_N] = {nullptr};
     const int32_t *burg_list_count = nullptr;             // device counter of the last one-pass Burg call (tests)
     const int32_t *roots_list_count = nullptr;            // the same for the resonance kernel of find_formants
@@ -58,6 +58,8 @@ struct vbx_ctx {
     std::map<std::tuple<size_t, size_t, double, double, double>, int32_t *> bins_cache;
     std::map<std::tuple<size_t, size_t, double, double, double>, double *> slopes_cache;   // [nb][2] i/up, i/down per bin
     std::map<std::tuple<int, int, int, int>, std::pair<void *, mfcc_interp_t>> interp_cache;   // (plan, n, b_lo, nb) -> tables of the interpolated MFCC bins (first == nullptr: no such form)
+    int last_spectral_split = 0;                          // the last fused / pitch call ran as two kernels (tests)
+    int pow2_split = -1;                                  // VBX_POW2_SPLIT=0: the 4096-point plan as ONE kernel (transforms and refinement fused, as before round 5; tests, A/B)
     int mfcc_interp = -1;                                 // VBX_MFCC_INTERP=0: never (the chirp-z kernel beside the fused one, as before round 5; tests, A/B)
     std::map<std::pair<size_t, double>, std::pair<int32_t *, double *>> resample_tabs;   // (n, ratio) -> (index, fraction)
     // timing
@@ -481,6 +483,7 @@ int vbx_ctx_create(vbx_ctx **out, int device, void *hip_stream) {
     { const char *e = std::getenv("VBX_MFCC_DFT2"); ctx->mfcc_force_dft2 = e && e[0] == '1'; }
     { const char *e = std::getenv("VBX_MFCC_MFMA"); ctx->mfcc_force_mfma = e && e[0] == '1'; }
     { const char *e = std::getenv("VBX_MFCC_CZT"); ctx->mfcc_czt = e ? (e[0] == '1' ? 1 : 0) : -1; }
+    { const char *e = std::getenv("VBX_POW2_SPLIT"); ctx->pow2_split = e ? (e[0] == '0' ? 0 : 1) : -1; }
     { const char *e = std::getenv("VBX_MFCC_INTERP"); ctx->mfcc_interp = e ? (e[0] == '0' ? 0 : 1) : -1; }
     { const char *e = std::getenv("VBX_MFCC_CZT_SPLIT"); ctx->mfcc_czt_split = e != nullptr && e[0] == '1'; }
     { const char *e = std::getenv("VBX_PITCH_CURVE_CUT"); ctx->pitch_whole_curve = e != nullptr && e[0] == '0'; }
@@ -779,7 +782,18 @@ static int launch_spectral(vbx_ctx *ctx, hipStream_t st, spectral_launch_t &L, c
     L.unsure_count = (int32_t *)w;                       // [0]: count, [4..]: frame indices
     L.unsure_list = (int32_t *)w + 4;
     VBX_HIP(ctx, hipMemsetAsync(L.unsure_count, 0, sizeof(int32_t), st));
-    { Prof p(ctx, prof_name, st); launch_analyze(st, L); }
+    // the 4096-point plan runs as two kernels with the lag curves in a scratch buffer between them (vbx_spectral.hpp, SP_ANALYZE_SPLIT):
+    // batches of up to 131,072 frames (~10 KB each)
+    L.curve_ws = nullptr; L.curve_ws_bytes = 0; L.split_always = ctx->pow2_split == 1;
+    const size_t rowb = (ctx->pow2_split != 0 && !L.whole_curve && !L.mfcc_only && L.out_r == nullptr) ? spectral_split_row_bytes(L.n, L.sample_rate, L.fmin) : 0;
+    if (rowb) {
+        const size_t frames = (size_t)L.F < 131072 ? (size_t)L.F : 131072;
+        void *cw = nullptr;
+        rc = ws_get(ctx, vbx_ctx::WS_CURVE, (frames < 1024 ? 1024 : frames) * rowb, &cw);
+        if (rc != VBX_SUCCESS) return rc;
+        L.curve_ws = (double *)cw; L.curve_ws_bytes = (frames < 1024 ? 1024 : frames) * rowb;
+    }
+    { Prof p(ctx, prof_name, st); ctx->last_spectral_split = launch_analyze(st, L); }
     {
         Prof p(ctx, "pitch_direct_fallback", st);
         // a fixed grid over a count only the device knows (almost always zero).  Every workgroup of this kernel allocates the
@@ -1295,6 +1309,7 @@ double *vbx_internal_stitch_state(vbx_ctx *ctx) {
     return ctx->stitch_state;
 }
 int vbx_internal_last_track_n_est(vbx_ctx *ctx) { return ctx ? ctx->last_track.n_est : 0; }
+int vbx_internal_last_spectral_split(vbx_ctx *ctx) { return ctx ? ctx->last_spectral_split : 0; }
 // every host-side condition of a stitch / hand-off on these rows, for callers that must know BEFORE they enqueue anything
 // a peer waits for (vbx_comm.hip: an early return between ncclRecv and ncclSend would leave the next rank blocked)
 int vbx_internal_track_check(vbx_ctx *ctx, const vbx_resonance *formants, size_t n_frames, size_t formants_ld) {

@@ -208,9 +208,12 @@ struct spectral_launch_t {
     bool pcm;                                                    // x points to int16 PCM samples (n == 1200 only)
     bool whole_curve;                                            // keep every lag of the curve in LDS (VBX_PITCH_CURVE_CUT=0; tests)
     bool interp; mfcc_interp_t ip;                               // MFCC by interpolation of the transform's bins (device pointers)
+    double *curve_ws; size_t curve_ws_bytes;                     // scratch for the split form of the 4096-point plan (lag curves between its two kernels); NULL: fused
+    bool split_always;                                           // VBX_POW2_SPLIT=1: wherever the form exists (tests), not only where it pays
 };
+size_t spectral_split_row_bytes(int n, double sample_rate, double fmin);   // bytes per frame of that scratch, 0: the shape has no split form
 bool spectral_supported(int n, int lpc_order, int mfcc_nb, int mfcc_b_lo, int num_coeffs);
-void launch_analyze(hipStream_t s, const spectral_launch_t &L);
+int launch_analyze(hipStream_t s, const spectral_launch_t &L);       // 1: the call ran as two kernels (SP_ANALYZE_SPLIT), 0: one
 
 // the f32 instantiation (Sample = f32): the same kernels with float frames and float outputs
 void launch_autocorr_fewlags_f32(hipStream_t s, const float *x, long F, int n, long stride, const float *window,

@@ -12,7 +12,14 @@ namespace vbx {
 
 // what a spectral kernel instantiation computes.  SP_MFCC_HALF (power-of-two kernels): MFCC::mfcc of a frame of 2 Nc samples --
 // the frame itself is the real sequence of the transform (no padding), its bins are the transform's bins
-enum { SP_ANALYZE = 0, SP_MFCC_ONLY = 1, SP_AC_ONLY = 2, SP_MFCC_HALF = 3, SP_ANALYZE_INTERP = 4 };
+enum { SP_ANALYZE = 0, SP_MFCC_ONLY = 1, SP_AC_ONLY = 2, SP_MFCC_HALF = 3, SP_ANALYZE_INTERP = 4, SP_ANALYZE_SPLIT = 5, SP_ANALYZE_INTERP_SPLIT = 6 };
+// SP_ANALYZE_SPLIT (+ _INTERP_SPLIT): the fused analysis WITHOUT the refinement -- the normalised lag curve goes to a scratch row in
+// HBM and refine_curve_kernel (k_spectral_pow2.hip) takes it from there.  For the 4096-point plan: its 35 KB exchange buffer holds a
+// CU to four frames, i.e. four refining wavefronts, one per SIMD, and a dependent FP64 chain alone on a SIMD runs at a third of
+// the rate three of them reach together (measured: 30 ns per frame of refinement against 16 at 1200 / 2048 samples).
+__host__ __device__ constexpr bool sp_is_interp(int mode) { return mode == SP_ANALYZE_INTERP || mode == SP_ANALYZE_INTERP_SPLIT; }
+__host__ __device__ constexpr bool sp_is_split(int mode) { return mode == SP_ANALYZE_SPLIT || mode == SP_ANALYZE_INTERP_SPLIT; }
+__host__ __device__ constexpr bool sp_is_analyze(int mode) { return mode == SP_ANALYZE || mode >= SP_ANALYZE_INTERP; }
 // SP_ANALYZE_INTERP: SP_ANALYZE of a frame whose length does not divide the transform's, with MFCC::mfcc's bins -- samples of
 // the frame's DTFT at k / n, between the transform's bins j / M -- interpolated from the transform (mfcc_interp_t, below).
 
@@ -44,6 +51,8 @@ struct spectral_args_t {
     int pcm;                                                 // 1: `frames` points to int16 PCM samples (widened in registers:
                                                              // s / 32767, vbx_device.hpp pcm16_value); full frames only
     mfcc_interp_t ip;                                        // SP_ANALYZE_INTERP
+    long f0, n_batch;                                        // power-of-two kernels: this launch covers frames [f0, f0 + n_batch)
+    double *curve; long curve_ld; double *curve_tol;         // SP_ANALYZE_SPLIT: [n_batch][curve_ld] lag curves (pp.ncurve lags + Y_PAD zeros), [n_batch] unc_tol
 };
 
 // The last SP_TAIL lags of the curve.  The lag window falls below 1e-8 there (1e-10 .. 1e-17 over the last twelve lags), so
@@ -107,6 +116,6 @@ __device__ __forceinline__ void levinson_regs(const double (&r)[P + 1], double (
 constexpr int SP_LPC_P = SPECTRAL_LPC_ORDER;
 
 // k_spectral_pow2.hip
-void launch_analyze_pow2(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a);
+int launch_analyze_pow2(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a);      // 1: ran in the split form
 
 }  // namespace vbx

@@ -30,6 +30,9 @@ namespace vbx {
 #ifndef VBX_POW2_U2_WAVES
 #define VBX_POW2_U2_WAVES 2
 #endif
+#ifndef VBX_POW2_SPLIT_MAX_N
+#define VBX_POW2_SPLIT_MAX_N 3584       // longest frame whose fused call (kmax = 1) runs as two kernels (launch_pow2_u)
+#endif
 
 // U: 16-point units per THREAD and stage; W: wavefronts per frame (1, or 2 for the 4096-point transform: 64 complex values per
 // lane of ONE wavefront are 512 registers + ~150 spilled at one wavefront per SIMD and three per CU; as two wavefronts each
@@ -261,13 +264,14 @@ __device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16
 // MODE (vbx_spectral.hpp): SP_ANALYZE the fused analysis; SP_MFCC_ONLY MFCC::mfcc alone (the forward transform and the mel / DCT
 // tail only); SP_AC_ONLY Autocorrelate::autocorrelate alone (both transforms, the fold seed, the lag sums stored).
 template <int U, bool LPC, bool MFCC, bool FULL, int MODE = SP_ANALYZE, int W = 1>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu((U == 1 && W == 1 && (MODE == SP_ANALYZE || MODE == SP_ANALYZE_INTERP)) ? VBX_POW2_U1_WAVES : U == 4 ? 1 : (U == 2 && MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? VBX_POW2_U2_WAVES : 2,
-                                                                     (U == 1 && W == 1 && (MODE == SP_ANALYZE || MODE == SP_ANALYZE_INTERP)) ? VBX_POW2_U1_WAVES : U == 4 ? ((MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? 1 : 2) : (MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? 2 : 4)))
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu((U == 1 && W == 1 && sp_is_analyze(MODE)) ? VBX_POW2_U1_WAVES : U == 4 ? 1 : (U == 2 && MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? VBX_POW2_U2_WAVES : 2,
+                                                                     (U == 1 && W == 1 && sp_is_analyze(MODE)) ? VBX_POW2_U1_WAVES : U == 4 ? ((MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? 1 : 2) : (MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? 2 : 4)))
 void analyze_pow2_kernel(const spectral_args_t a) {
     // pinned twiddle batches where registers are short: Nc = 1024 at three wavefronts per SIMD, Nc = 2048 at two
-    constexpr bool INTERP = MODE == SP_ANALYZE_INTERP;       // MFCC's bins lie between the transform's (mfcc_interp_t, vbx_kernels.hpp)
+    constexpr bool INTERP = sp_is_interp(MODE);              // MFCC's bins lie between the transform's (mfcc_interp_t, vbx_kernels.hpp)
+    constexpr bool SPLIT = sp_is_split(MODE);                // the lag curve goes to HBM, refine_curve_kernel takes it from there
     static_assert(!INTERP || (MFCC && !FULL), "interpolated bins: a padded frame's MFCC");
-    constexpr bool POW2_TIGHT = (MODE == SP_ANALYZE || INTERP) && W == 1 && ((U == 1 && VBX_POW2_U1_WAVES >= 3) || U == 2);
+    constexpr bool POW2_TIGHT = sp_is_analyze(MODE) && W == 1 && ((U == 1 && VBX_POW2_U1_WAVES >= 3) || U == 2);
     static_assert((MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) || (MFCC && FULL && !LPC), "the MFCC-only forms need the full frame and have no lag sums");
     static_assert(MODE != SP_AC_ONLY || (!MFCC && !LPC), "the autocorrelation-only form");
     constexpr bool PITCH = MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF;   // the second transform runs
@@ -276,8 +280,9 @@ void analyze_pow2_kernel(const spectral_args_t a) {
     constexpr int R = G::R, NC = G::NC, TP = G::TP, NT = G::NT, TQ = G::TQ;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double bcast[4 + W];                          // W > 1: values one wavefront hands the other (x0, S[0], the row maximum)
-    const long f = xcd_item(blockIdx.x, a.n_frames);
-    if (f >= a.n_frames) return;
+    const long fb = xcd_item(blockIdx.x, a.n_batch);        // (a launch covers frames [f0, f0 + n_batch): all of them unless the split form walks the batch in pieces)
+    if (fb >= a.n_batch) return;
+    const long f = a.f0 + fb;
     const int lane = lane_id();
     const int tid = pow2_tid<W>();                           // index inside the frame's workgroup (== lane for one wavefront)
     const int wave = W == 1 ? 0 : (int)(threadIdx.x >> 6);
@@ -595,6 +600,23 @@ void analyze_pow2_kernel(const spectral_args_t a) {
     const double scale = 1.0 / amax;                         // normalize (:404), then / lag window (:406-408)
     double *ys = smem;
     const int nst = (a.pp.ncurve > 0) ? a.pp.ncurve : n;     // lags the refinement can read (pitch_curve_entries; even when < n)
+    if constexpr (SPLIT) {                                   // the same values, to the frame's scratch row (nst even: every pair whole)
+        double *row = a.curve + fb * a.curve_ld;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const int i = 2 * jj[s];
+            if (i + 1 < nst) {
+                const double2 lw = *reinterpret_cast<const double2 *>(a.lag_window + i);
+                double2 y;
+                y.x = (r_e[s] * scale) / lw.x;
+                y.y = (r_o[s] * scale) / lw.y;
+                *reinterpret_cast<double2 *>(row + i) = y;
+            }
+        }
+        if (tid < Y_PAD) row[nst + tid] = 0.0;
+        if (tid == 0) a.curve_tol[fb] = SP_UNC_EPS * fabs(s0) * scale;
+        return;
+    }
     pow2_sync<W>();                                          // every thread is done with the exchange buffer
 #pragma unroll
     for (int s = 0; s < NS; s++) {
@@ -637,9 +659,13 @@ inline size_t pow2_lds_bytes(int n, int nb, int nst = 0) {
     return (need + 15) & ~(size_t)15;
 }
 
+void launch_refine_curve(hipStream_t s, const spectral_args_t &a, size_t lds);      // k_spectral_pow2.hip
+
+// returns 1 when the call ran in the split form, 0 fused
 template <int U, int W = 1>
-void launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a) {
+int launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a) {
     const dim3 grid((unsigned)L.F), block(64 * W);
+    a.f0 = 0; a.n_batch = L.F; a.curve = nullptr; a.curve_ld = 0; a.curve_tol = nullptr;
     a.pp.ncurve = (!L.whole_curve && L.out_r == nullptr && !L.mfcc_only) ? pitch_curve_entries(L.n, L.sample_rate, L.fmin) : 0;
     const size_t base = pow2_lds_bytes<U, W>(L.n, L.nb, a.pp.ncurve), extra = pitch_full_list_bytes(L.n, L.kmax);
     a.pp.full_off = extra ? (int)base : 0;
@@ -651,24 +677,60 @@ void launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a
         if (L.n == 2 * NC) {
             if constexpr (U * W <= 2) hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, true, SP_MFCC_HALF, W>), grid, block, lds_mfcc, s, a);
         } else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, true, SP_MFCC_ONLY, W>), grid, block, lds_mfcc, s, a);
-        return;
+        return 0;
     }
     if (L.out_r != nullptr) {                                // autocorrelate(n_lags) alone
         if (L.n == NC) hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, true, SP_AC_ONLY, W>), grid, block, lds_ac, s, a);
         else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, false, SP_AC_ONLY, W>), grid, block, lds_ac, s, a);
-        return;
+        return 0;
+    }
+    // The 4096-point plan in two kernels (vbx_spectral.hpp, SP_ANALYZE_SPLIT): transforms + LPC + MFCC per batch of frames, the lag curves
+    // through a scratch buffer, the refinement at twelve frames per CU.  Where the curve is cut (an even frame length at speech settings),
+    // the caller gave scratch and kmax needs no list region in LDS.
+    if constexpr (U * W == 4) {
+        const size_t row_doubles = (size_t)(a.pp.ncurve + Y_PAD);
+        const bool full = L.n == NC;
+        // Measured (tools/experiments/split_check.py, ns per frame fused -> split, kmax = 1): 2050 samples 68.6 -> 57.3, 2500: 71.7 -> 60.1,
+        // 3000: 72.5 -> 64.2, 4000: 79.0 -> 77.5, 4096: 70.0 -> 73.3 -- the longer the frame, the more of its curve the peak scan reads
+        // (n / 2 + 2 lags: 26 KB of refinement state at 4096 samples, six frames per CU) and the more transform time the fused kernel's lone
+        // refining wavefronts hide behind.  kmax = 8: 25-35 % faster split at every length (the refinement is most of the time).
+        const bool pays = L.n <= VBX_POW2_SPLIT_MAX_N || L.kmax >= 2 || L.split_always;
+        const bool want = L.curve_ws != nullptr && a.pp.ncurve > 0 && extra == 0 && (full || !mf || L.interp) && pays;
+        const size_t cap = want ? L.curve_ws_bytes / ((row_doubles + 1) * sizeof(double)) : 0;
+        if (want && cap >= 1024) {
+            a.ip = L.ip;
+            size_t la = pow2_lds_bytes<U, W>(0, mf ? L.nb : 0);
+            if (mf && !full && (size_t)L.ip.lds_bytes > la) la = ((size_t)L.ip.lds_bytes + 15) & ~(size_t)15;
+            const size_t lr = ((size_t)pitch_refine_lds_bytes(L.n, a.pp.ncurve) + 15) & ~(size_t)15;
+            a.curve = L.curve_ws; a.curve_ld = (long)row_doubles; a.curve_tol = L.curve_ws + cap * row_doubles;
+            for (long f0 = 0; f0 < L.F; f0 += (long)cap) {
+                a.f0 = f0; a.n_batch = (L.F - f0 < (long)cap) ? L.F - f0 : (long)cap;
+                const dim3 g((unsigned)a.n_batch);
+                if (full) {
+                    if (mf && lpc) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, true, true, SP_ANALYZE_SPLIT, W>), g, block, la, s, a);
+                    else if (mf) hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, true, SP_ANALYZE_SPLIT, W>), g, block, la, s, a);
+                    else if (lpc) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, false, true, SP_ANALYZE_SPLIT, W>), g, block, la, s, a);
+                    else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, true, SP_ANALYZE_SPLIT, W>), g, block, la, s, a);
+                } else if (mf && lpc) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, true, false, SP_ANALYZE_INTERP_SPLIT, W>), g, block, la, s, a);
+                else if (mf) hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, false, SP_ANALYZE_INTERP_SPLIT, W>), g, block, la, s, a);
+                else if (lpc) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, false, false, SP_ANALYZE_SPLIT, W>), g, block, la, s, a);
+                else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, false, SP_ANALYZE_SPLIT, W>), g, block, la, s, a);
+                launch_refine_curve(s, a, lr);
+            }
+            return 1;
+        }
     }
     if (L.interp && mf && L.n != NC) {         // a padded frame whose MFCC bins are interpolated from the transform's
         a.ip = L.ip;
         const size_t li = lds > (size_t)L.ip.lds_bytes ? lds : (((size_t)L.ip.lds_bytes + 15) & ~(size_t)15);
         if (lpc) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, true, false, SP_ANALYZE_INTERP, W>), grid, block, li, s, a);
         else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, false, SP_ANALYZE_INTERP, W>), grid, block, li, s, a);
-        return;
+        return 0;
     }
     if (L.n != NC) {                           // a padded frame; MFCC joins when its length divides M (U = 1: 512)
         if constexpr (U * W == 1) {
-            if (lpc && mf) { hipLaunchKernelGGL((analyze_pow2_kernel<U, true, true, false, SP_ANALYZE, W>), grid, block, lds, s, a); return; }
-            if (mf) { hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, false, SP_ANALYZE, W>), grid, block, lds, s, a); return; }
+            if (lpc && mf) { hipLaunchKernelGGL((analyze_pow2_kernel<U, true, true, false, SP_ANALYZE, W>), grid, block, lds, s, a); return 0; }
+            if (mf) { hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, false, SP_ANALYZE, W>), grid, block, lds, s, a); return 0; }
         }
         if (lpc) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, false, false, SP_ANALYZE, W>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, false, SP_ANALYZE, W>), grid, block, lds, s, a);
@@ -676,6 +738,7 @@ void launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a
     else if (lpc) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, false, true, SP_ANALYZE, W>), grid, block, lds, s, a);
     else if (mf) hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, true, SP_ANALYZE, W>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, true, SP_ANALYZE, W>), grid, block, lds, s, a);
+    return 0;
 }
 
 
