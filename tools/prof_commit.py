@@ -49,6 +49,7 @@ KEYS = {
     "pitch_1024": ("config3_1024", ["void analyze_pow2_kernel<1, false, false, true, 0,"], "frame"),
     "analyze_4096": ("pipeline_4096", ["void analyze_pow2_kernel<2, true, true, true, 0, 2"], "frame"),    # --frame-len 4096 --hop 2048: two wavefronts per frame
     "pitch_4096": ("config3_4096", ["void analyze_pow2_kernel<2, false, false, true, 0, 2"], "frame"),
+    "analyze_3000": ("pipeline_3000", ["void analyze_pow2_kernel<2, true, true, false, 6, 2", "vbx::refine_curve_kernel"], "frame"),   # --frame-len 3000 --hop 1200: two kernels, the curves through HBM
     "analyze_1103": ("pipeline_1103", ["void analyze_kernel<true, true, false, 4,"], "frame"),             # --frame-len 1103 --hop 441: MFCC by interpolated bins
     # Burg = the one-pass form (k_burg_fast.hip): lag sums, recursion, and the direct recursion on the frames its guard sent on
     "burg_lags_512": ("config4", ["void burg_lags_kernel<8, 12, double"], "frame"),

@@ -28,7 +28,9 @@ if [ -z "$QUICK" ]; then
   run trace_config3_4096 --kernel-trace --stats --output-format csv -d $O/trace_config3_4096 -- python3 bench.py --workload config3 --frame-len 4096 --hop 2048 --hours 2 --steps 3 --warmup 1 $B
   # 25 ms at 44.1 kHz: a length that does not divide its transform -- MFCC by interpolated bins inside the fused kernel (round 5)
   run trace_pipeline_1103 --kernel-trace --stats --output-format csv -d $O/trace_pipeline_1103 -- python3 bench.py --frame-len 1103 --hop 441 --hours 2 --steps 3 --warmup 1 $B
-  for w in pipeline_2048:pipeline:2048:1024 config3_2048:config3:2048:1024 config3_1024:config3:1024:512 pipeline_4096:pipeline:4096:2048 config3_4096:config3:4096:2048 pipeline_1103:pipeline:1103:441; do
+  # 62.5 ms frames: the 4096-point plan as two kernels (transforms + LPC + interpolated MFCC, then the refinement from the scratch rows)
+  run trace_pipeline_3000 --kernel-trace --stats --output-format csv -d $O/trace_pipeline_3000 -- python3 bench.py --frame-len 3000 --hop 1200 --hours 2 --steps 3 --warmup 1 $B
+  for w in pipeline_2048:pipeline:2048:1024 config3_2048:config3:2048:1024 config3_1024:config3:1024:512 pipeline_4096:pipeline:4096:2048 config3_4096:config3:4096:2048 pipeline_1103:pipeline:1103:441 pipeline_3000:pipeline:3000:1200; do
     IFS=: read name wl fl hop <<< "$w"
     run pmc_fetch_$name --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$name -- python3 bench.py --workload $wl --frame-len $fl --hop $hop --hours 0.5 --steps 1 --warmup 0 $B
     run pmc_write_$name --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$name -- python3 bench.py --workload $wl --frame-len $fl --hop $hop --hours 0.5 --steps 1 --warmup 0 $B

@@ -331,15 +331,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
     const int b_lo = MFCC ? a.bins[0] : 0;
     double pk[10], pn[10];                                   // P[m], P[N - m]
     double2 *zc = reinterpret_cast<double2 *>(ex);           // INTERP: Z[j - jmin] = X_M[j] e^{2 pi i j c / M}, Z[-j] = conj Z[j]
-    // (INTERP: copies of the lane index the compiler cannot see through -- the split's and exchange 4's bin indices are recomputed
-    // where they are used instead of being kept, and spilled, from exchange 3 on)
-    int lane_s = lane, lane_x = lane;
-    if constexpr (INTERP) { asm volatile("" : "+v"(lane_s)); }
     double2 rot_m = double2{1.0, 0.0}, rot_step = double2{1.0, 0.0};
     if constexpr (INTERP) { rot_m = reinterpret_cast<const double2 *>(a.ip.rot)[lane]; rot_step = reinterpret_cast<const double2 *>(a.ip.rot)[64]; }
 #pragma unroll
     for (int t = 0; t < 10; t++) {
-        const int m = lane_s + 64 * t;
+        const int m = lane + 64 * t;
         const double2 w = a.tab[SP_TM + ((m <= 600) ? m : 0)];
         const double er = 0.5 * (ar[t] + br[t]), ei = 0.5 * (ai[t] - bi[t]);
         const double o_r = 0.5 * (ai[t] + bi[t]), o_i = -0.5 * (ar[t] - br[t]);
@@ -386,16 +382,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
     }
 
     if constexpr (PITCH) {
-        if constexpr (INTERP) { asm volatile("" : "+v"(lane_x)); }
         // ---- exchange 4: G in natural order -> stage-1 layout of the second transform ----
         // (the ten twiddles W_M^m requested together and without a condition -- index 0 stands in past m = 600 --, not one
         // by one behind `if (m <= 600)`: a load inside a branch cannot be moved out of it, and each waited for its own)
         double2 wm[10];
     #pragma unroll
-        for (int t = 0; t < 10; t++) { const int m = lane_x + 64 * t; wm[t] = a.tab[SP_TM + ((m <= 600) ? m : 0)]; }
+        for (int t = 0; t < 10; t++) { const int m = lane + 64 * t; wm[t] = a.tab[SP_TM + ((m <= 600) ? m : 0)]; }
     #pragma unroll
         for (int t = 0; t < 10; t++) {
-            const int m = lane_x + 64 * t;
+            const int m = lane + 64 * t;
             if (m <= 600) {
                 const double2 w = wm[t];
                 const double sm = pk[t] + pn[t], d = pk[t] - pn[t];
@@ -409,7 +404,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
         wave_sync();
     #pragma unroll
         for (int t = 0; t < 10; t++) {
-            const int m = lane_x + 64 * t;
+            const int m = lane + 64 * t;
             if (m <= 600) {
                 const double2 w = wm[t];
                 const double gi = -((pk[t] - pn[t]) * w.x);
