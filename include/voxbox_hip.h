@@ -317,7 +317,13 @@ int vbx_find_formants_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t
 /* ------------------------------------------------------------------ spectrum.rs: MFCC */
 
 /* MFCC::mfcc(num_coeffs, (lo, hi), sample_rate) per frame (src/spectrum.rs:401-441).
- * out: [F, num_coeffs]; status[F]: VBX_FRAME_ERR_PANIC when a mel bin exceeds the spectrum. */
+ * out: [F, num_coeffs]; status[F]: VBX_FRAME_ERR_PANIC when a mel bin exceeds the spectrum.
+ * Which kernel runs depends on the frame length (results within 1e-6 of the reference's arithmetic in every case): a length
+ * that is (half of) a transform's takes the fused kernels' forward transform; other lengths from 513 samples take that transform
+ * of the zero-padded frame with the frame's DFT bins interpolated from it (vbx_analyze_frames_f64 below explains the
+ * interpolation; design error < 6e-13 of the largest bin) where that is the fastest form, the matrix-core two-stage DFT where
+ * the length factors suitably and is below 1400 samples, the chirp-z kernel where the filters reach above a quarter of the
+ * sampling rate, Goertzel below 600 samples.  VBX_MFCC_INTERP=0 in the environment: no interpolated form anywhere. */
 int vbx_mfcc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
                  const double *window, size_t num_coeffs, double lo_hz, double hi_hz,
                  double sample_rate, double *out, int32_t *status);

@@ -162,6 +162,34 @@ def test_mfcc_inside_the_fused_kernel_at_lengths_that_do_not_divide_the_transfor
     assert np.abs(r0[:, 10:23]).max() > 5.0
 
 
+@pytest.mark.parametrize("N,H,sr,interp", [(1103, 441, 44100.0, 1), (1600, 640, 48000.0, 1), (2047, 1024, 48000.0, 1), (3000, 1200, 48000.0, 1), (4000, 2000, 48000.0, 1),
+                                           (882, 441, 44100.0, 0), (1280, 640, 48000.0, 0)])
+def test_mfcc_alone_by_one_transform_and_interpolated_bins(pkg, oracle, monkeypatch, N, H, sr, interp):
+    """vbx_mfcc_f64 (MFCC::mfcc, src/spectrum.rs:401-441) at a length that does not divide a transform: the forward transform of the
+    zero-padded frame + interpolated bins where that is the faster form (no matrix-core plan, or >= 1400 samples), the kernels of
+    rounds 1-4 elsewhere and under VBX_MFCC_INTERP=0 -- within 1e-9 of each other, 1e-6 of the oracle."""
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VBX_MFCC_INTERP", mode)
+        ctx = pkg.VoxBox(0)
+        try:
+            audio = ctx.synth_speech(int(6 * sr), sample_offset=int(2 * sr))
+            F = pkg.frame_count(int(6 * sr), N, H)
+            han = ctx.window(pkg.WINDOW_HANNING, N)
+            mf, st = ctx.mfcc(audio, 13, (100.0, 8000.0), sr, frame_len=N, stride=H, n_frames=F, window=han)
+            got[mode] = (np.array(mf).copy(), np.array(st).copy(), int(ctx.L.vbx_internal_last_mfcc_interp(ctx.ctx)), audio.numpy().copy())
+            audio.free()
+        finally:
+            ctx.close()
+    assert got["0"][2] == 0 and got["1"][2] == interp
+    assert np.array_equal(got["0"][1], got["1"][1]) and not got["1"][1].any()
+    assert np.abs(got["0"][0] - got["1"][0]).max() <= 1e-9
+    x, w = got["1"][3], oracle.window("hanning", N)
+    for t in range(0, 40, 3):
+        s, m = oracle.mfcc(x[t * H:t * H + N] * w, 13, 100.0, 8000.0, sr)
+        assert s == 0 and np.all(rel_close(got["1"][0][t], m)), t
+
+
 @pytest.mark.parametrize("N,H", [(3000, 1200), (2500, 1000), (4096, 2048), (4000, 2000)])
 def test_the_4096_point_plan_as_two_kernels(pkg, monkeypatch, N, H):
     """Frames of 2049..4096 samples: the transforms + LPC + MFCC in one kernel, the lag curve through a scratch row, the refinement in

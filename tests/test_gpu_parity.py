@@ -860,11 +860,12 @@ def test_mfcc_four_kernels_agree(pkg, oracle, audio, monkeypatch):
                                           (4000, 13, 100.0, 8000.0, 48000.0), (3601, 13, 100.0, 8000.0, 44100.0), (4095, 20, 0.0, 11000.0, 48000.0)])
 def test_mfcc_chirp_z_kernel(pkg, oracle, audio, monkeypatch, n, k, lo, hi, sr):
     """Frame lengths with no transform and no matrix-core factorisation of their own (1103 = 25 ms at 44.1 kHz is prime; 2500 and
-    3000 need more bins than the two-stage kernel's tiles hold) take the chirp-z kernel (k_mfcc_czt.hip) by default;
+    3000 need more bins than the two-stage kernel's tiles hold) took the chirp-z kernel (k_mfcc_czt.hip) by default until round 5;
     VBX_MFCC_CZT=1 sends every length through it that fits (n + top - 1 <= 4096), VBX_MFCC_CZT=0 none: both against the oracle,
     and -- where the default is the chirp-z kernel -- the two must differ in the last bits (two kernels ran)."""
     x = _frames(audio, n, 977, range(0, 40, 4)) * oracle.window("hanning", n) * 40.0
     res = {}
+    interpolated = False
     for mode in ("1", "0", None):
         if mode is not None:
             monkeypatch.setenv("VBX_MFCC_CZT", mode)
@@ -873,6 +874,8 @@ def test_mfcc_chirp_z_kernel(pkg, oracle, audio, monkeypatch, n, k, lo, hi, sr):
             monkeypatch.delenv("VBX_MFCC_CZT")
         try:
             res[mode] = v.mfcc(x, k, (lo, hi), sr)
+            if mode is None:
+                interpolated = bool(v.L.vbx_internal_last_mfcc_interp(v.ctx))
         finally:
             v.close()
     for f in range(x.shape[0]):
@@ -883,7 +886,14 @@ def test_mfcc_chirp_z_kernel(pkg, oracle, audio, monkeypatch, n, k, lo, hi, sr):
     if n != 1200:                                              # (a frame that IS a transform's keeps the FFT kernel either way)
         assert not np.array_equal(res["1"][0], res["0"][0])
     if n in (1103, 3000, 2500, 997, 2049, 3301, 601, 4000, 3601, 4095):   # (the last three: too long for one transform, split in two)
-        assert np.array_equal(res[None][0], res["1"][0])       # the default IS the chirp-z kernel here
+        # the default WAS the chirp-z kernel here (rounds 3-4); since round 5 it is the fused kernels' forward transform with
+        # interpolated bins wherever that form exists (bins below a quarter of the transform, the staging inside the LDS budget:
+        # not 997 / 2049 / 3601 / 4095 with these filters), within 1e-9 of the chirp-z kernel's exact arithmetic
+        assert interpolated == (n in (1103, 3000, 2500, 3301, 601, 4000)), (n, interpolated)
+        if interpolated:
+            assert not np.array_equal(res[None][0], res["1"][0]) and np.all(rel_close(res[None][0], res["1"][0], 1e-9))
+        else:
+            assert np.array_equal(res[None][0], res["1"][0])
     if n in (1200, 64):
         assert np.array_equal(res[None][0], res["0"][0])       # ... and is not here (its own transform; too short)
 

@@ -234,12 +234,13 @@ __device__ __forceinline__ void fft1200(double (&re)[20], double (&im)[20], doub
 // operations that two wavefronts do not cover (measured at kmax = 2 / 8 / 64: 12.1 -> 13.6, 4.55 -> 5.65, 2.2 -> 2.7 M
 // frames/s; kmax = 1: 32.5 -> 31.7, hence the split).  The transforms then spill ~55 registers, which the refinement hides.
 template <bool LPC, bool MFCC, bool FULL, int MODE = SP_ANALYZE, int WAVES = VBX_SPECTRAL_WAVES>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_MFCC_ONLY ? 2 : WAVES, MODE == SP_MFCC_ONLY ? 4 : WAVES))) void analyze_kernel(const spectral_args_t a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sp_is_mfcc_only(MODE) ? 2 : WAVES, sp_is_mfcc_only(MODE) ? 4 : WAVES))) void analyze_kernel(const spectral_args_t a) {
     static_assert(MODE != SP_MFCC_ONLY || (MFCC && FULL && !LPC), "the MFCC-only form needs the full frame and has no lag sums");
     static_assert(MODE != SP_AC_ONLY || (!MFCC && !LPC), "the autocorrelation-only form");
-    static_assert(MODE != SP_ANALYZE_INTERP || (MFCC && !FULL), "interpolated bins: a padded frame's MFCC");
-    constexpr bool PITCH = MODE != SP_MFCC_ONLY;             // the second transform runs
-    constexpr bool INTERP = MODE == SP_ANALYZE_INTERP;       // MFCC's bins lie between the transform's (mfcc_interp_t, vbx_kernels.hpp)
+    static_assert(!sp_is_interp(MODE) || (MFCC && !FULL), "interpolated bins: a padded frame's MFCC");
+    static_assert(MODE != SP_MFCC_ONLY_INTERP || !LPC, "the MFCC-only forms have no lag sums");
+    constexpr bool PITCH = !sp_is_mfcc_only(MODE);           // the second transform runs
+    constexpr bool INTERP = sp_is_interp(MODE);              // MFCC's bins lie between the transform's (mfcc_interp_t, vbx_kernels.hpp)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const long f = xcd_item(blockIdx.x, a.n_frames);            // neighbouring frames on the same XCD: their overlap hits its L2
     if (f >= a.n_frames) return;
@@ -372,12 +373,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == SP_M
         }
         wave_sync();
         VBX_PHASE(a.work, f, 14);
-        const double2 t2v = a.tab[SP_T2 + np];               // the products may lie over the stage-2 twiddles: requested now, put back after the tail
+        double2 t2v = double2{0.0, 0.0};                     // the products may lie over the stage-2 twiddles: requested now, put back after the tail
+        if constexpr (PITCH) t2v = a.tab[SP_T2 + np];
         if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld, a.work, f);
         else mfcc_tail_m(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
         if (a.mfcc_status != nullptr && lane == 0) a.mfcc_status[f] = 0;
         wave_sync();
-        if (lane < 60) t2[lane] = t2v;
+        if (PITCH && lane < 60) t2[lane] = t2v;
         VBX_PHASE(a.work, f, 15);
     }
 
@@ -788,8 +790,12 @@ int launch_analyze(hipStream_t s, const spectral_launch_t &L) {
     if (extra && L.kmax >= pitch_full_list_entries(L.n) && L.out_r == nullptr && !L.mfcc_only) { a.pp.full_off = -1; extra = 0; }
     const size_t lds = base + extra;
     const bool lpc = L.out_lpc != nullptr, mf = L.out_mfcc != nullptr;
-    if (L.mfcc_only) {                                       // spectral_supported(): n == SP_N
-        hipLaunchKernelGGL((analyze_kernel<false, true, true, SP_MFCC_ONLY>), grid, block, spectral_lds_bytes(0), s, a);
+    if (L.mfcc_only) {                                       // n == SP_N, or a padded frame with interpolated bins
+        if (L.interp && L.n != SP_N) {
+            a.ip = L.ip;
+            const size_t li = spectral_lds_bytes(0) > (size_t)L.ip.lds_bytes ? spectral_lds_bytes(0) : (((size_t)L.ip.lds_bytes + 15) & ~(size_t)15);
+            hipLaunchKernelGGL((analyze_kernel<false, true, false, SP_MFCC_ONLY_INTERP>), grid, block, li, s, a);
+        } else hipLaunchKernelGGL((analyze_kernel<false, true, true, SP_MFCC_ONLY>), grid, block, spectral_lds_bytes(0), s, a);
         return 0;
     }
     if (L.out_r != nullptr) {                                // autocorrelate(n_lags) alone

@@ -58,6 +58,7 @@ struct vbx_ctx {
     std::map<std::tuple<size_t, size_t, double, double, double>, int32_t *> bins_cache;
     std::map<std::tuple<size_t, size_t, double, double, double>, double *> slopes_cache;   // [nb][2] i/up, i/down per bin
     std::map<std::tuple<int, int, int, int>, std::pair<void *, mfcc_interp_t>> interp_cache;   // (plan, n, b_lo, nb) -> tables of the interpolated MFCC bins (first == nullptr: no such form)
+    int last_mfcc_interp = 0;                             // the last vbx_mfcc_f64 call took the interpolated form (tests)
     int last_spectral_split = 0;                          // the last fused / pitch call ran as two kernels (tests)
     int pow2_split = -1;                                  // VBX_POW2_SPLIT=0: the 4096-point plan as ONE kernel (transforms and refinement fused, as before round 5; tests, A/B)
     int mfcc_interp = -1;                                 // VBX_MFCC_INTERP=0: never (the chirp-z kernel beside the fused one, as before round 5; tests, A/B)
@@ -1310,6 +1311,7 @@ double *vbx_internal_stitch_state(vbx_ctx *ctx) {
 }
 int vbx_internal_last_track_n_est(vbx_ctx *ctx) { return ctx ? ctx->last_track.n_est : 0; }
 int vbx_internal_last_spectral_split(vbx_ctx *ctx) { return ctx ? ctx->last_spectral_split : 0; }
+int vbx_internal_last_mfcc_interp(vbx_ctx *ctx) { return ctx ? ctx->last_mfcc_interp : 0; }
 // every host-side condition of a stitch / hand-off on these rows, for callers that must know BEFORE they enqueue anything
 // a peer waits for (vbx_comm.hip: an early return between ncclRecv and ncclSend would leave the next rank blocked)
 int vbx_internal_track_check(vbx_ctx *ctx, const vbx_resonance *formants, size_t n_frames, size_t formants_ld) {
@@ -1350,6 +1352,7 @@ static int run_mfcc(vbx_ctx *ctx, hipStream_t stm, const double *x, size_t n_fra
     VBX_REQUIRE(ctx, num_coeffs >= 1 && num_coeffs <= 64, "num_coeffs must be in [1, 64]");
     VBX_REQUIRE(ctx, out_ld >= num_coeffs, "output rows must hold num_coeffs entries");
     std::vector<int32_t> hb; bool bad = false; const int32_t *d_bins = nullptr;
+    ctx->last_mfcc_interp = 0;
     int rc = get_bins_dev(ctx, frame_len, num_coeffs, lo_hz, hi_hz, sample_rate, &d_bins, hb, bad);
     if (rc != VBX_SUCCESS) return rc;
     if (bad) {   // the reference panics on every frame (bins do not depend on the data)
@@ -1397,6 +1400,33 @@ static int run_mfcc(vbx_ctx *ctx, hipStream_t stm, const double *x, size_t n_fra
     const bool composite_ok = nb > 0 && !ctx->mfcc_force_goertzel;
     const mfcc_mplan_t mp = (composite_ok && !ctx->mfcc_force_dft2 && ctx->mfcc_czt != 1) ? mfcc_mfma_plan((int)frame_len, hb.front(), nb) : mfcc_mplan_t{};
     const mfcc_plan_t pl = (composite_ok && !mp.ok) ? mfcc_plan((int)frame_len, nb) : mfcc_plan_t{false, 0, 0, 0, 0};
+    // Round 5: the forward transform of the zero-padded frame that the fused kernels use, the frame's DFT bins interpolated from the
+    // transform's (mfcc_interp_t, vbx_kernels.hpp: 24-40 taps per bin, error < 6e-13 of the largest bin) -- one transform instead of the
+    // chirp-z kernel's two.  Where the matrix-core kernel has no plan, and from 1400 samples up where it has (measured, M frames/s,
+    // before -> interpolated: 1103: 63 -> 110, 2047: 30 -> 54, 3000: 29 -> 34, 4000: 12 -> 26; 1500 / 1600 / 1800: 61 -> 71, 62 -> 73,
+    // 48 -> 67; the matrix-core kernel stays at 700 / 882 / 1280: 209 / 161 / 94 against 133 / 123 / 74).
+    // VBX_MFCC_INTERP=0 / the force switches: the kernels below, as before.
+    if ((!mp.ok || frame_len >= 1400) && ctx->mfcc_interp != 0 && ctx->mfcc_czt != 1 && !ctx->mfcc_force_goertzel && !ctx->mfcc_force_dft2 && !ctx->mfcc_force_mfma &&
+        num_coeffs <= 64 && nb >= 1 && nb <= 4096 && hb.front() >= 0 && hb.front() + nb <= (int)frame_len / 2) {
+        const int plan = spectral_plan_mfcc((int)frame_len);
+        bool ok = false;
+        mfcc_interp_t ip{};
+        if (plan != SPECTRAL_PLAN_NONE && (2 * spectral_plan_nc(plan)) % (int)frame_len != 0 && (int)frame_len < spectral_plan_nc(plan)) {
+            rc = get_interp_dev(ctx, plan, (int)frame_len, hb.front(), nb, &ip, &ok); if (rc != VBX_SUCCESS) return rc;
+        }
+        if (ok) {
+            const double *tab = nullptr;
+            rc = get_spectral_tab(ctx, plan, &tab); if (rc != VBX_SUCCESS) return rc;
+            spectral_launch_t L{};
+            L.plan = plan; L.n = (int)frame_len; L.mfcc_only = true; L.interp = true; L.ip = ip;
+            ctx->last_mfcc_interp = 1;
+            L.x = x; L.F = (long)n_frames; L.stride = (long)stride; L.window = window; L.tab = tab;
+            L.out_mfcc = out; L.mfcc_ld = (long)out_ld; L.mfcc_status = status;
+            L.bins = d_bins; L.slopes = slopes; L.dct = dct; L.num_coeffs = (int)num_coeffs; L.nb = nb;
+            { Prof p(ctx, "mfcc", stm); launch_analyze(stm, L); }
+            return check_launch(ctx, "vbx_mfcc_f64");
+        }
+    }
     // no matrix-core factorisation (prime-ish lengths such as 1103 = 25 ms at 44.1 kHz, or too many bins for the two-stage
     // kernel's tiles: 2500, 3000): the needed bins by the chirp-z identity on a power-of-two transform (two complex FFTs per
     // frame, k_mfcc_czt.hip) instead of evaluating them bin by bin on the vector ALU.  Measured, MFCC alone / the whole

@@ -12,14 +12,16 @@ namespace vbx {
 
 // what a spectral kernel instantiation computes.  SP_MFCC_HALF (power-of-two kernels): MFCC::mfcc of a frame of 2 Nc samples --
 // the frame itself is the real sequence of the transform (no padding), its bins are the transform's bins
-enum { SP_ANALYZE = 0, SP_MFCC_ONLY = 1, SP_AC_ONLY = 2, SP_MFCC_HALF = 3, SP_ANALYZE_INTERP = 4, SP_ANALYZE_SPLIT = 5, SP_ANALYZE_INTERP_SPLIT = 6 };
+enum { SP_ANALYZE = 0, SP_MFCC_ONLY = 1, SP_AC_ONLY = 2, SP_MFCC_HALF = 3, SP_ANALYZE_INTERP = 4, SP_ANALYZE_SPLIT = 5, SP_ANALYZE_INTERP_SPLIT = 6,
+       SP_MFCC_ONLY_INTERP = 7 };                          // MFCC::mfcc alone of a padded frame whose bins are interpolated (one transform instead of the chirp-z kernel's two)
 // SP_ANALYZE_SPLIT (+ _INTERP_SPLIT): the fused analysis WITHOUT the refinement -- the normalised lag curve goes to a scratch row in
 // HBM and refine_curve_kernel (k_spectral_pow2.hip) takes it from there.  For the 4096-point plan: its 35 KB exchange buffer holds a
 // CU to four frames, i.e. four refining wavefronts, one per SIMD, and a dependent FP64 chain alone on a SIMD runs at a third of
 // the rate three of them reach together (measured: 30 ns per frame of refinement against 16 at 1200 / 2048 samples).
-__host__ __device__ constexpr bool sp_is_interp(int mode) { return mode == SP_ANALYZE_INTERP || mode == SP_ANALYZE_INTERP_SPLIT; }
+__host__ __device__ constexpr bool sp_is_interp(int mode) { return mode == SP_ANALYZE_INTERP || mode == SP_ANALYZE_INTERP_SPLIT || mode == SP_MFCC_ONLY_INTERP; }
+__host__ __device__ constexpr bool sp_is_mfcc_only(int mode) { return mode == SP_MFCC_ONLY || mode == SP_MFCC_HALF || mode == SP_MFCC_ONLY_INTERP; }
 __host__ __device__ constexpr bool sp_is_split(int mode) { return mode == SP_ANALYZE_SPLIT || mode == SP_ANALYZE_INTERP_SPLIT; }
-__host__ __device__ constexpr bool sp_is_analyze(int mode) { return mode == SP_ANALYZE || mode >= SP_ANALYZE_INTERP; }
+__host__ __device__ constexpr bool sp_is_analyze(int mode) { return mode == SP_ANALYZE || mode == SP_ANALYZE_INTERP || mode == SP_ANALYZE_SPLIT || mode == SP_ANALYZE_INTERP_SPLIT; }
 // SP_ANALYZE_INTERP: SP_ANALYZE of a frame whose length does not divide the transform's, with MFCC::mfcc's bins -- samples of
 // the frame's DTFT at k / n, between the transform's bins j / M -- interpolated from the transform (mfcc_interp_t, below).
 

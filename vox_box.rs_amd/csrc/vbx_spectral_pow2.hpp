@@ -264,8 +264,8 @@ __device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16
 // MODE (vbx_spectral.hpp): SP_ANALYZE the fused analysis; SP_MFCC_ONLY MFCC::mfcc alone (the forward transform and the mel / DCT
 // tail only); SP_AC_ONLY Autocorrelate::autocorrelate alone (both transforms, the fold seed, the lag sums stored).
 template <int U, bool LPC, bool MFCC, bool FULL, int MODE = SP_ANALYZE, int W = 1>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu((U == 1 && W == 1 && sp_is_analyze(MODE)) ? VBX_POW2_U1_WAVES : U == 4 ? 1 : (U == 2 && MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? VBX_POW2_U2_WAVES : 2,
-                                                                     (U == 1 && W == 1 && sp_is_analyze(MODE)) ? VBX_POW2_U1_WAVES : U == 4 ? ((MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? 1 : 2) : (MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) ? 2 : 4)))
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu((U == 1 && W == 1 && sp_is_analyze(MODE)) ? VBX_POW2_U1_WAVES : U == 4 ? 1 : (U == 2 && !sp_is_mfcc_only(MODE)) ? VBX_POW2_U2_WAVES : 2,
+                                                                     (U == 1 && W == 1 && sp_is_analyze(MODE)) ? VBX_POW2_U1_WAVES : U == 4 ? (!sp_is_mfcc_only(MODE) ? 1 : 2) : !sp_is_mfcc_only(MODE) ? 2 : 4)))
 void analyze_pow2_kernel(const spectral_args_t a) {
     // pinned twiddle batches where registers are short: Nc = 1024 at three wavefronts per SIMD, Nc = 2048 at two
     constexpr bool INTERP = sp_is_interp(MODE);              // MFCC's bins lie between the transform's (mfcc_interp_t, vbx_kernels.hpp)
@@ -273,8 +273,9 @@ void analyze_pow2_kernel(const spectral_args_t a) {
     static_assert(!INTERP || (MFCC && !FULL), "interpolated bins: a padded frame's MFCC");
     constexpr bool POW2_TIGHT = sp_is_analyze(MODE) && W == 1 && ((U == 1 && VBX_POW2_U1_WAVES >= 3) || U == 2);
     static_assert((MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF) || (MFCC && FULL && !LPC), "the MFCC-only forms need the full frame and have no lag sums");
+    static_assert(MODE != SP_MFCC_ONLY_INTERP || !LPC, "the MFCC-only forms have no lag sums");
     static_assert(MODE != SP_AC_ONLY || (!MFCC && !LPC), "the autocorrelation-only form");
-    constexpr bool PITCH = MODE != SP_MFCC_ONLY && MODE != SP_MFCC_HALF;   // the second transform runs
+    constexpr bool PITCH = !sp_is_mfcc_only(MODE);           // the second transform runs
     constexpr bool HALF = MODE == SP_MFCC_HALF;              // the frame has 2 Nc samples: every slot of the transform is data
     using G = pow2_geom<U, W>;
     constexpr int R = G::R, NC = G::NC, TP = G::TP, NT = G::NT, TQ = G::TQ;
@@ -407,7 +408,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
         }
         pow2_sync<W>();
         double2 t2v[(R * 16 + NT - 1) / NT];                 // the products may lie over the stage-2 twiddles (W == 1): requested now, put back after the tail
-        if constexpr (W == 1) {
+        if constexpr (W == 1 && PITCH) {
 #pragma unroll
             for (int i = 0; i < (R * 16 + NT - 1) / NT; i++) t2v[i] = a.tab[G::T2 + ((tid + NT * i < R * 16) ? tid + NT * i : 0)];
         }
@@ -417,7 +418,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
             if (a.mfcc_status != nullptr && lane == 0) a.mfcc_status[f] = 0;
         }
         pow2_sync<W>();
-        if constexpr (W == 1) {
+        if constexpr (W == 1 && PITCH) {
 #pragma unroll
             for (int i = 0; i < (R * 16 + NT - 1) / NT; i++) if (tid + NT * i < R * 16) t2[tid + NT * i] = t2v[i];
         }
@@ -676,6 +677,10 @@ int launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a)
     if (L.mfcc_only) {                                       // n == Nc, or (L.n == 2 Nc) the unpadded form
         if (L.n == 2 * NC) {
             if constexpr (U * W <= 2) hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, true, SP_MFCC_HALF, W>), grid, block, lds_mfcc, s, a);
+        } else if (L.interp && L.n != NC) {                  // a padded frame with interpolated bins
+            a.ip = L.ip;
+            const size_t li = lds_mfcc > (size_t)L.ip.lds_bytes ? lds_mfcc : (((size_t)L.ip.lds_bytes + 15) & ~(size_t)15);
+            hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, false, SP_MFCC_ONLY_INTERP, W>), grid, block, li, s, a);
         } else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, true, SP_MFCC_ONLY, W>), grid, block, lds_mfcc, s, a);
         return 0;
     }

@@ -187,6 +187,7 @@ def load_library():
         "vbx_internal_estimate_formants_counted": (C.c_int, [vp, vp, sz, sz, vp, vp, sz, vp, sz, vp, vp]),
         "vbx_internal_last_roots_direct_count": (C.c_int, [vp, vp]),
         "vbx_internal_last_spectral_split": (C.c_int, [vp]),
+        "vbx_internal_last_mfcc_interp": (C.c_int, [vp]),
         "vbx_record_doubles": (sz, [C.POINTER(AnalysisParams)]),
         "vbx_analyze_frames_f64": (C.c_int, [vp, vp, sz, sz, sz, C.POINTER(AnalysisParams), vp, sz, vp, sz, vp]),
         "vbx_analyze_frames_pcm16": (C.c_int, [vp, vp, sz, sz, sz, C.POINTER(AnalysisParams), vp, sz, vp, sz, vp]),
