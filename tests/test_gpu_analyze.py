@@ -162,6 +162,55 @@ def test_mfcc_inside_the_fused_kernel_at_lengths_that_do_not_divide_the_transfor
     assert np.abs(r0[:, 10:23]).max() > 5.0
 
 
+def test_interpolated_mfcc_at_random_shapes(pkg, monkeypatch):
+    """Thirty seeded random (frame length, hop, sample rate, filter count, band) combinations through the fused call and through
+    vbx_mfcc_f64, with and without the interpolated form: the same statuses, MFCC within 1e-9 (relative to the row's largest
+    coefficient, floor 1), every other column bit for bit.  Odd and even lengths and hops, bands from 0 Hz, up to 40 filters,
+    all four transform plans."""
+    rng = np.random.default_rng(20250105)
+    cases = []
+    while len(cases) < 30:
+        n = int(rng.integers(520, 4090))
+        sr = float(rng.choice([16000.0, 22050.0, 32000.0, 44100.0, 48000.0]))
+        hop = int(rng.integers(n // 4, n))
+        k = int(rng.choice([8, 13, 13, 20, 26, 40]))
+        lo = float(rng.choice([0.0, 50.0, 100.0, 300.0]))
+        hi = float(rng.choice([0.12, 0.17, 0.22, 0.22, 0.4]) * sr)      # (above a quarter of the rate there is no interpolated form: the other kernels)
+        bins, bad = pkg.mfcc_bins(n, k, lo, hi, sr)
+        if bad or bins[-1] - bins[0] < 2:
+            continue
+        cases.append((n, hop, sr, k, lo, hi))
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VBX_MFCC_INTERP", mode)
+        ctx = pkg.VoxBox(0)
+        try:
+            out = []
+            for (n, hop, sr, k, lo, hi) in cases:
+                ns = int(1.5 * sr) + 2 * n
+                audio = ctx.synth_speech(ns, sample_offset=int(3 * sr))
+                F = pkg.frame_count(ns, n, hop)
+                params = pkg.AnalysisParams.make(sr, pitch=(0.2, 75.0, 600.0), lpc_order=P, formant_order=0, mfcc=(k, lo, hi))
+                rec, st = ctx.analyze_frames(audio, params, frame_len=n, stride=hop, n_frames=F)
+                han = ctx.window(pkg.WINDOW_HANNING, n)
+                mf, mst = ctx.mfcc(audio, k, (lo, hi), sr, frame_len=n, stride=hop, n_frames=F, window=han)
+                out.append((rec.copy(), st.copy(), np.array(mf).copy(), np.array(mst).copy()))
+                audio.free()
+            res[mode] = out
+        finally:
+            ctx.close()
+    used = 0
+    for case, a, b in zip(cases, res["0"], res["1"]):
+        k = case[3]
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3]), case
+        assert np.array_equal(a[0][:, :2], b[0][:, :2]) and np.array_equal(a[0][:, 2 + k:2 + k + P + 1], b[0][:, 2 + k:2 + k + P + 1]), case   # (a padding column may follow)
+        for x, y in ((a[0][:, 2:2 + k], b[0][:, 2:2 + k]), (a[2], b[2])):
+            scale = np.maximum(np.abs(x).max(axis=1, keepdims=True), 1.0)
+            assert np.all(np.abs(x - y) <= 1e-9 * scale), (case, float(np.abs(x - y).max()))
+        used += int(not np.array_equal(a[0][:, 2:2 + k], b[0][:, 2:2 + k]))
+    assert used >= 8, used                                                # a third of them really took the interpolated form (the rest: bins above a quarter of the transform, or too many for the LDS budget)
+
+
 @pytest.mark.parametrize("N,H,sr,interp", [(1103, 441, 44100.0, 1), (1600, 640, 48000.0, 1), (2047, 1024, 48000.0, 1), (3000, 1200, 48000.0, 1), (4000, 2000, 48000.0, 1),
                                            (882, 441, 44100.0, 0), (1280, 640, 48000.0, 0)])
 def test_mfcc_alone_by_one_transform_and_interpolated_bins(pkg, oracle, monkeypatch, N, H, sr, interp):
