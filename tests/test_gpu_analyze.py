@@ -162,6 +162,25 @@ def test_mfcc_inside_the_fused_kernel_at_lengths_that_do_not_divide_the_transfor
     assert np.abs(r0[:, 10:23]).max() > 5.0
 
 
+@pytest.mark.parametrize("N,H,band", [(1200, 480, (0.0, 20000.0)), (1200, 480, (100.0, 8000.0)), (1024, 512, (50.0, 22000.0)), (800, 320, (0.0, 16000.0)),
+                                      (2048, 1024, (0.0, 20000.0)), (600, 240, (300.0, 23000.0))])
+def test_fused_mfcc_with_filters_above_a_quarter_of_the_rate(vb, pkg, oracle, audio_d, N, H, band):
+    """The fused kernels' MFCC products take the bins of P[m] alone when no mirrored bin n/2 - m/q can be one of the filters' (the
+    speech settings: round 5's one-sided form) and both sides otherwise: filters that reach up to 20-23 kHz of 24 against the
+    oracle, 40 filters among them."""
+    audio = audio_d.numpy()
+    F = min(pkg.frame_count(audio.size, N, H), 60)
+    w = oracle.window("hanning", N)
+    for k in (13, 40):
+        params = pkg.AnalysisParams.make(SR, pitch=(0.2, 75.0, 600.0), lpc_order=P, formant_order=0, mfcc=(k, band[0], band[1]))
+        rec, st = vb.analyze_frames(audio_d, params, frame_len=N, stride=H, n_frames=F)
+        for t in range(0, F, 4):
+            s, m = oracle.mfcc(audio[t * H:t * H + N] * w, k, band[0], band[1], SR)
+            assert st[2, t] == s
+            if s == 0:
+                assert np.all(rel_close(rec[t, 2:2 + k], m)), (k, t, float(np.abs(rec[t, 2:2 + k] - m).max()))
+
+
 def test_interpolated_mfcc_at_random_shapes(pkg, monkeypatch):
     """Thirty seeded random (frame length, hop, sample rate, filter count, band) combinations through the fused call and through
     vbx_mfcc_f64, with and without the interpolated form: the same statuses, MFCC within 1e-9 (relative to the row's largest
