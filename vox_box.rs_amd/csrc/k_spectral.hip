@@ -824,7 +824,7 @@ int launch_analyze(hipStream_t s, const spectral_launch_t &L) {
                    else hipLaunchKernelGGL((analyze_kernel<true, true, false, SP_ANALYZE_INTERP>), grid, block, li, s, a); }
         else { if (w3i) hipLaunchKernelGGL((analyze_kernel<false, true, false, SP_ANALYZE_INTERP, 3>), grid, block, li, s, a);
                else hipLaunchKernelGGL((analyze_kernel<false, true, false, SP_ANALYZE_INTERP>), grid, block, li, s, a); }
-    } else if (L.n != SP_N) {                                // a padded frame; MFCC joins when its length divides 2400
+    } else if (L.n != SP_N) {                                // a padded frame; MFCC from the transform's own bins when its length divides 2400
         if (lpc && mf) VBX_SP_LAUNCH(true, true, false);
         else if (mf) VBX_SP_LAUNCH(false, true, false);
         else if (lpc) VBX_SP_LAUNCH(true, false, false);

@@ -1635,8 +1635,9 @@ static int analyze_frames_impl(vbx_ctx *ctx, const char *fn, const double *x, co
         if (rc != VBX_SUCCESS) return rc;
         nb = hb.back() - hb.front();
     }
-    // (MFCC joins the fused kernel when the frame's length divides the transform's: n = 512, 600, 800, 1024, 1200, 2048, 4096; LPC only at the order
-    // the kernel's register Levinson is built for -- what cannot join runs from its own kernel on the side stream)
+    // (MFCC joins the fused kernel when the frame's length divides the transform's: n = 512, 600, 800, 1024, 1200, 2048, 4096 -- and, since
+    // round 5, at every other length by interpolated bins, below; LPC only at the order the kernel's register Levinson is built for -- what
+    // cannot join runs from its own kernel on the side stream)
     const bool fused = !ctx->pitch_force_mfma && spectral_supported((int)frame_len, 0, 0, 0, 0);
     const bool fused_lpc = fused && h_p->lpc_order == SPECTRAL_LPC_ORDER;
     // the transform: the one its length asks for, or -- if MFCC can join only there -- the one whose length the frame divides

@@ -260,7 +260,8 @@ __device__ __forceinline__ void fft_pow2(double (&re)[U][16], double (&im)[U][16
 // batches, twiddle_tight16; ~210 registers at two).  U = 2 with W = 1: two wavefronts per SIMD.  U = 2 (Nc = 2048: 32 complex values per lane, 17
 // spectrum pairs) needs ~290: at 256 a dozen to fifty of them spill, and the frame state (23 KB of LDS) admits six frames
 // per CU.  Measured at n = 2048: 25.2 M frames/s against 18.6 M with one wavefront per SIMD and no spills.
-// FULL: the frame fills the transform (n == Nc, the bounds tests fold away); otherwise n < Nc (MFCC joins when n divides M).
+// FULL: the frame fills the transform (n == Nc, the bounds tests fold away); otherwise n < Nc (MFCC joins when n divides M, or -- the
+// INTERP modes -- by interpolated bins).
 // MODE (vbx_spectral.hpp): SP_ANALYZE the fused analysis; SP_MFCC_ONLY MFCC::mfcc alone (the forward transform and the mel / DCT
 // tail only); SP_AC_ONLY Autocorrelate::autocorrelate alone (both transforms, the fold seed, the lag sums stored).
 template <int U, bool LPC, bool MFCC, bool FULL, int MODE = SP_ANALYZE, int W = 1>
@@ -732,7 +733,7 @@ int launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a)
         else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, false, SP_ANALYZE_INTERP, W>), grid, block, li, s, a);
         return 0;
     }
-    if (L.n != NC) {                           // a padded frame; MFCC joins when its length divides M (U = 1: 512)
+    if (L.n != NC) {                           // a padded frame; MFCC from the transform's own bins when its length divides M (U = 1: 512)
         if constexpr (U * W == 1) {
             if (lpc && mf) { hipLaunchKernelGGL((analyze_pow2_kernel<U, true, true, false, SP_ANALYZE, W>), grid, block, lds, s, a); return 0; }
             if (mf) { hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, false, SP_ANALYZE, W>), grid, block, lds, s, a); return 0; }
