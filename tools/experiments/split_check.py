@@ -12,7 +12,10 @@ def main():
     hours = float(sys.argv[sys.argv.index("--hours") + 1]) if "--hours" in sys.argv else 2.0
     pkg = g.load_package(); out = {}
     SR = 48000.0
-    for (n, hop) in [(4096, 2048), (4096, 1024), (3000, 1200), (4000, 2000), (2500, 1000), (2050, 1024), (4095, 2048)]:
+    shapes = [(4096, 2048), (4096, 1024), (3000, 1200), (4000, 2000), (2500, 1000), (2050, 1024), (4095, 2048)]
+    if "--shapes" in sys.argv:
+        shapes = [tuple(int(v) for v in s.split(":")) for s in sys.argv[sys.argv.index("--shapes") + 1].split(",")]
+    for (n, hop) in shapes:
         res = {}
         for mode in ("0", "1"):
             os.environ["VBX_POW2_SPLIT"] = mode

@@ -31,7 +31,7 @@ namespace vbx {
 #define VBX_POW2_U2_WAVES 2
 #endif
 #ifndef VBX_POW2_SPLIT_MAX_N
-#define VBX_POW2_SPLIT_MAX_N 3584       // longest frame whose fused call (kmax = 1) runs as two kernels (launch_pow2_u)
+#define VBX_POW2_SPLIT_MAX_N 3700       // longest frame whose fused call (kmax = 1) runs as two kernels (launch_pow2_u)
 #endif
 
 // U: 16-point units per THREAD and stage; W: wavefronts per frame (1, or 2 for the 4096-point transform: 64 complex values per
