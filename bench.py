@@ -364,8 +364,8 @@ PARITY_NOTE = {
                                   "sinc / Brent values beyond the one 150 Hz vector (1e-2 Hz)",
                                   "sample 0.10 window phase recurrence and the linear resampler (crate un-vendored)"],
     "designed_approximations": ["MFCC inside the fused call at frame lengths that do not divide its transform (not this workload's 1200): "
-                                "the frame's DFT bins are interpolated from the transform's by 24-40 taps, design error < 6e-13 of "
-                                "the largest bin (tests/test_mfcc_interp_table.py, exact DFT on the CPU); MFCC values within 1e-9 "
+                                "the frame's DFT bins are interpolated from the transform's by 24-40 taps, design error < 1e-14 of "
+                                "the largest bin (tests/test_mfcc_interp_table.py, exact DFT on the CPU); MFCC values within 1e-11 "
                                 "of the chirp-z kernel's exact arithmetic (tests/test_gpu_analyze.py), 1e-6 of the oracle's"]}
 
 

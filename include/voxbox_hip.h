@@ -321,7 +321,7 @@ int vbx_find_formants_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t
  * Which kernel runs depends on the frame length (results within 1e-6 of the reference's arithmetic in every case): a length
  * that is (half of) a transform's takes the fused kernels' forward transform; other lengths from 513 samples take that transform
  * of the zero-padded frame with the frame's DFT bins interpolated from it (vbx_analyze_frames_f64 below explains the
- * interpolation; design error < 6e-13 of the largest bin) where that is the fastest form, the matrix-core two-stage DFT where
+ * interpolation; design error < 1e-14 of the largest bin) where that is the fastest form, the matrix-core two-stage DFT where
  * the length factors suitably and is below 1400 samples, the chirp-z kernel where the filters reach above a quarter of the
  * sampling rate, Goertzel below 600 samples.  VBX_MFCC_INTERP=0 in the environment: no interpolated form anywhere. */
 int vbx_mfcc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
@@ -432,7 +432,7 @@ int vbx_pitch_f32_wide(vbx_ctx *ctx, const float *x, size_t n_frames, size_t fra
  * length divides the transform's (512, 600, 800, 1024, 1200, 2048, 4096) the frame's DFT bins are bins of the transform; at
  * the other lengths (25 ms at 44.1 kHz = 1102 / 1103 samples, ...) each bin is interpolated from 24-40 of the transform's --
  * the frame fills at most half of it, so its spectrum is oversampled twofold and the interpolation's error is a design
- * parameter: < 6e-13 of the largest bin (tests/test_mfcc_interp_table.py), MFCC values within 1e-9 of vbx_mfcc_f64's.
+ * parameter: < 1e-14 of the largest bin (tests/test_mfcc_interp_table.py), MFCC values within 1e-11 of the chirp-z kernel's exact arithmetic.
  * (Bins above a quarter of the transform -- mfcc_hi_hz beyond ~sample_rate / 4 at a length just below the transform's half --
  * fall back to vbx_mfcc_f64's kernel beside the fused one; VBX_MFCC_INTERP=0 in the environment forces that everywhere.)
  * Output: one record of vbx_record_doubles(params) doubles per frame,

@@ -1401,7 +1401,7 @@ static int run_mfcc(vbx_ctx *ctx, hipStream_t stm, const double *x, size_t n_fra
     const mfcc_mplan_t mp = (composite_ok && !ctx->mfcc_force_dft2 && ctx->mfcc_czt != 1) ? mfcc_mfma_plan((int)frame_len, hb.front(), nb) : mfcc_mplan_t{};
     const mfcc_plan_t pl = (composite_ok && !mp.ok) ? mfcc_plan((int)frame_len, nb) : mfcc_plan_t{false, 0, 0, 0, 0};
     // Round 5: the forward transform of the zero-padded frame that the fused kernels use, the frame's DFT bins interpolated from the
-    // transform's (mfcc_interp_t, vbx_kernels.hpp: 24-40 taps per bin, error < 6e-13 of the largest bin) -- one transform instead of the
+    // transform's (mfcc_interp_t, vbx_kernels.hpp: 24-40 taps per bin, error < 1e-14 of the largest bin) -- one transform instead of the
     // chirp-z kernel's two.  Where the matrix-core kernel has no plan, and from 1400 samples up where it has (measured, M frames/s,
     // before -> interpolated: 1103: 63 -> 110, 2047: 30 -> 54, 3000: 29 -> 34, 4000: 12 -> 26; 1500 / 1600 / 1800: 61 -> 71, 62 -> 73,
     // 48 -> 67; the matrix-core kernel stays at 700 / 882 / 1280: 209 / 161 / 94 against 133 / 123 / 74).

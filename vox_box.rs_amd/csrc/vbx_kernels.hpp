@@ -172,7 +172,7 @@ void spectral_pow2_fill_tab(int plan, double *h_out);
 // samples, so its DTFT is a band-limited function of the bin index sampled at more than twice its rate: with c = (n - 1) / 2
 //     X(k / n) e^{i w c} = sum_j  Z[j] K0(k M / n - j),      Z[j] = X_M[j] e^{2 pi i j c / M},
 // exactly, for any real K0 whose transform is 1 on |t| <= n / 2M and 0 on |t - m| <= n / 2M, m != 0.  K0 = sinc * (the transform of a
-// Kaiser-Bessel bump of half-width 1/2 - n / 2M) cut to 24 / 32 / 40 taps by M / n: the cut's error is < 6e-13 of the largest |X| of
+// Kaiser-Bessel bump of half-width 1/2 - n / 2M) cut to 24 / 32 / 40 taps by M / n: the cut's error is < 1e-14 of the largest |X| of
 // the transform at every M / n >= 2 (tests/test_mfcc_interp_table.py holds the tables to the exact DFT on the CPU) -- MFCC values
 // within 1e-10 of the chirp-z kernel's on speech.  The phase factor drops out of |X|^2.  ~600 vector instructions per frame instead of a chirp-z kernel of two more
 // transforms.  Host tables: rot[j] = e^{2 pi i j c / M} (j <= M / 4), per bin its first tap's index and its taps.
