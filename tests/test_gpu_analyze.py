@@ -278,9 +278,9 @@ def test_mfcc_alone_by_one_transform_and_interpolated_bins(pkg, oracle, monkeypa
 
 @pytest.mark.parametrize("N,H", [(3000, 1200), (2500, 1000), (4096, 2048), (4000, 2000)])
 def test_the_4096_point_plan_as_two_kernels(pkg, monkeypatch, N, H):
-    """Frames of 2049..4096 samples: the transforms + LPC + MFCC in one kernel, the lag curve through a scratch row, the refinement in
-    a second kernel at three wavefronts per SIMD (SP_ANALYZE_SPLIT; the default up to 3700 samples and from kmax = 2, forced here by
-    VBX_POW2_SPLIT=1) -- bit for bit the fused kernel's records, candidates, counts and statuses (VBX_POW2_SPLIT=0)."""
+    """Frames of 2049..4096 samples: the transforms + LPC + MFCC in one kernel, the lag curve through a scratch row, then the peak scan,
+    the refinement (eleven frames per CU) and the far frames in kernels of their own (SP_ANALYZE_SPLIT: the default) -- bit for bit
+    the fused kernel's records, candidates, counts and statuses (VBX_POW2_SPLIT=0)."""
     got = {}
     for mode in ("0", "1"):
         monkeypatch.setenv("VBX_POW2_SPLIT", mode)

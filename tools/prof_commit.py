@@ -47,9 +47,10 @@ KEYS = {
     "analyze_2048": ("pipeline_2048", ["void analyze_pow2_kernel<2, true, true, true, 0,"], "frame"),     # --frame-len 2048 --hop 1024
     "pitch_2048": ("config3_2048", ["void analyze_pow2_kernel<2, false, false, true, 0,"], "frame"),
     "pitch_1024": ("config3_1024", ["void analyze_pow2_kernel<1, false, false, true, 0,"], "frame"),
-    "analyze_4096": ("pipeline_4096", ["void analyze_pow2_kernel<2, true, true, true, 0, 2"], "frame"),    # --frame-len 4096 --hop 2048: two wavefronts per frame
-    "pitch_4096": ("config3_4096", ["void analyze_pow2_kernel<2, false, false, true, 0, 2"], "frame"),
-    "analyze_3000": ("pipeline_3000", ["void analyze_pow2_kernel<2, true, true, false, 6, 2", "vbx::refine_curve_kernel"], "frame"),   # --frame-len 3000 --hop 1200: two kernels, the curves through HBM
+    # --frame-len 4096 --hop 2048: two wavefronts per frame; since the end of round 5 the transforms, the peak scan, the refinement and the far frames are four kernels
+    "analyze_4096": ("pipeline_4096", ["void analyze_pow2_kernel<2, true, true, true, 5, 2", "vbx::scan_curve_kernel", "vbx::refine_list_kernel", "vbx::refine_far_kernel"], "frame"),
+    "pitch_4096": ("config3_4096", ["void analyze_pow2_kernel<2, false, false, true, 5, 2", "vbx::scan_curve_kernel", "vbx::refine_list_kernel", "vbx::refine_far_kernel"], "frame"),
+    "analyze_3000": ("pipeline_3000", ["void analyze_pow2_kernel<2, true, true, false, 6, 2", "vbx::scan_curve_kernel", "vbx::refine_list_kernel", "vbx::refine_far_kernel"], "frame"),   # --frame-len 3000 --hop 1200: the curves through HBM
     "analyze_1103": ("pipeline_1103", ["void analyze_kernel<true, true, false, 4,"], "frame"),             # --frame-len 1103 --hop 441: MFCC by interpolated bins
     # Burg = the one-pass form (k_burg_fast.hip): lag sums, recursion, and the direct recursion on the frames its guard sent on
     "burg_lags_512": ("config4", ["void burg_lags_kernel<8, 12, double"], "frame"),

@@ -790,8 +790,8 @@ static int launch_spectral(vbx_ctx *ctx, hipStream_t st, spectral_launch_t &L, c
     if (rowb) {
         const size_t frames = (size_t)L.F < 131072 ? (size_t)L.F : 131072;
         void *cw = nullptr;
-        if (ws_get(ctx, vbx_ctx::WS_CURVE, (frames < 1024 ? 1024 : frames) * rowb, &cw) == VBX_SUCCESS) {      // (no memory for it: the fused form)
-            L.curve_ws = (double *)cw; L.curve_ws_bytes = (frames < 1024 ? 1024 : frames) * rowb;
+        if (ws_get(ctx, vbx_ctx::WS_CURVE, (frames < 1024 ? 1024 : frames) * rowb + 64, &cw) == VBX_SUCCESS) {      // (no memory for it: the fused form)
+            L.curve_ws = (double *)cw; L.curve_ws_bytes = (frames < 1024 ? 1024 : frames) * rowb + 64;
         } else (void)hipGetLastError();
     }
     { Prof p(ctx, prof_name, st); ctx->last_spectral_split = launch_analyze(st, L); }

@@ -803,9 +803,10 @@ __device__ __forceinline__ int pick_best_pred(float *keys, const cand_t *cand_li
 // LDS of the refinement, in this order from `ys`:  y[n + Y_PAD] | p16[nblk + 1 (+pad)] | keys[n/4 + 8] (float) |
 // candidate list (uint16).  pitch_refine_lds_doubles(n) is that footprint in doubles (rounded up).
 // nst: lags of the curve that are stored (pitch_curve_entries; 0 = all n)
-__host__ __device__ constexpr int pitch_refine_lds_bytes(int n, int nst = 0) {
+// cap: entries of keys / candidate list when the list arrives filtered (pitch_refine_store<2>), 0 = n/4 + 8
+__host__ __device__ constexpr int pitch_refine_lds_bytes(int n, int nst = 0, int cap = 0) {
     const int m = (nst > 0) ? nst : n;
-    return (m + Y_PAD + ((((m + PB - 1) / PB) + 2) & ~1)) * 8 + (n / 4 + 8) * (int)(sizeof(float) + sizeof(cand_t));
+    return (m + Y_PAD + ((((m + PB - 1) / PB) + 2) & ~1)) * 8 + ((cap > 0) ? cap : n / 4 + 8) * (int)(sizeof(float) + sizeof(cand_t));
 }
 
 // How much of the lag curve the refinement can read, when that is less than all of it (0 = all n lags).  The peak scan looks
@@ -815,6 +816,13 @@ __host__ __device__ constexpr int pitch_refine_lds_bytes(int n, int nst = 0) {
 // past the data, zero, like everything from the cut on.)  For long frames at speech settings this is half of the curve:
 // at 4,096 samples / 48 kHz / fmin 75 Hz lags [0, 2050), and the frame state in LDS shrinks from 46 KB to what the transform's
 // exchange buffer needs anyway (35 KB: four frames per CU instead of three); at 2,048 from 22.9 to 17.4 KB (eight per CU, 7).
+// the lags a candidate's refinement can read (the first branch of pitch_curve_entries' maximum), 0 = no such bound
+inline int pitch_curve_reach(int n, double sample_rate, double fmin) {
+    if ((n & 1) || !(fmin > 0.0) || !(sample_rate > 0.0)) return 0;
+    const double reach = 2.0 * ceil(sample_rate / fmin) + 16.0;
+    if (!(reach < (double)n)) return 0;
+    return ((int)reach + 1) & ~1;
+}
 inline int pitch_curve_entries(int n, double sample_rate, double fmin) {
     if ((n & 1) || !(fmin > 0.0) || !(sample_rate > 0.0)) return 0;          // an odd n reads its last lag (:194); NaN: all
     const double reach = 2.0 * ceil(sample_rate / fmin) + 16.0;
@@ -850,11 +858,18 @@ __host__ __device__ constexpr int pitch_full_list_entries(int n) { return n / 4 
 // the lane-resident list holds).  Nothing is pruned; every refined candidate is parked at its candidate index, and the
 // frame ends with a rank sort by (strength desc, candidate index asc) == the reference's stable sort, whose first kmax
 // entries are written.
+// STAGE (round 5, the split form of the 4096-point plan): 0 = everything; 1 = the peak scan and the frequency filter only (returns
+// after them: *io_ncand candidates, in index order, at the head of the candidate list in LDS -- or at list_at, and then ys may be a
+// curve in MEMORY: only the list is written); 2 = everything AFTER them, from a list
+// a STAGE-1 call left (*io_ncand entries; keys / list regions of cand_cap entries; ys then only needs the lags a candidate's
+// refinement reads, pp.ncurve = pitch_curve_reach).  The same statements in the same order: 1 then 2 is 0, bit for bit.
+template <int STAGE = 0>
 __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitch_params_t &pp, long f,
                                                    double *__restrict__ out_cand, long cand_ld,
                                                    int32_t *__restrict__ out_count, int32_t *__restrict__ status,
                                                    unsigned long long *__restrict__ work, double unc_tol = 0.0,
-                                                   double2 *full = nullptr) {
+                                                   double2 *full = nullptr, int *io_ncand = nullptr, int cand_cap = 0,
+                                                   uint16_t *list_at = nullptr) {
     const int lane = lane_id();
     const double sample_rate = pp.sample_rate, threshold = pp.threshold, fmin = pp.fmin, fmax = pp.fmax;
     const int kmax = pp.kmax;
@@ -863,7 +878,9 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
     const int nblk = (nst + PB - 1) / PB;            // blocks of PB lags for the |y| prefix sums
     double *p16 = ys + nst + Y_PAD;
     float *keys = reinterpret_cast<float *>(p16 + ((nblk + 2) & ~1));
-    cand_t *cand_list = reinterpret_cast<cand_t *>(keys + (n / 4 + 8));
+    // (STAGE 1 reads ys and writes nothing but the list: with list_at the curve may stay where it is, in memory)
+    cand_t *cand_list = (STAGE == 1 && list_at != nullptr) ? reinterpret_cast<cand_t *>(list_at)
+                                                           : reinterpret_cast<cand_t *>(keys + ((STAGE == 2 && cand_cap > 0) ? cand_cap : n / 4 + 8));
     const int b = (int)floor(0.5 * (double)n);      // brent_ixmax, :414
     const int offset = -b - 1;                      // :429
     const int nx = b - offset;                      // :430
@@ -871,6 +888,9 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
     const int nvalid = nst + Y_PAD;
 
     VBX_PHASE_INIT();
+    int ncand = 0;
+    if constexpr (STAGE == 2) ncand = *io_ncand;
+    else {
     // a) peaks -> filtered candidate list.  Two passes so that the two divisions of the frequency filter run once per
     // 64 PEAKS, not once per 64 lags: first every strict local maximum is compacted (index order), then the filter.
     int npeak = 0;
@@ -892,7 +912,6 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
     if (unc_tol > 0.0 && __any(unsure)) return false;
     VBX_PHASE(work, f, 6);
     unsure = false;
-    int ncand = 0;
     for (int base = 0; base < npeak; base += 64) {  // in place: the write position never passes the read position
         const int i = base + lane;
         bool pass = false;
@@ -920,6 +939,8 @@ __device__ __forceinline__ bool pitch_refine_store(double *ys, int n, const pitc
 
     if (unc_tol > 0.0 && __any(unsure)) return false;         // a frequency within the curve's error of fmin / fmax
     VBX_PHASE(work, f, 7);
+    }
+    if constexpr (STAGE == 1) { *io_ncand = ncand; return true; }
 
     // a') first-evaluation bounds.  p16: prefix sums of |y| over blocks of PB; keys[c]: upper bound of candidate c's
     // strength, stored as a float rounded UP (still an upper bound; the whole frame then fits 12 wavefronts per CU)

@@ -15,9 +15,10 @@ namespace vbx {
 enum { SP_ANALYZE = 0, SP_MFCC_ONLY = 1, SP_AC_ONLY = 2, SP_MFCC_HALF = 3, SP_ANALYZE_INTERP = 4, SP_ANALYZE_SPLIT = 5, SP_ANALYZE_INTERP_SPLIT = 6,
        SP_MFCC_ONLY_INTERP = 7 };                          // MFCC::mfcc alone of a padded frame whose bins are interpolated (one transform instead of the chirp-z kernel's two)
 // SP_ANALYZE_SPLIT (+ _INTERP_SPLIT): the fused analysis WITHOUT the refinement -- the normalised lag curve goes to a scratch row in
-// HBM and refine_curve_kernel (k_spectral_pow2.hip) takes it from there.  For the 4096-point plan: its 35 KB exchange buffer holds a
-// CU to four frames, i.e. four refining wavefronts, one per SIMD, and a dependent FP64 chain alone on a SIMD runs at a third of
-// the rate three of them reach together (measured: 30 ns per frame of refinement against 16 at 1200 / 2048 samples).
+// HBM and scan_curve_kernel / refine_list_kernel / refine_far_kernel (k_spectral_pow2.hip) take it from there.  For the 4096-point
+// plan: its 35 KB exchange buffer holds a CU to four frames, i.e. four refining wavefronts, one per SIMD, and a dependent FP64 chain
+// alone on a SIMD runs at a third of the rate three of them reach together (measured: 30 ns per frame of refinement against 16
+// at 1200 / 2048 samples; split: 21 + 4 + 2).
 __host__ __device__ constexpr bool sp_is_interp(int mode) { return mode == SP_ANALYZE_INTERP || mode == SP_ANALYZE_INTERP_SPLIT || mode == SP_MFCC_ONLY_INTERP; }
 __host__ __device__ constexpr bool sp_is_mfcc_only(int mode) { return mode == SP_MFCC_ONLY || mode == SP_MFCC_HALF || mode == SP_MFCC_ONLY_INTERP; }
 __host__ __device__ constexpr bool sp_is_split(int mode) { return mode == SP_ANALYZE_SPLIT || mode == SP_ANALYZE_INTERP_SPLIT; }
@@ -55,6 +56,10 @@ struct spectral_args_t {
     mfcc_interp_t ip;                                        // SP_ANALYZE_INTERP
     long f0, n_batch;                                        // power-of-two kernels: this launch covers frames [f0, f0 + n_batch)
     double *curve; long curve_ld; double *curve_tol;         // SP_ANALYZE_SPLIT: [n_batch][curve_ld] lag curves (pp.ncurve lags + Y_PAD zeros), [n_batch] unc_tol
+    int32_t *curve_list; long list_ld; int reach, cand_cap;  // ... and per frame [list_ld] int32: the filtered candidate count (-1: the frame went to the
+                                                             // fallback list, -2: to far_list), then its candidates' lags as uint16 (scan_curve_kernel -> refine_list_kernel)
+    int32_t *far_list;                                       // [0]: count, [4..]: batch-local indices of frames with a candidate whose PEAK lies beyond the lags
+                                                             // refine_list_kernel holds (refine_far_kernel takes them with the whole curve)
 };
 
 // The last SP_TAIL lags of the curve.  The lag window falls below 1e-8 there (1e-10 .. 1e-17 over the last twelve lags), so

@@ -30,9 +30,6 @@ namespace vbx {
 #ifndef VBX_POW2_U2_WAVES
 #define VBX_POW2_U2_WAVES 2
 #endif
-#ifndef VBX_POW2_SPLIT_MAX_N
-#define VBX_POW2_SPLIT_MAX_N 3700       // longest frame whose fused call (kmax = 1) runs as two kernels (launch_pow2_u)
-#endif
 
 // U: 16-point units per THREAD and stage; W: wavefronts per frame (1, or 2 for the 4096-point transform: 64 complex values per
 // lane of ONE wavefront are 512 registers + ~150 spilled at one wavefront per SIMD and three per CU; as two wavefronts each
@@ -661,13 +658,16 @@ inline size_t pow2_lds_bytes(int n, int nb, int nst = 0) {
     return (need + 15) & ~(size_t)15;
 }
 
-void launch_refine_curve(hipStream_t s, const spectral_args_t &a, size_t lds);      // k_spectral_pow2.hip
+void launch_refine_curve(hipStream_t s, const spectral_args_t &a, size_t lds_scan, size_t lds_refine);      // k_spectral_pow2.hip
+// the split form's candidate list per frame: entries of keys / list in the refinement kernel, int32 words of the list's row in HBM
+inline int spectral_split_cand_cap(int reach) { return ((reach / 4 + 8) + 7) & ~7; }
+inline size_t spectral_split_list_ints(int reach) { return (size_t)(1 + (spectral_split_cand_cap(reach) + 1) / 2 + 1) & ~(size_t)1; }
 
 // returns 1 when the call ran in the split form, 0 fused
 template <int U, int W = 1>
 int launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a) {
     const dim3 grid((unsigned)L.F), block(64 * W);
-    a.f0 = 0; a.n_batch = L.F; a.curve = nullptr; a.curve_ld = 0; a.curve_tol = nullptr;
+    a.f0 = 0; a.n_batch = L.F; a.curve = nullptr; a.curve_ld = 0; a.curve_tol = nullptr; a.curve_list = nullptr; a.list_ld = 0; a.reach = 0; a.cand_cap = 0; a.far_list = nullptr;
     a.pp.ncurve = (!L.whole_curve && L.out_r == nullptr && !L.mfcc_only) ? pitch_curve_entries(L.n, L.sample_rate, L.fmin) : 0;
     const size_t base = pow2_lds_bytes<U, W>(L.n, L.nb, a.pp.ncurve), extra = pitch_full_list_bytes(L.n, L.kmax);
     a.pp.full_off = extra ? (int)base : 0;
@@ -690,25 +690,34 @@ int launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a)
         else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, false, SP_AC_ONLY, W>), grid, block, lds_ac, s, a);
         return 0;
     }
-    // The 4096-point plan in two kernels (vbx_spectral.hpp, SP_ANALYZE_SPLIT): transforms + LPC + MFCC per batch of frames, the lag curves
-    // through a scratch buffer, the refinement at twelve frames per CU.  Where the curve is cut (an even frame length at speech settings),
+    // The 4096-point plan in separate kernels (vbx_spectral.hpp, SP_ANALYZE_SPLIT; k_spectral_pow2.hip): transforms + LPC + MFCC per batch of
+    // frames, the lag curves through a scratch buffer, then the peak scan, the refinement at eleven frames per CU, the far frames.  Where the curve is cut (an even frame length at speech settings),
     // the caller gave scratch and kmax needs no list region in LDS.
     if constexpr (U * W == 4) {
         const size_t row_doubles = (size_t)(a.pp.ncurve + Y_PAD);
         const bool full = L.n == NC;
-        // Measured (tools/experiments/split_check.py, ns per frame fused -> split, kmax = 1): 2050 samples 68.6 -> 57.3, 2500: 71.7 -> 60.1,
-        // 3000: 72.5 -> 64.2, 4000: 79.0 -> 77.5, 4096: 70.0 -> 73.3 -- the longer the frame, the more of its curve the peak scan reads
-        // (n / 2 + 2 lags: 26 KB of refinement state at 4096 samples, six frames per CU) and the more transform time the fused kernel's lone
-        // refining wavefronts hide behind.  kmax = 8: 25-35 % faster split at every length (the refinement is most of the time).
-        const bool pays = L.n <= VBX_POW2_SPLIT_MAX_N || L.kmax >= 2 || L.split_always;
-        const bool want = L.curve_ws != nullptr && a.pp.ncurve > 0 && extra == 0 && (full || !mf || L.interp) && pays;
-        const size_t cap = want ? L.curve_ws_bytes / ((row_doubles + 1) * sizeof(double)) : 0;
+        // Measured (tools/experiments/split_check.py, 2 h of audio per step, pipeline M frames/s fused -> split, all bit-identical):
+        // 2050 / 1024: 11.7 -> 13.3, 2500 / 1000: 11.1 -> 12.5, 3000 / 1200: 10.8 -> 11.9, 4000 / 2000: 9.3 -> 10.2, 4096 / 2048: 11.2 -> 12.1,
+        // 4096 / 1024: 11.3 -> 12.5; pitch at kmax = 8 (40,000 frames): 13.9 -> 9.1 ms.  Per frame at 4096 / 2048: transforms 37.3 ns,
+        // scan 4.3, refinement 21.0 (eleven frames per CU), far frames 2.1 -- against 69 ns fused.  (A first form without the scan kernel
+        // -- the whole curve and the full-size candidate list in the refinement kernel's LDS, six frames per CU at 4096 samples -- lost
+        // to the fused kernel from 3,800 samples on.)
+        const bool pays = true;
+        (void)L.split_always;
+        const int reach = pitch_curve_reach(L.n, L.sample_rate, L.fmin);
+        const bool want = L.curve_ws != nullptr && a.pp.ncurve > 0 && reach > 0 && extra == 0 && (full || !mf || L.interp) && pays;
+        const size_t list_ints = spectral_split_list_ints(reach > 0 ? reach : 16);
+        const size_t cap = (want && L.curve_ws_bytes > 64) ? (L.curve_ws_bytes - 64) / ((row_doubles + 1) * sizeof(double) + (list_ints + 1) * sizeof(int32_t)) : 0;
         if (want && cap >= 1024) {
             a.ip = L.ip;
             size_t la = pow2_lds_bytes<U, W>(0, mf ? L.nb : 0);
             if (mf && !full && (size_t)L.ip.lds_bytes > la) la = ((size_t)L.ip.lds_bytes + 15) & ~(size_t)15;
-            const size_t lr = ((size_t)pitch_refine_lds_bytes(L.n, a.pp.ncurve) + 15) & ~(size_t)15;
+            a.reach = reach; a.cand_cap = spectral_split_cand_cap(reach);
+            const size_t ls = ((size_t)pitch_refine_lds_bytes(L.n, a.pp.ncurve) + 15) & ~(size_t)15;
+            const size_t lr = ((size_t)pitch_refine_lds_bytes(L.n, reach, a.cand_cap) + 15) & ~(size_t)15;
             a.curve = L.curve_ws; a.curve_ld = (long)row_doubles; a.curve_tol = L.curve_ws + cap * row_doubles;
+            a.curve_list = reinterpret_cast<int32_t *>(a.curve_tol + cap); a.list_ld = (long)list_ints;
+            a.far_list = a.curve_list + cap * list_ints;     // [4 + cap] int32
             for (long f0 = 0; f0 < L.F; f0 += (long)cap) {
                 a.f0 = f0; a.n_batch = (L.F - f0 < (long)cap) ? L.F - f0 : (long)cap;
                 const dim3 g((unsigned)a.n_batch);
@@ -721,7 +730,7 @@ int launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a)
                 else if (mf) hipLaunchKernelGGL((analyze_pow2_kernel<U, false, true, false, SP_ANALYZE_INTERP_SPLIT, W>), g, block, la, s, a);
                 else if (lpc) hipLaunchKernelGGL((analyze_pow2_kernel<U, true, false, false, SP_ANALYZE_SPLIT, W>), g, block, la, s, a);
                 else hipLaunchKernelGGL((analyze_pow2_kernel<U, false, false, false, SP_ANALYZE_SPLIT, W>), g, block, la, s, a);
-                launch_refine_curve(s, a, lr);
+                launch_refine_curve(s, a, ls, lr);
             }
             return 1;
         }
