@@ -785,7 +785,7 @@ static int launch_spectral(vbx_ctx *ctx, hipStream_t st, spectral_launch_t &L, c
     VBX_HIP(ctx, hipMemsetAsync(L.unsure_count, 0, sizeof(int32_t), st));
     // the 4096-point plan runs as two kernels with the lag curves in a scratch buffer between them (vbx_spectral.hpp, SP_ANALYZE_SPLIT):
     // batches of up to 131,072 frames (~10 KB each)
-    L.curve_ws = nullptr; L.curve_ws_bytes = 0; L.split_always = ctx->pow2_split == 1;
+    L.curve_ws = nullptr; L.curve_ws_bytes = 0;
     const size_t rowb = (ctx->pow2_split != 0 && !L.whole_curve && !L.mfcc_only && L.out_r == nullptr) ? spectral_split_row_bytes(L.n, L.sample_rate, L.fmin) : 0;
     if (rowb) {
         const size_t frames = (size_t)L.F < 131072 ? (size_t)L.F : 131072;

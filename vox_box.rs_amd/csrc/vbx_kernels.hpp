@@ -209,7 +209,6 @@ struct spectral_launch_t {
     bool whole_curve;                                            // keep every lag of the curve in LDS (VBX_PITCH_CURVE_CUT=0; tests)
     bool interp; mfcc_interp_t ip;                               // MFCC by interpolation of the transform's bins (device pointers)
     double *curve_ws; size_t curve_ws_bytes;                     // scratch for the split form of the 4096-point plan (lag curves between its two kernels); NULL: fused
-    bool split_always;                                           // VBX_POW2_SPLIT=1: wherever the form exists (tests), not only where it pays
 };
 size_t spectral_split_row_bytes(int n, double sample_rate, double fmin);   // bytes per frame of that scratch, 0: the shape has no split form
 bool spectral_supported(int n, int lpc_order, int mfcc_nb, int mfcc_b_lo, int num_coeffs);

@@ -702,10 +702,8 @@ int launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a)
         // scan 4.3, refinement 21.0 (eleven frames per CU), far frames 2.1 -- against 69 ns fused.  (A first form without the scan kernel
         // -- the whole curve and the full-size candidate list in the refinement kernel's LDS, six frames per CU at 4096 samples -- lost
         // to the fused kernel from 3,800 samples on.)
-        const bool pays = true;
-        (void)L.split_always;
         const int reach = pitch_curve_reach(L.n, L.sample_rate, L.fmin);
-        const bool want = L.curve_ws != nullptr && a.pp.ncurve > 0 && reach > 0 && extra == 0 && (full || !mf || L.interp) && pays;
+        const bool want = L.curve_ws != nullptr && a.pp.ncurve > 0 && reach > 0 && extra == 0 && (full || !mf || L.interp);
         const size_t list_ints = spectral_split_list_ints(reach > 0 ? reach : 16);
         const size_t cap = (want && L.curve_ws_bytes > 64) ? (L.curve_ws_bytes - 64) / ((row_doubles + 1) * sizeof(double) + (list_ints + 1) * sizeof(int32_t)) : 0;
         if (want && cap >= 1024) {
