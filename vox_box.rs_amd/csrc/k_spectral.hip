@@ -686,18 +686,18 @@ static void mfcc_interp_geom(int plan, long *M, int *nt, int *lds_cap) {
 static int mfcc_interp_slots(int plan, int nb) { long M; int nt, cap; mfcc_interp_geom(plan, &M, &nt, &cap); return (nb + nt - 1) / nt; }
 
 // Taps per bin.  The cut's error falls like e^{-pi tau W} / (pi W / 2) (tau = 1/2 - n / 2M, the Kaiser-Bessel bump's half-width; the sinc's
-// envelope at the cut): 40 taps up to M / n = 2.63, 32 up to 5, 24 beyond hold it at ~1e-15 of the transform's largest |X| -- the size of
+// envelope at the cut): 40 taps up to M / n = 2.47, 32 up to 5, 24 beyond hold it at ~1e-15 of the transform's largest |X| -- the size of
 // the transform's own rounding, so that the interpolation is never the limiting term, whatever the frame's dynamic range
 // (tests/test_mfcc_interp_table.py measures every class against the exact DFT: < 1e-14; tests/test_gpu_analyze.py: a pure tone, whose
 // filters hold only leakage).  The first choice of round 5 -- 32 taps at M / n = 2.18: 4e-13 -- measured no faster (29.3 against 29.6 M frames/s
-// at 1103 / 441) and passed the same tests; kept as VBX_EXP_INTERP_FEWER_TAPS.
+// at 1103 / 441 on one box, 30.3 against 30.0 on another: ~1 %) and passed the same tests; kept as VBX_EXP_INTERP_FEWER_TAPS.
 int mfcc_interp_taps(int plan, int n) {
     long M; int nt, cap; mfcc_interp_geom(plan, &M, &nt, &cap);
     const double tau = 0.5 - (double)n / (2.0 * (double)M);
 #ifdef VBX_EXP_INTERP_FEWER_TAPS
     return tau >= 0.36 ? 24 : tau >= 0.268 ? 32 : MFCC_INTERP_MAX_TAPS;
 #endif
-    return tau >= 0.40 ? 24 : tau >= 0.31 ? 32 : MFCC_INTERP_MAX_TAPS;
+    return tau >= 0.401 ? 24 : tau >= 0.298 ? 32 : MFCC_INTERP_MAX_TAPS;     // the smallest W of 24 / 32 / 40 with e^{-pi tau W} / (pi W / 2) <= 2e-15
 }
 
 size_t mfcc_interp_table_bytes(int plan, int nb) {
