@@ -276,11 +276,12 @@ def test_mfcc_alone_by_one_transform_and_interpolated_bins(pkg, oracle, monkeypa
         assert s == 0 and np.all(rel_close(got["1"][0][t], m)), t
 
 
-@pytest.mark.parametrize("N,H", [(3000, 1200), (2500, 1000), (4096, 2048), (4000, 2000)])
+@pytest.mark.parametrize("N,H", [(3000, 1200), (2500, 1000), (4096, 2048), (4000, 2000), (4095, 2048), (2205, 882)])
 def test_the_4096_point_plan_as_two_kernels(pkg, monkeypatch, N, H):
     """Frames of 2049..4096 samples: the transforms + LPC + MFCC in one kernel, the lag curve through a scratch row, then the peak scan,
     the refinement (eleven frames per CU) and the far frames in kernels of their own (SP_ANALYZE_SPLIT: the default) -- bit for bit
-    the fused kernel's records, candidates, counts and statuses (VBX_POW2_SPLIT=0)."""
+    the fused kernel's records, candidates, counts and statuses (VBX_POW2_SPLIT=0).  Odd lengths too: their whole curve goes to the scratch
+    row (with the fused kernel's exact last lags) for the far frames, the scan and the refinement read no more of it than of an even one."""
     got = {}
     for mode in ("0", "1"):
         monkeypatch.setenv("VBX_POW2_SPLIT", mode)

@@ -92,14 +92,14 @@ __global__ __launch_bounds__(64) void refine_far_kernel(const spectral_args_t a)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = lane_id();
     const int count = a.far_list[0];
-    const int nst = a.pp.ncurve;
+    const int nst = a.pp.ncurve > 0 ? a.pp.ncurve : a.n;    // (an odd n: the whole curve; its row ends in one more zero)
     for (int i = (int)blockIdx.x; i < count; i += (int)gridDim.x) {
         const long fb = a.far_list[4 + i];
         const long f = a.f0 + fb;
         const double2 *row = reinterpret_cast<const double2 *>(a.curve + fb * a.curve_ld);
         double2 *ys2 = reinterpret_cast<double2 *>(smem);
         wave_sync();                                         // the previous frame's reads
-        for (int j = lane; j < (nst + Y_PAD) / 2; j += 64) ys2[j] = row[j];
+        for (int j = lane; j < (nst + Y_PAD + 1) / 2; j += 64) ys2[j] = row[j];
         const double unc_tol = a.curve_tol[fb];
         wave_sync();
         if (!pitch_refine_store(smem, a.n, a.pp, f, a.out_cand, a.cand_ld, a.out_count, a.pitch_status, a.work, unc_tol, nullptr)) {
@@ -120,7 +120,9 @@ void launch_refine_curve(hipStream_t s, const spectral_args_t &a, size_t lds_sca
 // bytes per frame of the scratch between the kernels (the cut curve + its zeros, one tolerance, the candidate list), 0 where there is no split form
 size_t spectral_split_row_bytes(int n, double sample_rate, double fmin) {
     if (spectral_plan(n) != SPECTRAL_PLAN_4096) return 0;
-    const int nst = pitch_curve_entries(n, sample_rate, fmin), reach = pitch_curve_reach(n, sample_rate, fmin);
+    int nst = pitch_curve_entries(n, sample_rate, fmin);
+    const int reach = pitch_curve_reach(n, sample_rate, fmin);
+    if (nst <= 0 && (n & 1)) nst = n + 1;                    // an odd length's whole curve
     if (nst <= 0 || reach <= 0) return 0;
     return (size_t)(nst + Y_PAD + 1) * sizeof(double) + (spectral_split_list_ints(reach) + 1) * sizeof(int32_t) + 16;    // (+ far_list: one index per frame, the count)
 }

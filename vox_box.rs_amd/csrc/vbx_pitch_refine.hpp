@@ -817,8 +817,11 @@ __host__ __device__ constexpr int pitch_refine_lds_bytes(int n, int nst = 0, int
 // at 4,096 samples / 48 kHz / fmin 75 Hz lags [0, 2050), and the frame state in LDS shrinks from 46 KB to what the transform's
 // exchange buffer needs anyway (35 KB: four frames per CU instead of three); at 2,048 from 22.9 to 17.4 KB (eight per CU, 7).
 // the lags a candidate's refinement can read (the first branch of pitch_curve_entries' maximum), 0 = no such bound
+// (for an odd n too: its last lag, which pitch_curve_entries keeps the whole curve for, is read by a candidate of :194 only -- one whose
+// abscissa lies past lag n/2, i.e. not one the frequency filter lets through from a peak below 2 sr / fmin; the split form sends the others
+// to its whole-curve kernel)
 inline int pitch_curve_reach(int n, double sample_rate, double fmin) {
-    if ((n & 1) || !(fmin > 0.0) || !(sample_rate > 0.0)) return 0;
+    if (!(fmin > 0.0) || !(sample_rate > 0.0)) return 0;
     const double reach = 2.0 * ceil(sample_rate / fmin) + 16.0;
     if (!(reach < (double)n)) return 0;
     return ((int)reach + 1) & ~1;

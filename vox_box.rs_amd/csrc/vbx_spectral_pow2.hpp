@@ -599,7 +599,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
     const double scale = 1.0 / amax;                         // normalize (:404), then / lag window (:406-408)
     double *ys = smem;
     const int nst = (a.pp.ncurve > 0) ? a.pp.ncurve : n;     // lags the refinement can read (pitch_curve_entries; even when < n)
-    if constexpr (SPLIT) {                                   // the same values, to the frame's scratch row (nst even: every pair whole)
+    if constexpr (SPLIT) {                                   // the same values, to the frame's scratch row
         double *row = a.curve + fb * a.curve_ld;
 #pragma unroll
         for (int s = 0; s < NS; s++) {
@@ -610,10 +610,18 @@ void analyze_pow2_kernel(const spectral_args_t a) {
                 y.x = (r_e[s] * scale) / lw.x;
                 y.y = (r_o[s] * scale) / lw.y;
                 *reinterpret_cast<double2 *>(row + i) = y;
+            } else if (i < nst) {                            // the last lag of an odd n
+                row[i] = (r_e[s] * scale) / a.lag_window[i];
             }
         }
-        if (tid < Y_PAD) row[nst + tid] = 0.0;
+        if (tid < Y_PAD + (nst & 1)) row[nst + tid] = 0.0;   // (an odd n: one more, its row is read in pairs)
         if (tid == 0) a.curve_tol[fb] = SP_UNC_EPS * fabs(s0) * scale;
+#ifndef VBX_EXP_NO_EXACT_TAIL
+        if (!FULL && nst == n) {                             // an odd n keeps every lag: the last sixteen exactly, as in the fused kernel
+            if constexpr (W > 1) { __syncthreads(); if (wave != 0) return; }
+            spectral_exact_tail(row, n, xf, a.window, a.lag_window, x0, scale, lane);
+        }
+#endif
         return;
     }
     pow2_sync<W>();                                          // every thread is done with the exchange buffer
@@ -694,7 +702,11 @@ int launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a)
     // frames, the lag curves through a scratch buffer, then the peak scan, the refinement at eleven frames per CU, the far frames.  Where the curve is cut (an even frame length at speech settings),
     // the caller gave scratch and kmax needs no list region in LDS.
     if constexpr (U * W == 4) {
-        const size_t row_doubles = (size_t)(a.pp.ncurve + Y_PAD);
+        // an odd frame length keeps its whole curve (a.pp.ncurve == 0: pitch_curve_entries) -- in the scratch row too, for the whole-curve
+        // kernel of the far frames; the scan and the refinement kernel need no more of it than of an even length's
+        const bool odd_ok = (L.n & 1) && !L.whole_curve && L.out_r == nullptr && !L.mfcc_only;
+        const int nst_row = a.pp.ncurve > 0 ? a.pp.ncurve : (odd_ok ? L.n + 1 : 0);
+        const size_t row_doubles = (size_t)(nst_row + Y_PAD);
         const bool full = L.n == NC;
         // Measured (tools/experiments/split_check.py, 2 h of audio per step, pipeline M frames/s fused -> split, all bit-identical):
         // 2050 / 1024: 11.7 -> 13.3, 2500 / 1000: 11.1 -> 12.5, 3000 / 1200: 10.8 -> 11.9, 4000 / 2000: 9.3 -> 10.2, 4096 / 2048: 11.2 -> 12.1,
@@ -703,7 +715,7 @@ int launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a)
         // -- the whole curve and the full-size candidate list in the refinement kernel's LDS, six frames per CU at 4096 samples -- lost
         // to the fused kernel from 3,800 samples on.)
         const int reach = pitch_curve_reach(L.n, L.sample_rate, L.fmin);
-        const bool want = L.curve_ws != nullptr && a.pp.ncurve > 0 && reach > 0 && extra == 0 && (full || !mf || L.interp);
+        const bool want = L.curve_ws != nullptr && nst_row > 0 && reach > 0 && extra == 0 && (full || !mf || L.interp);
         const size_t list_ints = spectral_split_list_ints(reach > 0 ? reach : 16);
         const size_t cap = (want && L.curve_ws_bytes > 64) ? (L.curve_ws_bytes - 64) / ((row_doubles + 1) * sizeof(double) + (list_ints + 1) * sizeof(int32_t)) : 0;
         if (want && cap >= 1024) {
@@ -711,7 +723,7 @@ int launch_pow2_u(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a)
             size_t la = pow2_lds_bytes<U, W>(0, mf ? L.nb : 0);
             if (mf && !full && (size_t)L.ip.lds_bytes > la) la = ((size_t)L.ip.lds_bytes + 15) & ~(size_t)15;
             a.reach = reach; a.cand_cap = spectral_split_cand_cap(reach);
-            const size_t ls = ((size_t)pitch_refine_lds_bytes(L.n, a.pp.ncurve) + 15) & ~(size_t)15;
+            const size_t ls = ((size_t)pitch_refine_lds_bytes(L.n, a.pp.ncurve) + 16 + 15) & ~(size_t)15;      // (the whole-curve kernel: + the odd row's pair partner)
             const size_t lr = ((size_t)pitch_refine_lds_bytes(L.n, reach, a.cand_cap) + 15) & ~(size_t)15;
             a.curve = L.curve_ws; a.curve_ld = (long)row_doubles; a.curve_tol = L.curve_ws + cap * row_doubles;
             a.curve_list = reinterpret_cast<int32_t *>(a.curve_tol + cap); a.list_ld = (long)list_ints;
