@@ -203,7 +203,7 @@ int vbx_improve_extremum_ex_f64(vbx_ctx *ctx, const double *y, size_t ylen, long
  * bits of a candidate's sinc sums); between the two classes a candidate agrees to ~1e-7 relative in Hz.
  * Which shapes are fast (one MI355X, kmax = 1, frames/s; the table in DESIGN.md section 4 is kept current): 512..1024 samples
  * 44-56 M, 1025..1200 39-42 M, 1201..2048 29 M, 2049..4096 16-17 M (that range runs its refinement in kernels of its
- * own, with the lag curves in a context-owned scratch buffer between them: <= 2.3 GB),
+ * own, with the lag curves in a context-owned scratch buffer between them: <= 2.3 GB, 4.4 GB at an odd length),
  * below 512 samples the direct lag sums on the matrix cores 50-70 M.  kmax 2 / 8 / 64 / whole Vec at 1200: 13.5 / 6.5 / 3.25 / 2.7 M. */
 int vbx_pitch_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len, size_t stride,
                   const double *window, double sample_rate, double threshold, double fmin, double fmax,
