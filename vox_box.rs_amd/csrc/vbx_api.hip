@@ -786,7 +786,8 @@ static int launch_spectral(vbx_ctx *ctx, hipStream_t st, spectral_launch_t &L, c
     // the 4096-point plan runs as two kernels with the lag curves in a scratch buffer between them (vbx_spectral.hpp, SP_ANALYZE_SPLIT):
     // batches of up to 131,072 frames (~10 KB each)
     L.curve_ws = nullptr; L.curve_ws_bytes = 0;
-    const size_t rowb = (ctx->pow2_split != 0 && !L.whole_curve && !L.mfcc_only && L.out_r == nullptr) ? spectral_split_row_bytes(L.n, L.sample_rate, L.fmin) : 0;
+    const size_t rowb = (ctx->pow2_split != 0 && !L.whole_curve && !L.mfcc_only && L.out_r == nullptr && pitch_full_list_bytes(L.n, L.kmax) == 0)
+                            ? spectral_split_row_bytes(L.n, L.sample_rate, L.fmin) : 0;      // (a list region in LDS, kmax > 64: the fused kernel)
     if (rowb) {
         const size_t frames = (size_t)L.F < 131072 ? (size_t)L.F : 131072;
         void *cw = nullptr;
