@@ -62,3 +62,63 @@ def test_headline_roofline_is_the_executed_fraction():
     assert ref["flops_per_frame"] > 4 * roof["flops_per_frame"] and "NOT a roofline" in ref["meaning"]
     assert hbm["bound"] == "hbm" and hbm["algorithmic_bytes_per_frame"] == 480 * 8 + 16 + 104 + 104
     assert "issue_frac" in roof
+
+
+def _canned_record(b, blowup=1):
+    """A full record of the shape run_rank assembles (round 5's default run: 14 pipeline shapes, speech, config 5 whole), with
+    `blowup` x the per-shape tables -- the part that grew 3.9 -> 25 KB over rounds 2-5."""
+    prof = {"analyze": (3 * 125.0, 3), "burg_lags": (3 * 2.7, 3), "burg_recursion": (3 * 8.0, 3), "formant_resonances": (3 * 15.3, 3),
+            "tracker_chunked": (3 * 8.1, 3), "burg_direct_list": (1.1, 3), "pitch_direct_fallback": (0.02, 3)}
+    work = (3 * 4_500_000, 3 * 4_500_000 * 43, 3 * 4_500_000 * 21, 3 * 4_500_000 * 14_824)
+    roof, hbm, kms, _ = b.roofline_for("pipeline", prof, work, 4_500_000, 1200, 480, 3)
+    shapes = [{"frame_len": n, "hop": h, "frames": 1000, "value": 1.23456789e7, "ms_per_step": 1.0, "dominant_kernel": "analyze",
+               "kernels_ms": dict(kms), "beside_it": sorted(kms)} for n, h in b.PIPELINE_SHAPES] * blowup
+    sub = [{"name": f"config3_kmax{k}", "workload": "x" * 200, "value": 4.2e7, "roofline": roof, "kernels_ms": kms} for k in (1, 8, 302)]
+    sub += [{"name": "config2", "value": 1.15e9, "roofline": hbm}, {"name": "config4", "value": 4.6e8, "roofline": hbm},
+            {"name": "pipeline_shapes", "shapes": shapes},
+            {"name": "speech_44k", "shapes": [{"frame_len": n, "hop": h, "speech": {"value": 2.4e7, "burg_direct": 0.4, "kernels_ms": kms},
+                                               "synthetic": {"value": 2.8e7, "burg_direct": 0.01}} for n, h in b.SPEECH_SHAPES]},
+            {"name": "config5_100h_1gpu", "skipped": "RuntimeError('HIP out of memory')" * 20}]
+    return {"metric": b.METRIC, "value": 35971000.123456, "unit": "frames/s", "n_gpus": 1, "steps": 3, "warmup": 1, "ms_per_step": 125.1,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "full pitch+LPC+formants+MFCC pipeline, 12.5 h/GPU synthetic 48 kHz, 25 ms / 10 ms hop", "frames_per_gpu": 4500000,
+                       "frame_len": 1200, "hop": 480, "parallelism": "frame-range split x1, one process per GPU, RCCL gather of the records to rank 0",
+                       "gather": "g" * 400},
+            "roofline": roof, "roofline_hbm": hbm, "kernels_ms": kms, "parity": b.PARITY_NOTE, "sub_benchmarks": sub,
+            "cpu_baseline": {"value": 1641.05, "unit": "frames/s", "cores": 16, "kind": "port", "sample": "s" * 600,
+                             "one_core": {"value": 101.2, "unit": "frames/s", "cores": 1, "frames": 811, "seconds": 8.0}}}
+
+
+def test_the_stdout_line_stays_under_the_drivers_window():
+    """Round 5: the line reached 25 KB, the driver keeps the last 8 KB of stdout, BENCH_r05.parsed = null.  The line bench.py prints is
+    assembled by compact_line() from the full record; it must stay under LINE_LIMIT whatever the sub-benchmarks carry, keep every
+    contract key, `roofline` and `cpu_baseline`, and reduce each sub-benchmark to numbers."""
+    b = _bench()
+    assert b.LINE_LIMIT <= 6000
+    for blowup in (1, 40):
+        rec = _canned_record(b, blowup)
+        assert len(json.dumps(rec)) > 3 * b.LINE_LIMIT                       # the full record is what used to be printed
+        text = b.compact_line(rec, os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+        assert "\n" not in text and len(text) < b.LINE_LIMIT, len(text)
+        d = json.loads(text)
+        for k in b.CONTRACT_KEYS + ("config", "roofline", "cpu_baseline"):
+            assert k in d, k
+        assert d["metric"] == b.METRIC and d["dtype"] == "f64" and d["config"]["frame_len"] == 1200
+        r = d["roofline"]
+        assert r["kernel"] == "analyze" and r["bound"] == "fp64_valu" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
+        assert r["traffic"] and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 16
+        assert d["detail"] == "gpurun_out/bench_detail.json"
+    d = json.loads(b.compact_line(_canned_record(b), None))
+    sub = d["sub_benchmarks"]
+    assert sub["config2"] == 1.15e9 and sub["pipeline_shapes"]["1200/480"] == 12345700.0 and "error" in sub["config5_100h_1gpu"]
+    assert sub["speech_44k"]["1103/441"]["burg_direct"] == 0.4
+
+
+def test_a_failing_sub_benchmark_becomes_a_record_not_a_lost_headline():
+    b = _bench()
+
+    def boom():
+        raise RuntimeError("hipMalloc failed")
+    r = b.guarded("config5_100h_1gpu", boom)
+    assert r["name"] == "config5_100h_1gpu" and "hipMalloc" in r["error"]
+    assert b.guarded("ok", lambda: {"name": "ok", "value": 1.0}) == {"name": "ok", "value": 1.0}
