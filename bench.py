@@ -123,22 +123,37 @@ def launch_ranks(args):
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
-    # wait for all ranks; if one dies the others would sit in a rendezvous or a collective until its timeout,
-    # so its exit ends them too (these are exactly the children started above)
+    return supervise(procs)
+
+
+def supervise(procs, grace_s=10.0, poll_s=0.2, relay=sys.stdout):
+    """Wait for the rank processes.  If one dies (or the watchdog ends it: exit code 5) the others would sit in a rendezvous or
+    a collective until its timeout, so its exit ends them too: terminate(), and after `grace_s` seconds kill() whatever ignored
+    that (a rank stuck inside a RCCL kernel does not run Python signal handlers).  These are exactly the children started by
+    launch_ranks.  Relays rank 0's stdout; returns 0 only if every rank exited 0."""
+    failed = False
     while any(p.poll() is None for p in procs):
         if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
             for p in procs:
                 if p.poll() is None:
                     p.terminate()
+            deadline = time.monotonic() + grace_s
+            while any(p.poll() is None for p in procs) and time.monotonic() < deadline:
+                time.sleep(poll_s)
+            for r, p in enumerate(procs):
+                if p.poll() is None:
+                    sys.stderr.write(f"bench.py: rank {r} ignored terminate() for {grace_s:.0f} s: kill()\n")
+                    p.kill()
             break
-        time.sleep(0.2)
+        time.sleep(poll_s)
     out0 = procs[0].stdout.read() if procs[0].stdout else ""
     codes = [p.wait() for p in procs]
-    if out0:
-        sys.stdout.write(out0)
-        sys.stdout.flush()
+    if out0 and relay is not None:
+        relay.write(out0)
+        relay.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
+    if bad or failed:
         sys.stderr.write(f"bench.py: ranks failed (rank, exit code): {bad}\n")
         return 1
     return 0
@@ -866,6 +881,41 @@ def guarded(name, fn, torch=None):
 
 
 # ------------------------------------------------------------------------------------------------
+# the pipeline's step at any world size.  tests/test_shard_cpu.py runs exactly these two functions at world 8 over gloo with test
+# doubles for the context and the communicator (the N > 1 path has never run on hardware: its control flow at least has run).
+# ------------------------------------------------------------------------------------------------
+def pipeline_buffers(torch, dev, world, rank, F, FA, REC):
+    """The record buffers of one rank: `rec[b]` is what analyze writes ([FA, REC]: the rank's warm-up rows, then its own F rows),
+    `gathered[b]` what the gather fills on rank 0 ([world * F, REC]; None elsewhere).  Rank 0 has no warm-up rows and writes its
+    rows in place, straight into the gathered array.  Double-buffered at N > 1: step i + 1's kernels overlap step i's transfer."""
+    f64 = torch.float64
+    nbuf = 2 if world > 1 else 1
+    if rank == 0:
+        gathered = [torch.empty((world * F, REC), dtype=f64, device=dev) for _ in range(nbuf)]
+        rec = [g[:F] for g in gathered]                                   # rank 0 owns rows [0, F): written in place
+    else:
+        gathered = [None] * nbuf
+        rec = [torch.empty((FA, REC), dtype=f64, device=dev) for _ in range(nbuf)]      # rows [warm, FA) are the rank's own
+    return rec, gathered
+
+
+def pipeline_step(vb, comm, audio, params, seg, frame_len, stride, FA, warm, REC, rec, gathered, st3, counts, plan, stitch):
+    """step(i): wait for buffer i % nbuf's last transfer (device-side) -> analyze -> tracker hand-off along the ranks (an
+    utterance cut by the rank boundary) -> gather of the rank's OWN rows (past the warm-up rows) to rank 0."""
+    def step(i):
+        b = i % len(rec)
+        if comm is not None:
+            comm.wait(b)                                                  # device-side: buffer b's last transfer is done
+        vb.analyze_frames(audio, params, seg_start=seg, frame_len=frame_len, stride=stride, n_frames=FA,
+                          out=rec[b], record_ld=REC, status=st3)
+        if stitch:                 # the tracker's state along the chain of ranks; formant columns start at double 2 of a record
+            comm.stitch_tracks(rec[b].data_ptr() + 16, FA, REC, plan, None, slot=b)
+        if comm is not None:       # per-frame records to rank 0 over RCCL/xGMI
+            comm.gather_records(rec[b].data_ptr() + warm * REC * 8, counts, REC, 0, out=gathered[b], slot=b)
+    return step
+
+
+# ------------------------------------------------------------------------------------------------
 def run_rank(args):
     import torch
     import torch.distributed as dist
@@ -1019,15 +1069,10 @@ def run_rank(args):
         params = pkg.AnalysisParams.make(SR, pitch=(0.2, 75.0, 600.0), lpc_order=P, formant_order=P, est_init=est0,
                                          mfcc=(13, 100.0, 8000.0))
         REC = int(vb.L.vbx_record_doubles(params))
-        nbuf = 2 if world > 1 else 1
-        if rank == 0:
-            gathered = [torch.empty((world * F, REC), dtype=f64, device=dev) for _ in range(nbuf)]
-            rec = [g[:F] for g in gathered]                                   # rank 0 owns rows [0, F): written in place
-        else:
-            gathered = [None] * nbuf
-            rec = [torch.empty((FA, REC), dtype=f64, device=dev) for _ in range(nbuf)]      # rows [warm, FA) are the rank's own
+        rec, gathered = pipeline_buffers(torch, dev, world, rank, F, FA, REC)
         st3 = torch.empty((3, FA), dtype=torch.int32, device=dev)
         stitch = comm is not None and (plan.continues_prev or plan.continues_next)
+        step = pipeline_step(vb, comm, audio, params, seg, frame_len, stride, FA, warm, REC, rec, gathered, st3, counts, plan, stitch)
     else:
         REC = 0
         o_cand = torch.empty((F, args.kmax, 2), dtype=f64, device=dev)
@@ -1039,24 +1084,14 @@ def run_rank(args):
         o_fst = torch.empty(F, dtype=torch.int32, device=dev)
         ff = {"formants": o_form, "res": None, "count": None, "coeffs": None, "status": o_fst}
 
-    def step(i):
-        if wl == "pipeline":
-            b = i % len(rec)
-            if comm is not None:
-                comm.wait(b)                                                  # device-side: buffer b's last transfer is done
-            vb.analyze_frames(audio, params, seg_start=seg, frame_len=frame_len, stride=stride, n_frames=FA,
-                              out=rec[b], record_ld=REC, status=st3)
-            if stitch:             # an utterance cut by the rank boundary: the tracker's state along the chain of ranks
-                comm.stitch_tracks(rec[b].data_ptr() + 16, FA, REC, plan, None, slot=b)
-            if comm is not None:   # per-frame records to rank 0 over RCCL/xGMI
-                comm.gather_records(rec[b].data_ptr() + warm * REC * 8, counts, REC, 0, out=gathered[b], slot=b)
-        elif wl == "config4":
-            vb.find_formants(audio, SR, P, est0, seg_start=seg, frame_len=frame_len, stride=stride, n_frames=F, out=ff)
-        elif wl == "config2":
-            vb.autocorr_lpc(audio, P, frame_len=frame_len, stride=stride, n_frames=F, window=win, out=(o_r, o_a))
-        elif wl == "config3":
-            vb.pitch(audio.data_ptr() + warm * stride * 8, SR, 0.2, 75.0, 600.0, kmax=args.kmax, frame_len=frame_len, stride=stride,
-                     n_frames=F, window=win, out=(o_cand, o_cnt, o_pst))
+        def step(i):
+            if wl == "config4":
+                vb.find_formants(audio, SR, P, est0, seg_start=seg, frame_len=frame_len, stride=stride, n_frames=F, out=ff)
+            elif wl == "config2":
+                vb.autocorr_lpc(audio, P, frame_len=frame_len, stride=stride, n_frames=F, window=win, out=(o_r, o_a))
+            elif wl == "config3":
+                vb.pitch(audio.data_ptr() + warm * stride * 8, SR, 0.2, 75.0, 600.0, kmax=args.kmax, frame_len=frame_len, stride=stride,
+                         n_frames=F, window=win, out=(o_cand, o_cnt, o_pst))
 
     # N > 1 has never run on hardware in this build's rounds: a collective that never completes must not hang the node.  A
     # watchdog ends THIS rank (exit code 5, a message on stderr) if warm-up + the timed steps take absurdly long; the launcher

@@ -310,3 +310,183 @@ def test_bench_gpus_n_launches_n_ranks_itself():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                            env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode != 0
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Round 6: bench.py's OWN N > 1 step (pipeline_buffers + pipeline_step: wait -> analyze -> stitch -> gather, double-buffered slots,
+# the warm-up rows' offset into the send buffer) at world 8 over gloo, with test doubles for the two things a CPU box lacks: the
+# context (its analyze_frames is the oracle's walk of the rank's frames, tracked from a GUESS at the first warm-up frame, as the
+# library does) and the communicator (gloo send / recv of the same rows the library moves with ncclSend / ncclRecv; the repair step
+# is shard.stitch_rows = what tracker_stitch_kernel does).  The doubles live HERE; the product never sees them.
+# ------------------------------------------------------------------------------------------------------------------------
+REC_DOUBLES = 36      # pitch (2) | formants (8) | lpc (13) | mfcc (13): vbx_record_doubles of the bench's parameters
+
+
+def _view(ptr, rows, ld):
+    """[rows, ld] doubles at a raw address (what the C ABI is handed: rec[b].data_ptr() + an offset)"""
+    import ctypes
+    return np.ctypeslib.as_array((ctypes.c_double * (rows * ld)).from_address(int(ptr))).reshape(rows, ld)
+
+
+class _OracleContext:
+    """Stands in for VoxBox in bench.pipeline_step: analyze_frames fills the record rows of frames [first, first + n_frames)."""
+
+    def __init__(self, o, sh, pkg, first_frame, rank):
+        self.o, self.sh, self.pkg, self.first, self.rank, self.calls = o, sh, pkg, first_frame, rank, 0
+        self._cache = None
+
+    def analyze_frames(self, audio, params, seg_start=None, frame_len=N, stride=H, n_frames=0, out=None, record_ld=0, status=None):
+        self.calls += 1
+        if self._cache is None:                     # the analysis does not depend on the step: computed once, written every step
+            est0 = np.array([[f, 1.0] for f in self.pkg.MALE_FORMANT_ESTIMATES])
+            sk = self.o.soak(audio.numpy(), frame_len, stride, 0, n_frames, P, SR, self.o.SOAK_FORMANTS, n_threads=1)
+            self._cache = (sk, self.o.soak_track(sk["res"], sk["ff_status"], est0, seg_start))
+        sk, rows = self._cache
+        rec = out.numpy()
+        rec[:] = -1.0                               # stale rows of the slot's previous use must not survive
+        rec[:, 0] = self.first + np.arange(n_frames)          # the frame's GLOBAL index where the pitch frequency would be
+        rec[:, 1] = self.rank
+        rec[:, 2:10] = rows.reshape(n_frames, 8)
+        status.zero_()
+
+
+class _GlooComm:
+    """Stands in for voxbox.Comm: same calls, same raw pointers, torch.distributed (gloo) underneath."""
+
+    def __init__(self, dist, torch, world, rank, sh, o, ctx):
+        self.dist, self.torch, self.world, self.rank, self.sh, self.o, self.ctx = dist, torch, world, rank, sh, o, ctx
+        self.log, self.changed = [], 0
+
+    def wait(self, slot):
+        self.log.append(("wait", slot))
+
+    def stitch_tracks(self, formants_ptr, n_frames, ld, plan, changed=None, slot=0):
+        self.log.append(("stitch", slot))
+        pl = plan.as_dict()
+        rows = _view(formants_ptr - 16, n_frames, ld)         # the record rows; formants are doubles 2 .. 9
+        sk, _ = self.ctx._cache
+        if pl["continues_prev"]:
+            state = self.torch.zeros(8, dtype=self.torch.float64)
+            self.dist.recv(state, src=self.rank - 1)
+            trk = rows[:, 2:10].reshape(n_frames, 4, 2).copy()
+            step = lambda st, t: (self.o.estimate_formants(st, sk["res"][t]) if sk["ff_status"][t] == 0 else st)
+            self.changed += self.sh.stitch_rows(trk, pl["warm"], pl["stop"], state.numpy().reshape(4, 2), step)
+            rows[:, 2:10] = trk.reshape(n_frames, 8)
+        if pl["continues_next"]:
+            self.dist.send(self.torch.from_numpy(rows[-1, 2:10].copy()), dst=self.rank + 1)
+
+    def gather_records(self, local_ptr, counts, row_doubles, dst=0, out=None, slot=0):
+        self.log.append(("gather", slot))
+        mine = self.torch.from_numpy(_view(local_ptr, counts[self.rank], row_doubles).copy())
+        if self.rank == dst:
+            off = 0
+            for r in range(self.world):
+                if r != dst:
+                    buf = self.torch.empty((counts[r], row_doubles), dtype=self.torch.float64)
+                    self.dist.recv(buf, src=r)
+                    out[off:off + counts[r]] = buf
+                else:
+                    assert out.data_ptr() + off * row_doubles * 8 == local_ptr      # rank 0's rows are written in place
+                off += counts[r]
+        else:
+            self.dist.send(mine, dst=dst)
+
+
+def _bench_step_worker(rank, world, port, out_path, F, steps):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import importlib
+    import importlib.util
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    o = g.load_oracle()
+    synth = importlib.import_module(g.PKG_NAME + ".synth")
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # run_rank's shard geometry, verbatim: the recording is ONE utterance of world * F frames
+    plan = pkg.shard_plan(world * F, world, rank, None)
+    lo, hi, warm = plan.lo, plan.hi, plan.warm
+    assert hi - lo == F
+    seg = pkg.shard_local_segments(plan, None)
+    s0, s1 = pkg.shard_samples(lo - warm, hi, N, H)
+    audio = torch.from_numpy(synth.synth_speech(s1 - s0, sample_offset=s0))
+    FA = F + warm
+    counts = [F] * world
+    ctx = _OracleContext(o, pkg.shard, pkg, lo - warm, rank)
+    comm = _GlooComm(dist, torch, world, rank, pkg.shard, o, ctx)
+    rec, gathered = bench.pipeline_buffers(torch, "cpu", world, rank, F, FA, REC_DOUBLES)
+    assert len(rec) == 2 and (rank != 0 or rec[0].data_ptr() == gathered[0].data_ptr())
+    st3 = torch.empty((3, FA), dtype=torch.int32)
+    stitch = bool(plan.continues_prev or plan.continues_next)
+    step = bench.pipeline_step(ctx, comm, audio, None, seg, N, H, FA, warm, REC_DOUBLES, rec, gathered, st3, counts, plan, stitch)
+    for i in range(steps):
+        step(i)
+    per_step = [("wait", None), ("stitch", None), ("gather", None)] if stitch else [("wait", None), ("gather", None)]
+    assert [k for k, _ in comm.log] == [k for k, _ in per_step] * steps, comm.log
+    assert [s for _, s in comm.log] == [i % 2 for i in range(steps) for _ in per_step], comm.log       # the two slots alternate
+    assert ctx.calls == steps
+    ch = [None] * world
+    dist.all_gather_object(ch, comm.changed)
+    if rank == 0:
+        np.save(out_path, np.stack([g_.numpy() for g_ in gathered]))
+        np.save(out_path + ".changed.npy", np.array(ch))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,F,steps", [(8, 80, 3), (2, 150, 2)])
+def test_bench_pipeline_step_at_world_8_over_gloo(tmp_path, pkg, oracle, world, F, steps):
+    """bench.py's own step() ordering and buffer arithmetic at world 8 (VERDICT r05 next 7a): after `steps` steps BOTH slots of rank 0's
+    gathered array hold, for every frame of the 8 x F-frame utterance in order, its global index, its rank, and the formant track of
+    the single-process sequential scan -- bit for bit.  Wrong warm-row offsets, a slot mix-up or a gather that lands rows in the wrong
+    place all show here."""
+    import importlib
+    import torch.multiprocessing as mp
+    import __graft_entry__ as g
+    synth = importlib.import_module(g.PKG_NAME + ".synth")
+    out = str(tmp_path / "gathered.npy")
+    mp.start_processes(_bench_step_worker, args=(world, _free_port(), out, F, steps), nprocs=world, join=True, start_method="spawn")
+    got = np.load(out)                                  # [2 slots, world * F, REC]
+    total = world * F
+    audio = synth.synth_speech((total - 1) * H + N, sample_offset=0)
+    est0 = np.array([[f, 1.0] for f in pkg.MALE_FORMANT_ESTIMATES])
+    sk = oracle.soak(audio, N, H, 0, total, P, SR, oracle.SOAK_FORMANTS)
+    exp = oracle.soak_track(sk["res"], sk["ff_status"], est0, None).reshape(total, 8)
+    slots_used = {i % 2 for i in range(steps)}
+    for b in sorted(slots_used):
+        assert np.array_equal(got[b][:, 0], np.arange(total)), f"slot {b}: rows out of place"
+        assert np.array_equal(got[b][:, 1], np.repeat(np.arange(world), F)), f"slot {b}: rows from the wrong rank"
+        assert np.array_equal(got[b][:, 2:10], exp), f"slot {b}: tracks differ from the single-process scan"
+    assert np.load(out + ".changed.npy")[0] == 0
+
+
+def test_the_launcher_kills_ranks_that_ignore_terminate():
+    """bench.supervise: when one rank dies the launcher terminate()s the others and, after a grace period,
+    kill()s whatever ignored that -- a rank stuck inside a collective does not run signal handlers -- and returns non-zero."""
+    import importlib.util
+    import subprocess
+    import time
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    stubborn = "import signal, time, sys\nsignal.signal(signal.SIGTERM, signal.SIG_IGN)\nprint('{\"rank0\": 1}', flush=True)\ntime.sleep(120)\n"
+    dies = "import sys, time\ntime.sleep(0.5)\nsys.exit(5)\n"
+    procs = [subprocess.Popen([sys.executable, "-c", stubborn], stdout=subprocess.PIPE, text=True),
+             subprocess.Popen([sys.executable, "-c", dies])]
+    t0 = time.monotonic()
+    rc = bench.supervise(procs, grace_s=2.0, relay=None)
+    dt = time.monotonic() - t0
+    assert rc == 1 and dt < 30.0, (rc, dt)
+    assert procs[0].returncode == -9 and procs[1].returncode == 5, [p.returncode for p in procs]
+    # all ranks fine: 0, and rank 0's line is relayed
+    import io
+    ok = [subprocess.Popen([sys.executable, "-c", "print('{\"v\": 1}')"], stdout=subprocess.PIPE, text=True),
+          subprocess.Popen([sys.executable, "-c", "pass"])]
+    buf = io.StringIO()
+    assert bench.supervise(ok, relay=buf) == 0 and buf.getvalue().strip() == '{"v": 1}'

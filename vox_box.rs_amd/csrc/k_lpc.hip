@@ -36,6 +36,11 @@ __device__ __forceinline__ void levinson_uniform(const double (&r)[P + 1], doubl
     }
 }
 
+// the conditioning probe's perturbations (levinson_rows_kernel_t below has the reasoning): sign pattern `pat` of +-d on the lag sums
+constexpr int LPC_PROBE_NPAT = 4;
+__device__ __forceinline__ double lpc_probe_lag(double v, double d, unsigned h, int k) { return v + ((((h >> (k & 31)) & 1u) != 0) ? d : -d); }
+__host__ __device__ constexpr unsigned lpc_probe_hash(int pat) { return (unsigned)pat * 0x9E3779B1u ^ ((unsigned)pat << 7); }
+
 #ifndef VBX_AC_FPW
 #define VBX_AC_FPW 16
 #endif
@@ -58,7 +63,8 @@ constexpr int AC_FPW = VBX_AC_FPW;   // frames per wavefront: short enough that 
 template <int EPL, int NL, typename T>
 __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
     const T *__restrict__ x, long n_frames, int n, long stride, const T *__restrict__ window,
-    int n_lags, int normalize, T *__restrict__ out_r, T *__restrict__ out_lpc, long lpc_ld) {
+    int n_lags, int normalize, T *__restrict__ out_r, T *__restrict__ out_lpc, long lpc_ld,
+    int32_t *__restrict__ lpc_list, int32_t *__restrict__ lpc_count) {
     constexpr int FPW = AC_FPW;
     constexpr int TS = NL | 1;                       // odd row stride: conflict-free column reads
     __shared__ double TR[64 * TS];                   // per-frame transpose buffer [lane][lag]
@@ -142,10 +148,15 @@ __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
         for (int e = 0; e < EPL; e++) { cur[e] = nxt[e]; nxt[e] = nx2[e]; }
     }
 
-    // lane f <-> frame f0 + f
+    // lane f <-> frame f0 + f.  With the conditioning probe (lpc_list != NULL; f64 only): lanes FPW .. 4 FPW - 1 run the SAME
+    // recursion for frame lane % FPW on lag sums moved by +-16 eps of r[0] (three sign patterns per frame: the lanes are idle
+    // otherwise), and a frame whose row such a perturbation moves by more than LPC_PROBE_TOL in the parity metric goes to
+    // lpc_exact_list_kernel (k_lpc_exact.hip; vbx_spectral.hpp levinson_probe has the reasoning).
+    const bool probe = 4 * FPW <= 64 && sizeof(T) == 8 && lpc_list != nullptr && out_lpc != nullptr;      // uniform
+    const int fi = probe ? (lane & (FPW - 1)) : lane, pat = probe ? lane / FPW : 0;
     double r[NL];
 #pragma unroll
-    for (int k = 0; k < NL; k++) r[k] = (lane < nf) ? R[lane * TS + k] : 1.0;
+    for (int k = 0; k < NL; k++) r[k] = (fi < nf) ? R[fi * TS + k] : 1.0;
     if (normalize) {   // Normalize::normalize over the n_lags coefficients (max |.| over all, Q2)
         double m = fabs(r[0]);
 #pragma unroll
@@ -154,8 +165,10 @@ __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
 #pragma unroll
         for (int k = 0; k < NL; k++) r[k] = r[k] * scale;
         wave_sync();
+        if (lane < FPW) {
 #pragma unroll
-        for (int k = 0; k < NL; k++) R[lane * TS + k] = r[k];
+            for (int k = 0; k < NL; k++) R[lane * TS + k] = r[k];
+        }
         wave_sync();
     }
     if (out_r != nullptr) {          // [nf, n_lags] block, contiguous in the output
@@ -167,11 +180,34 @@ __global__ __launch_bounds__(64) void autocorr_fewlags_kernel(
     }
     if (out_lpc != nullptr) {        // only instantiated/called with n_lags == NL
         double ac[NL];
+        if (probe && pat > 0) {
+            const double d = LPC_PROBE_EPS * fabs(r[0]);
+            const unsigned h = lpc_probe_hash(pat);
+#pragma unroll
+            for (int k = 0; k < NL; k++) r[k] = lpc_probe_lag(r[k], d, h, k);
+        }
         levinson_uniform<NL - 1>(r, ac);
         wave_sync();
+        if (lane < FPW) {
 #pragma unroll
-        for (int k = 0; k < NL; k++) R[lane * TS + k] = ac[k];
+            for (int k = 0; k < NL; k++) R[lane * TS + k] = ac[k];
+        }
         wave_sync();
+        if (probe) {
+            double amax = 1.0;
+#pragma unroll
+            for (int k = 1; k < NL; k++) { const double m = fabs(R[fi * TS + k]); amax = (m > amax) ? m : amax; }
+            const double flo = 1e-6 * amax;
+            bool bad = false;
+#pragma unroll
+            for (int k = 1; k < NL; k++) {
+                const double a0 = R[fi * TS + k], m = fabs(a0);
+                bad = bad || (fabs(ac[k] - a0) > LPC_PROBE_TOL * ((m > flo) ? m : flo));
+            }
+            const unsigned long long mask = __ballot(bad && fi < nf);
+            const unsigned long long mine = (1ull << fi) | (1ull << (fi + FPW)) | (1ull << (fi + 2 * FPW)) | (1ull << (fi + 3 * FPW));
+            if (lane < nf && (mask & mine) != 0) lpc_list[atomicAdd(lpc_count, 1)] = (int32_t)(f0 + lane);
+        }
         T *o = out_lpc + f0 * lpc_ld;            // rows lpc_ld elements apart (NL when dense)
         for (int idx = lane; idx < nf * NL; idx += 64) {
             const int fr = idx / NL, k = idx - fr * NL;
@@ -251,24 +287,112 @@ __global__ void levinson_rows_kernel(const T *__restrict__ r, long n_rows, long 
     for (int i = 0; i <= p; i++) aco[i] = (T)ac[i];
 }
 
+// LPC::lpc on rows of lag sums that were computed from FRAMES, with the conditioning probe (round 6).
+// The recursion amplifies the rounding of its lag sums by the conditioning of the frame's Toeplitz system; on oversampled speech
+// (order 12-13 at 44.1 kHz) a few eps of r[0] move a coefficient that is small against the row's largest by 1e-6 .. 1e-4 of the
+// parity metric (|a - b| / max(|b|, 1e-6 max |b|)) -- in the reference's own f64 result (its sequential fold carries ~sqrt(n) eps)
+// more than in this one: on 6,000 frames of the 44.1 kHz fixture the ORACLE's rows are up to 3e-4 from the same recursion in long
+// double on long-double lag sums, the GPU's up to 1e-5 (profiles/r06_lpc_exact_check.txt).  No f64 evaluation can agree with another
+// to 1e-6 on such a row; what CAN be done is to return the exact answer.  So the recursion is repeated on lag sums moved by
+// +-LPC_PROBE_EPS of r[0] (NPAT sign patterns; a lane per row: the repeats cost a few instructions per frame), and a row that such
+// a perturbation moves by more than LPC_PROBE_TOL in the parity metric is listed; lpc_exact_list_kernel (k_lpc_exact.hip) redoes
+// the listed frames from their samples in double-double -- the exact row rounded once.  A row that stays is within
+// LPC_PROBE_TOL / 2 of the exact answer (the lag sums' own error is < 8 eps of r[0] by two transforms, ~1 eps by direct sums).
+// IN PLACE is allowed (r == out, r_stride == out_ld): the fused kernels leave r[0..12] in the frame's LPC row.
+
+template <int P, bool PROBE>
+__global__ __launch_bounds__(64) void levinson_rows_kernel_t(const double *__restrict__ r, long n_rows, long r_stride, double *__restrict__ out,
+                                                             long out_ld, int32_t *__restrict__ lpc_list, int32_t *__restrict__ lpc_count) {
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    double rr[P + 1], a0[P + 1];
+#pragma unroll
+    for (int k = 0; k <= P; k++) rr[k] = r[row * r_stride + k];
+    levinson_uniform<P>(rr, a0);
+    double *aco = out + row * out_ld;
+#pragma unroll
+    for (int k = 0; k <= P; k++) aco[k] = a0[k];
+    if constexpr (PROBE) {
+        double amax = 1.0;
+#pragma unroll
+        for (int k = 1; k <= P; k++) { const double m = fabs(a0[k]); amax = (m > amax) ? m : amax; }
+        const double flo = 1e-6 * amax, d = LPC_PROBE_EPS * fabs(rr[0]);
+        bool bad = false;
+        for (int pat = 1; pat <= LPC_PROBE_NPAT; pat++) {
+            const unsigned h = lpc_probe_hash(pat);
+            double rp[P + 1], ap[P + 1];
+#pragma unroll
+            for (int k = 0; k <= P; k++) rp[k] = lpc_probe_lag(rr[k], d, h, k);
+            levinson_uniform<P>(rp, ap);
+#pragma unroll
+            for (int k = 1; k <= P; k++) {
+                const double m = fabs(a0[k]);
+                bad = bad || (fabs(ap[k] - a0[k]) > LPC_PROBE_TOL * ((m > flo) ? m : flo));      // a NaN row (the reference's NaN row) is never listed
+            }
+        }
+        if (bad) lpc_list[atomicAdd(lpc_count, 1)] = (int32_t)row;
+    }
+}
+
+// any order (runtime loops, rows in scratch): autocorrelate -> levinson of vbx_autocorr_lpc_f64 at the orders without a fused kernel
+__global__ void levinson_rows_probe_kernel(const double *__restrict__ r, long n_rows, long r_stride, int p,
+                                           double *__restrict__ out, long out_ld, int32_t *__restrict__ lpc_list,
+                                           int32_t *__restrict__ lpc_count) {
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    const double *rr = r + row * r_stride;
+    double *aco = out + row * out_ld;
+    double ac[VBX_MAX_LPC_ORDER_K + 1], tmp[VBX_MAX_LPC_ORDER_K + 1], r0[VBX_MAX_LPC_ORDER_K + 1];
+    for (int i = 0; i <= p; i++) r0[i] = rr[i];             // (in place: the row is read before it is written)
+    bool bad = false;
+    double amax = 1.0;
+    for (int pat = 0; pat <= LPC_PROBE_NPAT; pat++) {
+        const double d = pat ? LPC_PROBE_EPS * fabs(r0[0]) : 0.0;
+        const unsigned h = lpc_probe_hash(pat);
+        auto lag = [&](int k) { return pat ? lpc_probe_lag(r0[k], d, h, k) : r0[k]; };
+        double err = lag(0);
+        ac[0] = 1.0;
+        for (int i = 1; i <= p; i++) ac[i] = 0.0;
+        for (int i = 1; i <= p; i++) {
+            double acc = lag(i);
+            for (int j = 1; j < i; j++) acc = acc + ac[j] * lag(i - j);
+            const double k = -acc / err;
+            ac[i] = k;
+            for (int j = 0; j < p; j++) tmp[j] = ac[j];
+            for (int j = 1; j < i; j++) ac[j] = ac[j] + k * tmp[i - j];
+            err = err * (1.0 - k * k);
+        }
+        if (pat == 0) {
+            for (int i = 0; i <= p; i++) { aco[i] = ac[i]; const double m = fabs(ac[i]); amax = (m > amax) ? m : amax; }
+        } else {
+            const double flo = 1e-6 * amax;
+            for (int i = 1; i <= p; i++) {
+                const double a0 = aco[i], m = fabs(a0);
+                bad = bad || (fabs(ac[i] - a0) > LPC_PROBE_TOL * ((m > flo) ? m : flo));
+            }
+        }
+    }
+    if (bad) lpc_list[atomicAdd(lpc_count, 1)] = (int32_t)row;
+}
+
 // ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
 
 template <int EPL, int NL, typename T>
 static void launch_fewlags(hipStream_t s, const T *x, long F, int n, long stride, const T *window,
-                           int n_lags, int normalize, T *out_r, T *out_lpc, long lpc_ld) {
+                           int n_lags, int normalize, T *out_r, T *out_lpc, long lpc_ld, int32_t *lpc_list, int32_t *lpc_count) {
     hipLaunchKernelGGL((autocorr_fewlags_kernel<EPL, NL, T>), dim3((unsigned)((F + AC_FPW - 1) / AC_FPW)), dim3(64), 0, s,
-                       x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
+                       x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld, lpc_list, lpc_count);
 }
 
 template <int NL, typename T>
 static bool dispatch_epl(hipStream_t s, const T *x, long F, int n, long stride, const T *window,
-                         int n_lags, int normalize, T *out_r, T *out_lpc, long lpc_ld) {
-    if (n <= 64 * 8) launch_fewlags<8, NL, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
-    else if (n <= 64 * 16) launch_fewlags<16, NL, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
-    else if (n <= 64 * 20) launch_fewlags<20, NL, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
-    else if (n <= 64 * 32) launch_fewlags<32, NL, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
+                         int n_lags, int normalize, T *out_r, T *out_lpc, long lpc_ld, int32_t *lpc_list = nullptr, int32_t *lpc_count = nullptr) {
+    if (n <= 64 * 8) launch_fewlags<8, NL, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld, lpc_list, lpc_count);
+    else if (n <= 64 * 16) launch_fewlags<16, NL, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld, lpc_list, lpc_count);
+    else if (n <= 64 * 20) launch_fewlags<20, NL, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld, lpc_list, lpc_count);
+    else if (n <= 64 * 32) launch_fewlags<32, NL, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld, lpc_list, lpc_count);
     else return false;
     return true;
 }
@@ -282,14 +406,15 @@ bool fewlags_supported(int n, int n_lags, bool want_lpc) {
 
 template <typename T>
 static void launch_autocorr_fewlags_t(hipStream_t s, const T *x, long F, int n, long stride, const T *window,
-                                      int n_lags, int normalize, T *out_r, T *out_lpc, long lpc_ld) {
+                                      int n_lags, int normalize, T *out_r, T *out_lpc, long lpc_ld, int32_t *lpc_list = nullptr,
+                                      int32_t *lpc_count = nullptr) {
     if (lpc_ld <= 0) lpc_ld = n_lags;
     if (out_lpc != nullptr) {
         switch (n_lags) {
-            case 9:  dispatch_epl<9, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld); break;
-            case 11: dispatch_epl<11, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld); break;
-            case 13: dispatch_epl<13, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld); break;
-            case 17: dispatch_epl<17, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld); break;
+            case 9:  dispatch_epl<9, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld, lpc_list, lpc_count); break;
+            case 11: dispatch_epl<11, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld, lpc_list, lpc_count); break;
+            case 13: dispatch_epl<13, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld, lpc_list, lpc_count); break;
+            case 17: dispatch_epl<17, T>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld, lpc_list, lpc_count); break;
         }
         return;
     }
@@ -299,8 +424,8 @@ static void launch_autocorr_fewlags_t(hipStream_t s, const T *x, long F, int n, 
 }
 
 void launch_autocorr_fewlags(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
-                             int n_lags, int normalize, double *out_r, double *out_lpc, long lpc_ld) {
-    launch_autocorr_fewlags_t<double>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld);
+                             int n_lags, int normalize, double *out_r, double *out_lpc, long lpc_ld, int32_t *lpc_list, int32_t *lpc_count) {
+    launch_autocorr_fewlags_t<double>(s, x, F, n, stride, window, n_lags, normalize, out_r, out_lpc, lpc_ld, lpc_list, lpc_count);
 }
 void launch_autocorr_fewlags_f32(hipStream_t s, const float *x, long F, int n, long stride, const float *window,
                                  int n_lags, int normalize, float *out_r, float *out_lpc, long lpc_ld) {
@@ -329,6 +454,19 @@ void launch_levinson_rows(hipStream_t s, const double *r, long rows, long r_stri
                           double *out_kc) {
     const int bs = 64;
     hipLaunchKernelGGL(levinson_rows_kernel<double>, dim3((unsigned)((rows + bs - 1) / bs)), dim3(bs), 0, s, r, rows, r_stride, p, out, out_ld, out_kc);
+}
+void launch_levinson_rows_probe(hipStream_t s, const double *r, long rows, long r_stride, int p, double *out, long out_ld,
+                                int32_t *lpc_list, int32_t *lpc_count) {
+    const int bs = 64;
+    const dim3 grid((unsigned)((rows + bs - 1) / bs));
+    if (p == 12) {                                           // the fused kernels' order: rows in registers
+        if (lpc_list != nullptr) hipLaunchKernelGGL((levinson_rows_kernel_t<12, true>), grid, dim3(bs), 0, s, r, rows, r_stride, out, out_ld, lpc_list, lpc_count);
+        else hipLaunchKernelGGL((levinson_rows_kernel_t<12, false>), grid, dim3(bs), 0, s, r, rows, r_stride, out, out_ld, lpc_list, lpc_count);
+        return;
+    }
+    if (lpc_list == nullptr) { launch_levinson_rows(s, r, rows, r_stride, p, out, out_ld, nullptr); return; }
+    hipLaunchKernelGGL(levinson_rows_probe_kernel, dim3((unsigned)((rows + bs - 1) / bs)), dim3(bs), 0, s, r, rows, r_stride, p, out, out_ld,
+                       lpc_list, lpc_count);
 }
 void launch_levinson_rows_f32(hipStream_t s, const float *r, long rows, long r_stride, int p, float *out, long out_ld,
                               float *out_kc) {

@@ -548,15 +548,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sp_is_mfcc_o
         }
         return;
     }
-    if (LPC) {                                               // LPC::lpc(12) on the raw autocorrelation r[0..12]
-        double rr[SP_LPC_P + 1], ac[SP_LPC_P + 1];
-#pragma unroll
-        for (int k = 0; k <= SP_LPC_P; k++) rr[k] = readlane_f64((k & 1) ? r_o[0] : r_e[0], k >> 1);
-        levinson_regs<SP_LPC_P>(rr, ac);
-        double mine = 0.0;
-#pragma unroll
-        for (int k = 0; k <= SP_LPC_P; k++) mine = (lane == k) ? ac[k] : mine;
-        if (lane <= SP_LPC_P) a.out_lpc[f * a.lpc_ld + lane] = mine;
+    if (LPC) {                                               // the raw autocorrelation r[0..12] into the frame's LPC row: lane l holds r[2l], r[2l + 1];
+        // levinson_rows_kernel_t makes it LPC::lpc(12) afterwards, one row per lane (vbx_spectral.hpp)
+        static_assert(SP_LPC_P == 12, "seven lanes hold r[0..12]");
+        double *row = a.out_lpc + f * a.lpc_ld;
+        if (lane < 7) { row[2 * lane] = r_e[0]; if (lane < 6) row[2 * lane + 1] = r_o[0]; }
     }
     double amax = -1.0;                                      // max_amplitude over ALL n lags (Q2; NaN never wins)
 #pragma unroll

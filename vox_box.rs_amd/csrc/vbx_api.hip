@@ -39,7 +39,7 @@ struct vbx_ctx {
     std::string arch;
     int cu_count = 0;
     // workspaces (grown on demand, never shrunk)
-    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_UNSURE, WS_F32_IN, WS_F32_OUT, WS_TRK, WS_BURG_LIST, WS_ROOTS_LIST, WS_LONG, WS_LONG2, WS_CZT, WS_CURVE, WS_N };
+    enum { WS_COEFFS, WS_RES, WS_COUNT, WS_STATUS, WS_MISC, WS_SEG, WS_EST, WS_UNSURE, WS_F32_IN, WS_F32_OUT, WS_TRK, WS_BURG_LIST, WS_ROOTS_LIST, WS_LONG, WS_LONG2, WS_CZT, WS_CURVE, WS_LPC_LIST, WS_N };
     void *ws[WS_N] = {nullptr};
     const int32_t *burg_list_count = nullptr;             // device counter of the last one-pass Burg call (tests)
     const int32_t *roots_list_count = nullptr;            // the same for the resonance kernel of find_formants
@@ -60,6 +60,7 @@ struct vbx_ctx {
     std::map<std::tuple<int, int, int, int>, std::pair<void *, mfcc_interp_t>> interp_cache;   // (plan, n, b_lo, nb) -> tables of the interpolated MFCC bins (first == nullptr: no such form)
     int last_mfcc_interp = 0;                             // the last vbx_mfcc_f64 call took the interpolated form (tests)
     int last_spectral_split = 0;                          // the last fused / pitch call ran as two kernels (tests)
+    int lpc_exact = 1;                                    // VBX_LPC_EXACT=0: no conditioning probe, no double-double redo of flagged LPC rows (rounds 1-5; tests, A/B)
     int pow2_split = -1;                                  // VBX_POW2_SPLIT=0: the 4096-point plan as ONE kernel (transforms and refinement fused, as before round 5; tests, A/B)
     int mfcc_interp = -1;                                 // VBX_MFCC_INTERP=0: never (the chirp-z kernel beside the fused one, as before round 5; tests, A/B)
     std::map<std::pair<size_t, double>, std::pair<int32_t *, double *>> resample_tabs;   // (n, ratio) -> (index, fraction)
@@ -484,6 +485,7 @@ int vbx_ctx_create(vbx_ctx **out, int device, void *hip_stream) {
     { const char *e = std::getenv("VBX_MFCC_DFT2"); ctx->mfcc_force_dft2 = e && e[0] == '1'; }
     { const char *e = std::getenv("VBX_MFCC_MFMA"); ctx->mfcc_force_mfma = e && e[0] == '1'; }
     { const char *e = std::getenv("VBX_MFCC_CZT"); ctx->mfcc_czt = e ? (e[0] == '1' ? 1 : 0) : -1; }
+    { const char *e = std::getenv("VBX_LPC_EXACT"); ctx->lpc_exact = (e && e[0] == '0') ? 0 : 1; }
     { const char *e = std::getenv("VBX_POW2_SPLIT"); ctx->pow2_split = e ? (e[0] == '0' ? 0 : 1) : -1; }
     { const char *e = std::getenv("VBX_MFCC_INTERP"); ctx->mfcc_interp = e ? (e[0] == '0' ? 0 : 1) : -1; }
     { const char *e = std::getenv("VBX_MFCC_CZT_SPLIT"); ctx->mfcc_czt_split = e != nullptr && e[0] == '1'; }
@@ -783,6 +785,16 @@ static int launch_spectral(vbx_ctx *ctx, hipStream_t st, spectral_launch_t &L, c
     L.unsure_count = (int32_t *)w;                       // [0]: count, [4..]: frame indices
     L.unsure_list = (int32_t *)w + 4;
     VBX_HIP(ctx, hipMemsetAsync(L.unsure_count, 0, sizeof(int32_t), st));
+    // LPC rows: levinson_rows_kernel_t (k_lpc.hip) lists the frames whose Levinson row a few eps of lag-sum rounding can move by more
+    // than 1e-6; lpc_exact_list_kernel redoes those in double-double.  VBX_LPC_EXACT=0: no probe, the rows of rounds 1-5 (A/B, tests).
+    L.lpc_list = nullptr; L.lpc_count = nullptr;
+    if (L.out_lpc != nullptr && ctx->lpc_exact) {
+        void *lw = nullptr;
+        rc = ws_get(ctx, vbx_ctx::WS_LPC_LIST, ((size_t)L.F + 4) * sizeof(int32_t), &lw);
+        if (rc != VBX_SUCCESS) return rc;
+        L.lpc_count = (int32_t *)lw; L.lpc_list = (int32_t *)lw + 4;
+        VBX_HIP(ctx, hipMemsetAsync(L.lpc_count, 0, sizeof(int32_t), st));
+    }
     // the 4096-point plan runs as two kernels with the lag curves in a scratch buffer between them (vbx_spectral.hpp, SP_ANALYZE_SPLIT):
     // batches of up to 131,072 frames (~10 KB each)
     L.curve_ws = nullptr; L.curve_ws_bytes = 0;
@@ -806,6 +818,17 @@ static int launch_spectral(vbx_ctx *ctx, hipStream_t st, spectral_launch_t &L, c
         launch_pitch_list(st, L.unsure_list, L.unsure_count, grid, L.x, L.n, L.stride, L.window, L.lag_window,
                           L.sample_rate, L.threshold, L.fmin, L.fmax, L.kmax, L.out_cand, L.cand_ld, L.out_count,
                           L.pitch_status, L.work, L.pcm);
+    }
+    if (L.out_lpc != nullptr) {
+        // the fused kernel left r[0..12] in every frame's LPC row: LPC::lpc(12) in place, one row per lane (+ the conditioning probe), then
+        // the listed rows again from their frames in double-double
+        { Prof p(ctx, "lpc_rows", st);
+          launch_levinson_rows_probe(st, L.out_lpc, L.F, L.lpc_ld, SPECTRAL_LPC_ORDER, L.out_lpc, L.lpc_ld, L.lpc_list, L.lpc_count); }
+        if (L.lpc_list != nullptr) {
+            Prof p(ctx, "lpc_exact_list", st);
+            const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+            launch_lpc_exact_list(st, L.lpc_list, L.lpc_count, cus * 8, L.x, L.n, L.stride, L.window, L.pcm, SPECTRAL_LPC_ORDER, L.out_lpc, L.lpc_ld);
+        }
     }
     return check_launch(ctx, "launch_spectral");
 }
@@ -910,9 +933,27 @@ static int run_autocorr_lpc(vbx_ctx *ctx, hipStream_t st, const double *x, size_
     VBX_REQUIRE(ctx, lpc_ld >= n_coeffs + 1, "LPC rows must hold n_coeffs + 1 entries");
     const int n_lags = (int)n_coeffs + 1;
     int rc;
+    // LPC rows: a conditioning probe lists the frames whose row a few eps of lag-sum rounding can move by more than 1e-6; those are
+    // redone from the frame in double-double (k_lpc_exact.hip).  VBX_LPC_EXACT=0: the rows of rounds 1-5.
+    int32_t *lpc_list = nullptr, *lpc_count = nullptr;
+    if (out_lpc != nullptr && ctx->lpc_exact && lpc_exact_supported((int)frame_len, (int)n_coeffs)) {
+        void *lw = nullptr;
+        rc = ws_get(ctx, vbx_ctx::WS_LPC_LIST, (n_frames + 4) * sizeof(int32_t), &lw);
+        if (rc != VBX_SUCCESS) return rc;
+        lpc_count = (int32_t *)lw; lpc_list = (int32_t *)lw + 4;
+        VBX_HIP(ctx, hipMemsetAsync(lpc_count, 0, sizeof(int32_t), st));
+    }
+    auto redo = [&]() {
+        if (lpc_list == nullptr) return;
+        Prof p(ctx, "lpc_exact_list", st);
+        const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+        launch_lpc_exact_list(st, lpc_list, lpc_count, cus * 8, x, (int)frame_len, (long)stride, window, false, (int)n_coeffs, out_lpc, (long)lpc_ld);
+    };
     if (fewlags_supported((int)frame_len, n_lags, out_lpc != nullptr)) {
-        Prof p(ctx, "autocorr_lpc", st);
-        launch_autocorr_fewlags(st, x, (long)n_frames, (int)frame_len, (long)stride, window, n_lags, normalize, out_r, out_lpc, (long)lpc_ld);
+        { Prof p(ctx, "autocorr_lpc", st);
+          launch_autocorr_fewlags(st, x, (long)n_frames, (int)frame_len, (long)stride, window, n_lags, normalize, out_r, out_lpc, (long)lpc_ld,
+                                  lpc_list, lpc_count); }
+        redo();
         return check_launch(ctx, "vbx_autocorr_lpc_f64");
     }
     // general shapes: autocorrelate -> [normalize] -> Levinson as three launches
@@ -926,7 +967,12 @@ static int run_autocorr_lpc(vbx_ctx *ctx, hipStream_t st, const double *x, size_
     rc = run_autocorrelate(ctx, st, x, n_frames, frame_len, stride, window, (size_t)n_lags, r);
     if (rc != VBX_SUCCESS) return rc;
     if (normalize) { Prof p(ctx, "normalize_rows", st); launch_normalize_rows(st, r, (long)n_frames, n_lags); }
-    if (out_lpc) { Prof p(ctx, "levinson_rows", st); launch_levinson_rows(st, r, (long)n_frames, n_lags, (int)n_coeffs, out_lpc, (long)lpc_ld); }
+    if (out_lpc) {
+        Prof p(ctx, "levinson_rows", st);
+        if (lpc_list != nullptr) launch_levinson_rows_probe(st, r, (long)n_frames, n_lags, (int)n_coeffs, out_lpc, (long)lpc_ld, lpc_list, lpc_count);
+        else launch_levinson_rows(st, r, (long)n_frames, n_lags, (int)n_coeffs, out_lpc, (long)lpc_ld);
+    }
+    redo();
     return check_launch(ctx, "vbx_autocorr_lpc_f64");
 }
 
@@ -2046,6 +2092,18 @@ int vbx_internal_last_unsure_count(vbx_ctx *ctx, int32_t *h_count) {
     VBX_HIP(ctx, hipSetDevice(ctx->device));
     VBX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     VBX_HIP(ctx, hipMemcpy(h_count, ctx->ws[vbx_ctx::WS_UNSURE], sizeof(int32_t), hipMemcpyDeviceToHost));
+    return VBX_SUCCESS;
+}
+
+// internal (tests, bench): how many frames of the last fused analyze call the Levinson probe handed to the double-double
+// recursion (k_lpc_exact.hip); -1 if the call had no LPC rows or the probe is off
+int vbx_internal_last_lpc_exact_count(vbx_ctx *ctx, int32_t *h_count) {
+    VBX_REQUIRE(ctx, ctx && h_count, "null argument");
+    *h_count = -1;
+    if (!ctx->ws[vbx_ctx::WS_LPC_LIST] || !ctx->lpc_exact) return VBX_SUCCESS;
+    VBX_HIP(ctx, hipSetDevice(ctx->device));
+    VBX_HIP(ctx, hipDeviceSynchronize());
+    VBX_HIP(ctx, hipMemcpy(h_count, ctx->ws[vbx_ctx::WS_LPC_LIST], sizeof(int32_t), hipMemcpyDeviceToHost));
     return VBX_SUCCESS;
 }
 

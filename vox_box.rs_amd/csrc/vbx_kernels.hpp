@@ -33,12 +33,23 @@ struct cplx32_t { float re, im; };
 // k_lpc.hip
 bool fewlags_supported(int n, int n_lags, bool want_lpc);
 void launch_autocorr_fewlags(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
-                             int n_lags, int normalize, double *out_r, double *out_lpc, long lpc_ld = 0 /* 0: n_lags */);
+                             int n_lags, int normalize, double *out_r, double *out_lpc, long lpc_ld = 0 /* 0: n_lags */,
+                             int32_t *lpc_list = nullptr, int32_t *lpc_count = nullptr /* the conditioning probe's list (below) */);
 void launch_autocorr_tiles(hipStream_t s, const double *x, long F, int n, long stride, const double *window,
                            int n_lags, double *out);
 void launch_normalize_rows(hipStream_t s, double *data, long rows, int n);
 void launch_levinson_rows(hipStream_t s, const double *r, long rows, long r_stride, int p, double *out, long out_ld,
                           double *out_kc = nullptr /* [rows, p] reflection coefficients */);
+// The conditioning probe of the Levinson rows computed from FRAMES (round 6; reasoning at levinson_probe, vbx_spectral.hpp): the
+// recursion is repeated on lag sums moved by +-LPC_PROBE_EPS of r[0]; a row that moves by more than LPC_PROBE_TOL in the parity metric
+// (|a - b| / max(|b|, 1e-6 max |b|)) is listed and redone from the frame in double-double (k_lpc_exact.hip).
+constexpr double LPC_PROBE_EPS = 16.0 * 2.220446049250313e-16;
+#ifndef VBX_EXP_LPC_PROBE_TOL
+#define VBX_EXP_LPC_PROBE_TOL 1e-6
+#endif
+constexpr double LPC_PROBE_TOL = VBX_EXP_LPC_PROBE_TOL;
+void launch_levinson_rows_probe(hipStream_t s, const double *r, long rows, long r_stride, int p, double *out, long out_ld,
+                                int32_t *lpc_list, int32_t *lpc_count);
 
 // k_burg.hip
 bool burg_supported(int n, int p);
@@ -203,6 +214,7 @@ struct spectral_launch_t {
     double *out_mfcc; long mfcc_ld; int32_t *mfcc_status;        // NULL: no MFCC
     const int32_t *bins; const double *slopes; const double *dct; int num_coeffs; int nb;
     int32_t *unsure_list; int32_t *unsure_count;                 // frames handed to launch_pitch_list
+    int32_t *lpc_list; int32_t *lpc_count;                       // frames handed to launch_lpc_exact_list (ill-conditioned LPC rows); NULL: no probe
     bool mfcc_only;                                              // MFCC::mfcc alone (n == the plan's Nc): no pitch, no LPC
     double *out_r; int n_lags;                                   // non-NULL: Autocorrelate::autocorrelate(n_lags) alone, [F, n_lags]
     bool pcm;                                                    // x points to int16 PCM samples (n == 1200 only)
@@ -213,6 +225,11 @@ struct spectral_launch_t {
 size_t spectral_split_row_bytes(int n, double sample_rate, double fmin);   // bytes per frame of that scratch, 0: the shape has no split form
 bool spectral_supported(int n, int lpc_order, int mfcc_nb, int mfcc_b_lo, int num_coeffs);
 int launch_analyze(hipStream_t s, const spectral_launch_t &L);       // 1: the call ran as two kernels (SP_ANALYZE_SPLIT), 0: one
+// k_lpc_exact.hip: LPC::lpc(p) of the listed frames from double-double lag sums and a double-double recursion (the exact
+// answer rounded once), over a list only the device knows the length of
+bool lpc_exact_supported(int n, int p);                               // frames of 2..4096 samples, orders 1..31
+void launch_lpc_exact_list(hipStream_t s, const int32_t *frame_list, const int32_t *list_count, int grid, const double *x, int n,
+                           long stride, const double *window, bool pcm, int p, double *out_lpc, long lpc_ld);
 
 // the f32 instantiation (Sample = f32): the same kernels with float frames and float outputs
 void launch_autocorr_fewlags_f32(hipStream_t s, const float *x, long F, int n, long stride, const float *window,

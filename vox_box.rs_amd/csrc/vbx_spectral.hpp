@@ -122,6 +122,12 @@ __device__ __forceinline__ void levinson_regs(const double (&r)[P + 1], double (
 
 constexpr int SP_LPC_P = SPECTRAL_LPC_ORDER;
 
+// LPC::lpc inside the fused call (round 6).  Rounds 1-5 ran the recursion in the frame's wavefront: sixty-four lanes on the same
+// thirteen values, twelve IEEE divisions, ~450 vector instructions per frame for what ONE lane can do.  The kernels now store the
+// lag sums r[0..12] in the frame's LPC row and levinson_rows_kernel_t (k_lpc.hip) turns the rows into coefficients afterwards, one
+// row per LANE, in place -- the same operations in the same order (bit-identical rows), 64 x fewer instructions, and the
+// conditioning probe + double-double redo of ill-conditioned rows (k_lpc_exact.hip) ride on that kernel for nothing.
+
 // k_spectral_pow2.hip
 int launch_analyze_pow2(hipStream_t s, const spectral_launch_t &L, spectral_args_t &a);      // 1: ran in the split form
 

@@ -184,6 +184,7 @@ def load_library():
         "vbx_selftest_lanes": (C.c_int, [vp, vp]),
         "vbx_internal_last_unsure_count": (C.c_int, [vp, vp]),
         "vbx_internal_last_burg_direct_count": (C.c_int, [vp, vp]),
+        "vbx_internal_last_lpc_exact_count": (C.c_int, [vp, vp]),
         "vbx_internal_estimate_formants_counted": (C.c_int, [vp, vp, sz, sz, vp, vp, sz, vp, sz, vp, vp]),
         "vbx_internal_last_roots_direct_count": (C.c_int, [vp, vp]),
         "vbx_internal_last_spectral_split": (C.c_int, [vp]),
@@ -208,6 +209,8 @@ def load_library():
         "vbx_comm_selftest": (C.c_int, [vp, vp, sz]),
     }
     for name, (res, args) in sig.items():
+        if name.startswith("vbx_internal_") and os.environ.get("VBX_LIB_PATH") and not hasattr(L, name):
+            continue                   # an experiment build of an earlier round (tools/experiments/bitcompare_libs.py): probes it does not have
         fn = getattr(L, name)          # AttributeError here = symbol missing from the build
         fn.restype = res
         fn.argtypes = args
@@ -1011,6 +1014,13 @@ class VoxBox:
         (test probe); -1 if that call did not take the one-pass form."""
         n = C.c_int32(0)
         self._check(self.L.vbx_internal_last_burg_direct_count(self.ctx, C.byref(n)))
+        return int(n.value)
+
+    def last_lpc_exact_count(self):
+        """Frames of the last fused analyze call whose Levinson row the conditioning probe handed to the double-double recursion
+        (k_lpc_exact.hip); -1 if the call wrote no LPC rows or VBX_LPC_EXACT=0."""
+        n = C.c_int32(0)
+        self._check(self.L.vbx_internal_last_lpc_exact_count(self.ctx, C.byref(n)))
         return int(n.value)
 
     def last_roots_direct_count(self):
