@@ -71,6 +71,8 @@ ALG_BYTES = {
     "tracker_chunked": lambda n, hop, p: 2 * ((p // 2) * 16 + 8) + 64,   # warm-up: every row is read twice
     "mfcc": lambda n, hop, p: hop * 8 + 13 * 8,
     "pcm16": lambda n, hop, p: 10,
+    "lpc_rows": lambda n, hop, p: 2 * (p + 1) * 8,                # lag sums in, coefficients out (in place in the record's LPC row)
+    "lpc_exact_list": lambda n, hop, p: hop * 8 + (p + 1) * 8,    # per frame ON THE LIST (~0.1 % of the synthetic signal's frames)
 }
 
 
@@ -642,6 +644,7 @@ def bench_speech(vb, torch, dev, pkg, hours=1.0, steps=2, warmup=1, shapes=SPEEC
                          "sinc_evals_per_frame": evals_w / max(frames_w, 1), "sinc_terms_per_frame": terms_w / max(frames_w, 1),
                          "candidates_per_frame": cand_w / max(frames_w, 1),
                          "burg_direct": vb.last_burg_direct_count() / F, "roots_direct": vb.last_roots_direct_count() / F,
+                         "lpc_exact": vb.last_lpc_exact_count() / F,
                          "frames_with_nonzero_status": int((st3 != 0).any(dim=0).sum().item()),
                          "dominant_kernel": dominant_kernel(prof), "kernels_ms": kms}
         row["speech_over_synthetic"] = row["speech"]["value"] / row["synthetic"]["value"]
@@ -711,7 +714,11 @@ def pipeline_shapes(vb, torch, dev, pkg, audio48, hours=1.0, shapes=PIPELINE_SHA
         kms = {k: round(ms / max(c, 1), 3) for k, (ms, c) in prof.items()}
         dom = dominant_kernel(prof)
         rows.append({"frame_len": n, "hop": hop, "frames": F, "value": F * 2 / dt, "ms_per_step": dt / 2 * 1e3, "dominant_kernel": dom,
-                     "kernels_ms": kms, "beside_it": sorted(k for k in kms if PROF_STREAMS.get(k, 0) != 0)})
+                     "kernels_ms": kms, "beside_it": sorted(k for k in kms if PROF_STREAMS.get(k, 0) != 0),
+                     # the fast paths' hand-overs (shares of the frames): one-pass Burg -> direct recursion, conjugate-pair roots ->
+                     # the reference's iteration, Levinson rows redone in double-double
+                     "burg_direct": vb.last_burg_direct_count() / F, "roots_direct": vb.last_roots_direct_count() / F,
+                     "lpc_exact": vb.last_lpc_exact_count() / F})
         del rec, st3
     return rows
 

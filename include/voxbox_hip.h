@@ -533,7 +533,9 @@ int vbx_gather_records_f64(vbx_ctx *ctx, vbx_comm *comm, const double *local, co
  * on when h_plan->continues_next.  n_frames = hi - lo + warm rows as in vbx_track_stitch_f64.  Queue the record gather after
  * it with the same `slot`: vbx_comm_wait(slot) then covers both.  A rank that receives makes the context's stream wait (on
  * the device) until its stitch is through: the repair reads the resonance rows the context holds, which the context's next
- * call overwrites. */
+ * call overwrites.  Errors: argument / plan checks run before the first RCCL call; once this rank's receive is posted its send
+ * is posted too whatever fails in between (the next rank waits for it), and the first error is returned afterwards -- a
+ * VBX_E_* from this call means the chain's rows are not to be trusted: destroy the communicator on EVERY rank. */
 int vbx_comm_stitch_tracks_f64(vbx_ctx *ctx, vbx_comm *comm, vbx_resonance *formants, size_t n_frames, size_t formants_ld,
                                const vbx_shard_plan_t *h_plan, int32_t *d_changed, int slot);
 /* The transfer list of that gather as one rank sees it, on the host (no GPU, no RCCL: what vbx_gather_records_f64 posts,

@@ -6,7 +6,8 @@ an SQ pass exists, vector instructions per frame and the share of SIMD time the 
 FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled (gfx950 tallies a 128-B request of a wide streaming read at
 64 B, MI355X_MICROARCH.md "HBM").  A kernel listed in KEYS that the counter files do not hold is a HARD ERROR (a kernel
 renamed in the sources must not silently drop out of the evidence); shapes that were not profiled (prof_r03.sh quick) are
-skipped as a whole and say so.  usage: tools/prof_commit.py <tag> [git-commit]"""
+skipped as a whole and say so.  usage: tools/prof_commit.py <tag> [git-commit] [subdirectory of profiles/ for the copied files]
+(pmc_traffic.json stays at profiles/pmc_traffic.json: bench.py reads it there)"""
 import glob
 import json
 import os
@@ -17,8 +18,11 @@ import sys
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
-dst = os.path.join(root, "profiles")
-commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+sub = sys.argv[3] if len(sys.argv) > 3 else ""
+dst = os.path.join(root, "profiles", sub) if sub else os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+rel = ("profiles/" + sub + "/" if sub else "profiles/")
+commit = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] else subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
 summ = json.load(open(os.path.join(src, "summary.json")))
 
 for t in glob.glob(os.path.join(src, "trace_*")):
@@ -65,6 +69,9 @@ KEYS = {
                                         "void tracker_sweep_kernel<4>"], "frame"),
     "tracker_chunked": ("pipeline", ["void tracker_spec_kernel<4>", "void tracker_check_kernel<4>", "void tracker_repair_kernel<4>",
                                      "void tracker_sweep_kernel<4>"], "frame"),
+    # round 6: LPC::lpc of the fused call as its own lane-per-row kernel (+ the conditioning probe), and the double-double redo of the rows it lists
+    "lpc_rows": ("pipeline", ["void levinson_rows_kernel_t<12, true>"], "frame"),
+    "lpc_exact_list": ("pipeline", ["vbx::lpc_exact_list_kernel"], "frame"),
     "autocorr_lpc_512": ("config2", ["void autocorr_fewlags_kernel<8, 13, double"], "frame"),
     "pcm16": ("frontend", ["void pcm16_kernel", "pcm16_kernel"], "sample"),
 }
@@ -99,7 +106,7 @@ for key, (wl, prefixes, unit) in KEYS.items():
     write_b = sum(a * n for a, n in wr) / steps_total * 1024.0
     e = {"bytes_per_frame": (fetch_b + write_b) / units, "fetch_bytes_per_frame": fetch_b / units,
          "write_bytes_per_frame": write_b / units, "per": unit, "units_per_step": units, "kernels": prefixes,
-         "source": f"profiles/{tag}_pmc_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+         "source": f"{rel}{tag}_pmc_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                    "FETCH_SIZE x1024 x2, WRITE_SIZE x1024; launches of one step summed)", "commit": commit}
     sq = "pmc_sq_" + wl
     if sq in summ["pmc"]:
@@ -113,9 +120,9 @@ for key, (wl, prefixes, unit) in KEYS.items():
             e.update({"valu_insts_per_frame": insts / units,
                       "valu_busy": act / simd_quads, "wave_quad_cycles_per_wave": wcyc / max(waves, 1),
                       "valu_active_quad_cycles_per_wave": act / max(waves, 1),
-                      "sq_source": f"profiles/{tag}_pmc_counters.json {sq}: SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 / 4 x {N_SIMD} SIMDs)"})
+                      "sq_source": f"{rel}{tag}_pmc_counters.json {sq}: SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 / 4 x {N_SIMD} SIMDs)"})
     traffic[key] = e
-json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+json.dump(traffic, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 for k, v in traffic.items():
     print("%-24s %10.1f B/%s (fetch %.1f + write %.1f)%s" % (k, v["bytes_per_frame"], v["per"], v["fetch_bytes_per_frame"], v["write_bytes_per_frame"],
                                                          "  VALU busy %.2f, %.0f VALU insts/%s" % (v["valu_busy"], v["valu_insts_per_frame"], v["per"]) if "valu_busy" in v else ""))

@@ -430,6 +430,23 @@ __device__ __forceinline__ void trk_frame(const trk_in_t &in, long f, double (&e
     for (int i = 0; i < TRK_PF; i++) pre[i] = (i < in.n_res) ? row[i] : res_t{0.0, 0.0};
     estimate_formants_any<NE>(ef, eb, pre, row, in.n_res, cnt, in.res_count != nullptr, in.general != 0);
 }
+// The chunked scan's steps with the NEXT frame's status, count and leading row entries requested before the current frame is
+// processed (round 6; tracker_kernel above always did): a chunk is a chain of 64 dependent steps, and every step of rounds 4-5
+// began by waiting for its own row to arrive from the L2 / HBM -- the lane's wavefront is alone on its SIMD (1 M frames are
+// 488 wavefronts), nothing else covers that wait.  Same operations on the same values.
+struct trk_row_t { res_t pre[TRK_PF]; int cnt; bool ok; };
+__device__ __forceinline__ void trk_fetch(const trk_in_t &in, long f, trk_row_t &r) {
+    r.ok = (in.frame_status == nullptr) || in.frame_status[f] == 0;
+    r.cnt = (in.res_count != nullptr) ? in.res_count[f] : in.n_res;
+    const res_t *row = in.res + f * (long)in.n_res;
+#pragma unroll
+    for (int i = 0; i < TRK_PF; i++) r.pre[i] = (i < in.n_res) ? row[i] : res_t{0.0, 0.0};
+}
+template <int NE>
+__device__ __forceinline__ void trk_frame_pre(const trk_in_t &in, long f, const trk_row_t &r, double (&ef)[NS], double (&eb)[NS]) {
+    if (!r.ok) return;                                        // a frame whose status is not 0 leaves the estimates untouched (src/lib.rs:75)
+    estimate_formants_any<NE>(ef, eb, r.pre, in.res + f * (long)in.n_res, in.n_res, r.cnt, in.res_count != nullptr, in.general != 0);
+}
 // index of the utterance that holds frame f, and the frame at which the next one starts
 __device__ __forceinline__ long trk_segment_of(const trk_in_t &in, long f, long &next_start) {
     if (in.seg_start == nullptr) { next_start = in.n_frames; return 0; }
@@ -453,7 +470,11 @@ __global__ __launch_bounds__(64) void tracker_spec_kernel(const trk_in_t in, con
     long stop = f_end;
     double ef[NS], eb[NS];
     trk_init<NE>(in, ef, eb);
+    trk_row_t cur;
+    trk_fetch(in, w_begin, cur);
     for (long f = w_begin; f < f_end; f++) {
+        trk_row_t nxt = cur;
+        if (f + 1 < f_end) trk_fetch(in, f + 1, nxt);
         if (f == next_start) {                                 // an utterance starts here: the state is known
             trk_init<NE>(in, ef, eb);
             exact = true;
@@ -468,8 +489,9 @@ __global__ __launch_bounds__(64) void tracker_spec_kernel(const trk_in_t in, con
             for (int e = 0; e < NS; e++) { sp.entry[g * 2 * NS + 2 * e] = ef[e]; sp.entry[g * 2 * NS + 2 * e + 1] = eb[e]; }
             sp.exact[g] = exact ? 1 : 0;
         }
-        trk_frame<NE>(in, f, ef, eb);
+        trk_frame_pre<NE>(in, f, cur, ef, eb);
         if (f >= f_begin) trk_store_row<NE>(in, f, ef, eb);
+        cur = nxt;
     }
     sp.stop[g] = stop;
 }
@@ -510,10 +532,16 @@ __global__ __launch_bounds__(64) void tracker_repair_kernel(const trk_in_t in, c
         sp.entry[g * 2 * NS + 2 * e] = ef[e]; sp.entry[g * 2 * NS + 2 * e + 1] = eb[e];      // what the rows now follow from
     }
     const long stop = sp.stop[g];
+    if (g * TRK_CHUNK >= stop) return;
+    trk_row_t cur;
+    trk_fetch(in, g * TRK_CHUNK, cur);
     for (long f = g * TRK_CHUNK; f < stop; f++) {
-        trk_frame<NE>(in, f, ef, eb);
+        trk_row_t nxt = cur;
+        if (f + 1 < stop) trk_fetch(in, f + 1, nxt);           // (a redo usually ends after a few frames: one row requested in vain)
+        trk_frame_pre<NE>(in, f, cur, ef, eb);
         if (trk_row_is<NE>(in, f, ef, eb)) break;              // met the old scan: its remaining rows stand
         trk_store_row<NE>(in, f, ef, eb);
+        cur = nxt;
     }
 }
 

@@ -318,6 +318,13 @@ int get_interp_dev(vbx_ctx *ctx, int plan, int n, int b_lo, int nb, mfcc_interp_
     auto key = std::make_tuple(plan, n, b_lo, nb);
     auto it = ctx->interp_cache.find(key);
     if (it == ctx->interp_cache.end()) {
+        // a caller that sweeps frame lengths or bands would grow the cache without bound (48-200 KB of device memory per entry):
+        // past 64 entries everything is dropped (every stream drained first: a queued kernel may still read a table)
+        if (ctx->interp_cache.size() >= 64) {
+            VBX_HIP(ctx, hipDeviceSynchronize());
+            for (auto &kv : ctx->interp_cache) if (kv.second.first) (void)hipFree(kv.second.first);
+            ctx->interp_cache.clear();
+        }
         mfcc_interp_t d{};
         void *dev = nullptr;
         {
@@ -325,7 +332,10 @@ int get_interp_dev(vbx_ctx *ctx, int plan, int n, int b_lo, int nb, mfcc_interp_
             std::vector<char> h(bytes, 0);
             if (mfcc_interp_fill(plan, n, b_lo, nb, h.data(), &d)) {
                 VBX_HIP(ctx, hipMalloc(&dev, bytes));
-                VBX_HIP(ctx, hipMemcpy(dev, h.data(), bytes, hipMemcpyHostToDevice));
+                if (hipMemcpy(dev, h.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+                    (void)hipFree(dev);
+                    return fail(ctx, VBX_E_RUNTIME, "get_interp_dev: hipMemcpy of the interpolation tables failed");
+                }
                 char *b = static_cast<char *>(dev);
                 d.rot = reinterpret_cast<const double *>(b);
                 d.coef = reinterpret_cast<const double *>(b + mfcc_interp_coef_offset(plan));

@@ -163,26 +163,34 @@ int vbx_comm_stitch_tracks_f64(vbx_ctx *ctx, vbx_comm *c, vbx_resonance *formant
     VBXC_HIP(ctx, hipEventRecord(c->ready, main));                       // the shard's own scan is done
     VBXC_HIP(ctx, hipStreamWaitEvent(c->stream, c->ready, 0));
     const int n_est = vbx_internal_last_track_n_est(ctx);
+    // From the first NCCL call on, nothing returns before this rank's ncclSend is posted (round-5 advisor finding): the next rank
+    // sits in the matching ncclRecv.  The first error is remembered, the send still goes out (the row it carries may then be
+    // unrepaired: the caller gets the error and must abort the communicator on every rank), and the error is returned last.
+    int first_rc = VBX_SUCCESS;
+    auto keep = [&](int rc) { if (first_rc == VBX_SUCCESS && rc != VBX_SUCCESS) first_rc = rc; };
+    auto hip_ok = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess) keep(fail(ctx, VBX_E_RUNTIME, std::string("vbx_comm_stitch_tracks_f64: ") + what + ": " + hipGetErrorString(e)));
+    };
     if (recv) {
         // the row the previous rank ends with: 2 n_est doubles over the direct link from rank - 1 (it sends after ITS stitch)
         VBXC_NCCL(ctx, ncclRecv(state, (size_t)(2 * n_est), ncclDouble, c->rank - 1, c->nccl, c->stream));
-        int rc = vbx_internal_track_stitch(ctx, (void *)c->stream, formants, n_frames, formants_ld, h_plan->warm, h_plan->stop, state, d_changed);
-        if (rc != VBX_SUCCESS) return rc;
+        keep(vbx_internal_track_stitch(ctx, (void *)c->stream, formants, n_frames, formants_ld, h_plan->warm, h_plan->stop, state, d_changed));
         // the repair reads the resonance rows in the CONTEXT's scratch, which the context's next find_formants / analyze call
         // overwrites: that call must not start before the stitch is through (a wait on the device; it costs the chain's
         // latency -- one tiny message and kernel per rank ahead -- once per step)
-        VBXC_HIP(ctx, hipEventRecord(c->stitched, c->stream));
-        VBXC_HIP(ctx, hipStreamWaitEvent(main, c->stitched, 0));
+        hip_ok(hipEventRecord(c->stitched, c->stream), "hipEventRecord");
+        hip_ok(hipStreamWaitEvent(main, c->stitched, 0), "hipStreamWaitEvent");
     } else if (d_changed) {
-        VBXC_HIP(ctx, hipMemsetAsync(d_changed, 0, sizeof(int32_t), c->stream));
+        hip_ok(hipMemsetAsync(d_changed, 0, sizeof(int32_t), c->stream), "hipMemsetAsync");
     }
     if (send) {
         const double *last = (const double *)formants + (n_frames - 1) * formants_ld;
-        VBXC_NCCL(ctx, ncclSend(last, (size_t)(2 * n_est), ncclDouble, c->rank + 1, c->nccl, c->stream));
+        const ncclResult_t r = ncclSend(last, (size_t)(2 * n_est), ncclDouble, c->rank + 1, c->nccl, c->stream);
+        if (r != ncclSuccess) keep(fail(ctx, VBX_E_RUNTIME, std::string("ncclSend: ") + ncclGetErrorString(r)));
     }
-    VBXC_HIP(ctx, hipEventRecord(c->done[slot], c->stream));
+    hip_ok(hipEventRecord(c->done[slot], c->stream), "hipEventRecord");
     c->used[slot] = true;
-    return VBX_SUCCESS;
+    return first_rc;
 }
 
 int vbx_comm_wait(vbx_ctx *ctx, vbx_comm *c, int slot) {
