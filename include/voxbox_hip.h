@@ -222,7 +222,12 @@ int vbx_lpc_mut_f64(vbx_ctx *ctx, const double *r, size_t n_frames, size_t r_str
 
 /* frame.autocorrelate(n_coeffs+1) [-> .normalize()] -> .lpc(n_coeffs) fused, one pass over the
  * samples (LPCSolver usage, src/spectrum.rs:40-42,470-479).  out_r: [F, n_coeffs+1] (after the
- * optional normalize), out_lpc: [F, n_coeffs+1]; either may be NULL. */
+ * optional normalize), out_lpc: [F, n_coeffs+1]; either may be NULL.
+ * Ill-conditioned rows (round 6; also the LPC column of vbx_analyze_frames_f64): every row's conditioning is probed -- the
+ * recursion repeated on lag sums moved by +-16 eps of r[0] -- and a row such a perturbation moves by more than 1e-6 in the parity
+ * metric is recomputed from the frame's samples with the lag sums and the recursion in double-double: the exact row of the f64
+ * frame, rounded once, where the reference's own f64 row (src/periodic.rs:284 + src/spectrum.rs:63-84) is 1e-6 .. 3e-4 from it
+ * (frame_len <= 4096, n_coeffs <= 31; VBX_LPC_EXACT=0 turns it off). */
 int vbx_autocorr_lpc_f64(vbx_ctx *ctx, const double *x, size_t n_frames, size_t frame_len,
                          size_t stride, const double *window, size_t n_coeffs, int normalize,
                          double *out_r, double *out_lpc);
