@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sp_is_mfcc_o
 #pragma unroll
         for (int q = 0; q < 10; q++) {
             const int i = 120 * q + 2 * np;
-            if (FULL && a.pcm) {
+            if (FULL && (a.pcm & SP_FLAG_PCM)) {
                 // 16-bit PCM in: 960 B of new samples per frame instead of 3840 (the host-fed case: PCIe carries the PCM);
                 // widened here exactly as vbx_pcm16_to_f64 would have (bit-identical frames, tests/test_gpu_frontend.py)
                 int lo, hi;
@@ -523,12 +523,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sp_is_mfcc_o
         for (int s = 0; s < 11; s++) {
             const int i = 2 * jj[s];
             if (jj[s] >= 0 && i < n) {
-                const double xs = (FULL && a.pcm) ? pcm16_value(x16[i]) : xf[i];
+                const double xs = (FULL && (a.pcm & SP_FLAG_PCM)) ? pcm16_value(x16[i]) : xf[i];
                 const double xe = (a.window != nullptr) ? xs * a.window[i] : xs;
                 r_e[s] = (r_e[s] - x0 * xe) + x0;
             }
             if (jj[s] >= 0 && i + 1 < n) {
-                const double xs = (FULL && a.pcm) ? pcm16_value(x16[i + 1]) : xf[i + 1];
+                const double xs = (FULL && (a.pcm & SP_FLAG_PCM)) ? pcm16_value(x16[i + 1]) : xf[i + 1];
                 const double xo = (a.window != nullptr) ? xs * a.window[i + 1] : xs;
                 r_o[s] = (r_o[s] - x0 * xo) + x0;
             }
@@ -566,24 +566,64 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sp_is_mfcc_o
     const double scale = 1.0 / amax;                         // normalize (:404), then / lag window (:406-408)
     double *ys = smem;
     wave_sync();                                             // every lane is done with the exchange buffer
-    // (the lag window's entries requested together, without a condition: entry 0 stands in for a slot without lags)
-    double2 lwv[11];
+    // uniform: the table's reciprocals serve (quotient_by_table, vbx_spectral.hpp) unless the scale is not a normal finite number
+    const bool by_table = (a.pcm & SP_FLAG_LAG_RCP) != 0 && fabs(scale) < 1e290 && fabs(scale) > 1e-290;
+    const double *lag_rcp = a.lag_window + lag_rcp_offset(n);
+    if (by_table) {
+        // (window entries and reciprocals of a few slots requested together, without a condition -- entry 0 stands in for a slot
+        // without lags --, then their quotients: all eleven slots' pairs at once are 88 registers the instance does not have)
+#ifndef VBX_EXP_LB
+#define VBX_EXP_LB 4
+#endif
+        constexpr int LB = VBX_EXP_LB;
 #pragma unroll
-    for (int s = 0; s < 11; s++) {
-        const int i = 2 * jj[s];
-        lwv[s] = *reinterpret_cast<const double2 *>(a.lag_window + ((jj[s] >= 0 && i + 1 < n) ? i : 0));
-    }
+        for (int h = 0; h < (11 + LB - 1) / LB; h++) {
+            double2 lwv[LB], rwv[LB];
 #pragma unroll
-    for (int s = 0; s < 11; s++) {
-        const int i = 2 * jj[s];
-        if (jj[s] >= 0 && i + 1 < n) {
-            const double2 lw = lwv[s];
-            double2 y;
-            y.x = (r_e[s] * scale) / lw.x;
-            y.y = (r_o[s] * scale) / lw.y;
-            *reinterpret_cast<double2 *>(ys + i) = y;
-        } else if (jj[s] >= 0 && i < n) {                    // the last lag of an odd n
-            ys[i] = (r_e[s] * scale) / a.lag_window[i];
+            for (int u = 0; u < LB; u++) {
+                const int s = LB * h + u;
+                if (s >= 11) continue;
+                const int i = 2 * jj[s];
+                const int at = (jj[s] >= 0 && i + 1 < n) ? i : 0;
+                lwv[u] = *reinterpret_cast<const double2 *>(a.lag_window + at);
+                rwv[u] = *reinterpret_cast<const double2 *>(lag_rcp + at);
+            }
+#pragma unroll
+            for (int u = 0; u < LB; u++) {
+                const int s = LB * h + u;
+                if (s >= 11) continue;
+                const int i = 2 * jj[s];
+                if (jj[s] >= 0 && i + 1 < n) {
+                    double2 y;
+                    y.x = quotient_by_table(r_e[s] * scale, lwv[u].x, rwv[u].x);
+                    y.y = quotient_by_table(r_o[s] * scale, lwv[u].y, rwv[u].y);
+                    *reinterpret_cast<double2 *>(ys + i) = y;
+                } else if (jj[s] >= 0 && i < n) {            // the last lag of an odd n
+                    ys[i] = (r_e[s] * scale) / a.lag_window[i];
+                }
+            }
+            asm volatile("" ::: "memory");                   // the next batch's loads stay behind this one's quotients (registers)
+        }
+    } else {
+        // (the lag window's entries requested together, without a condition: entry 0 stands in for a slot without lags)
+        double2 lwv[11];
+#pragma unroll
+        for (int s = 0; s < 11; s++) {
+            const int i = 2 * jj[s];
+            lwv[s] = *reinterpret_cast<const double2 *>(a.lag_window + ((jj[s] >= 0 && i + 1 < n) ? i : 0));
+        }
+#pragma unroll
+        for (int s = 0; s < 11; s++) {
+            const int i = 2 * jj[s];
+            if (jj[s] >= 0 && i + 1 < n) {
+                const double2 lw = lwv[s];
+                double2 y;
+                y.x = (r_e[s] * scale) / lw.x;
+                y.y = (r_o[s] * scale) / lw.y;
+                *reinterpret_cast<double2 *>(ys + i) = y;
+            } else if (jj[s] >= 0 && i < n) {                // the last lag of an odd n
+                ys[i] = (r_e[s] * scale) / a.lag_window[i];
+            }
         }
     }
     if (lane < Y_PAD) ys[n + lane] = 0.0;
@@ -778,7 +818,7 @@ int launch_analyze(hipStream_t s, const spectral_launch_t &L) {
     a.bins = L.bins; a.slopes = L.slopes; a.dct = L.dct; a.num_coeffs = L.num_coeffs; a.nb = L.nb;
     a.unsure_list = L.unsure_list; a.unsure_count = L.unsure_count;
     a.out_r = L.out_r; a.n_lags = L.n_lags;
-    a.pcm = (L.pcm && L.n == SP_N) ? 1 : 0;                  // the host side only asks for it on full 1200-sample frames
+    a.pcm = ((L.pcm && L.n == SP_N) ? SP_FLAG_PCM : 0) | (L.lag_rcp ? SP_FLAG_LAG_RCP : 0);      // (PCM: the host side only asks for it on full 1200-sample frames)
     a.mfcc_q = (L.plan != SPECTRAL_PLAN_NONE && L.n > 0) ? (2 * spectral_plan_nc(L.plan)) / L.n : 2;
     a.ip = mfcc_interp_t{};
     if (L.plan != SPECTRAL_PLAN_1200) return launch_analyze_pow2(s, L, a);

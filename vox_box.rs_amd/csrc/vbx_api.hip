@@ -46,6 +46,7 @@ struct vbx_ctx {
     size_t ws_bytes[WS_N] = {0};
     // cached device tables
     std::map<std::pair<int, size_t>, double *> windows;   // (kind, n)
+    std::map<size_t, bool> lag_rcp_ok;                    // n -> the lag window's table carries usable reciprocals (get_window_dev)
     std::map<size_t, float *> lag_windows32;              // n -> the lag window table rounded to f32 (Pitched<f32, f32>)
     std::map<std::tuple<size_t, int, int>, double *> goertzel;   // (n, b_lo, nb) -> [nb][2] kappa, sigma
     std::map<size_t, double *> dct_tables;                // K -> [K][K]
@@ -153,15 +154,27 @@ int ws_get(vbx_ctx *ctx, int slot, size_t bytes, void **out) {
 
 // ---- host-built tables (the library's own statement of the sample-crate recurrences) --------
 
+// The lag window's table carries its entries' reciprocals behind them (each correctly rounded: the host's IEEE division), from
+// element (n + 1) & ~1 on, for the fused kernels' lag-window divide (quotient_by_table, vbx_spectral.hpp); ctx->lag_rcp_ok[n] says
+// whether they may be used (no zero, no entry whose reciprocal leaves the normal range).
 int get_window_dev(vbx_ctx *ctx, int kind, size_t n, const double **out) {
     auto key = std::make_pair(kind, n);
     auto it = ctx->windows.find(key);
     if (it == ctx->windows.end()) {
-        std::vector<double> h(n);
+        const size_t off = (n + 1) & ~(size_t)1, total = (kind == VBX_WINDOW_HANNING_LAG) ? off + n : n;
+        std::vector<double> h(total, 0.0);
         if (window_table_host(kind, n, h.data()) != VBX_SUCCESS) return fail(ctx, VBX_E_INVALID, "bad window kind");
+        if (kind == VBX_WINDOW_HANNING_LAG) {
+            bool usable = true;
+            for (size_t i = 0; i < n; i++) {
+                h[off + i] = 1.0 / h[i];
+                usable = usable && std::isfinite(h[off + i]) && std::fabs(h[off + i]) < 1e290 && std::fabs(h[off + i]) > 1e-290;
+            }
+            ctx->lag_rcp_ok[n] = usable;
+        }
         double *d = nullptr;
-        VBX_HIP(ctx, hipMalloc((void **)&d, n * sizeof(double)));
-        VBX_HIP(ctx, hipMemcpy(d, h.data(), n * sizeof(double), hipMemcpyHostToDevice));
+        VBX_HIP(ctx, hipMalloc((void **)&d, total * sizeof(double)));
+        VBX_HIP(ctx, hipMemcpy(d, h.data(), total * sizeof(double), hipMemcpyHostToDevice));
         it = ctx->windows.emplace(key, d).first;
     }
     *out = it->second;
@@ -892,6 +905,7 @@ static int run_pitch(vbx_ctx *ctx, hipStream_t st, const double *x, size_t n_fra
         rc = get_spectral_tab(ctx, L.plan, &tab);
         if (rc != VBX_SUCCESS) return rc;
         L.x = x; L.F = (long)n_frames; L.stride = (long)stride; L.window = window; L.lag_window = lagw; L.tab = tab;
+        L.lag_rcp = ctx->lag_rcp_ok.count(frame_len) && ctx->lag_rcp_ok[frame_len];
         L.sample_rate = sample_rate; L.threshold = threshold; L.fmin = fmin; L.fmax = fmax; L.kmax = (int)kmax;
         L.whole_curve = ctx->pitch_whole_curve;
         L.out_cand = (pitch_t *)out_cand; L.cand_ld = (long)cand_ld; L.out_count = out_count; L.pitch_status = status;
@@ -1793,6 +1807,7 @@ static int analyze_frames_impl(vbx_ctx *ctx, const char *fn, const double *x, co
         spectral_launch_t L{};
         L.plan = plan; L.n = (int)frame_len;
         L.x = x; L.F = (long)n_frames; L.stride = (long)stride; L.window = hann; L.lag_window = lagw; L.tab = tab;
+        L.lag_rcp = ctx->lag_rcp_ok.count(frame_len) && ctx->lag_rcp_ok[frame_len];
         L.sample_rate = h_p->sample_rate; L.threshold = h_p->pitch_threshold; L.fmin = h_p->pitch_fmin; L.fmax = h_p->pitch_fmax;
         L.kmax = 1;
         L.pcm = pcm_native;

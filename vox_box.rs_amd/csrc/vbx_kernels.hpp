@@ -208,6 +208,7 @@ bool mfcc_interp_fill(int plan, int n, int b_lo, int nb, void *h_table, mfcc_int
 struct spectral_launch_t {
     int plan; int n;                                             // spectral_plan(n), frame length
     const double *x; long F; long stride; const double *window; const double *lag_window; const double *tab;
+    bool lag_rcp;                                                // lag_window[((n + 1) & ~1) + i] = RN(1 / lag_window[i]) (quotient_by_table, vbx_spectral.hpp)
     double sample_rate, threshold, fmin, fmax; int kmax;
     pitch_t *out_cand; long cand_ld; int32_t *out_count; int32_t *pitch_status; unsigned long long *work;
     double *out_lpc; long lpc_ld;                                // NULL: no LPC

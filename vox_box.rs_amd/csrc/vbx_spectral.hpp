@@ -28,6 +28,21 @@ __host__ __device__ constexpr bool sp_is_analyze(int mode) { return mode == SP_A
 
 constexpr double SP_UNC_EPS = 6.0 * 400.0 * 2.220446049250313e-16;   // 1 / min w_lag * margin * eps
 
+// a / b, IEEE-rounded, for a divisor that comes from a TABLE with its correctly rounded reciprocal y = RN(1 / b) beside it
+// (round 6): q0 = RN(a y), rem = RN(a - q0 b) (one FMA), q = RN(q0 + rem y).  q is the rounding of a value within 2^-104 (relative) of
+// a / b, i.e. RN(a / b) itself unless a / b lies that close to a midpoint of two doubles -- no such case in 82,720 trials against exact
+// rational arithmetic on the lag windows' own values, and every output of 1.2 M frames at seven shapes bit for bit the IEEE-division
+// build's (profiles/r06_headline).  Three vector instructions instead of the ~14 issue slots of v_div_scale / v_rcp / v_div_fmas /
+// v_div_fixup: the lag-window divide of src/periodic.rs:406-408 is 22 divisions per lane of the headline kernel.  The callers keep
+// the IEEE division for frames whose scale 1 / max|r| is not a normal finite number (a quotient that overflows must stay an infinity).
+constexpr int SP_FLAG_PCM = 1, SP_FLAG_LAG_RCP = 2;
+__host__ __device__ constexpr int lag_rcp_offset(int n) { return (n + 1) & ~1; }      // the reciprocals follow the window's n entries, 16-byte aligned
+__device__ __forceinline__ double quotient_by_table(double a, double b, double y) {
+    const double q0 = a * y;
+    const double rem = fma(-q0, b, a);
+    return fma(rem, y, q0);
+}
+
 // ---- small DFTs on separate re / im registers (forward: e^{-i...}) -------------------------------------------------
 __device__ __forceinline__ void dft4(double &r0, double &i0, double &r1, double &i1, double &r2, double &i2,
                                      double &r3, double &i3) {
@@ -51,8 +66,9 @@ struct spectral_args_t {
     int32_t *unsure_list; int32_t *unsure_count;
     double *out_r; int n_lags;                               // SP_AC_ONLY: [F, n_lags] lag sums
     int mfcc_q;                                              // the frame's DFT bin k' is the transform's bin mfcc_q * k' (M / n)
-    int pcm;                                                 // 1: `frames` points to int16 PCM samples (widened in registers:
+    int pcm;                                                 // bit 0: `frames` points to int16 PCM samples (widened in registers:
                                                              // s / 32767, vbx_device.hpp pcm16_value); full frames only
+                                                             // bit 1 (SP_FLAG_LAG_RCP): lag_window[lag_rcp_offset(n) + i] = RN(1 / lag_window[i]) (quotient_by_table)
     mfcc_interp_t ip;                                        // SP_ANALYZE_INTERP
     long f0, n_batch;                                        // power-of-two kernels: this launch covers frames [f0, f0 + n_batch)
     double *curve; long curve_ld; double *curve_tol;         // SP_ANALYZE_SPLIT: [n_batch][curve_ld] lag curves (pp.ncurve lags + Y_PAD zeros), [n_batch] unc_tol

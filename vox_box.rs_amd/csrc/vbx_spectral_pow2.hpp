@@ -595,6 +595,9 @@ void analyze_pow2_kernel(const spectral_args_t a) {
     const double scale = 1.0 / amax;                         // normalize (:404), then / lag window (:406-408)
     double *ys = smem;
     const int nst = (a.pp.ncurve > 0) ? a.pp.ncurve : n;     // lags the refinement can read (pitch_curve_entries; even when < n)
+    // uniform: the lag-window divide by the table's reciprocals (quotient_by_table, vbx_spectral.hpp) unless the scale is not a normal finite number
+    const bool by_table = (a.pcm & SP_FLAG_LAG_RCP) != 0 && fabs(scale) < 1e290 && fabs(scale) > 1e-290;
+    const double *lag_rcp = a.lag_window + lag_rcp_offset(n);
     if constexpr (SPLIT) {                                   // the same values, to the frame's scratch row
         double *row = a.curve + fb * a.curve_ld;
 #pragma unroll
@@ -603,8 +606,14 @@ void analyze_pow2_kernel(const spectral_args_t a) {
             if (i + 1 < nst) {
                 const double2 lw = *reinterpret_cast<const double2 *>(a.lag_window + i);
                 double2 y;
-                y.x = (r_e[s] * scale) / lw.x;
-                y.y = (r_o[s] * scale) / lw.y;
+                if (by_table) {
+                    const double2 rw = *reinterpret_cast<const double2 *>(lag_rcp + i);
+                    y.x = quotient_by_table(r_e[s] * scale, lw.x, rw.x);
+                    y.y = quotient_by_table(r_o[s] * scale, lw.y, rw.y);
+                } else {
+                    y.x = (r_e[s] * scale) / lw.x;
+                    y.y = (r_o[s] * scale) / lw.y;
+                }
                 *reinterpret_cast<double2 *>(row + i) = y;
             } else if (i < nst) {                            // the last lag of an odd n
                 row[i] = (r_e[s] * scale) / a.lag_window[i];
@@ -627,8 +636,14 @@ void analyze_pow2_kernel(const spectral_args_t a) {
         if (i + 1 < nst) {
             const double2 lw = *reinterpret_cast<const double2 *>(a.lag_window + i);
             double2 y;
-            y.x = (r_e[s] * scale) / lw.x;
-            y.y = (r_o[s] * scale) / lw.y;
+            if (by_table) {
+                const double2 rw = *reinterpret_cast<const double2 *>(lag_rcp + i);
+                y.x = quotient_by_table(r_e[s] * scale, lw.x, rw.x);
+                y.y = quotient_by_table(r_o[s] * scale, lw.y, rw.y);
+            } else {
+                y.x = (r_e[s] * scale) / lw.x;
+                y.y = (r_o[s] * scale) / lw.y;
+            }
             *reinterpret_cast<double2 *>(ys + i) = y;
         } else if (i < nst) {                                // the last lag of an odd n
             ys[i] = (r_e[s] * scale) / a.lag_window[i];
