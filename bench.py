@@ -72,6 +72,7 @@ ALG_BYTES = {
     "mfcc": lambda n, hop, p: hop * 8 + 13 * 8,
     "pcm16": lambda n, hop, p: 10,
     "lpc_rows": lambda n, hop, p: 2 * (p + 1) * 8,                # lag sums in, coefficients out (in place in the record's LPC row)
+    "mfcc_rows": lambda n, hop, p: 2 * 13 * 8,                    # filter sums in, coefficients out (in place in the record's MFCC row)
     "lpc_exact_list": lambda n, hop, p: hop * 8 + (p + 1) * 8,    # per frame ON THE LIST (~0.1 % of the synthetic signal's frames)
 }
 

@@ -366,4 +366,31 @@ void launch_dct_rows(hipStream_t s, const double *in, long rows, int n, const do
     hipLaunchKernelGGL(dct_rows_kernel, dim3((unsigned)rows), dim3(64), 0, s, in, rows, n, dct_table, out);
 }
 
+// The deferred tail of MFCC::mfcc (src/spectrum.rs:434-439, :391-397; vbx_mfcc_tail.hpp mfcc_tail_q with defer): every row holds its
+// num_coeffs mel filter sums; log10 clamped at 1e-10 (f64::max: NaN yields the other operand), then the DCT-II x 2, in place, one row
+// per lane.  The operations of mfcc_tail_q's last two steps in their order (bit-identical rows: tools/experiments/bitcompare_libs.py).
+__global__ __launch_bounds__(64) void mfcc_rows_kernel(double *__restrict__ rows, long n_rows, long ld, int num_coeffs,
+                                                       const double *__restrict__ dct_table) {
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    double *r = rows + row * ld;
+    double en[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const double tot = r[(j < num_coeffs) ? j : num_coeffs - 1];
+        const double lg = log10(tot);
+        en[j] = (lg != lg || lg < 1.0e-10) ? 1.0e-10 : lg;
+    }
+    for (int w = 0; w < num_coeffs; w++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) if (j < num_coeffs) acc = acc + en[j] * dct_table[w * num_coeffs + j];
+        r[w] = 2.0 * acc;
+    }
+}
+
+void launch_mfcc_rows(hipStream_t s, double *rows, long F, long ld, int num_coeffs, const double *dct) {
+    hipLaunchKernelGGL(mfcc_rows_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, s, rows, F, ld, num_coeffs, dct);
+}
+
 }  // namespace vbx

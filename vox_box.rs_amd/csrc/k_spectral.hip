@@ -375,7 +375,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sp_is_mfcc_o
         VBX_PHASE(a.work, f, 14);
         double2 t2v = double2{0.0, 0.0};                     // the products may lie over the stage-2 twiddles: requested now, put back after the tail
         if constexpr (PITCH) t2v = a.tab[SP_T2 + np];
-        if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld, a.work, f);
+        if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld, a.work, f, (a.pcm & SP_FLAG_MFCC_DEFER) != 0);
         else mfcc_tail_m(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
         if (a.mfcc_status != nullptr && lane == 0) a.mfcc_status[f] = 0;
         wave_sync();
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sp_is_mfcc_o
         }
         wave_sync();
         VBX_PHASE(a.work, f, 13);
-        if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld, a.work, f);
+        if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld, a.work, f, (a.pcm & SP_FLAG_MFCC_DEFER) != 0);
         else mfcc_tail_m(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
         if (a.mfcc_status != nullptr && lane == 0) a.mfcc_status[f] = 0;
         wave_sync();
@@ -818,7 +818,7 @@ int launch_analyze(hipStream_t s, const spectral_launch_t &L) {
     a.bins = L.bins; a.slopes = L.slopes; a.dct = L.dct; a.num_coeffs = L.num_coeffs; a.nb = L.nb;
     a.unsure_list = L.unsure_list; a.unsure_count = L.unsure_count;
     a.out_r = L.out_r; a.n_lags = L.n_lags;
-    a.pcm = ((L.pcm && L.n == SP_N) ? SP_FLAG_PCM : 0) | (L.lag_rcp ? SP_FLAG_LAG_RCP : 0);      // (PCM: the host side only asks for it on full 1200-sample frames)
+    a.pcm = ((L.pcm && L.n == SP_N) ? SP_FLAG_PCM : 0) | (L.lag_rcp ? SP_FLAG_LAG_RCP : 0) | ((L.mfcc_defer && L.num_coeffs <= 16) ? SP_FLAG_MFCC_DEFER : 0);      // (PCM: the host side only asks for it on full 1200-sample frames)
     a.mfcc_q = (L.plan != SPECTRAL_PLAN_NONE && L.n > 0) ? (2 * spectral_plan_nc(L.plan)) / L.n : 2;
     a.ip = mfcc_interp_t{};
     if (L.plan != SPECTRAL_PLAN_1200) return launch_analyze_pow2(s, L, a);

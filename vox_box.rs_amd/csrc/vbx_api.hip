@@ -61,6 +61,7 @@ struct vbx_ctx {
     std::map<std::tuple<int, int, int, int>, std::pair<void *, mfcc_interp_t>> interp_cache;   // (plan, n, b_lo, nb) -> tables of the interpolated MFCC bins (first == nullptr: no such form)
     int last_mfcc_interp = 0;                             // the last vbx_mfcc_f64 call took the interpolated form (tests)
     int last_spectral_split = 0;                          // the last fused / pitch call ran as two kernels (tests)
+    int mfcc_defer = 1;                                   // VBX_MFCC_DEFER=0: log10 + DCT of the fused call's MFCC rows inside the frame's wavefront (rounds 2-5; A/B)
     int lpc_exact = 1;                                    // VBX_LPC_EXACT=0: no conditioning probe, no double-double redo of flagged LPC rows (rounds 1-5; tests, A/B)
     int pow2_split = -1;                                  // VBX_POW2_SPLIT=0: the 4096-point plan as ONE kernel (transforms and refinement fused, as before round 5; tests, A/B)
     int mfcc_interp = -1;                                 // VBX_MFCC_INTERP=0: never (the chirp-z kernel beside the fused one, as before round 5; tests, A/B)
@@ -508,6 +509,7 @@ int vbx_ctx_create(vbx_ctx **out, int device, void *hip_stream) {
     { const char *e = std::getenv("VBX_MFCC_DFT2"); ctx->mfcc_force_dft2 = e && e[0] == '1'; }
     { const char *e = std::getenv("VBX_MFCC_MFMA"); ctx->mfcc_force_mfma = e && e[0] == '1'; }
     { const char *e = std::getenv("VBX_MFCC_CZT"); ctx->mfcc_czt = e ? (e[0] == '1' ? 1 : 0) : -1; }
+    { const char *e = std::getenv("VBX_MFCC_DEFER"); ctx->mfcc_defer = (e && e[0] == '0') ? 0 : 1; }
     { const char *e = std::getenv("VBX_LPC_EXACT"); ctx->lpc_exact = (e && e[0] == '0') ? 0 : 1; }
     { const char *e = std::getenv("VBX_POW2_SPLIT"); ctx->pow2_split = e ? (e[0] == '0' ? 0 : 1) : -1; }
     { const char *e = std::getenv("VBX_MFCC_INTERP"); ctx->mfcc_interp = e ? (e[0] == '0' ? 0 : 1) : -1; }
@@ -830,7 +832,10 @@ static int launch_spectral(vbx_ctx *ctx, hipStream_t st, spectral_launch_t &L, c
             L.curve_ws = (double *)cw; L.curve_ws_bytes = (frames < 1024 ? 1024 : frames) * rowb + 64;
         } else (void)hipGetLastError();
     }
+    // MFCC::mfcc's log10 + DCT out of the frame's wavefront (mfcc_tail_q's `defer`): the kernel leaves the filter sums in the row
+    L.mfcc_defer = L.out_mfcc != nullptr && !L.mfcc_only && L.num_coeffs >= 1 && L.num_coeffs <= 16 && ctx->mfcc_defer;
     { Prof p(ctx, prof_name, st); ctx->last_spectral_split = launch_analyze(st, L); }
+    if (L.mfcc_defer) { Prof p(ctx, "mfcc_rows", st); launch_mfcc_rows(st, L.out_mfcc, L.F, L.mfcc_ld, L.num_coeffs, L.dct); }
     {
         Prof p(ctx, "pitch_direct_fallback", st);
         // a fixed grid over a count only the device knows (almost always zero).  Every workgroup of this kernel allocates the

@@ -208,6 +208,7 @@ bool mfcc_interp_fill(int plan, int n, int b_lo, int nb, void *h_table, mfcc_int
 struct spectral_launch_t {
     int plan; int n;                                             // spectral_plan(n), frame length
     const double *x; long F; long stride; const double *window; const double *lag_window; const double *tab;
+    bool mfcc_defer;                                             // the MFCC rows leave the kernel as filter sums; launch_mfcc_rows finishes them (num_coeffs <= 16)
     bool lag_rcp;                                                // lag_window[((n + 1) & ~1) + i] = RN(1 / lag_window[i]) (quotient_by_table, vbx_spectral.hpp)
     double sample_rate, threshold, fmin, fmax; int kmax;
     pitch_t *out_cand; long cand_ld; int32_t *out_count; int32_t *pitch_status; unsigned long long *work;
@@ -228,6 +229,8 @@ bool spectral_supported(int n, int lpc_order, int mfcc_nb, int mfcc_b_lo, int nu
 int launch_analyze(hipStream_t s, const spectral_launch_t &L);       // 1: the call ran as two kernels (SP_ANALYZE_SPLIT), 0: one
 // k_lpc_exact.hip: LPC::lpc(p) of the listed frames from double-double lag sums and a double-double recursion (the exact
 // answer rounded once), over a list only the device knows the length of
+// k_mfcc.hip: log10 (clamped at 1e-10) + DCT of rows of mel filter sums, in place, a lane per row (the deferred tail of MFCC::mfcc, vbx_mfcc_tail.hpp)
+void launch_mfcc_rows(hipStream_t s, double *rows, long F, long ld, int num_coeffs, const double *dct);
 bool lpc_exact_supported(int n, int p);                               // frames of 2..4096 samples, orders 1..31
 void launch_lpc_exact_list(hipStream_t s, const int32_t *frame_list, const int32_t *list_count, int grid, const double *x, int n,
                            long stride, const double *window, bool pcm, int p, double *out_lpc, long lpc_ld);

@@ -45,7 +45,8 @@ __device__ __forceinline__ void mfcc_tail_m(const double *pu, const double *pd, 
 // Must be called from converged code.
 __device__ __forceinline__ void mfcc_tail_q(const double *pu, const double *pd, double *en, const int32_t *bins,
                                             const double *dct_table, int num_coeffs, int b_lo, int lane,
-                                            double *out_row, unsigned long long *work = nullptr, long f = 0) {
+                                            double *out_row, unsigned long long *work = nullptr, long f = 0,
+                                            const bool defer = false) {
     VBX_PHASE_INIT();
     const int w = lane >> 2, sub = lane & 3;
     const bool have = w < num_coeffs;
@@ -72,6 +73,13 @@ __device__ __forceinline__ void mfcc_tail_q(const double *pu, const double *pd, 
     }
     VBX_PHASE(work, f, 10);
     const double tot = group_sum<4>(up_sum + down_sum);
+    // defer (round 6, the fused frame loop): the filter's sum goes into the frame's MFCC row as it is; mfcc_rows_kernel (k_mfcc.hip)
+    // takes log10, the clamp and the DCT afterwards, a LANE per row -- ~200 vector instructions of this wavefront (the log's range
+    // reduction and polynomial, sixteen table loads, the DCT) for 13 numbers one lane handles.  Same operations in the same order.
+    if (defer) {
+        if (have && sub == 0) out_row[w] = tot;
+        return;
+    }
     if (have && sub == 0) {
         const double lg = log10(tot);
         en[w] = (lg != lg || lg < 1.0e-10) ? 1.0e-10 : lg;    // f64::max(1e-10): NaN yields the other operand

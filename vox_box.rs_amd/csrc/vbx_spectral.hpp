@@ -35,7 +35,7 @@ constexpr double SP_UNC_EPS = 6.0 * 400.0 * 2.220446049250313e-16;   // 1 / min 
 // build's (profiles/r06_headline).  Three vector instructions instead of the ~14 issue slots of v_div_scale / v_rcp / v_div_fmas /
 // v_div_fixup: the lag-window divide of src/periodic.rs:406-408 is 22 divisions per lane of the headline kernel.  The callers keep
 // the IEEE division for frames whose scale 1 / max|r| is not a normal finite number (a quotient that overflows must stay an infinity).
-constexpr int SP_FLAG_PCM = 1, SP_FLAG_LAG_RCP = 2;
+constexpr int SP_FLAG_PCM = 1, SP_FLAG_LAG_RCP = 2, SP_FLAG_MFCC_DEFER = 4;      // MFCC_DEFER: mfcc_tail_q leaves the filter sums in the row (mfcc_rows_kernel finishes)
 __host__ __device__ constexpr int lag_rcp_offset(int n) { return (n + 1) & ~1; }      // the reciprocals follow the window's n entries, 16-byte aligned
 __device__ __forceinline__ double quotient_by_table(double a, double b, double y) {
     const double q0 = a * y;

@@ -411,7 +411,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
             for (int i = 0; i < (R * 16 + NT - 1) / NT; i++) t2v[i] = a.tab[G::T2 + ((tid + NT * i < R * 16) ? tid + NT * i : 0)];
         }
         if (wave == 0) {
-            if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
+            if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld, nullptr, 0, (a.pcm & SP_FLAG_MFCC_DEFER) != 0);
             else mfcc_tail_m(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
             if (a.mfcc_status != nullptr && lane == 0) a.mfcc_status[f] = 0;
         }
@@ -512,7 +512,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
         }
         pow2_sync<W>();
         if (wave == 0) {
-            if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
+            if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld, nullptr, 0, (a.pcm & SP_FLAG_MFCC_DEFER) != 0);
             else mfcc_tail_m(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
             if (a.mfcc_status != nullptr && lane == 0) a.mfcc_status[f] = 0;
         }
