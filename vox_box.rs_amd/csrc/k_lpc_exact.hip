@@ -48,15 +48,27 @@ __device__ __forceinline__ dd dd_mul(dd x, dd y) {
     p.l = p.l + (x.h * y.l + x.l * y.h);
     return fast_two_sum(p.h, p.l);
 }
-__device__ __forceinline__ dd dd_div(dd x, dd y) {            // three quotient digits: ~1e-32 relative
+__device__ __forceinline__ dd dd_div(dd x, dd y) {            // three quotient digits from ONE reciprocal: ~1e-32 relative
 #pragma clang fp contract(off)
-    const double q1 = x.h / y.h;
+    const double yi = 1.0 / y.h;
+    const double q1 = x.h * yi;
     dd r = dd_add(x, dd_neg(dd_mul(y, dd{q1, 0.0})));
-    const double q2 = r.h / y.h;
+    const double q2 = r.h * yi;
     r = dd_add(r, dd_neg(dd_mul(y, dd{q2, 0.0})));
-    const double q3 = r.h / y.h;
+    const double q3 = r.h * yi;
     dd q = fast_two_sum(q1, q2);
     return dd_add(q, dd{q3, 0.0});
+}
+// sum of n <= 16 double-doubles as a balanced tree: four dependent additions instead of fifteen (a listed frame is a latency:
+// its wavefront is alone on its SIMD, nothing else covers a chain)
+template <int N>
+__device__ __forceinline__ dd dd_tree_sum(dd (&t)[N], const int n) {      // n <= N entries (n known after unrolling: the guards fold away)
+#pragma unroll
+    for (int stride = 1; stride < N; stride *= 2) {
+#pragma unroll
+        for (int i = 0; i + stride < N; i += 2 * stride) if (i + stride < n) t[i] = dd_add(t[i], t[i + stride]);
+    }
+    return t[0];
 }
 
 constexpr int LX_FPW = 16;            // frames per wavefront pass: their recursions run one per lane afterwards
@@ -167,9 +179,11 @@ __global__ __launch_bounds__(64) void lpc_exact_list_kernel(const int32_t *__res
                 for (int k = 1; k <= P12; k++) ac[k] = dd{0.0, 0.0};
 #pragma unroll
                 for (int i = 1; i <= P12; i++) {
-                    dd acc = r[i];
+                    dd terms[P12 + 1];                       // r[i] and the i - 1 products, summed as a tree (any order: 1e-30)
+                    terms[0] = r[i];
 #pragma unroll
-                    for (int j = 1; j < i; j++) acc = dd_add(acc, dd_mul(ac[j], r[i - j]));
+                    for (int j = 1; j <= P12; j++) terms[j] = (j < i) ? dd_mul(ac[j], r[i - j]) : dd{0.0, 0.0};
+                    const dd acc = dd_tree_sum<P12 + 1>(terms, i);
                     const dd k = dd_div(dd_neg(acc), err);
                     ac[i] = k;
 #pragma unroll
@@ -203,11 +217,20 @@ __global__ __launch_bounds__(64) void lpc_exact_list_kernel(const int32_t *__res
 
 bool lpc_exact_supported(int n, int p) { return p >= 1 && p + 1 <= LX_NLMAX && n >= 2 && n <= 4096; }
 
-void launch_lpc_exact_list(hipStream_t s, const int32_t *frame_list, const int32_t *list_count, int grid, const double *x, int n,
+void launch_lpc_exact_list(hipStream_t s, const int32_t *frame_list, const int32_t *list_count, int cus, const double *x, int n,
                            long stride, const double *window, bool pcm, int p, double *out_lpc, long lpc_ld) {
     const size_t nx = (size_t)n + LX_NLMAX + 1;
-    const size_t lds = (((nx + 1) & ~(size_t)1) + LX_KB * 65 * 2) * sizeof(double) + 3 * (size_t)LX_NLMAX * LX_FPW * sizeof(dd);
-    hipLaunchKernelGGL(lpc_exact_list_kernel, dim3((unsigned)grid), dim3(64), lds, s, frame_list, list_count, x, n, stride, window,
+    // order 12 runs its recursion in registers: no rows in LDS (acs / tms), more workgroups per CU
+    const size_t rows = (p + 1 == 13) ? 1 : 3;
+    const size_t lds = (((nx + 1) & ~(size_t)1) + LX_KB * 65 * 2) * sizeof(double) + rows * (size_t)LX_NLMAX * LX_FPW * sizeof(dd);
+    // A grid the chip holds AT ONCE (LDS-limited workgroups per CU): the list's length is only known on the device, every workgroup
+    // takes ceil(count / grid) frames (<= 16 per pass), and a frame is ~10-30 us of dependent double-double arithmetic -- with a grid
+    // of several residencies the first one's workgroups held all the work and the kernel lasted two or three of them (round 6: config
+    // 2's 1,000 listed frames took 70 us on a grid of 2,048).
+    size_t per_cu = (160 * 1024) / lds;
+    per_cu = per_cu < 1 ? 1 : per_cu > 8 ? 8 : per_cu;
+    const unsigned grid = (unsigned)((cus > 0 ? cus : 256) * per_cu);
+    hipLaunchKernelGGL(lpc_exact_list_kernel, dim3(grid), dim3(64), lds, s, frame_list, list_count, x, n, stride, window,
                        pcm ? 1 : 0, p + 1, out_lpc, lpc_ld);
 }
 

@@ -855,7 +855,7 @@ static int launch_spectral(vbx_ctx *ctx, hipStream_t st, spectral_launch_t &L, c
         if (L.lpc_list != nullptr) {
             Prof p(ctx, "lpc_exact_list", st);
             const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
-            launch_lpc_exact_list(st, L.lpc_list, L.lpc_count, cus * 8, L.x, L.n, L.stride, L.window, L.pcm, SPECTRAL_LPC_ORDER, L.out_lpc, L.lpc_ld);
+            launch_lpc_exact_list(st, L.lpc_list, L.lpc_count, cus, L.x, L.n, L.stride, L.window, L.pcm, SPECTRAL_LPC_ORDER, L.out_lpc, L.lpc_ld);
         }
     }
     return check_launch(ctx, "launch_spectral");
@@ -976,7 +976,7 @@ static int run_autocorr_lpc(vbx_ctx *ctx, hipStream_t st, const double *x, size_
         if (lpc_list == nullptr) return;
         Prof p(ctx, "lpc_exact_list", st);
         const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
-        launch_lpc_exact_list(st, lpc_list, lpc_count, cus * 8, x, (int)frame_len, (long)stride, window, false, (int)n_coeffs, out_lpc, (long)lpc_ld);
+        launch_lpc_exact_list(st, lpc_list, lpc_count, cus, x, (int)frame_len, (long)stride, window, false, (int)n_coeffs, out_lpc, (long)lpc_ld);
     };
     if (fewlags_supported((int)frame_len, n_lags, out_lpc != nullptr)) {
         { Prof p(ctx, "autocorr_lpc", st);

@@ -232,7 +232,7 @@ int launch_analyze(hipStream_t s, const spectral_launch_t &L);       // 1: the c
 // k_mfcc.hip: log10 (clamped at 1e-10) + DCT of rows of mel filter sums, in place, a lane per row (the deferred tail of MFCC::mfcc, vbx_mfcc_tail.hpp)
 void launch_mfcc_rows(hipStream_t s, double *rows, long F, long ld, int num_coeffs, const double *dct);
 bool lpc_exact_supported(int n, int p);                               // frames of 2..4096 samples, orders 1..31
-void launch_lpc_exact_list(hipStream_t s, const int32_t *frame_list, const int32_t *list_count, int grid, const double *x, int n,
+void launch_lpc_exact_list(hipStream_t s, const int32_t *frame_list, const int32_t *list_count, int cus, const double *x, int n,
                            long stride, const double *window, bool pcm, int p, double *out_lpc, long lpc_ld);
 
 // the f32 instantiation (Sample = f32): the same kernels with float frames and float outputs
