@@ -71,7 +71,7 @@ ALG_BYTES = {
     "tracker_chunked": lambda n, hop, p: 2 * ((p // 2) * 16 + 8) + 64,   # warm-up: every row is read twice
     "mfcc": lambda n, hop, p: hop * 8 + 13 * 8,
     "pcm16": lambda n, hop, p: 10,
-    "lpc_rows": lambda n, hop, p: 2 * (p + 1) * 8,                # lag sums in, coefficients out (in place in the record's LPC row)
+    "lpc_rows": lambda n, hop, p: 2 * (p + 1) * 8 + 2 * 13 * 8,    # lag sums in, coefficients out (in place in the record's LPC row) + the MFCC row's deferred tail
     "mfcc_rows": lambda n, hop, p: 2 * 13 * 8,                    # filter sums in, coefficients out (in place in the record's MFCC row)
     "lpc_exact_list": lambda n, hop, p: hop * 8 + (p + 1) * 8,    # per frame ON THE LIST (~0.1 % of the synthetic signal's frames)
 }

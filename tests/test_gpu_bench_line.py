@@ -65,6 +65,10 @@ def test_default_workload_line():
         assert 0.0 <= row["speech"]["burg_direct"] <= 1.0 and row["speech"]["roots_direct"] >= 0.0
         assert row["speech"]["dominant_kernel"] == "analyze"        # the critical stream's kernel, not a co-resident one's event time
     assert all(r["dominant_kernel"] in ("analyze", "pitch") for r in sub["pipeline_shapes"]["shapes"])
+    # round 6: the fast paths' hand-over shares per shape -- on the synthetic signal the one-pass Burg hands <= 2 % of the frames of
+    # ANY shape to the direct recursion, and a fraction of a per cent of the Levinson rows are redone exactly
+    for r in sub["pipeline_shapes"]["shapes"]:
+        assert 0.0 <= r["burg_direct"] <= 0.02 and 0.0 <= r["roots_direct"] <= 0.02 and -1e-4 <= r["lpc_exact"] <= 0.02, r      # (-1 / F: the call wrote no probed LPC rows)
     c2 = sub["config2"]["roofline"]
     assert c2["bound"] == "hbm" and c2["kernel"] == "autocorr_lpc" and 0.4 < c2["frac"] < 1.0
     assert c2["traffic"] is not None and abs(c2["traffic"] / sub["config2"]["frames"] - 4304) < 0.05 * 4304

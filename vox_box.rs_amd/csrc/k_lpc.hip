@@ -5,6 +5,7 @@
 //            src/spectrum.rs:63-92 (lpc_mut / lpc).
 #include "vbx_autocorr.hpp"
 #include "vbx_kernels.hpp"
+#include "vbx_mfcc_tail.hpp"
 
 namespace vbx {
 
@@ -300,14 +301,20 @@ __global__ void levinson_rows_kernel(const T *__restrict__ r, long n_rows, long 
 // LPC_PROBE_TOL / 2 of the exact answer (the lag sums' own error is < 8 eps of r[0] by two transforms, ~1 eps by direct sums).
 // IN PLACE is allowed (r == out, r_stride == out_ld): the fused kernels leave r[0..12] in the frame's LPC row.
 
+// mfcc_rows != NULL: the same lane also finishes the row's MFCC (the deferred tail of MFCC::mfcc, k_mfcc.hip mfcc_row_tail: log10 + DCT of
+// the num_coeffs mel filter sums the fused kernel left there) -- in the fused call's record the two rows are neighbours, one pass
+// over the record's cache lines instead of two.
 template <int P, bool PROBE>
 __global__ __launch_bounds__(64) void levinson_rows_kernel_t(const double *__restrict__ r, long n_rows, long r_stride, double *__restrict__ out,
-                                                             long out_ld, int32_t *__restrict__ lpc_list, int32_t *__restrict__ lpc_count) {
+                                                             long out_ld, int32_t *__restrict__ lpc_list, int32_t *__restrict__ lpc_count,
+                                                             double *__restrict__ mfcc_rows, long mfcc_ld, int num_coeffs,
+                                                             const double *__restrict__ dct_table) {
     const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
     double rr[P + 1], a0[P + 1];
 #pragma unroll
     for (int k = 0; k <= P; k++) rr[k] = r[row * r_stride + k];
+    if (mfcc_rows != nullptr) mfcc_row_tail(mfcc_rows + row * mfcc_ld, num_coeffs, dct_table);
     levinson_uniform<P>(rr, a0);
     double *aco = out + row * out_ld;
 #pragma unroll
@@ -456,12 +463,14 @@ void launch_levinson_rows(hipStream_t s, const double *r, long rows, long r_stri
     hipLaunchKernelGGL(levinson_rows_kernel<double>, dim3((unsigned)((rows + bs - 1) / bs)), dim3(bs), 0, s, r, rows, r_stride, p, out, out_ld, out_kc);
 }
 void launch_levinson_rows_probe(hipStream_t s, const double *r, long rows, long r_stride, int p, double *out, long out_ld,
-                                int32_t *lpc_list, int32_t *lpc_count) {
+                                int32_t *lpc_list, int32_t *lpc_count, double *mfcc_rows, long mfcc_ld, int num_coeffs, const double *dct) {
     const int bs = 64;
     const dim3 grid((unsigned)((rows + bs - 1) / bs));
     if (p == 12) {                                           // the fused kernels' order: rows in registers
-        if (lpc_list != nullptr) hipLaunchKernelGGL((levinson_rows_kernel_t<12, true>), grid, dim3(bs), 0, s, r, rows, r_stride, out, out_ld, lpc_list, lpc_count);
-        else hipLaunchKernelGGL((levinson_rows_kernel_t<12, false>), grid, dim3(bs), 0, s, r, rows, r_stride, out, out_ld, lpc_list, lpc_count);
+        if (lpc_list != nullptr) hipLaunchKernelGGL((levinson_rows_kernel_t<12, true>), grid, dim3(bs), 0, s, r, rows, r_stride, out, out_ld, lpc_list, lpc_count,
+                                                    mfcc_rows, mfcc_ld, num_coeffs, dct);
+        else hipLaunchKernelGGL((levinson_rows_kernel_t<12, false>), grid, dim3(bs), 0, s, r, rows, r_stride, out, out_ld, lpc_list, lpc_count,
+                                mfcc_rows, mfcc_ld, num_coeffs, dct);
         return;
     }
     if (lpc_list == nullptr) { launch_levinson_rows(s, r, rows, r_stride, p, out, out_ld, nullptr); return; }

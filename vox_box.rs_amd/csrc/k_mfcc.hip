@@ -13,6 +13,7 @@
 // K x K DCT-II (x2) is applied from a host-built cosine table.
 #include "vbx_device.hpp"
 #include "vbx_kernels.hpp"
+#include "vbx_mfcc_tail.hpp"
 
 namespace vbx {
 
@@ -373,20 +374,7 @@ __global__ __launch_bounds__(64) void mfcc_rows_kernel(double *__restrict__ rows
                                                        const double *__restrict__ dct_table) {
     const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
-    double *r = rows + row * ld;
-    double en[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const double tot = r[(j < num_coeffs) ? j : num_coeffs - 1];
-        const double lg = log10(tot);
-        en[j] = (lg != lg || lg < 1.0e-10) ? 1.0e-10 : lg;
-    }
-    for (int w = 0; w < num_coeffs; w++) {
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < 16; j++) if (j < num_coeffs) acc = acc + en[j] * dct_table[w * num_coeffs + j];
-        r[w] = 2.0 * acc;
-    }
+    mfcc_row_tail(rows + row * ld, num_coeffs, dct_table);
 }
 
 void launch_mfcc_rows(hipStream_t s, double *rows, long F, long ld, int num_coeffs, const double *dct) {

@@ -833,9 +833,11 @@ static int launch_spectral(vbx_ctx *ctx, hipStream_t st, spectral_launch_t &L, c
         } else (void)hipGetLastError();
     }
     // MFCC::mfcc's log10 + DCT out of the frame's wavefront (mfcc_tail_q's `defer`): the kernel leaves the filter sums in the row
-    L.mfcc_defer = L.out_mfcc != nullptr && !L.mfcc_only && L.num_coeffs >= 1 && L.num_coeffs <= 16 && ctx->mfcc_defer;
+    // (the 1200-point plan only: in the power-of-two kernels the deferred form changes the register allocation -- thirteen index registers
+    // spilled across the second transform, 3 KB of scratch traffic per frame -- for the same ~1 %; they keep the tail)
+    L.mfcc_defer = L.out_mfcc != nullptr && !L.mfcc_only && L.num_coeffs >= 1 && L.num_coeffs <= 16 && ctx->mfcc_defer && L.plan == SPECTRAL_PLAN_1200;
     { Prof p(ctx, prof_name, st); ctx->last_spectral_split = launch_analyze(st, L); }
-    if (L.mfcc_defer) { Prof p(ctx, "mfcc_rows", st); launch_mfcc_rows(st, L.out_mfcc, L.F, L.mfcc_ld, L.num_coeffs, L.dct); }
+    if (L.mfcc_defer && L.out_lpc == nullptr) { Prof p(ctx, "mfcc_rows", st); launch_mfcc_rows(st, L.out_mfcc, L.F, L.mfcc_ld, L.num_coeffs, L.dct); }
     {
         Prof p(ctx, "pitch_direct_fallback", st);
         // a fixed grid over a count only the device knows (almost always zero).  Every workgroup of this kernel allocates the
@@ -851,7 +853,8 @@ static int launch_spectral(vbx_ctx *ctx, hipStream_t st, spectral_launch_t &L, c
         // the fused kernel left r[0..12] in every frame's LPC row: LPC::lpc(12) in place, one row per lane (+ the conditioning probe), then
         // the listed rows again from their frames in double-double
         { Prof p(ctx, "lpc_rows", st);
-          launch_levinson_rows_probe(st, L.out_lpc, L.F, L.lpc_ld, SPECTRAL_LPC_ORDER, L.out_lpc, L.lpc_ld, L.lpc_list, L.lpc_count); }
+          launch_levinson_rows_probe(st, L.out_lpc, L.F, L.lpc_ld, SPECTRAL_LPC_ORDER, L.out_lpc, L.lpc_ld, L.lpc_list, L.lpc_count,
+                                     L.mfcc_defer ? L.out_mfcc : nullptr, L.mfcc_ld, L.num_coeffs, L.dct); }        // (+ the deferred MFCC tail of the same record)
         if (L.lpc_list != nullptr) {
             Prof p(ctx, "lpc_exact_list", st);
             const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;

@@ -49,7 +49,8 @@ constexpr double LPC_PROBE_EPS = 16.0 * 2.220446049250313e-16;
 #endif
 constexpr double LPC_PROBE_TOL = VBX_EXP_LPC_PROBE_TOL;
 void launch_levinson_rows_probe(hipStream_t s, const double *r, long rows, long r_stride, int p, double *out, long out_ld,
-                                int32_t *lpc_list, int32_t *lpc_count);
+                                int32_t *lpc_list, int32_t *lpc_count, double *mfcc_rows = nullptr, long mfcc_ld = 0, int num_coeffs = 0,
+                                const double *dct = nullptr /* p == 12: the same lane finishes the row's deferred MFCC tail */);
 
 // k_burg.hip
 bool burg_supported(int n, int p);

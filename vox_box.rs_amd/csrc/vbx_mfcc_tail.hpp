@@ -100,4 +100,28 @@ __device__ __forceinline__ void mfcc_tail_q(const double *pu, const double *pd, 
     VBX_PHASE(work, f, 12);
 }
 
+// The deferred tail of MFCC::mfcc (src/spectrum.rs:434-439, :391-397; mfcc_tail_q with `defer`) on ONE row by ONE lane: the row holds its
+// num_coeffs (<= 16) mel filter sums; log10 clamped at 1e-10 (f64::max: NaN yields the other operand), then the DCT-II x 2, in place.  The
+// operations of mfcc_tail_q's last two steps in their order (bit-identical rows: tools/experiments/bitcompare_libs.py); the results leave
+// in one burst of stores (thirteen 8-byte stores spread over the DCT's arithmetic were written back line by line: 600 B per row).
+__device__ __forceinline__ void mfcc_row_tail(double *__restrict__ r, int num_coeffs, const double *__restrict__ dct_table) {
+    double en[16], outv[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const double tot = r[(j < num_coeffs) ? j : num_coeffs - 1];
+        const double lg = log10(tot);
+        en[j] = (lg != lg || lg < 1.0e-10) ? 1.0e-10 : lg;
+    }
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        double acc = 0.0;
+        const int wr = (w < num_coeffs) ? w : num_coeffs - 1;
+#pragma unroll
+        for (int j = 0; j < 16; j++) if (j < num_coeffs) acc = acc + en[j] * dct_table[wr * num_coeffs + j];
+        outv[w] = 2.0 * acc;
+    }
+#pragma unroll
+    for (int w = 0; w < 16; w++) if (w < num_coeffs) r[w] = outv[w];
+}
+
 }  // namespace vbx

@@ -24,6 +24,63 @@
 
 namespace vbx {
 
+// y[lag] = (r[lag] * scale) / w_lag (src/periodic.rs:404-408) for the thread's NS pairs of lags (jj[s] = the pair's index; entries past
+// nst are not stored), into the LDS curve or the split form's scratch row.  by_table: the divide by the window table's reciprocals
+// (quotient_by_table, vbx_spectral.hpp), a few slots' window entries and reciprocals requested together and their quotients formed
+// before the next slots' loads may start (a compiler barrier: all NS slots' pairs at once are registers the instances do not have).
+template <int NS>
+__device__ __forceinline__ void store_lag_curve(double *dst, const double (&r_e)[NS], const double (&r_o)[NS], const int (&jj)[NS], int nst,
+                                                double scale, const double *__restrict__ lag_window, const double *__restrict__ lag_rcp,
+                                                bool by_table) {
+    if (by_table) {
+        constexpr int LB = 4;
+#pragma unroll
+        for (int h = 0; h < (NS + LB - 1) / LB; h++) {
+            double2 lwv[LB], rwv[LB];
+#pragma unroll
+            for (int u = 0; u < LB; u++) {
+                const int s = LB * h + u;
+                if (s >= NS) continue;
+                const int i = 2 * jj[s];
+                const int at = (i + 1 < nst) ? i : 0;
+                lwv[u] = *reinterpret_cast<const double2 *>(lag_window + at);
+                rwv[u] = *reinterpret_cast<const double2 *>(lag_rcp + at);
+            }
+#pragma unroll
+            for (int u = 0; u < LB; u++) {
+                const int s = LB * h + u;
+                if (s >= NS) continue;
+                const int i = 2 * jj[s];
+                if (i + 1 < nst) {
+                    double2 y;
+                    y.x = quotient_by_table(r_e[s] * scale, lwv[u].x, rwv[u].x);
+                    y.y = quotient_by_table(r_o[s] * scale, lwv[u].y, rwv[u].y);
+                    *reinterpret_cast<double2 *>(dst + i) = y;
+                } else if (i < nst) {                        // the last lag of an odd n
+                    dst[i] = (r_e[s] * scale) / lag_window[i];
+                }
+            }
+            asm volatile("" ::: "memory");
+        }
+        return;
+    }
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const int i = 2 * jj[s];
+        if (i + 1 < nst) {
+            const double2 lw = *reinterpret_cast<const double2 *>(lag_window + i);
+            double2 y;
+            y.x = (r_e[s] * scale) / lw.x;
+            y.y = (r_o[s] * scale) / lw.y;
+            *reinterpret_cast<double2 *>(dst + i) = y;
+        } else if (i < nst) {                                // the last lag of an odd n
+            dst[i] = (r_e[s] * scale) / lag_window[i];
+        }
+    }
+}
+
+
+
 #ifndef VBX_POW2_U1_WAVES
 #define VBX_POW2_U1_WAVES 3                     // Nc = 1024, the fused analysis: three wavefronts per SIMD (168 registers, pinned twiddle batches)
 #endif
@@ -411,7 +468,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
             for (int i = 0; i < (R * 16 + NT - 1) / NT; i++) t2v[i] = a.tab[G::T2 + ((tid + NT * i < R * 16) ? tid + NT * i : 0)];
         }
         if (wave == 0) {
-            if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld, nullptr, 0, (a.pcm & SP_FLAG_MFCC_DEFER) != 0);
+            if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
             else mfcc_tail_m(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
             if (a.mfcc_status != nullptr && lane == 0) a.mfcc_status[f] = 0;
         }
@@ -512,7 +569,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
         }
         pow2_sync<W>();
         if (wave == 0) {
-            if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld, nullptr, 0, (a.pcm & SP_FLAG_MFCC_DEFER) != 0);
+            if (a.num_coeffs <= 16) mfcc_tail_q(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
             else mfcc_tail_m(pu, pd, en, a.bins, a.dct, a.num_coeffs, b_lo, lane, a.out_mfcc + f * a.mfcc_ld);
             if (a.mfcc_status != nullptr && lane == 0) a.mfcc_status[f] = 0;
         }
@@ -600,25 +657,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
     const double *lag_rcp = a.lag_window + lag_rcp_offset(n);
     if constexpr (SPLIT) {                                   // the same values, to the frame's scratch row
         double *row = a.curve + fb * a.curve_ld;
-#pragma unroll
-        for (int s = 0; s < NS; s++) {
-            const int i = 2 * jj[s];
-            if (i + 1 < nst) {
-                const double2 lw = *reinterpret_cast<const double2 *>(a.lag_window + i);
-                double2 y;
-                if (by_table) {
-                    const double2 rw = *reinterpret_cast<const double2 *>(lag_rcp + i);
-                    y.x = quotient_by_table(r_e[s] * scale, lw.x, rw.x);
-                    y.y = quotient_by_table(r_o[s] * scale, lw.y, rw.y);
-                } else {
-                    y.x = (r_e[s] * scale) / lw.x;
-                    y.y = (r_o[s] * scale) / lw.y;
-                }
-                *reinterpret_cast<double2 *>(row + i) = y;
-            } else if (i < nst) {                            // the last lag of an odd n
-                row[i] = (r_e[s] * scale) / a.lag_window[i];
-            }
-        }
+        store_lag_curve<NS>(row, r_e, r_o, jj, nst, scale, a.lag_window, lag_rcp, by_table);
         if (tid < Y_PAD + (nst & 1)) row[nst + tid] = 0.0;   // (an odd n: one more, its row is read in pairs)
         if (tid == 0) a.curve_tol[fb] = SP_UNC_EPS * fabs(s0) * scale;
 #ifndef VBX_EXP_NO_EXACT_TAIL
@@ -630,25 +669,7 @@ void analyze_pow2_kernel(const spectral_args_t a) {
         return;
     }
     pow2_sync<W>();                                          // every thread is done with the exchange buffer
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-        const int i = 2 * jj[s];
-        if (i + 1 < nst) {
-            const double2 lw = *reinterpret_cast<const double2 *>(a.lag_window + i);
-            double2 y;
-            if (by_table) {
-                const double2 rw = *reinterpret_cast<const double2 *>(lag_rcp + i);
-                y.x = quotient_by_table(r_e[s] * scale, lw.x, rw.x);
-                y.y = quotient_by_table(r_o[s] * scale, lw.y, rw.y);
-            } else {
-                y.x = (r_e[s] * scale) / lw.x;
-                y.y = (r_o[s] * scale) / lw.y;
-            }
-            *reinterpret_cast<double2 *>(ys + i) = y;
-        } else if (i < nst) {                                // the last lag of an odd n
-            ys[i] = (r_e[s] * scale) / a.lag_window[i];
-        }
-    }
+    store_lag_curve<NS>(ys, r_e, r_o, jj, nst, scale, a.lag_window, lag_rcp, by_table);
     if (tid < Y_PAD) ys[nst + tid] = 0.0;
     if constexpr (W > 1) {
         __syncthreads();                                     // the curve is complete in LDS: the refinement is one wavefront's work
