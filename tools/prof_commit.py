@@ -70,8 +70,7 @@ KEYS = {
     "tracker_chunked": ("pipeline", ["void tracker_spec_kernel<4>", "void tracker_check_kernel<4>", "void tracker_repair_kernel<4>",
                                      "void tracker_sweep_kernel<4>"], "frame"),
     # round 6: LPC::lpc of the fused call as its own lane-per-row kernel (+ the conditioning probe), and the double-double redo of the rows it lists
-    "lpc_rows": ("pipeline", ["void levinson_rows_kernel_t<12, true>"], "frame"),
-    "mfcc_rows": ("pipeline", ["mfcc_rows_kernel", "vbx::mfcc_rows_kernel"], "frame"),      # MFCC::mfcc's log10 + DCT, a lane per row (round 6)
+    "lpc_rows": ("pipeline", ["void levinson_rows_kernel_t<12, true>"], "frame"),          # + the deferred MFCC tail of the same record
     "lpc_exact_list": ("pipeline", ["lpc_exact_list_kernel", "vbx::lpc_exact_list_kernel"], "frame"),
     "autocorr_lpc_512": ("config2", ["void autocorr_fewlags_kernel<8, 13, double"], "frame"),
     "pcm16": ("frontend", ["void pcm16_kernel", "pcm16_kernel"], "sample"),
