@@ -9,7 +9,8 @@
 // zero-padded windowed frame, length M = 2N = 2400:
 //     X = FFT_M(x_w padded)                      |X[k]|^2 -> inverse FFT -> S[lag] = sum_i x[i] x[i+lag], every lag
 //     X[2k'] = the N-point DFT bin k' of the frame  -> the |X|^2 and |X| the mel filters of MFCC::mfcc read
-//     S[0..12]                                      -> the Levinson recursion of LPC::lpc
+//     S[0..12]                                      -> the lag sums of LPC::lpc (round 6: the recursion itself, like MFCC's log10 + DCT,
+//                                                      runs afterwards in levinson_rows_kernel_t, k_lpc.hip: a lane per record)
 // (Q1: the reference's fold is seeded with x[0], r[lag] = S[lag] - x0*x[lag] + x0; applied afterwards.)  This replaces
 // 1.44 MFLOP of autocorrelation MACs per frame by about 0.3 MFLOP and removes the MFCC and LPC kernels' passes over the
 // same frame.  Accuracy: forward + inverse f64 FFT, error ~1e-16 * S[0] per lag (measured against the oracle in
