@@ -36,6 +36,7 @@ struct vbx_ctx {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     std::string last_error;
+    size_t curve_failed_bytes = 0;                        // a WS_CURVE size hipMalloc refused (launch_spectral: not retried per call)
     std::string arch;
     int cu_count = 0;
     // workspaces (grown on demand, never shrunk)
@@ -827,10 +828,15 @@ static int launch_spectral(vbx_ctx *ctx, hipStream_t st, spectral_launch_t &L, c
                             ? spectral_split_row_bytes(L.n, L.sample_rate, L.fmin) : 0;      // (a list region in LDS, kmax > 64: the fused kernel)
     if (rowb) {
         const size_t frames = (size_t)L.F < 131072 ? (size_t)L.F : 131072;
+        const size_t need = (frames < 1024 ? 1024 : frames) * rowb + 64;
         void *cw = nullptr;
-        if (ws_get(ctx, vbx_ctx::WS_CURVE, (frames < 1024 ? 1024 : frames) * rowb + 64, &cw) == VBX_SUCCESS) {      // (no memory for it: the fused form)
-            L.curve_ws = (double *)cw; L.curve_ws_bytes = (frames < 1024 ? 1024 : frames) * rowb + 64;
-        } else (void)hipGetLastError();
+        // (no memory for it: the fused form.  A size that failed once is not asked for again on every call -- each attempt drains the
+        // streams and fails a multi-GB hipMalloc --, and the fallback is not an error of this call: the error string is put back)
+        if (ctx->curve_failed_bytes == 0 || need < ctx->curve_failed_bytes) {
+            const std::string before = ctx->last_error;
+            if (ws_get(ctx, vbx_ctx::WS_CURVE, need, &cw) == VBX_SUCCESS) { L.curve_ws = (double *)cw; L.curve_ws_bytes = need; }
+            else { (void)hipGetLastError(); ctx->curve_failed_bytes = need; ctx->last_error = before; g_last_error = before; }
+        }
     }
     // MFCC::mfcc's log10 + DCT out of the frame's wavefront (mfcc_tail_q's `defer`): the kernel leaves the filter sums in the row
     // (the 1200-point plan only: in the power-of-two kernels the deferred form changes the register allocation -- thirteen index registers
