@@ -769,8 +769,19 @@ ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic
                  "launches_per_step", "algorithmic_bytes_per_frame", "flops_per_frame", "sinc_terms_per_frame")
 
 
+def _json_default(o):
+    """numpy scalars / arrays that found their way into a record must not cost the line"""
+    if isinstance(o, np.generic):
+        return o.item()
+    if isinstance(o, np.ndarray):
+        return o.tolist()
+    return str(o)
+
+
 def _sig(x, digits=6):
     """Floats to `digits` significant digits (the detail file keeps them whole); containers recursively."""
+    if isinstance(x, np.generic):
+        x = x.item()
     if isinstance(x, float):
         return float(f"{x:.{digits}g}") if np.isfinite(x) else None
     if isinstance(x, dict):
@@ -845,14 +856,14 @@ def compact_line(out, detail_path=None):
         line["parity"] = "GPU == oracle through the C ABI (tests/ -m gpu); oracle pinned by the reference's 26 KATs + WAV fixtures; see detail"
     if detail_path:
         line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path.startswith(ROOT) else detail_path
-    text = json.dumps(_sig(line))
+    text = json.dumps(_sig(line), default=_json_default)
     if len(text) > LINE_LIMIT:                                           # never again an unparsable line: shed the optional parts
         for k in ("sub_benchmarks", "parity", "kernels_ms", "roofline_hbm"):
             if k == "sub_benchmarks" and isinstance(line.get(k), dict):
                 line[k] = {n: (v if isinstance(v, (int, float)) else "see detail") for n, v in line[k].items()}
             else:
                 line.pop(k, None)
-            text = json.dumps(_sig(line))
+            text = json.dumps(_sig(line), default=_json_default)
             if len(text) <= LINE_LIMIT:
                 break
     return text
@@ -865,7 +876,7 @@ def emit(out, detail_path):
         try:
             os.makedirs(os.path.dirname(os.path.abspath(detail_path)), exist_ok=True)
             with open(detail_path, "w") as f:
-                json.dump(out, f, indent=1)
+                json.dump(out, f, indent=1, default=_json_default)
                 f.write("\n")
             written = os.path.abspath(detail_path)
         except OSError as e:
