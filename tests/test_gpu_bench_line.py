@@ -49,6 +49,11 @@ def test_default_workload_line():
     assert r["bound"] in ("hbm", "fp64_valu") and r["kernel"] == "analyze" and 0.0 < r["frac"] < 1.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 * r["frac"]      # (the line carries six significant digits)
     assert r["traffic"] is not None and r["traffic"] > 0.9 * 4064 * d["config"]["frames_per_gpu"]     # at least the algorithmic bytes
+    # round 6: the traffic is MEASURED IN THE RUN (two rocprofv3 --pmc child passes), agrees with the committed evidence file's
+    # figure within 5 %, and stays below 1.3x the algorithmic bytes
+    assert r["traffic_source"].startswith("measured in this run") and "live_traffic_error" not in d, (r["traffic_source"], d.get("live_traffic_error"))
+    live, committed = full["roofline"]["traffic_source"]["bytes_per_frame"], full["roofline"]["traffic_committed_evidence"]["bytes_per_frame"]
+    assert abs(live - committed) <= 0.05 * committed and 4064 <= live <= 1.3 * 4064, (live, committed)
     # the headline fraction is the EXECUTED one (FFTs + evaluated sinc terms); the comparison with the reference's O(N^2) sums has its own key
     assert r["frac"] < 0.5 and r["reference_sums_at_peak_ratio"] > r["frac"] and 0.3 < r["issue_frac"] <= 1.0
     assert full["roofline"]["reference_sums_at_peak"]["ratio"] == pytest.approx(r["reference_sums_at_peak_ratio"], rel=1e-5)

@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 cd $R
-B="--no-cpu --no-sub"
+B="--no-cpu --no-sub --no-live-traffic"
 run() { local name=$1; shift; rocprofv3 "$@" > $O/$name.log 2>&1; grep '^{"metric' $O/$name.log > $O/$name.bench_line.json; }
 # kernel traces
 run trace_pipeline --kernel-trace --stats --output-format csv -d $O/trace_pipeline -- python3 bench.py --hours 2 --steps 3 --warmup 1 $B

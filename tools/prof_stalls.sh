@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/stalls_$TAG
 rm -rf $O; mkdir -p $O
 cd $R
-B="--no-cpu --no-sub"
+B="--no-cpu --no-sub --no-live-traffic"
 run() { local name=$1; shift; rocprofv3 "$@" > $O/$name.log 2>&1; }
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"
 P2="SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_INST_CYCLES_SALU SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_SMEM GRBM_GUI_ACTIVE"
