@@ -272,8 +272,8 @@ LIVE_KERNELS = {"analyze": "void vbx::analyze_kernel<true, true, true, 0,"}
 
 
 def live_traffic(dom, hours=0.5, timeout_s=90.0):
-    """HBM bytes per frame of the dominant kernel, MEASURED IN THIS RUN (round 6; the round-5 review: a figure read from a committed
-    file can never be refuted by a driver line): two child processes, each `rocprofv3 --pmc <one counter> -- python3 bench.py --hours
+    """HBM bytes per frame (and the vector ALU's busy share) of the dominant kernel, MEASURED IN THIS RUN (round 6; the round-5 review: a figure read from a committed
+    file can never be refuted by a driver line): three child processes, each `rocprofv3 --pmc <one counter; the third: one SQ group> -- python3 bench.py --hours
     0.5 --steps 1 --warmup 0 --no-cpu --no-sub --no-live-traffic` (separate passes, counters only -- no trace domains --, as
     MI355X_MICROARCH.md prescribes; the children are fresh processes, started from /tmp), FETCH_SIZE x 1024 x 2 (gfx950 tallies a 128-B
     request of a streaming read at 64 B) + WRITE_SIZE x 1024 of the kernel's ONE launch over the child's 180,000 frames.
@@ -289,31 +289,35 @@ def live_traffic(dom, hours=0.5, timeout_s=90.0):
     got, frames = {}, None
     tmp = tempfile.mkdtemp(prefix="vbx_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out_dir = os.path.join(tmp, counter)
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE"):
+            out_dir = os.path.join(tmp, counter.split()[0])
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "VBX_BENCH_SELFCHECK"):
                 env.pop(k, None)
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", sys.executable, os.path.abspath(__file__),
+            cmd = [exe, "--pmc"] + counter.split() + ["--output-format", "csv", "-d", out_dir, "--", sys.executable, os.path.abspath(__file__),
                    "--hours", str(hours), "--steps", "1", "--warmup", "0", "--no-cpu", "--no-sub", "--no-live-traffic",
-                   "--detail", os.path.join(tmp, counter + "_detail.json")]
+                   "--detail", os.path.join(tmp, counter.split()[0] + "_detail.json")]
             p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
             line = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
             if p.returncode != 0 or not line:
                 raise RuntimeError(f"rocprofv3 --pmc {counter} child failed (rc {p.returncode}): {p.stderr[-300:]}")
             frames = json.loads(line[-1])["config"]["frames_per_gpu"]
-            vals = []
-            for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
-                for r in csv.DictReader(open(f)):
-                    if r["Kernel_Name"].startswith(prefix) and r["Counter_Name"] == counter:
-                        vals.append(float(r["Counter_Value"]))
-            if len(vals) != 1:
-                raise RuntimeError(f"{counter}: expected one launch of '{prefix}', found {len(vals)}")
-            got[counter] = vals[0]
+            for name in counter.split():
+                vals = []
+                for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        if r["Kernel_Name"].startswith(prefix) and r["Counter_Name"] == name:
+                            vals.append(float(r["Counter_Value"]))
+                if len(vals) != 1:
+                    raise RuntimeError(f"{name}: expected one launch of '{prefix}', found {len(vals)}")
+                got[name] = vals[0]
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     fetch_b, write_b = got["FETCH_SIZE"] * 1024.0 * 2.0, got["WRITE_SIZE"] * 1024.0
+    # SQ_ACTIVE_INST_VALU counts quad-cycles summed over every SIMD; GRBM_GUI_ACTIVE is summed over the 8 XCDs (tools/prof_commit.py)
+    simd_quads = got["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0
     return (fetch_b + write_b) / frames, {
+        "valu_busy": got["SQ_ACTIVE_INST_VALU"] / simd_quads, "valu_insts_per_frame": got["SQ_INSTS_VALU"] / max(got["SQ_WAVES"], 1.0),
         "bytes_per_frame": (fetch_b + write_b) / frames, "fetch_bytes_per_frame": fetch_b / frames, "write_bytes_per_frame": write_b / frames,
         "source": f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate child passes of this bench, {hours:g} h = {frames} frames, one launch of "
                   f"{prefix}...>; FETCH_SIZE x1024 x2, WRITE_SIZE x1024)", "commit": "this run"}
@@ -820,7 +824,7 @@ def cross_rank_check(vb, torch, dev, pkg, params, REC, rows_all, frame_len, stri
 LINE_LIMIT = 6000
 CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                  "dtype", "data")
-ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "issue_frac", "ms_avg", "frames_per_launch",
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "issue_frac", "valu_insts_per_frame", "ms_avg", "frames_per_launch",
                  "launches_per_step", "algorithmic_bytes_per_frame", "flops_per_frame", "sinc_terms_per_frame")
 
 
@@ -1230,6 +1234,10 @@ def run_rank(args):
                         r["traffic_committed_evidence"] = r.get("traffic_source")
                         r["traffic"] = bpf * r["frames_per_launch"]
                         r["traffic_source"] = src
+                if "issue_frac" in roof:                              # the vector ALU's busy share and the instruction count, from this run's SQ pass
+                    roof["issue_frac_committed_evidence"] = roof["issue_frac"]
+                    roof["issue_frac"], roof["valu_insts_per_frame"] = src["valu_busy"], src["valu_insts_per_frame"]
+                    roof["issue_frac_source"] = "live: rocprofv3 --pmc SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 / 4 x 1024 SIMDs), a child pass of this bench"
             else:
                 out["live_traffic_error"] = lt.get("error")
         # what "parity" means for this line: GPU == oracle is tested; oracle == reference is pinned

@@ -54,6 +54,9 @@ def test_default_workload_line():
     assert r["traffic_source"].startswith("measured in this run") and "live_traffic_error" not in d, (r["traffic_source"], d.get("live_traffic_error"))
     live, committed = full["roofline"]["traffic_source"]["bytes_per_frame"], full["roofline"]["traffic_committed_evidence"]["bytes_per_frame"]
     assert abs(live - committed) <= 0.05 * committed and 4064 <= live <= 1.3 * 4064, (live, committed)
+    # ... and so are the vector ALU's busy share and the kernel's vector instructions per frame (an SQ child pass)
+    assert full["roofline"]["issue_frac_source"].startswith("live") and 9000 < r["valu_insts_per_frame"] < 13000
+    assert abs(r["issue_frac"] - full["roofline"]["issue_frac_committed_evidence"]) < 0.05
     # the headline fraction is the EXECUTED one (FFTs + evaluated sinc terms); the comparison with the reference's O(N^2) sums has its own key
     assert r["frac"] < 0.5 and r["reference_sums_at_peak_ratio"] > r["frac"] and 0.3 < r["issue_frac"] <= 1.0
     assert full["roofline"]["reference_sums_at_peak"]["ratio"] == pytest.approx(r["reference_sums_at_peak_ratio"], rel=1e-5)
