@@ -490,3 +490,28 @@ def test_the_launcher_kills_ranks_that_ignore_terminate():
           subprocess.Popen([sys.executable, "-c", "pass"])]
     buf = io.StringIO()
     assert bench.supervise(ok, relay=buf) == 0 and buf.getvalue().strip() == '{"v": 1}'
+
+
+def test_bench_dry_run_at_world_8_plans_the_chain_of_seven_hand_offs():
+    """`python bench.py --gpus 8` (dry run: rendezvous over gloo, host arithmetic only): eight ranks, BASELINE config 5's 100 h as ONE
+    utterance split evenly -- every rank but the first warms its tracker up over 64 frames and continues its predecessor's track,
+    every rank but the last passes its own on; the gather's transfer list has rank 0 receive seven shards in rank order."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["VBX_BENCH_DRY_RUN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["dry_run"] and line["n_gpus"] == 8 and sorted(x[0] for x in line["ranks"]) == list(range(8))
+    F = 4_500_000
+    plans = line["shard_plans"]
+    assert [p["lo"] for p in plans] == [r_ * F for r_ in range(8)] and [p["hi"] for p in plans] == [(r_ + 1) * F for r_ in range(8)]
+    assert [p["warm"] for p in plans] == [0] + [64] * 7
+    assert [p["continues_prev"] for p in plans] == [0] + [1] * 7 and [p["continues_next"] for p in plans] == [1] * 7 + [0]
+    gp = line["gather_plan"]
+    assert gp["rows"] == [F] * 8 and gp["offsets"] == [r_ * F * gp["record_doubles"] for r_ in range(8)]
+    assert gp["ops_by_rank"][0] == [3] + [1] * 7                              # rank 0: its own rows in place, a receive per peer
+    for r_ in range(1, 8):
+        assert gp["ops_by_rank"][r_] == [2] + [0] * 7                          # every peer: one send to rank 0
