@@ -271,6 +271,26 @@ def measured_traffic(kernel, frames):
 LIVE_KERNELS = {"analyze": "void vbx::analyze_kernel<true, true, true, 0,"}
 
 
+def counter_values(out_dir, prefix, names):
+    """{counter: value} of the ONE launch of the kernel whose name starts with `prefix` in rocprofv3's *counter_collection.csv files under
+    out_dir (columns Kernel_Name, Counter_Name, Counter_Value: one row per dispatch and counter).  Anything but exactly one launch is an
+    error: a kernel renamed in the sources must not silently read as zero traffic."""
+    import csv
+    import glob
+    out = {}
+    for name in names:
+        vals = []
+        for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    if r["Kernel_Name"].startswith(prefix) and r["Counter_Name"] == name:
+                        vals.append(float(r["Counter_Value"]))
+        if len(vals) != 1:
+            raise RuntimeError(f"{name}: expected one launch of '{prefix}', found {len(vals)}")
+        out[name] = vals[0]
+    return out
+
+
 def live_traffic(dom, hours=0.5, timeout_s=90.0):
     """HBM bytes per frame (and the vector ALU's busy share) of the dominant kernel, MEASURED IN THIS RUN (round 6; the round-5 review: a figure read from a committed
     file can never be refuted by a driver line): three child processes, each `rocprofv3 --pmc <one counter; the third: one SQ group> -- python3 bench.py --hours
@@ -278,8 +298,6 @@ def live_traffic(dom, hours=0.5, timeout_s=90.0):
     MI355X_MICROARCH.md prescribes; the children are fresh processes, started from /tmp), FETCH_SIZE x 1024 x 2 (gfx950 tallies a 128-B
     request of a streaming read at 64 B) + WRITE_SIZE x 1024 of the kernel's ONE launch over the child's 180,000 frames.
     Returns (bytes_per_frame, source dict) or raises."""
-    import csv
-    import glob
     import shutil
     import tempfile
     prefix = LIVE_KERNELS[dom]
@@ -302,15 +320,7 @@ def live_traffic(dom, hours=0.5, timeout_s=90.0):
             if p.returncode != 0 or not line:
                 raise RuntimeError(f"rocprofv3 --pmc {counter} child failed (rc {p.returncode}): {p.stderr[-300:]}")
             frames = json.loads(line[-1])["config"]["frames_per_gpu"]
-            for name in counter.split():
-                vals = []
-                for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
-                    for r in csv.DictReader(open(f)):
-                        if r["Kernel_Name"].startswith(prefix) and r["Counter_Name"] == name:
-                            vals.append(float(r["Counter_Value"]))
-                if len(vals) != 1:
-                    raise RuntimeError(f"{name}: expected one launch of '{prefix}', found {len(vals)}")
-                got[name] = vals[0]
+            got.update(counter_values(out_dir, prefix, counter.split()))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     fetch_b, write_b = got["FETCH_SIZE"] * 1024.0 * 2.0, got["WRITE_SIZE"] * 1024.0

@@ -122,3 +122,25 @@ def test_a_failing_sub_benchmark_becomes_a_record_not_a_lost_headline():
     r = b.guarded("config5_100h_1gpu", boom)
     assert r["name"] == "config5_100h_1gpu" and "hipMalloc" in r["error"]
     assert b.guarded("ok", lambda: {"name": "ok", "value": 1.0}) == {"name": "ok", "value": 1.0}
+
+
+def test_live_counter_csv_parsing(tmp_path):
+    """bench.py measures the headline kernel's traffic in the run from rocprofv3's counter CSVs: the one launch of the kernel is found by
+    its name's prefix, other kernels' rows do not count, and zero or several launches are an error (never a silent zero)."""
+    import pytest
+    b = _bench()
+    d = tmp_path / "FETCH_SIZE" / "runc"
+    d.mkdir(parents=True)
+    head = "Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp\n"
+    row = lambda disp, kern, cnt, val: f'1,{disp},0,1,1,1,64,1,"{kern}",64,0,0,168,0,104,{cnt},{val},0,1\n'
+    k = "void vbx::analyze_kernel<true, true, true, 0, 3>(vbx::spectral_args_t)"
+    (d / "1_counter_collection.csv").write_text(head + row(1, "vbx::synth_kernel(double*)", "FETCH_SIZE", 5.0) + row(2, k, "FETCH_SIZE", 364397.0)
+                                                + row(3, "void vbx::analyze_kernel<false, false, true, 0, 3>(vbx::spectral_args_t)", "FETCH_SIZE", 7.0))
+    got = b.counter_values(str(tmp_path / "FETCH_SIZE"), b.LIVE_KERNELS["analyze"], ["FETCH_SIZE"])
+    assert got == {"FETCH_SIZE": 364397.0}
+    assert abs(got["FETCH_SIZE"] * 1024 * 2 / 180000 - 4146.03) < 0.01                  # x1024 x2 per frame of the 0.5 h child run
+    with pytest.raises(RuntimeError):
+        b.counter_values(str(tmp_path / "FETCH_SIZE"), "void vbx::renamed_kernel<", ["FETCH_SIZE"])
+    (d / "2_counter_collection.csv").write_text(head + row(9, k, "FETCH_SIZE", 1.0))
+    with pytest.raises(RuntimeError):
+        b.counter_values(str(tmp_path / "FETCH_SIZE"), b.LIVE_KERNELS["analyze"], ["FETCH_SIZE"])
