@@ -20,18 +20,21 @@ when the timed region ends).  The audio is generated on the device before the ti
 frames are range-split over ranks (weak scaling: --hours is per GPU; the default 12.5 h/GPU is BASELINE config 5's 100 h
 over 8 GPUs).
 
-Rank 0 prints ONE JSON line with the contract fields plus
+Rank 0 prints ONE JSON line under 6 KB (compact_line: the driver keeps the last 8 KB of stdout) with the contract fields plus
   roofline        the kernel with the largest measured time against the roof that binds it.  pitch / analyze -> FP64
                   vector peak with the flops the kernel EXECUTES (`frac`), `issue_frac` = the share of SIMD time the vector
-                  ALU is issuing (SQ counters of the committed PMC pass) and, under `reference_sums_at_peak`, how the kernel
-                  compares with running the reference's O(N^2) lag sums at peak (a speed-up statement, not a roofline);
-                  everything else -> HBM, algorithmic bytes.  `traffic` = measured HBM bytes per launch from the PMC passes
-                  committed under profiles/ (profiles/pmc_traffic.json), scaled to this launch's frames.
+                  ALU is issuing; everything else -> HBM, algorithmic bytes.  `traffic` = measured HBM bytes per launch;
+                  for the headline kernel `traffic`, `issue_frac` and `valu_insts_per_frame` are MEASURED IN THE RUN (three
+                  short `rocprofv3 --pmc` child passes, live_traffic()), elsewhere they come from the committed PMC passes
+                  (profiles/pmc_traffic.json): `traffic_source` says which
   roofline_hbm    the pitch kernel against the HBM roof, as north_star asks (tiny by construction)
   cpu_baseline    the CPU oracle (C restatement of the reference path) timed natively (oracle/vbx_cpu_bench.c) on
                   1 core and on all the cores the process may use, at the GPU leg's frame geometry
-  sub_benchmarks  (default run, N = 1) BASELINE configs 2, 3 (kmax 1 / 8 / the whole candidate Vec) and 4, a few steps
-                  each outside the headline's timed region, each with its own roofline
+  sub_benchmarks  (default run, N = 1) {name: frames/s}: BASELINE configs 2, 3 (kmax 1 / 8 / the whole candidate Vec), 4, fourteen
+                  other frame shapes, the pipeline on real 44.1 kHz speech, config 5 whole on one GPU -- a few steps each
+                  outside the headline's timed region
+and writes the FULL record (every sub-benchmark's kernels and rooflines, per-shape tables, the parity note, the model strings) to
+--detail (default gpurun_out/bench_detail.json).
 Other workloads (--workload config2|config3|config4|frontend) time a single BASELINE config; --frame-len / --hop move the
 pipeline and config3 to another frame shape (2048 / 1024 is the reference example's), under its own metric name.
 """
