@@ -294,7 +294,7 @@ def counter_values(out_dir, prefix, names):
     return out
 
 
-def live_traffic(dom, hours=0.5, timeout_s=90.0):
+def live_traffic(dom, hours=0.5, timeout_s=45.0):
     """HBM bytes per frame (and the vector ALU's busy share) of the dominant kernel, MEASURED IN THIS RUN (round 6; the round-5 review: a figure read from a committed
     file can never be refuted by a driver line): three child processes, each `rocprofv3 --pmc <one counter; the third: one SQ group> -- python3 bench.py --hours
     0.5 --steps 1 --warmup 0 --no-cpu --no-sub --no-live-traffic` (separate passes, counters only -- no trace domains --, as
