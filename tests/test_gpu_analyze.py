@@ -349,3 +349,35 @@ def test_rccl_record_gather_single_rank(vb, pkg):
         d_src.free(); d_out.free()
     finally:
         comm.close()
+
+
+def test_rows_kernel_forms_are_bit_identical_to_the_in_wavefront_forms(pkg, monkeypatch):
+    """Round 6 moved Levinson and MFCC's log10 + DCT out of the 1200-point kernel's wavefront into a lane-per-record kernel (same
+    operations in the same order).  VBX_MFCC_DEFER=0 keeps the MFCC tail in the wavefront: every record column bit for bit the same;
+    and with VBX_LPC_EXACT=0 (no probe, no double-double redo) the LPC column too is what one f64 recursion on the same lag sums gives --
+    checked against vbx_lpc_f64 on the autocorrelation rows vbx_autocorrelate_f64 returns for the same frames (the same two transforms)."""
+    N, H, sr = 1200, 480, 48000.0
+    got = {}
+    for defer, exact in (("1", "0"), ("0", "0"), ("1", "1")):
+        monkeypatch.setenv("VBX_MFCC_DEFER", defer)
+        monkeypatch.setenv("VBX_LPC_EXACT", exact)
+        with pkg.VoxBox(0) as ctx:
+            audio = ctx.synth_speech(int(20 * sr), sample_offset=int(3 * sr))
+            F = pkg.frame_count(int(20 * sr), N, H)
+            params = pkg.AnalysisParams.make(sr, pitch=(0.2, 75.0, 600.0), lpc_order=P, formant_order=0, mfcc=(13, 100.0, 8000.0))
+            rec, st = ctx.analyze_frames(audio, params, frame_len=N, stride=H, n_frames=F)
+            if (defer, exact) == ("1", "0"):
+                han = ctx.window(pkg.WINDOW_HANNING, N)
+                r = ctx.autocorrelate(audio, N, frame_len=N, stride=H, n_frames=F, window=han)
+                a_rows = ctx.lpc(r[:, :P + 1].copy(), P)
+            got[(defer, exact)] = (rec.copy(), st.copy())
+    base, st0 = got[("1", "0")]
+    other, st1 = got[("0", "0")]
+    assert np.array_equal(base.view(np.int64), other.view(np.int64)) and np.array_equal(st0, st1)
+    l0, ln = params.columns()["lpc"]
+    assert np.array_equal(base[:, l0:l0 + ln].view(np.int64), np.asarray(a_rows).view(np.int64))
+    # the default build differs from it on the listed rows' LPC column only
+    dflt, _ = got[("1", "1")]
+    diff = np.any(dflt.view(np.int64) != base.view(np.int64), axis=1)
+    cols = np.flatnonzero(np.any(dflt.view(np.int64) != base.view(np.int64), axis=0))
+    assert diff.sum() <= F // 50 and (cols.size == 0 or (cols.min() >= l0 and cols.max() < l0 + ln)), (diff.sum(), cols)
