@@ -304,7 +304,7 @@ def test_soak_real_speech_44k(vb, oracle, pkg, golden_dir, n, hop):
     import wave
     import torch
     from importlib import import_module
-    F, order = 20000, 13
+    F, order = int(os.environ.get("VBX_SOAK_SPEECH_FRAMES", "20000")), 13      # (evidence runs: 200,000)
     with wave.open(os.path.join(golden_dir, "sample-two_vowels.wav"), "rb") as w:
         sr = float(w.getframerate())
         pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
